@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Derive the polynomial coefficients of the sbx math spec (docs in DESIGN.md §Math spec).
+
+The reference (valentingalea/shaderbox) leaves sin/cos/exp/pow/acos/atan to its
+environment (GLSL driver / HLSL / VML+libm, see src/def.h:1-42), so this build has
+to *define* them once and use the same definition bit-for-bit in the CPU oracle
+(oracle/sbx_math_ref.h) and in the HIP kernels (shaderbox_amd/csrc/sbx_math.h).
+
+This script produces the fp32 minimax coefficients for
+
+  sin(r)  = r + r^3 * P(r^2),      r in [-pi/2, pi/2],   P of degree 4
+  exp(r)  = 1 + r + r^2 * Q(r),    r in [-ln2/2, ln2/2], Q of degree 4
+
+by solving the discrete weighted minimax problem as a linear program, with
+sequential rounding of the coefficients to binary32 (leading coefficient first).
+Run:  python tools/gen_math_coeffs.py      (prints C initialisers)
+"""
+import numpy as np
+import mpmath as mp
+from scipy.optimize import linprog
+
+mp.mp.prec = 120
+
+
+def minimax_lp(A, g, w, fixed=None):
+    """min_c max_i |w_i * (A c - g)_i| ; `fixed` = {index: value} pins coefficients."""
+    n = A.shape[1]
+    fixed = fixed or {}
+    free = [j for j in range(n) if j not in fixed]
+    g2 = g - sum(A[:, j] * v for j, v in fixed.items())
+    Af = A[:, free] * w[:, None]
+    gf = g2 * w
+    m = len(free)
+    # variables: c_free (m), E
+    c = np.zeros(m + 1)
+    c[-1] = 1.0
+    A_ub = np.vstack([np.hstack([Af, -np.ones((len(gf), 1))]),
+                      np.hstack([-Af, -np.ones((len(gf), 1))])])
+    b_ub = np.concatenate([gf, -gf])
+    res = linprog(c, A_ub=A_ub, b_ub=b_ub, bounds=[(None, None)] * m + [(0, None)],
+                  method="highs")
+    assert res.status == 0, res.message
+    out = np.zeros(n)
+    for j, v in fixed.items():
+        out[j] = v
+    for k, j in enumerate(free):
+        out[j] = res.x[k]
+    return out, res.x[-1]
+
+
+def seq_round(A, g, w):
+    """Sequentially round coefficients to fp32, lowest order first, re-solving the rest."""
+    n = A.shape[1]
+    fixed = {}
+    for j in range(n):
+        c, E = minimax_lp(A, g, w, fixed)
+        fixed[j] = float(np.float32(c[j]))
+    c = np.array([fixed[j] for j in range(n)])
+    E = np.max(np.abs(w * (A @ c - g)))
+    return c, E
+
+
+def fit_sin():
+    N = 4000
+    # Chebyshev-distributed nodes in r on (0, pi/2]
+    k = np.arange(1, N + 1)
+    r = (np.pi / 2) * np.sin(0.5 * np.pi * k / N) ** 1.0
+    r = np.unique(np.concatenate([r, np.linspace(1e-3, np.pi / 2, N)]))
+    s = r * r
+    # g(s) = (sin(r) - r) / r^3 evaluated in high precision
+    g = np.array([float((mp.sin(mp.mpf(x)) - mp.mpf(x)) / mp.mpf(x) ** 3) for x in r])
+    A = np.stack([s ** j for j in range(5)], axis=1)
+    # error in sin = r^3 * dP ; relative to sin(r)
+    w = r ** 3 / np.sin(r)
+    c, E = seq_round(A, g, w)
+    return c, E
+
+
+def fit_exp():
+    N = 4000
+    h = float(mp.log(2) / 2) * 1.0001
+    r = np.unique(np.concatenate([h * np.cos(np.pi * (np.arange(N) + 0.5) / N),
+                                  np.linspace(-h, h, N)]))
+    r = r[np.abs(r) > 1e-4]
+    g = np.array([float((mp.exp(mp.mpf(x)) - 1 - mp.mpf(x)) / mp.mpf(x) ** 2) for x in r])
+    A = np.stack([r ** j for j in range(5)], axis=1)
+    w = r ** 2 / np.exp(r)
+    c, E = seq_round(A, g, w)
+    return c, E
+
+
+def hexf(x):
+    return float(np.float32(x)).hex()
+
+
+if __name__ == "__main__":
+    c, E = fit_sin()
+    print("// sin(r) = r + r^3*(S0 + S1 s + S2 s^2 + S3 s^3 + S4 s^4), s=r^2 ; max rel err (exact arith) = %.3g" % E)
+    for j, v in enumerate(c):
+        print("  S%d = %s  /* %.10e */" % (j, hexf(v), v))
+    c, E = fit_exp()
+    print("// exp(r) = 1 + r + r^2*(E0 + E1 r + E2 r^2 + E3 r^3 + E4 r^4) ; max rel err (exact arith) = %.3g" % E)
+    for j, v in enumerate(c):
+        print("  E%d = %s  /* %.10e */" % (j, hexf(v), v))
+    # Cody-Waite splits
+    pi = mp.pi
+    hi = np.float32(float(pi))
+    mid = np.float32(float(pi - mp.mpf(float(hi))))
+    lo = np.float32(float(pi - mp.mpf(float(hi)) - mp.mpf(float(mid))))
+    print("// pi = PI_HI + PI_MID + PI_LO")
+    print("  PI_HI = %s, PI_MID = %s, PI_LO = %s" % (hexf(hi), hexf(mid), hexf(lo)))
+    hp = pi / 2
+    hi = np.float32(float(hp))
+    mid = np.float32(float(hp - mp.mpf(float(hi))))
+    lo = np.float32(float(hp - mp.mpf(float(hi)) - mp.mpf(float(mid))))
+    print("  PIO2_HI = %s, PIO2_MID = %s, PIO2_LO = %s" % (hexf(hi), hexf(mid), hexf(lo)))
+    print("  INV_PI = %s" % hexf(float(1 / pi)))
+    ln2 = mp.log(2)
+    hi = np.float32(float(ln2))
+    lo = np.float32(float(ln2 - mp.mpf(float(hi))))
+    print("  LN2_HI = %s, LN2_LO = %s, LOG2E = %s" % (hexf(hi), hexf(lo), hexf(float(1 / ln2))))
+    print("  (double) 1/ln2 = %s ; ln2 = %s" % (float(1 / ln2).hex(), float(ln2).hex()))
