@@ -1,0 +1,136 @@
+/* include/sbx.h — C ABI of libsbx: the MI355X drop-in for shaderbox's mainImage() hot path.
+ *
+ * What this boundary replaces.  In the reference a *host* evaluates
+ *     void mainImage(out vec4 fragColor, in vec2 fragCoord)        (src/main.h:6-53)
+ * once per pixel for the app chosen by one global APP_* define (README.md:11-22,
+ * src/Makefile:9): the external VML/SDL harness on the C++ path (src/Makefile:21), or the
+ * D3D11 host util/hlsltoy (its per-frame Draw, util/hlsltoy/src/hlsltoy.cpp:494-495, with
+ * the uniforms of src/uniform_buffer.h uploaded as cbuffers b0/b1, hlsltoy.cpp:402-426,
+ * 502-516).  A per-pixel FFI into a GPU is meaningless, so the boundary is frame-granular:
+ * one call renders rows of one frame of one app into a caller-owned RGBA32F framebuffer in
+ * device memory.  Everything a host needs is plain C: pointers, sizes, POD structs.
+ *
+ * Conventions (all from the reference):
+ *   - framebuffer: row-major float4 RGBA, 16 B/pixel, row 0 = BOTTOM row (main.h:40-43: the
+ *     y flip is HLSL-only), alpha = 1 (main.h:52);
+ *   - fragCoord of pixel (x, y) is (x + .5, y + .5);
+ *   - `_mutable` globals have GLSL per-invocation meaning (def.h:18): every pixel starts from
+ *     the initialisers;
+ *   - errors: the reference has none (void everywhere, NaN flows to the framebuffer).  Here every
+ *     entry point returns 0 on success or a negative sbx_status; NaNs stay data; nothing aborts.
+ *   - threading: one caller per sbx_ctx at a time; calls are asynchronous on the given HIP
+ *     stream (hipStream_t passed as void*; NULL = the default stream).
+ */
+#ifndef SBX_H
+#define SBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBX_ABI_VERSION 1
+
+/* App selector = the reference's APP_* project defines, in README.md:15-22 order, plus
+ * APP_SDF_AO (src/uniform_buffer.h:56, util/hlsltoy/src/hlsltoy.cpp:488). */
+typedef enum sbx_app {
+    SBX_APP_PLANET = 0,
+    SBX_APP_CLOUDS = 1,
+    SBX_APP_VINYL = 2,      /* not on the accelerated path: returns SBX_ERR_UNSUPPORTED */
+    SBX_APP_EGG = 3,
+    SBX_APP_RAYTRACER = 4,
+    SBX_APP_ATMOSPHERE = 5,
+    SBX_APP_SDF_AO = 6
+} sbx_app;
+
+typedef enum sbx_status {
+    SBX_OK = 0,
+    SBX_ERR_ARG = -1,          /* NULL pointer, bad row range, bad resolution ... */
+    SBX_ERR_UNSUPPORTED = -2,  /* app not on the accelerated path */
+    SBX_ERR_HIP = -3,          /* a HIP runtime call failed; see sbx_last_error() */
+    SBX_ERR_NO_DEVICE = -4     /* no gfx950 device visible: the library never falls back to a CPU */
+} sbx_status;
+
+/* cbuffer b0 (src/uniform_buffer.h:25-30): u_res@c0.xy, u_mouse@c0.zw, u_time@c1.x.
+ * On the C++/Shadertoy path these are iResolution / iMouse / iGlobalTime (:32-36). */
+typedef struct sbx_uniforms {
+    float u_res[2];
+    float u_mouse[2];
+    float u_time;
+    float _pad[3];
+} sbx_uniforms;
+
+/* cbuffer b1 for APP_CLOUDS (src/uniform_buffer.h:39-55), same packoffsets and defaults.
+ * Pass NULL as `aux` to get the defaults (what the C++/GLSL builds compile in, :13). */
+typedef struct sbx_aux_clouds {
+    float wind_dir[3];   float _pad0;   /* c0   default (0, 0, .2)     */
+    float sun_dir[3];    float _pad1;   /* c1   default (0, 0, -1)     */
+    float sun_color[3];  float _pad2;   /* c2   default (1, .7, .55)   */
+    float sun_power;                    /* c3.x default 8              */
+    int32_t cld_march_steps;            /* c3.y default 100            */
+    int32_t illum_march_steps;          /* c3.z default 6              */
+    float sigma_scattering;             /* c3.w default .15            */
+    float cld_coverage;                 /* c4.x default .535           */
+    float cld_thick;                    /* c4.y default 125            */
+    float atm_radius;                   /* c4.z default 5000 (SKY_SPHERE only, unused) */
+    float atm_ground_y;                 /* c4.w default 4750 (SKY_SPHERE only, unused) */
+} sbx_aux_clouds;
+
+/* cbuffer b1 for APP_SDF_AO (src/uniform_buffer.h:56-60) */
+typedef struct sbx_aux_sdf_ao {
+    float fog_density;   /* c0.x default .1 */
+    float fog_falloff;   /* c0.y default .5 */
+    float _pad[2];
+} sbx_aux_sdf_ao;
+
+typedef struct sbx_ctx sbx_ctx;
+
+/* Fill the aux blocks with the reference's defaults. */
+void sbx_aux_clouds_defaults(sbx_aux_clouds* aux);
+void sbx_aux_sdf_ao_defaults(sbx_aux_sdf_ao* aux);
+
+/* Create / destroy a context bound to HIP device `device`.  Owns only small device scratch
+ * (trig tables, timing events); the framebuffer always belongs to the caller. */
+int sbx_create(int device, sbx_ctx** out);
+void sbx_destroy(sbx_ctx* ctx);
+
+/* Render rows [y0, y1) of the frame described by `uni` (u_res = full frame size) for `app`.
+ * `rgba` points at device memory for row y0: pixel (x, y) lands at rgba[((y - y0) * W + x) * 4].
+ * This is the replacement of "for every pixel: mainImage(fragColor, fragCoord)". */
+int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
+                    int y0, int y1, float* rgba, void* stream);
+
+/* Render the cyclic row-blocks owned by one rank of an N-way split: blocks of
+ * `block_rows` rows, rank r owns blocks r, r+N, r+2N, ...  The rank's rows are written densely,
+ * in increasing y, into `rgba` (capacity sbx_rank_rows() rows).  Each pixel is computed from its
+ * GLOBAL (x, y), so the assembled frame is bit-identical to a 1-GPU render. */
+int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
+                    int block_rows, int rank, int nranks, float* rgba, void* stream);
+/* Number of rows rank `rank` owns (<= sbx_rank_rows_max). */
+int sbx_rank_rows(int height, int block_rows, int rank, int nranks);
+/* Rows every rank's buffer must hold so that an equal-count gather works: max over ranks. */
+int sbx_rank_rows_max(int height, int block_rows, int nranks);
+/* Root-side frame assembly after the gather: `gathered` holds nranks slabs of
+ * sbx_rank_rows_max() rows each (rank-major); scatter them to their global rows of `frame`. */
+int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks,
+                 const float* gathered, float* frame, void* stream);
+
+/* Per-launch timing: when enabled, every render call brackets its kernel with HIP events on the
+ * launch stream; sbx_last_kernel_ms() synchronises on the last pair and returns the duration. */
+int sbx_set_timing(sbx_ctx* ctx, int enabled);
+int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms);
+
+/* Device evaluation of the math spec, elementwise over device arrays (for parity tests):
+ * fn in {"sin","cos","tan","exp","pow","acos","atan2","hash"}; b may be NULL for unary fns. */
+int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, float* out,
+                  size_t n, void* stream);
+
+const char* sbx_last_error(sbx_ctx* ctx);
+const char* sbx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBX_H */
