@@ -1,0 +1,207 @@
+"""shaderbox_amd — MI355X-native renderer for shaderbox's mainImage() hot path.
+
+Python host layer over the C ABI of libsbx.so (include/sbx.h).  PyTorch is used only as plumbing:
+device memory (framebuffers are torch CUDA tensors), streams and torch.distributed.  All pixels
+are produced by the hand-written HIP kernels in shaderbox_amd/csrc; there is no CPU or PyTorch
+fallback — if the library or a gfx950 device is missing, construction raises.
+
+The surface mirrors the reference's: an app is chosen by its APP_* project define
+(/root/reference/README.md:11-22), a frame is a pure function of the uniforms u_res / u_time /
+u_mouse (+ the per-app aux block with the defaults of /root/reference/src/uniform_buffer.h:39-60).
+"""
+import ctypes
+import os
+
+from . import shard  # noqa: F401  (pure-python row-block arithmetic, no GPU needed)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsbx.so")
+
+APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO = range(7)
+APPS = {"APP_PLANET": APP_PLANET, "APP_CLOUDS": APP_CLOUDS, "APP_VINYL": APP_VINYL, "APP_EGG": APP_EGG,
+        "APP_RAYTRACER": APP_RAYTRACER, "APP_ATMOSPHERE": APP_ATMOSPHERE, "APP_SDF_AO": APP_SDF_AO}
+
+SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+
+
+class SbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsbx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Uniforms(ctypes.Structure):           # sbx_uniforms (cbuffer b0)
+    _fields_ = [("u_res", ctypes.c_float * 2), ("u_mouse", ctypes.c_float * 2), ("u_time", ctypes.c_float),
+                ("_pad", ctypes.c_float * 3)]
+
+
+class AuxClouds(ctypes.Structure):          # sbx_aux_clouds (cbuffer b1, APP_CLOUDS)
+    _fields_ = [("wind_dir", ctypes.c_float * 3), ("_pad0", ctypes.c_float),
+                ("sun_dir", ctypes.c_float * 3), ("_pad1", ctypes.c_float),
+                ("sun_color", ctypes.c_float * 3), ("_pad2", ctypes.c_float),
+                ("sun_power", ctypes.c_float), ("cld_march_steps", ctypes.c_int32),
+                ("illum_march_steps", ctypes.c_int32), ("sigma_scattering", ctypes.c_float),
+                ("cld_coverage", ctypes.c_float), ("cld_thick", ctypes.c_float),
+                ("atm_radius", ctypes.c_float), ("atm_ground_y", ctypes.c_float)]
+
+
+class AuxSdfAo(ctypes.Structure):           # sbx_aux_sdf_ao (cbuffer b1, APP_SDF_AO)
+    _fields_ = [("fog_density", ctypes.c_float), ("fog_falloff", ctypes.c_float), ("_pad", ctypes.c_float * 2)]
+
+
+def app_id(app):
+    """Accepts an int, 'APP_CLOUDS', 'clouds', ..."""
+    if isinstance(app, int):
+        return app
+    key = str(app).upper()
+    if not key.startswith("APP_"):
+        key = "APP_" + key
+    if key not in APPS:
+        raise ValueError("unknown app %r" % (app,))
+    return APPS[key]
+
+
+def load_library(path=None):
+    """dlopen libsbx.so and declare the prototypes of include/sbx.h.  Raises if it is not built."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("libsbx.so is not built (%s). Run `python -m shaderbox_amd.build`; "
+                          "there is no fallback path." % path)
+    lib = ctypes.CDLL(path)
+    vp, ci, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    lib.sbx_aux_clouds_defaults.argtypes = [ctypes.POINTER(AuxClouds)]
+    lib.sbx_aux_clouds_defaults.restype = None
+    lib.sbx_aux_sdf_ao_defaults.argtypes = [ctypes.POINTER(AuxSdfAo)]
+    lib.sbx_aux_sdf_ao_defaults.restype = None
+    lib.sbx_create.argtypes = [ci, ctypes.POINTER(vp)]
+    lib.sbx_destroy.argtypes = [vp]
+    lib.sbx_destroy.restype = None
+    lib.sbx_render_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, fp, vp]
+    lib.sbx_render_rank.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, fp, vp]
+    lib.sbx_rank_rows.argtypes = [ci, ci, ci, ci]
+    lib.sbx_rank_rows_max.argtypes = [ci, ci, ci]
+    lib.sbx_assemble.argtypes = [vp, ci, ci, ci, ci, fp, fp, vp]
+    lib.sbx_set_timing.argtypes = [vp, ci]
+    lib.sbx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.sbx_math_eval.argtypes = [vp, ctypes.c_char_p, fp, fp, fp, ctypes.c_size_t, vp]
+    lib.sbx_last_error.argtypes = [vp]
+    lib.sbx_last_error.restype = ctypes.c_char_p
+    lib.sbx_version.restype = ctypes.c_char_p
+    return lib
+
+
+def clouds_defaults(lib=None):
+    lib = lib or load_library()
+    a = AuxClouds()
+    lib.sbx_aux_clouds_defaults(ctypes.byref(a))
+    return a
+
+
+def sdf_ao_defaults(lib=None):
+    lib = lib or load_library()
+    a = AuxSdfAo()
+    lib.sbx_aux_sdf_ao_defaults(ctypes.byref(a))
+    return a
+
+
+class Renderer:
+    """One sbx_ctx on one GPU.  Framebuffers are float32 torch tensors [rows, W, 4] on that GPU,
+    row 0 = bottom row of the strip (reference convention, src/main.h:40-43)."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise SbxError(SBX_ERR_NO_DEVICE, "no GPU visible; shaderbox_amd has no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        rc = self.lib.sbx_create(self.device, ctypes.byref(h))
+        if rc != SBX_OK:
+            raise SbxError(rc, "sbx_create failed (need a gfx950 device; there is no fallback)")
+        self.ctx = h
+        self.tdev = torch.device("cuda", self.device)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.sbx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != SBX_OK:
+            raise SbxError(rc, (self.lib.sbx_last_error(self.ctx) or b"").decode())
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    @staticmethod
+    def uniforms(width, height, time, mouse=(0.0, 0.0)):
+        u = Uniforms()
+        u.u_res[0], u.u_res[1] = float(width), float(height)
+        u.u_mouse[0], u.u_mouse[1] = float(mouse[0]), float(mouse[1])
+        u.u_time = float(time)
+        return u
+
+    @staticmethod
+    def _auxp(aux):
+        return ctypes.cast(ctypes.byref(aux), ctypes.c_void_p) if aux is not None else None
+
+    def _buffer(self, rows, width, out):
+        if out is None:
+            return self.torch.empty((rows, width, 4), dtype=self.torch.float32, device=self.tdev)
+        assert out.is_cuda and out.dtype == self.torch.float32 and out.is_contiguous()
+        assert out.numel() >= rows * width * 4
+        return out
+
+    # -- the hot path ---------------------------------------------------------------------------
+    def render(self, app, width, height, time, mouse=(0.0, 0.0), aux=None, rows=None, out=None):
+        """Render rows [y0, y1) (default: the whole frame) of `app`; asynchronous on the current stream."""
+        y0, y1 = (0, int(height)) if rows is None else (int(rows[0]), int(rows[1]))
+        u = self.uniforms(width, height, time, mouse)
+        buf = self._buffer(max(y1 - y0, 0), int(width), out)
+        self._check(self.lib.sbx_render_rows(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), y0, y1,
+                                             ctypes.c_void_p(buf.data_ptr()), self._stream()))
+        return buf
+
+    def render_rank(self, app, width, height, time, block_rows, rank, nranks, mouse=(0.0, 0.0), aux=None, out=None):
+        """Render the cyclic row-blocks of `rank`; `out` has shard.rank_rows_max() rows (tail rows unused)."""
+        u = self.uniforms(width, height, time, mouse)
+        buf = self._buffer(shard.rank_rows_max(int(height), block_rows, nranks), int(width), out)
+        self._check(self.lib.sbx_render_rank(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
+                                             rank, nranks, ctypes.c_void_p(buf.data_ptr()), self._stream()))
+        return buf
+
+    def assemble(self, gathered, width, height, block_rows, nranks, out=None):
+        """Root side: scatter the rank-major gathered slabs to their global rows -> [H, W, 4]."""
+        frame = self._buffer(int(height), int(width), out)
+        self._check(self.lib.sbx_assemble(self.ctx, int(width), int(height), block_rows, nranks,
+                                          ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
+                                          self._stream()))
+        return frame
+
+    def set_timing(self, enabled=True):
+        self._check(self.lib.sbx_set_timing(self.ctx, 1 if enabled else 0))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self._check(self.lib.sbx_last_kernel_ms(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+    def math(self, fn, a, b=None):
+        """Evaluate the device math spec elementwise (parity tests)."""
+        a = a.to(self.tdev, self.torch.float32).contiguous()
+        bp = None
+        if b is not None:
+            b = b.to(self.tdev, self.torch.float32).contiguous()
+            bp = ctypes.c_void_p(b.data_ptr())
+        out = self.torch.empty_like(a)
+        self._check(self.lib.sbx_math_eval(self.ctx, fn.encode(), ctypes.c_void_p(a.data_ptr()), bp,
+                                           ctypes.c_void_p(out.data_ptr()), a.numel(), self._stream()))
+        return out

@@ -1,0 +1,136 @@
+// shaderbox_amd/csrc/kern_egg.hip — APP_EGG: sphere-traced SDF scene ("Vectorpark egg").
+//
+// Follows /root/reference/src/app_egg.h: sdf :38-144, shadowmarch :161-186, render_scene
+// :190-231, render (bars overlay) :233-251, with the SDF library of src/sdf.h and the IK solver of
+// src/IK.h.  Everything in sdf() that does not depend on the sample point (the turntable and
+// pedal rotations, both feet, both IK knees, the Bezier frames of the legs, the toe cylinders'
+// axes) is a frame constant evaluated once on the host (FrameEgg); only the point-dependent part
+// runs per march step.  `depth` (a _mutable global, :188) is a per-thread register that starts
+// at -max_dist for every pixel = GLSL per-invocation semantics.
+#include "sbx_device.h"
+
+namespace sbx {
+
+__device__ __forceinline__ float op_blend(float a, float b, float k) {      // sdf.h:38-47
+    float h = clamp_(0.5f + 0.5f * (b - a) / k, 0.0f, 1.0f);
+    return mix_(b, a, h) - k * h * (1.0f - h);
+}
+__device__ __forceinline__ float det2(v2 a, v2 b) { return a.x * b.y - b.x * a.y; }   // sdf.h:114-119
+
+// sd_bezier, point-dependent part                                          sdf.h:120-159
+__device__ __forceinline__ float sd_bezier_x(const BezierFrame& B, v3 p, float thickness) {
+    const v3 q = p - B.b;
+    const v3 p3 = V3(dot(q, B.u), dot(q, B.v), dot(q, B.w));
+    const v2 pxy = V2(p3.x, p3.y);
+    const v2 b0 = B.a2 - pxy, b1 = V2(0.f, 0.f) - pxy, b2 = B.c2 - pxy;
+    // sd_bezier_get_closest :120-139
+    const float a = det2(b0, b2);
+    const float b = 2.0f * det2(b1, b0);
+    const float d = 2.0f * det2(b2, b1);
+    const float f = b * d - a * a;
+    const v2 d21 = b2 - b1, d10 = b1 - b0, d20 = b2 - b0;
+    v2 gf = 2.0f * (b * d21 + d * d10 + a * d20);
+    gf = V2(gf.y, -gf.x);
+    const v2 pp = (-f * gf) / dot(gf, gf);
+    const v2 d0p = b0 - pp;
+    const float ap = det2(d0p, d20);
+    const float bp = 2.0f * det2(d10, d0p);
+    const float t = clamp_((ap + bp) / (2.0f * a + b + d), 0.0f, 1.0f);
+    const v2 cp = mix2(mix2(b0, b1, t), mix2(b1, b2, t), t);
+    return 0.85f * (sqrt_(dot(cp, cp) + p3.z * p3.z) - thickness);
+}
+// sd_cylinder(P, 0, P1, R), point-dependent part                            sdf.h:95-109
+__device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) {
+    const float dist = length(cross(C.dir, P - V3(0.f, 0.f, 0.f)));
+    const float plane_1 = dot(C.dir, P) + C.len1;
+    const float plane_2 = dot(-C.dir, P) + (-C.len0);
+    return fmax_(fmax_(dist, -plane_1), -plane_2) - R;           // op_sub(op_sub(dist,p1),p2) - R
+}
+
+struct D2 { float d, m; };   // (distance, material id) pairs; op_add keeps the nearer   sdf.h:5-11
+__device__ __forceinline__ D2 op_add2(D2 a, D2 b) { return a.d < b.d ? a : b; }
+
+__device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
+    const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                         // :40-41
+    const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
+    const float egg_y = 0.65f;
+    const float egg_m = length(p - V3(0, egg_y, 0)) - 0.475f;                  // :47-49
+    const float egg_b = length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
+    const float egg_t = length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
+    const float egg_1 = op_blend(egg_m, egg_b, .5f);
+    const float egg_2 = op_blend(egg_1, egg_t, .5f);
+    const D2 egg = {egg_2, mat_egg};
+
+    const float thick = .05f;
+    const D2 legs = op_add2(D2{sd_bezier_x(F.leg_l, p, thick), mat_egg},      // :102-118
+                            D2{sd_bezier_x(F.leg_r, p, thick), mat_egg});
+    const D2 left_foot = {sd_cylinder0(F.foot_l, p + F.left_foot, thick), mat_egg};    // :120-123
+    const D2 right_foot = {sd_cylinder0(F.foot_r, p + F.right_foot, thick), mat_egg};  // :125-128
+    const D2 feet = op_add2(left_foot, right_foot);
+
+    const v3 wheel_pos = V3(0, 1.2f, 0);
+    const v3 pw = p + wheel_pos;
+    const D2 bike = {length(V2(length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f, mat_bike};   // sd_torus sdf.h:75-83
+    const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};           // sd_plane :136-138
+
+    const D2 _1 = op_add2(feet, bike);
+    const D2 _2 = op_add2(egg, _1);
+    const D2 _3 = op_add2(legs, _2);
+    return op_add2(ground, _3);
+}
+
+__device__ __forceinline__ float egg_shadowmarch(const FrameEgg& F, v3 ro, v3 rd) {   // :161-186
+    float t = 0.f, umbra = 1.f;
+    for (int i = 0; i < 20; ++i) {
+        const v3 p = ro + rd * t;
+        const D2 d = egg_sdf(F, p);
+        if (t > 10.f) break;
+        if (d.d < 0.001f) return 0.1f;
+        t += d.d;
+        umbra = fmin_(umbra, 15.f * d.d / t);
+    }
+    return umbra;
+}
+
+__global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float* __restrict__ out) {
+    const Pixel px = pixel_of_thread(M);
+    if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
+
+    float depth = -1e8f;                                    // :188, fresh per pixel
+    v3 color = V3(.1f, .1f, .7f);                           // background :9-12
+    float t = 0.f;
+    for (int i = 0; i < 80; ++i) {                          // render_scene :190-231
+        const v3 p = ro + rd * t;
+        const D2 d = egg_sdf(F, p);
+        if (t > 15.f) break;
+        if (d.d < 0.001f) {
+            const int mat = (int)d.m;
+            if (mat == 1 || mat == 2) depth = fmax_(depth, p.z);
+            float s = 1.f;
+            if (mat == 3) {
+                const v3 sh_dir = V3(0, 1, 1);
+                s = egg_shadowmarch(F, p + sh_dir * 0.05f, sh_dir);
+            }
+            v3 base = V3(1, 1, 1);                          // illuminate :29-35
+            if (mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
+            else if (mat == 1) base = V3(0.9f, 0.95f, 0.95f);
+            else if (mat == 2) base = V3(.2f, .2f, .2f);
+            color = base * s;
+            break;
+        }
+        t += d.d;
+    }
+    // bars overlay :233-251
+    const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);
+    const float depth_factor = 1.f - step_(1.f, depth);
+    color = abs3(mix3(color, V3(.6f, .6f, .6f), bar_factor * depth_factor));
+    store_rgba(out, px.idx, to_srgb(color));
+}
+
+void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_egg, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+}
+
+}  // namespace sbx

@@ -1,0 +1,173 @@
+// shaderbox_amd/csrc/kern_planet.hip — APP_PLANET: fBm terrain sphere + volumetric cloud shell.
+//
+// Follows /root/reference/src/app_planet.h (CLOUDS and LIGHT defined, :63,249): render :303-367,
+// sdf_terrain_map :175-186, sdf_terrain_map_detail :188-199, sdf_terrain_normal :201-212,
+// clouds_map :102-119, clouds_march :121-141, clouds_shadow_march :143-160, integrate_volume
+// :79-100, setup_lights :217-236, illuminate :238-298, background :23-41.  The three rotation
+// matrices, transpose(rot) and the light vector are frame constants (FramePlanet).
+// NaN policy: smoothstep(1-.3s, 1-.2s, N) with s = 0 is 0/0 for N == 1 (:270-273); NaN is data and
+// flows to the framebuffer exactly as IEEE arithmetic dictates.
+#include "sbx_device.h"
+#include "sbx_noise.h"
+
+namespace sbx {
+
+constexpr float PL_MAX_HEIGHT = .4f;                    // :20
+constexpr float PL_MAX_RAY_DIST = PL_MAX_HEIGHT * 4.f;  // :21
+
+struct Vol { v3 origin, pos; float height, transmittance, radiance, alpha; };   // volumetric.h:47-68 (radiance r=g=b)
+__device__ __forceinline__ Vol make_vol(v3 o) { return Vol{o, o, 0.f, 1.f, 0.f, 0.f}; }
+
+__device__ __forceinline__ float band(float start, float peak, float end, float t) {   // util.h:103-112
+    return smoothstep_(start, peak, t) * (1.f - smoothstep_(peak, end, t));
+}
+__device__ __forceinline__ float anoise(v3 p) { return abs_(noise_iq(p) * 2.f - 1.f); }          // :65
+__device__ __forceinline__ float rnoise(v3 p) { return 1.f - abs_(noise_iq(p) * 2.f - 1.f); }    // :167
+
+__device__ __forceinline__ void clouds_map(Vol& c, float t_step) {                     // :102-119 + :79-100
+    float dens = fbm<4>(c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f), 2.0276f, .5f, .5f, anoise);
+    const float cov = .29475675f, fuzzy = .0335f;
+    dens *= smoothstep_(cov, cov + fuzzy, dens);
+    dens *= band(.2f, .35f, .65f, c.height);
+    const float T_i = exp_(-30.034f * dens * t_step);
+    c.transmittance *= T_i;
+    c.radiance += dens * (exp_(c.height) / .055f) * c.transmittance * t_step;
+    c.alpha += (1.f - T_i) * (1.f - c.alpha);
+}
+
+template <int OCT>
+__device__ __forceinline__ v2 terrain_map(v3 pos) {                                    // :175-199
+    const float h0 = fbm<OCT>(pos * 2.0987f, 2.0244f, .454f, .454f, [](v3 p) { return noise_iq(p); });
+    const float n0 = smoothstep_(.35f, 1.f, h0);
+    const float h1 = fbm<OCT>(pos * 1.50987f + V3(1.9489f, 2.435f, .5483f), 2.0244f, .454f, .454f, rnoise);
+    const float n1 = smoothstep_(.6f, 1.f, h1);
+    const float n = n0 + n1;
+    return V2(length(pos) - 1.f - n * PL_MAX_HEIGHT, n / PL_MAX_HEIGHT);
+}
+
+__device__ __forceinline__ v3 setup_lights(v3 L, v3 normal) {                          // :217-236
+    v3 diffuse = V3(0, 0, 0);
+    diffuse = diffuse + fmax_(0.f, dot(L, normal)) * V3(7, 5, 3);
+    const float hemi = clamp_(.25f + .5f * normal.y, .0f, 1.f);
+    diffuse = diffuse + hemi * V3(.4f, .6f, .8f) * .2f;
+    const float amb = clamp_(.12f + .8f * fmax_(0.f, dot(-L, normal)), 0.f, 1.f);
+    diffuse = diffuse + amb * V3(.4f, .5f, .6f);
+    return diffuse;
+}
+
+__device__ __forceinline__ v3 planet_background(v3 dir) {                              // :23-41
+    const v3 sun_color = V3(1.f, .9f, .55f);
+    const float sun_amount = clamp_(dot(dir, V3(0, 0, 1)), 0.f, 1.f);
+    v3 sky = mix3(V3(.0f, .05f, .2f), V3(.15f, .3f, .4f), 1.0f - dir.y);
+    sky = sky + sun_color * clamp_(pow_(sun_amount, 30.0f) * 5.0f, 0.f, 1.f);
+    sky = sky + sun_color * clamp_(pow_(sun_amount, 10.0f) * .6f, 0.f, 1.f);
+    return abs3(sky);
+}
+
+__global__ void __launch_bounds__(WG_THREADS) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
+    const Pixel px = pixel_of_thread(M);
+    if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
+
+    // intersect_sphere(eye, atmosphere = {0, 1 + max_height}) on no_hit      intersect.h:7-33
+    bool hit_atm = false;
+    v3 hit_o = V3(0, 0, 0);
+    {
+        const float radius = 1.f + PL_MAX_HEIGHT;
+        const v3 rc = V3(0, 0, 0) - ro;
+        const float radius2 = radius * radius;
+        const float tca = dot(rc, rd);
+        if (!(tca < 0.f)) {
+            const float d2 = dot(rc, rc) - tca * tca;
+            if (!(d2 > radius2)) {
+                const float thc = sqrt_(radius2 - d2);
+                float t0 = tca - thc;
+                const float t1 = tca + thc;
+                if (t0 < 0.f) t0 = t1;
+                if (!(t0 > (float)(1e8f + 1e1f))) { hit_atm = true; hit_o = ro + rd * t0; }
+            }
+        }
+    }
+    v3 col;
+    if (!hit_atm) {
+        col = planet_background(rd);                              // :316-318
+    } else {
+        float t = 0.f;
+        v2 df = V2(1, PL_MAX_HEIGHT);
+        v3 pos = V3(0, 0, 0);
+        float max_cld = PL_MAX_RAY_DIST;
+        for (int i = 0; i < 120; ++i) {                           // :328-342
+            if (t > PL_MAX_RAY_DIST) break;
+            const v3 o = hit_o + t * rd;
+            pos = mul(F.rot, o - V3(0, 0, 0));
+            df = terrain_map<3>(pos);
+            if (df.x < .005f) { max_cld = t; break; }
+            t += df.x * .4567f;
+        }
+        Vol cloud = make_vol(hit_o);                              // :345-346, clouds_march :121-141
+        {
+            const float t_step = PL_MAX_RAY_DIST / 75.f;
+            float tc = 0.f;
+            for (int i = 0; i < 75; ++i) {
+                if (tc > max_cld || cloud.alpha >= 1.f) break;
+                const v3 o = cloud.origin + tc * rd;
+                cloud.pos = mul(F.rot_cloud, o - V3(0, 0, 0));
+                cloud.height = (length(cloud.pos) - 1.f) / PL_MAX_HEIGHT;
+                tc += t_step;
+                clouds_map(cloud, t_step);
+            }
+        }
+        if (df.x < .005f) {                                       // :349-363
+            // illuminate :238-298
+            const float h = df.y;
+            const v3 w_normal = normalize(pos);
+            const float e = 0.001f;
+            const v3 normal = normalize(V3(                        // sdf_terrain_normal :201-212
+                terrain_map<7>(pos + V3(e, 0, 0)).x - terrain_map<7>(pos - V3(e, 0, 0)).x,
+                terrain_map<7>(pos + V3(0, e, 0)).x - terrain_map<7>(pos - V3(0, e, 0)).x,
+                terrain_map<7>(pos + V3(0, 0, e)).x - terrain_map<7>(pos - V3(0, 0, e)).x));
+            const float N = dot(normal, w_normal);
+            const v3 c_water = V3(.015f, .110f, .455f), c_grass = V3(.086f, .132f, .018f),
+                     c_beach = V3(.153f, .172f, .121f), c_rock = V3(.080f, .050f, .030f),
+                     c_snow = V3(.600f, .600f, .600f);
+            const float l_water = .05f, l_shore = .17f, l_grass = .211f, l_rock = .351f;
+            const float s = smoothstep_(.4f, 1.f, h);
+            const v3 rock = mix3(c_rock, c_snow, smoothstep_(1.f - .3f * s, 1.f - .2f * s, N));
+            const v3 grass = mix3(c_grass, rock, smoothstep_(l_grass, l_rock, h));
+            v3 shoreline = mix3(c_beach, grass, smoothstep_(l_shore, l_grass, h));
+            const v3 water = mix3(c_water / 2.f, c_water, smoothstep_(0.f, l_water, h));
+            shoreline = shoreline * setup_lights(F.L, normal);
+            const v3 ocean = setup_lights(F.L, w_normal) * water;
+            const v3 c_terr = mix3(ocean, shoreline, smoothstep_(l_water, l_shore, h));
+
+            const float c_cld = cloud.radiance, alpha = cloud.alpha;
+            // cloud shadow on the ground :355-360, clouds_shadow_march :143-160
+            const v3 lp = mul(F.rot_t, pos);
+            Vol sh = make_vol(lp);
+            const v3 local_up = normalize(lp);
+            {
+                const float t_step = PL_MAX_HEIGHT / 5.f;
+                float ts = 0.f;
+                for (int i = 0; i < 5; ++i) {
+                    const v3 o = sh.origin + ts * local_up;
+                    sh.pos = mul(F.rot_cloud, o - V3(0, 0, 0));
+                    sh.height = (length(sh.pos) - 1.f) / PL_MAX_HEIGHT;
+                    ts += t_step;
+                    clouds_map(sh, t_step);
+                }
+            }
+            const float shadow = mix_(.7f, 1.f, step_(sh.alpha, 0.33f));
+            col = abs3(mix3(c_terr * shadow, V3s(c_cld), alpha));
+        } else {
+            col = abs3(mix3(planet_background(rd), V3s(cloud.radiance), cloud.alpha));   // :364-366
+        }
+    }
+    store_rgba(out, px.idx, to_srgb(col));
+}
+
+void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_planet, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+}
+
+}  // namespace sbx

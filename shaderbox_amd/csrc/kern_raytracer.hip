@@ -1,0 +1,134 @@
+// shaderbox_amd/csrc/kern_raytracer.hip — APP_RAYTRACER: Cornell box, Cook-Torrance, 2 bounces.
+//
+// Follows /root/reference/src/app_raytracer.h (render :88-136, raytrace_iteration :70-86,
+// illuminate :46-68), src/intersect.h (intersect_plane :61-77, intersect_sphere :7-33),
+// src/light.h (illum_cook_torrance :64-92), src/util_optics.h (fresnel_factor :5-14, reflect
+// :17-22), src/material.h, src/cornell_box.h.  The whole scene (6 planes, 3 spheres, 8 material
+// slots, the light) is frame-constant: it is built on the host (setup_scene :18-36 +
+// setup_cornell_box cornell_box.h:39-87) and arrives as kernel arguments in SGPRs.
+#include "sbx_device.h"
+
+namespace sbx {
+
+struct Hit { float t; int mat; v3 n, o; };
+
+__device__ __forceinline__ float fresnel_factor(float n1, float n2, float VdotH) {   // util_optics.h:5-14
+    float Rn = (n1 - n2) / (n1 + n2);
+    float R0 = Rn * Rn;
+    float F = 1.f - VdotH;
+    return R0 + (1.f - R0) * (F * F * F * F * F);
+}
+
+__device__ __forceinline__ void hit_plane(v3 ro, v3 rd, const RtPlane& p, Hit& hit) {  // intersect.h:61-77
+    const float denom = dot(p.n, rd);
+    if (denom < 1e-6f) return;
+    const v3 P0 = V3(p.d, p.d, p.d);
+    const float t = dot(P0 - ro, p.n) / denom;
+    if (t < 0.f || t > hit.t) return;
+    hit.t = t;
+    hit.mat = p.mat;
+    hit.o = ro + rd * t;
+    hit.n = dot(p.n, rd) < 0 ? p.n : -p.n;          // faceforward(N, I, Nref = N)  util.h:85-93
+}
+__device__ __forceinline__ void hit_sphere(v3 ro, v3 rd, const RtSphere& s, Hit& hit) {   // intersect.h:7-33
+    const v3 rc = s.o - ro;
+    const float radius2 = s.r * s.r;
+    const float tca = dot(rc, rd);
+    if (tca < 0.f) return;
+    const float d2 = dot(rc, rc) - tca * tca;
+    if (d2 > radius2) return;
+    const float thc = sqrt_(radius2 - d2);
+    float t0 = tca - thc;
+    const float t1 = tca + thc;
+    if (t0 < 0.f) t0 = t1;
+    if (t0 > hit.t) return;
+    const v3 impact = ro + rd * t0;
+    hit.t = t0;
+    hit.mat = s.mat;
+    hit.o = impact;
+    hit.n = (impact - s.o) / s.r;
+}
+__device__ __forceinline__ Hit trace(const FrameRaytracer& F, v3 ro, v3 rd, int mat_to_ignore) {   // :70-86
+    Hit hit;
+    hit.t = (float)(1e8f + 1e1f); hit.mat = -1; hit.n = V3(0, 0, 0); hit.o = V3(0, 0, 0);   // no_hit def.h:78-83
+#pragma unroll
+    for (int i = 0; i < 6; ++i) hit_plane(ro, rd, F.planes[i], hit);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (F.spheres[i].mat != mat_to_ignore) hit_sphere(ro, rd, F.spheres[i], hit);
+    return hit;
+}
+// get_material: linear scan; an id outside 0..7 yields the zero-initialised material (App. B5)
+__device__ __forceinline__ RtMaterial material_of(const FrameRaytracer& F, int id) {
+    RtMaterial m;
+    m.base_color = V3(0, 0, 0); m.roughness = 0.f; m.ior = 0.f; m.reflectivity = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i == id) m = F.mats[i];
+    return m;
+}
+__device__ __forceinline__ v3 cook_torrance(v3 V, v3 L, const Hit& hit, const RtMaterial& mat) {   // light.h:64-92
+    const v3 H = normalize(L + V);
+    const float NdotL = dot(hit.n, L), NdotH = dot(hit.n, H), NdotV = dot(hit.n, V), VdotH = dot(V, H);
+    const float geo_a = (2.f * NdotH * NdotV) / VdotH;
+    const float geo_b = (2.f * NdotH * NdotL) / VdotH;
+    const float geo_term = fmin_(1.f, fmin_(geo_a, geo_b));
+    const float rough_sq = mat.roughness * mat.roughness;
+    const float rough_a = 1.f / (rough_sq * NdotH * NdotH * NdotH * NdotH);
+    const float rough_exp = (NdotH * NdotH - 1.f) / (rough_sq * NdotH * NdotH);
+    const float rough_term = rough_a * exp_(rough_exp);
+    const float fresnel_term = fresnel_factor(1.f, mat.ior, VdotH);
+    const float specular = (geo_term * rough_term * fresnel_term) / (3.14159265359f * NdotV * NdotL);
+    return fmax_(0.f, NdotL) * (specular + mat.base_color);
+}
+__device__ __forceinline__ v3 rt_illuminate(const FrameRaytracer& F, v3 eye, const Hit& hit) {   // :46-68
+    const RtMaterial mat = material_of(F, hit.mat);
+    if (hit.mat == 0) return F.mats[0].base_color;               // mat_debug: flat
+    v3 accum = V3(.01f, .01f, .01f);                              // ambient_light light.h:16
+    const v3 V = normalize(eye - hit.o);
+    const v3 L = normalize(F.light - hit.o);                      // point light, light.h:18-27
+    accum = accum + cook_torrance(V, L, hit, mat);
+    return accum;
+}
+
+__global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowMap M, float* __restrict__ out) {
+    const Pixel px = pixel_of_thread(M);
+    if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 eye = F.cam.eye;
+    v3 ro = eye, rd = primary_dir(F.cam, pc);
+
+    v3 color = V3(0, 0, 0), accum = V3(1, 1, 1);
+    for (int i = 0; i < 2; ++i) {                                 // :96-133
+        const Hit hit = trace(F, ro, rd, -1);
+        if (hit.t >= 1e8f) {
+            color = color + accum * V3(0, 0, 0);                  // background :13-16
+            break;
+        }
+        const float f = fresnel_factor(1.f, 1.f, dot(hit.n, -rd));
+        color = color + (1.f - f) * accum * rt_illuminate(F, eye, hit);   // primary origin on every bounce (:105)
+        if (i == 0) {                                             // shadow ray :108-121
+            const v3 shadow_line = F.light - hit.o;
+            const v3 shadow_dir = normalize(shadow_line);
+            const Hit sh = trace(F, hit.o + shadow_dir * 1e-4f, shadow_dir, 0);
+            if (sh.t < length(shadow_line)) color = color * 0.1f;
+        }
+        const RtMaterial mat = material_of(F, hit.mat);
+        if (mat.reflectivity > 0.f) {
+            accum = accum * f;
+            // reflect(hit.normal, ray.direction): arguments swapped in the reference (:127), kept
+            const v3 refl = normalize(hit.n - 2.f * dot(rd, hit.n) * rd);
+            ro = hit.o + refl * 1e-4f;
+            rd = refl;
+        } else {
+            break;
+        }
+    }
+    store_rgba(out, px.idx, to_srgb(color));
+}
+
+void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_raytracer, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+}
+
+}  // namespace sbx

@@ -1,0 +1,131 @@
+// shaderbox_amd/csrc/kern_sdf_ao.hip — APP_SDF_AO: skate-ramp SDF with distance-field AO and fog.
+//
+// Follows /root/reference/src/app_sdf_ao.h: sdf_pipe :54-113, sdf :115-150, sdf_normal :152-163,
+// sdf_ao :165-181, illuminate :211-243, render_impl :245-285 (shadow march compiled out, :269-274),
+// render (height fog) :287-311; SDF primitives from src/sdf.h.  The two constant-angle rotations
+// (rotate_around_x(-90), rotate_around_y(180)) and normalize(1,2,1) are frame constants.
+#include "sbx_device.h"
+
+namespace sbx {
+
+struct D2 { float d, m; };
+__device__ __forceinline__ D2 op_add2(D2 a, D2 b) { return a.d < b.d ? a : b; }                  // sdf.h:5-11
+__device__ __forceinline__ float sd_box(v3 p, v3 b) {                                            // sdf.h:67-73
+    return fmax_(abs_(p.x) - b.x, fmax_(abs_(p.y) - b.y, abs_(p.z) - b.z));
+}
+__device__ __forceinline__ float sd_y_cylinder(v3 p, float r, float h) {                          // sdf.h:85-93
+    return fmax_(length(V2(p.x, p.z)) - r, abs_(p.y) - h / 2.f);
+}
+
+__device__ __forceinline__ D2 ao_sdf_pipe(const FrameSdfAo& F, v3 pos) {                          // :54-113
+    const v3 size = V3(1.3f, 1.f, 1.25f);                                                          // :52
+    v3 p = pos - V3(0, size.y, 0);
+    const float b = sd_box(p, size);
+    p = p - V3(.7f, .5f, 0);
+    p = mul(p, F.rx_m90);
+    const float c = sd_y_cylinder(p, size.y + .55f, 2.f * size.z + .1f);
+    const D2 pipe = {fmax_(b, -c), 2.f};                                                           // op_sub, mat_pipe
+
+    p = pos - V3(0, size.y, 0);
+    p = p - V3(-size.x + .525f, size.y, 0);
+    p = mul(p, F.rx_m90);
+    const D2 coping = {sd_y_cylinder(p, .025f, 2.f * size.z), 5.f};                                // mat_coping
+
+    p = pos - V3(0, size.y * 2.f, 0);
+    const float rail = sd_box(p + V3(size.x, -.25f, 0), V3(.025f, .05f, size.z));
+    const v3 B = V3(.025f, .125f, .025f);
+    const float H = -.125f;
+    const float bar_1 = sd_box(p + V3(size.x, H, 0), B);
+    const float bar_2 = sd_box(p + V3(size.x, H, size.z / 2.f), B);
+    const float bar_3 = sd_box(p + V3(size.x, H, size.z), B);
+    const float bar_4 = sd_box(p + V3(size.x, H, -size.z / 2.f), B);
+    const float bar_5 = sd_box(p + V3(size.x, H, -size.z), B);
+    const float b_a = fmin_(bar_1, bar_2);
+    const float b_b = fmin_(b_a, bar_3);
+    const float b_c = fmin_(bar_4, bar_5);
+    const float bars = fmin_(b_b, b_c);
+    const D2 railing = {fmin_(rail, bars), 4.f};                                                   // mat_deck
+    const D2 deck = op_add2(railing, coping);
+    return op_add2(pipe, deck);
+}
+
+__device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos) {                                // :115-150
+    const v3 size = V3(1.3f, 1.f, 1.25f);
+    const float B = .15f;
+    v3 p = pos - V3(0, B, 0);
+    const D2 bottom = {sd_box(p, V3(2.25f * size.x, B, size.z)), 3.f};                             // mat_bottom
+    const D2 pipe1 = ao_sdf_pipe(F, p + V3(1.25f * size.x, 0, 0));
+    p = p - V3(1.25f * size.x, 0, 0);
+    p = mul(p, F.ry_180);
+    const D2 pipe2 = ao_sdf_pipe(F, p);
+    const D2 pipe = op_add2(pipe1, pipe2);
+    const D2 ref = {sd_box(pos, V3(.025f, 15, .025f)), 0.f};                                       // mat_debug
+    const D2 ground = {dot(V3(0, 1, 0), pos) + 0.f, 1.f};                                          // sd_plane, mat_ground
+    const D2 g = op_add2(ground, ref);
+    const D2 b = op_add2(pipe, bottom);
+    return op_add2(b, g);
+}
+
+__global__ void __launch_bounds__(WG_THREADS) k_sdf_ao(FrameSdfAo F, RowMap M, float* __restrict__ out) {
+    const Pixel px = pixel_of_thread(M);
+    if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
+
+    v3 rgb = V3(.1f, .1f, .7f);                                   // background :9-12
+    float t = 0.f;
+    for (int i = 0; i < 70; ++i) {                                // render_impl :245-285
+        const v3 p = ro + rd * t;
+        const D2 d = ao_sdf(F, p);
+        if (t > 20.f) break;
+        if (d.d < .005f) {
+            const int mat = (int)d.m;
+            // sdf_normal :152-163
+            const float e = 0.001f;
+            const v3 n = normalize(V3(
+                ao_sdf(F, p + V3(e, 0, 0)).d - ao_sdf(F, p - V3(e, 0, 0)).d,
+                ao_sdf(F, p + V3(0, e, 0)).d - ao_sdf(F, p - V3(0, e, 0)).d,
+                ao_sdf(F, p + V3(0, 0, e)).d - ao_sdf(F, p - V3(0, 0, e)).d));
+            // sdf_ao :165-181
+            float occlusion = 0.f;
+            for (float k = 1.f; k <= 5.f; k += 1.f) {
+                const v3 q = p + .5f * k * n;
+                const float dd = ao_sdf(F, q).d;
+                occlusion += 1.f / pow_(2.f, k) * (.5f * k - dd);
+            }
+            const float ao = 1.f - clamp_(occlusion, 0.f, 1.f);
+            const float sh = 1.f;
+            // illuminate :211-243
+            v3 accum = V3(0, 0, 0);
+            const float sun_ray = fmax_(0.f, dot(F.sun_dir, n));
+            accum = accum + sh * sun_ray * V3(1.2f, 1.3f, 1.f);
+            accum = accum + ao * n.y * V3(.15f, .15f, .4f);
+            const float ind = fmax_(0.f, dot(F.sun_dir * V3(-1, 0, -1), n));
+            accum = accum + ao * ind * V3(.4f, .28f, .2f);
+            v3 mat_c = V3(0, 0, 0);                               // get_material :23-33 / setup_scene :35-43
+            if (mat == 0) mat_c = V3(1, 1, 1);
+            else if (mat == 1) mat_c = V3(0, .2f, 0);
+            else if (mat == 2 || mat == 3 || mat == 4) mat_c = V3(.1f, .1f, .1f);
+            else if (mat == 5) mat_c = V3(.4f, .4f, .4f);
+            if (mat == 1) {
+                const float cb = mod_(floor_(p.x * .5f) + floor_(p.z * .5f), 2.0f);   // checkboard_pattern util.h:95-101
+                mat_c = mix3(mat_c - .15f * mat_c, mat_c + .15f * mat_c, cb);
+            }
+            rgb = accum * mat_c;
+            break;
+        }
+        t += d.d;
+    }
+    // fog :287-311 (t is the march length at exit)
+    const float fog_factor = F.fog_density * exp_(-ro.y * F.fog_falloff)
+                           * (1.f - exp_(-t * rd.y * F.fog_falloff))
+                           / (rd.y * F.fog_falloff);
+    const v3 col = abs3(mix3(rgb, V3(1, 1, 1), fog_factor));
+    store_rgba(out, px.idx, to_srgb(col));
+}
+
+void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sdf_ao, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+}
+
+}  // namespace sbx

@@ -1,0 +1,58 @@
+// shaderbox_amd/csrc/kern_util.hip — frame assembly after the multi-GPU gather, and the
+// elementwise math-spec evaluator used by the parity tests.
+#include "sbx_device.h"
+#include "sbx_noise.h"
+
+namespace sbx {
+
+// `gathered` = nranks slabs (rank-major) of rows_max rows; slab r holds rank r's cyclic row-blocks
+// densely in increasing y (sbx_render_rank).  One thread moves one float4 pixel; consecutive
+// threads move consecutive pixels of a row, so both the read and the write are coalesced 16-B
+// accesses.  Each XCD streams whole rows; there is no reuse to tile for.
+__global__ void __launch_bounds__(256) k_assemble(int width, int height, int block_rows, int nranks, int rows_max,
+                                                   const float4* __restrict__ gathered, float4* __restrict__ frame) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)width * height;
+    if (i >= total) return;
+    const int y = (int)(i / width), x = (int)(i - (size_t)y * width);
+    const int blk = y / block_rows, in_blk = y - blk * block_rows;
+    const int rank = blk % nranks, local_blk = blk / nranks;
+    const size_t src = ((size_t)rank * rows_max + (size_t)local_blk * block_rows + in_blk) * width + x;
+    frame[i] = gathered[src];
+}
+
+void launch_assemble(int width, int height, int block_rows, int nranks, int rows_max,
+                     const float* gathered, float* frame, hipStream_t s) {
+    const size_t total = (size_t)width * height;
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, width, height, block_rows,
+                       nranks, rows_max, reinterpret_cast<const float4*>(gathered), reinterpret_cast<float4*>(frame));
+}
+
+__global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restrict__ a, const float* __restrict__ b,
+                                                    float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    const float y = b ? b[i] : 0.f;
+    float r;
+    switch (fn) {
+    case 0: r = sin_(x); break;
+    case 1: r = cos_(x); break;
+    case 2: r = tan_(x); break;
+    case 3: r = exp_(x); break;
+    case 4: r = pow_(x, y); break;
+    case 5: r = acos_(x); break;
+    case 6: r = atan2_(x, y); break;
+    case 7: r = hash1(x); break;
+    default: r = 0.f;
+    }
+    out[i] = r;
+}
+
+int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t n, hipStream_t s) {
+    if (fn < 0 || fn > 7) return -1;
+    hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, a, b, out, n);
+    return 0;
+}
+
+}  // namespace sbx

@@ -1,0 +1,351 @@
+// shaderbox_amd/csrc/sbx_capi.hip — the C ABI of libsbx (include/sbx.h) and the host-side frame setup.
+//
+// Host side of the drop-in: what the reference's hosts do around mainImage() — own the uniforms
+// and the render target, pick the app, issue one draw per frame (util/hlsltoy/src/hlsltoy.cpp:
+// 402-426, 494-516) — reduced to: validate, build the per-frame constant block for the app with the
+// shared math spec, launch the app's kernel on the caller's stream.  There is NO CPU fallback: without
+// a gfx950 device sbx_create fails with SBX_ERR_NO_DEVICE.
+#include "../../include/sbx.h"
+#include "sbx_device.h"
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace sbx;
+
+struct sbx_ctx {
+    int device = 0;
+    bool timing = false;
+    bool have_events = false;
+    hipEvent_t ev0{}, ev1{};
+    std::string err;
+};
+
+static int fail(sbx_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame builders: the frame-constant part of setup_camera()/setup_scene()/sdf() per app
+// ---------------------------------------------------------------------------------------------
+static FrameClouds build_clouds(const sbx_uniforms& U, const sbx_aux_clouds& A) {
+    FrameClouds F;
+    // setup_camera app_clouds.h:23-30
+    const v3 eye = V3(0, -.5f, 0);
+    const float angle = U.u_mouse[0] * .5f;
+    const v3 look_at = mul(rotate_around_y(angle), V3(0, 0, -1));
+    F.cam = make_camera(U.u_res[0], U.u_res[1], 1.f, eye, look_at);   // FOV 1. :219
+    F.sun_dir = V3(A.sun_dir[0], A.sun_dir[1], A.sun_dir[2]);
+    F.sun_color = V3(A.sun_color[0], A.sun_color[1], A.sun_color[2]);
+    const v3 wind = V3(A.wind_dir[0], A.wind_dir[1], A.wind_dir[2]);
+    F.wind_off = wind * U.u_time * (1.f / .001f);                      // :167
+    F.sun_power = A.sun_power;
+    F.sigma = A.sigma_scattering;
+    F.steps = A.cld_march_steps;
+    F.lsteps = A.illum_march_steps;
+    F.dt = A.cld_thick / (float)A.cld_march_steps;                     // :98,180
+    F.cov = 1.f - A.cld_coverage;                                      // :83
+    F.cov_hi = F.cov + .0135f;                                         // :84
+    return F;
+}
+
+static BezierFrame bezier_frame(v3 a, v3 b, v3 c) {                    // sdf.h:147-153
+    BezierFrame B;
+    B.b = b;
+    B.w = normalize(cross(c - b, a - b));
+    B.u = normalize(c - b);
+    B.v = normalize(cross(B.w, B.u));
+    B.a2 = V2(dot(a - b, B.u), dot(a - b, B.v));
+    B.c2 = V2(dot(c - b, B.u), dot(c - b, B.v));
+    return B;
+}
+static CylFrame cyl_frame(v3 P0, v3 P1) {                              // sdf.h:104,106-107
+    CylFrame C;
+    C.dir = normalize(P1 - P0);
+    C.len1 = length(P1);
+    C.len0 = length(P0);
+    return C;
+}
+static v3 ik_solver(v3 start, v3 goal_abs, float L1, float L2) {       // IK.h:5-52
+    const v3 goal = goal_abs - start;
+    const float G = length(goal);
+    const float cos_theta = (L1 * L1 + G * G - L2 * L2) / (2.f * L1 * G);
+    const float sin_theta = sqrt_(1.f - cos_theta * cos_theta);
+    const m3 rot = M3(cos_theta, -sin_theta, 0, sin_theta, cos_theta, 0, 0, 0, 1.f);
+    return start + mul(rot, normalize(goal) * L1);
+}
+static FrameEgg build_egg(const sbx_uniforms& U) {
+    FrameEgg F;
+    F.cam = make_camera(U.u_res[0], U.u_res[1], 1.f, V3(.0f, .25f, 5.25f), V3(.0f, .25f, .0f));   // app_egg.h:23-27,253
+    const float t = U.u_time;
+    F.rot_y = rotate_around_y(t * -100.0f);                            // :40
+    const v3 wheel_pos = V3(0, 1.2f, 0);
+    const float pedal_radius = 0.3f, pedal_speed = 400.f, pedal_off = 0.2f;
+    const m3 rot_z = rotate_around_z(-t * pedal_speed);                // :73,76
+    F.left_foot = wheel_pos + mul(rot_z, V3(0.f, pedal_radius, pedal_off));
+    F.right_foot = wheel_pos + mul(rot_z, V3(0.f, -pedal_radius, -pedal_off));
+    const v3 side = V3(0, 0, pedal_off);
+    const float femur = 0.8f, tibia = 0.75f;
+    const v3 zero = V3(0.f, 0.f, 0.f);
+    const v3 knee_l = ik_solver(zero + side, F.left_foot, femur, tibia);   // :84-85
+    const v3 knee_r = ik_solver(zero - side, F.right_foot, femur, tibia);  // :95-96
+    F.leg_l = bezier_frame(-(zero + side), -knee_l, -F.left_foot);         // :111-113
+    F.leg_r = bezier_frame(-(zero - side), -knee_r, -F.right_foot);        // :114-116
+    const v3 left_toe = normalize(V3(F.left_foot.y - knee_l.y, knee_l.x - F.left_foot.x, 0));     // :120
+    const v3 right_toe = normalize(V3(F.right_foot.y - knee_r.y, knee_r.x - F.right_foot.x, 0));  // :125
+    F.foot_l = cyl_frame(zero, left_toe / 8.f);
+    F.foot_r = cyl_frame(zero, right_toe / 8.f);
+    return F;
+}
+
+static FrameRaytracer build_raytracer(const sbx_uniforms& U) {
+    FrameRaytracer F;
+    const float cb = 2.f;                                              // cb_plane_dist cornell_box.h:62
+    // setup_camera app_raytracer.h:38-44
+    v2 mouse = V2(0, 0);
+    if (!(U.u_mouse[0] < 1e-4f)) mouse = V2(2.f * (U.u_res[0] / U.u_mouse[0]) - 1.f, 2.f * (U.u_res[1] / U.u_mouse[1]) - 1.f);
+    const m3 rot_y = rotate_around_y(mouse.x * 30.f);
+    const v3 eye = mul(rot_y, V3(0, cb, 2.333f * cb));
+    F.cam = make_camera(U.u_res[0], U.u_res[1], tan_(radians_(30.f)), eye, V3(0, cb, 0));   // FOV :138
+    // materials: zero-initialised slots (App. B5), mat_debug :20-25, cornell box cornell_box.h:47-55
+    for (int i = 0; i < 8; ++i) F.mats[i] = RtMaterial{V3(0, 0, 0), 0.f, 0.f, 0.f};
+    F.mats[0] = RtMaterial{V3(1.f, 1.f, 1.f), 0.f, 1.f, 0.f};
+    F.mats[1] = RtMaterial{V3(0.7913f, 0.7913f, 0.7913f), .5f, 1.f, 0.f};
+    F.mats[2] = RtMaterial{V3(0.6795f, 0.0612f, 0.0529f), .5f, 1.f, 0.f};
+    F.mats[3] = RtMaterial{V3(0.1878f, 0.1274f, 0.4287f), .5f, 1.f, 0.f};
+    F.mats[4] = RtMaterial{V3(0.95f, 0.64f, 0.54f), .1f, 1.f, 1.f};
+    F.mats[5] = RtMaterial{V3(1.f, 0.77f, 0.345f), .05f, 1.333f, 1.f};
+    // planes, in array-index order ground, behind, front, ceiling, left, right  cornell_box.h:57-69
+    F.planes[0] = RtPlane{V3(0, -1, 0), 0.f, 1};
+    F.planes[1] = RtPlane{V3(0, 0, -1), -cb, 1};
+    F.planes[2] = RtPlane{V3(0, 0, 1), cb, 1};
+    F.planes[3] = RtPlane{V3(0, 1, 0), 2.f * cb, 1};
+    F.planes[4] = RtPlane{V3(1, 0, 0), cb, 2};
+    F.planes[5] = RtPlane{V3(-1, 0, 0), -cb, 3};
+    // spheres cornell_box.h:71-82 + animation app_raytracer.h:29-34
+    const float s = sin_(U.u_time), c = cos_(U.u_time);
+    F.spheres[0] = RtSphere{V3(0, 2.5f * cb + 0.4f, 0), 1.5f, 0};
+    F.spheres[1] = RtSphere{V3(0.75f, 1, -0.75f) + V3(0, abs_(s), c + 1.f), 0.75f, 4};
+    F.spheres[2] = RtSphere{V3(-0.75f, 0.75f, 0.f), 0.75f, 5};
+    F.light = V3(0, 2.f * cb - 0.2f, 1.5f);
+    return F;
+}
+
+static FrameAtmosphere build_atmosphere(const sbx_uniforms& U) {
+    FrameAtmosphere F;
+    F.cam = make_camera(U.u_res[0], U.u_res[1], 1.f, V3(0, 0, 0), V3(0, 1, 0));   // app_atmosphere.h:164-175,230
+    const m3 rot = rotate_around_x(-abs_(sin_(U.u_time / 2.f)) * 90.f);             // :179
+    F.sun_dir = mul(V3(0, 1, 0), rot);                                              // :180 (v * M)
+    return F;
+}
+
+static FrameSdfAo build_sdf_ao(const sbx_uniforms& U, const sbx_aux_sdf_ao& A) {
+    FrameSdfAo F;
+    const m3 rot = rotate_around_y(U.u_time * 50.f);                   // app_sdf_ao.h:45-50
+    F.cam = make_camera(U.u_res[0], U.u_res[1], 1.f, mul(rot, V3(0, 3, 5)), V3(0, 0, 0));
+    F.rx_m90 = rotate_around_x(-90.f);
+    F.ry_180 = rotate_around_y(180.f);
+    F.sun_dir = normalize(V3(1, 2, 1));
+    F.fog_density = A.fog_density;
+    F.fog_falloff = A.fog_falloff;
+    return F;
+}
+
+static FramePlanet build_planet(const sbx_uniforms& U) {
+    FramePlanet F;
+    F.cam = make_camera(U.u_res[0], U.u_res[1], tan_(radians_(30.f)), V3(0, 0, -2.5f), V3(0, 0, 2));   // app_planet.h:47-58,368
+    const m3 rot_y = rotate_around_y(27.f);                            // :307
+    F.rot = mul(rotate_around_x(U.u_time * -12.f), rot_y);             // :308
+    F.rot_cloud = mul(rotate_around_x(U.u_time * 8.f), rot_y);         // :309
+    F.rot_t = transpose(F.rot);                                        // :356
+    F.L = mul(F.rot, normalize(V3(1, 1, 0)));                          // :289
+    return F;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+void sbx_aux_clouds_defaults(sbx_aux_clouds* a) {                      // uniform_buffer.h:39-55
+    if (!a) return;
+    std::memset(a, 0, sizeof(*a));
+    a->wind_dir[2] = .2f;
+    a->sun_dir[2] = -1.f;
+    a->sun_color[0] = 1.f; a->sun_color[1] = .7f; a->sun_color[2] = .55f;
+    a->sun_power = 8.f;
+    a->cld_march_steps = 100;
+    a->illum_march_steps = 6;
+    a->sigma_scattering = .15f;
+    a->cld_coverage = .535f;
+    a->cld_thick = 125.f;
+    a->atm_radius = 5000.f;
+    a->atm_ground_y = 4750.f;
+}
+void sbx_aux_sdf_ao_defaults(sbx_aux_sdf_ao* a) {                      // uniform_buffer.h:56-60
+    if (!a) return;
+    std::memset(a, 0, sizeof(*a));
+    a->fog_density = .1f;
+    a->fog_falloff = .5f;
+}
+
+int sbx_create(int device, sbx_ctx** out) {
+    if (!out) return SBX_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SBX_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return SBX_ERR_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SBX_ERR_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SBX_ERR_NO_DEVICE;   // kernels exist for gfx950 only
+    sbx_ctx* ctx = new sbx_ctx();
+    ctx->device = device;
+    *out = ctx;
+    return SBX_OK;
+}
+
+void sbx_destroy(sbx_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->have_events) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
+    delete ctx;
+}
+
+static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, const RowMap& M,
+                         float* rgba, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    if (M.nrows == 0) return SBX_OK;
+    if (ctx->timing) {
+        if (!ctx->have_events) {
+            if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess)
+                return fail(ctx, SBX_ERR_HIP, "hipEventCreate", e);
+            ctx->have_events = true;
+        }
+        (void)hipEventRecord(ctx->ev0, s);
+    }
+    switch (app) {
+    case SBX_APP_CLOUDS: {
+        sbx_aux_clouds A;
+        if (aux) A = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&A);
+        if (A.cld_march_steps < 0 || A.illum_march_steps < 0) return fail(ctx, SBX_ERR_ARG, "negative march steps");
+        launch_clouds(build_clouds(*uni, A), M, rgba, s);
+        break;
+    }
+    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s); break;
+    case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
+    case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
+    case SBX_APP_SDF_AO: {
+        sbx_aux_sdf_ao A;
+        if (aux) A = *(const sbx_aux_sdf_ao*)aux; else sbx_aux_sdf_ao_defaults(&A);
+        launch_sdf_ao(build_sdf_ao(*uni, A), M, rgba, s);
+        break;
+    }
+    case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s); break;
+    default: return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
+    }
+    if (ctx->timing) (void)hipEventRecord(ctx->ev1, s);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "kernel launch", e);
+    return SBX_OK;
+}
+
+static int check_common(sbx_ctx* ctx, const sbx_uniforms* uni, const float* rgba, int& W, int& H) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!uni || !rgba) return fail(ctx, SBX_ERR_ARG, "NULL uniforms or framebuffer");
+    W = (int)uni->u_res[0]; H = (int)uni->u_res[1];
+    if (W <= 0 || H <= 0 || (float)W != uni->u_res[0] || (float)H != uni->u_res[1] || W > 65536 || H > 65536)
+        return fail(ctx, SBX_ERR_ARG, "u_res must be positive integers <= 65536");
+    if (((uintptr_t)rgba & 15u) != 0) return fail(ctx, SBX_ERR_ARG, "framebuffer must be 16-byte aligned");
+    return SBX_OK;
+}
+
+int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int y0, int y1, float* rgba,
+                    void* stream) {
+    int W, H;
+    int rc = check_common(ctx, uni, rgba, W, H);
+    if (rc != SBX_OK) return rc;
+    if (y0 < 0 || y1 < y0 || y1 > H) return fail(ctx, SBX_ERR_ARG, "bad row range");
+    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0};
+    return render_mapped(ctx, app, uni, aux, M, rgba, stream);
+}
+
+int sbx_rank_rows(int height, int block_rows, int rank, int nranks) {
+    if (height <= 0 || block_rows <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return SBX_ERR_ARG;
+    const int nblocks = (height + block_rows - 1) / block_rows;
+    int rows = 0;
+    for (int b = rank; b < nblocks; b += nranks) {
+        const int y = b * block_rows;
+        rows += (y + block_rows <= height) ? block_rows : (height - y);
+    }
+    return rows;
+}
+int sbx_rank_rows_max(int height, int block_rows, int nranks) {
+    if (height <= 0 || block_rows <= 0 || nranks <= 0) return SBX_ERR_ARG;
+    const int nblocks = (height + block_rows - 1) / block_rows;
+    return ((nblocks + nranks - 1) / nranks) * block_rows;
+}
+
+int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                    int nranks, float* rgba, void* stream) {
+    int W, H;
+    int rc = check_common(ctx, uni, rgba, W, H);
+    if (rc != SBX_OK) return rc;
+    const int rows = sbx_rank_rows(H, block_rows, rank, nranks);
+    if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
+    RowMap M{W, H, 0, block_rows, nranks, rank, rows};
+    return render_mapped(ctx, app, uni, aux, M, rgba, stream);
+}
+
+int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, const float* gathered,
+                 float* frame, void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!gathered || !frame || width <= 0 || height <= 0 || block_rows <= 0 || nranks <= 0)
+        return fail(ctx, SBX_ERR_ARG, "bad assemble arguments");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    launch_assemble(width, height, block_rows, nranks, sbx_rank_rows_max(height, block_rows, nranks), gathered, frame,
+                    (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "assemble launch", e);
+    return SBX_OK;
+}
+
+int sbx_set_timing(sbx_ctx* ctx, int enabled) {
+    if (!ctx) return SBX_ERR_ARG;
+    ctx->timing = enabled != 0;
+    return SBX_OK;
+}
+int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return SBX_ERR_ARG;
+    if (!ctx->have_events) return fail(ctx, SBX_ERR_ARG, "no timed launch yet");
+    hipError_t e = hipEventSynchronize(ctx->ev1);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipEventSynchronize", e);
+    e = hipEventElapsedTime(ms, ctx->ev0, ctx->ev1);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipEventElapsedTime", e);
+    return SBX_OK;
+}
+
+int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, float* out, size_t n, void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!fn || !a || !out) return fail(ctx, SBX_ERR_ARG, "NULL argument");
+    static const char* names[] = {"sin", "cos", "tan", "exp", "pow", "acos", "atan2", "hash"};
+    int id = -1;
+    for (int i = 0; i < 8; ++i) if (std::strcmp(fn, names[i]) == 0) id = i;
+    if (id < 0) return fail(ctx, SBX_ERR_ARG, "unknown math function");
+    if ((id == 4 || id == 6) && !b) return fail(ctx, SBX_ERR_ARG, "binary function needs b");
+    if (n == 0) return SBX_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    launch_math_eval(id, a, b, out, n, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "math_eval launch", e);
+    return SBX_OK;
+}
+
+const char* sbx_last_error(sbx_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+const char* sbx_version(void) { return "libsbx 0.1 (gfx950, ABI 1)"; }
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// shaderbox_amd/csrc/sbx_frame.h — per-frame constant blocks and the row map.
+//
+// The reference recomputes frame constants per pixel (mainImage calls setup_camera() and
+// setup_scene() for every fragment, /root/reference/src/main.h:35-38; APP_EGG even rebuilds its
+// rotations and IK inside every sdf() call, src/app_egg.h:40-128).  They depend only on the
+// uniforms, so the host evaluates them ONCE per frame with the same math spec (sbx_math.h is
+// bit-identical on host and device) and passes them as kernel arguments: on gfx950 kernel
+// arguments are wave-uniform and live in SGPRs, which is the "per-tile camera/uniform
+// constants" staging the design calls for without spending LDS or VGPRs on them.
+#pragma once
+#include "sbx_vec.h"
+
+namespace sbx {
+
+// local row r of a launch -> global row y of the frame.
+//   contiguous strip:  block_rows = nrows, nranks = 1, rank = 0      -> y = y0 + r
+//   cyclic row-blocks: rank owns blocks rank, rank+nranks, ...        
+struct RowMap {
+    int width, height;
+    int y0, block_rows, nranks, rank;
+    int nrows;   // local rows in this launch
+};
+SBX_HD int row_to_y(const RowMap& m, int r) {
+    int blk = r / m.block_rows;
+    return m.y0 + (blk * m.nranks + m.rank) * m.block_rows + (r - blk * m.block_rows);
+}
+
+// Camera part of mainImage (src/main.h:33-48) + get_primary_ray (src/util.h:5-20)
+struct Camera {
+    float res_x, res_y;
+    float aspect_x;   // u_res.x / u_res.y
+    float fov;
+    v3 eye, fwd, up, right;
+};
+SBX_HD Camera make_camera(float res_x, float res_y, float fov, v3 eye, v3 look_at) {
+    Camera c;
+    c.res_x = res_x; c.res_y = res_y;
+    c.aspect_x = res_x / res_y;            // main.h:33
+    c.fov = fov;
+    c.eye = eye;
+    c.fwd = normalize(look_at - eye);      // util.h:10
+    v3 up = V3(0, 1, 0);
+    c.right = cross(up, c.fwd);            // util.h:12
+    c.up = cross(c.fwd, c.right);          // util.h:13
+    return c;
+}
+// point_cam.xy for fragCoord (main.h:40,44-46); point_cam.z = -1
+SBX_HD v2 point_cam(const Camera& c, float fx, float fy) {
+    float nx = fx / c.res_x, ny = fy / c.res_y;
+    return V2(((2.0f * nx - 1.0f) * c.aspect_x) * c.fov, ((2.0f * ny - 1.0f) * 1.0f) * c.fov);
+}
+SBX_HD v3 primary_dir(const Camera& c, v2 pc) {
+    return normalize(c.fwd + c.up * pc.y + c.right * pc.x);   // util.h:17
+}
+// linear_to_srgb (src/util.h:72-77): p = 1/2.2 in binary32
+SBX_HD v3 to_srgb(v3 c) {
+    const float p = 1.f / 2.2f;
+    return V3(pow_(c.x, p), pow_(c.y, p), pow_(c.z, p));
+}
+
+// ---- APP_CLOUDS (src/app_clouds.h, src/uniform_buffer.h:39-55) ----------------------------
+struct FrameClouds {
+    Camera cam;
+    v3 sun_dir, sun_color;
+    v3 wind_off;          // wind_dir * u_time * (1/cld_noise_factor)   app_clouds.h:167
+    float sun_power, sigma;
+    int steps, lsteps;
+    float dt;             // cld_thick / float(cld_march_steps)         app_clouds.h:98,180
+    float cov, cov_hi;    // 1 - cld_coverage, cov + .0135              app_clouds.h:83-84
+};
+
+// ---- APP_EGG (src/app_egg.h) ----------------------------------------------------------------
+struct BezierFrame {      // the P-independent part of sd_bezier (src/sdf.h:147-153)
+    v3 b, u, v, w;
+    v2 a2, c2;
+};
+struct CylFrame {         // the P-independent part of sd_cylinder with P0 = 0 (src/sdf.h:104,106-107)
+    v3 dir;
+    float len1, len0;
+};
+struct FrameEgg {
+    Camera cam;
+    m3 rot_y;             // rotate_around_y(u_time * -100)            app_egg.h:40
+    v3 left_foot, right_foot;   //                                      app_egg.h:73-77
+    BezierFrame leg_l, leg_r;   //                                      app_egg.h:111-116
+    CylFrame foot_l, foot_r;    //                                      app_egg.h:120-128
+};
+
+// ---- APP_RAYTRACER (src/app_raytracer.h, cornell_box.h) -------------------------------------
+struct RtPlane { v3 n; float d; int mat; };
+struct RtSphere { v3 o; float r; int mat; };
+struct RtMaterial { v3 base_color; float roughness, ior, reflectivity; };
+struct FrameRaytracer {
+    Camera cam;
+    RtPlane planes[6];
+    RtSphere spheres[3];
+    RtMaterial mats[8];
+    v3 light;             // lights[0].L
+};
+
+// ---- APP_ATMOSPHERE (src/app_atmosphere.h) --------------------------------------------------
+struct FrameAtmosphere {
+    Camera cam;
+    v3 sun_dir;           // (0,1,0) * rotate_around_x(-|sin(t/2)|*90)  app_atmosphere.h:177-181
+};
+
+// ---- APP_SDF_AO (src/app_sdf_ao.h) ----------------------------------------------------------
+struct FrameSdfAo {
+    Camera cam;
+    m3 rx_m90;            // rotate_around_x(-90)   app_sdf_ao.h:63,77
+    m3 ry_180;            // rotate_around_y(180)   app_sdf_ao.h:134
+    v3 sun_dir;           // normalize(1,2,1)       app_sdf_ao.h:209
+    float fog_density, fog_falloff;
+};
+
+// ---- APP_PLANET (src/app_planet.h) ----------------------------------------------------------
+struct FramePlanet {
+    Camera cam;
+    m3 rot, rot_cloud, rot_t;   // app_planet.h:307-309, transpose(rot) :356
+    v3 L;                       // rot * normalize(1,1,0)   app_planet.h:289
+};
+
+}  // namespace sbx
