@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mpixels/s of the mainImage() hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--app clouds] [--width 3840] [--height 2160]
+
+Workload (BASELINE.json `metric`): APP_CLOUDS, 3840x2160, canonical frame u_time = 0.37, u_mouse = 0,
+default aux uniforms.  One "step" = one whole frame rendered into an RGBA32F framebuffer resident in
+HBM (nothing crosses PCIe inside the timed region).
+
+N = 1 : the frame is one kernel launch.
+N > 1 : one process per GPU (torch.distributed / RCCL).  The SAME frame is sharded as cyclic 8-row
+        blocks (shaderbox_amd/shard.py), every rank renders its blocks, ONE gather over xGMI brings the
+        slabs to rank 0, and one small kernel scatters them to their rows.  Total work is fixed ->
+        "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
+
+Extra objects on the JSON line:
+  roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel
+                 of HBM traffic), so bound = "valu": achieved = algorithmic scalar fp ops per launch
+                 (SURVEY.md §8d per-pixel count x pixels) / mean launch duration measured with HIP events on
+                 the launch stream; peak = 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md).  `hbm` gives the
+                 framebuffer store rate for completeness.
+  cpu_baseline : the CPU oracle (kind "port") timed on this host's cores on a bounded sample of the same
+                 frame (every 8th row), rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic scalar fp ops per pixel at the canonical frame (every
+# transcendental counted as ONE op), measured at the listed resolution
+OPS_PER_PIXEL = {"clouds": 60248.0, "egg": 15276.0, "raytracer": 564.0, "atmosphere": 2493.0,
+                 "planet": 21253.0, "sdf_ao": 7255.0}
+PEAK_FP32_VECTOR_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--app", default="clouds")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--time", type=float, default=0.37)
+    ap.add_argument("--block-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-stride", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import shaderbox_amd
+    from shaderbox_amd import shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    R = shaderbox_amd.Renderer(local_rank)
+    R.set_timing(True)
+    W, H, app, t = args.width, args.height, args.app, args.time
+    br = args.block_rows
+
+    if world == 1:
+        frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+
+        def step():
+            R.render(app, W, H, t, out=frame)
+    else:
+        rmax = shard.rank_rows_max(H, br, world)
+        slab = torch.zeros((rmax, W, 4), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world, rmax, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
+        glist = [gathered[i] for i in range(world)] if rank == 0 else None
+        frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
+
+        def step():
+            R.render_rank(app, W, H, t, br, rank, world, out=slab)
+            dist.gather(slab, glist, dst=0)          # the single RCCL collective of the path
+            if rank == 0:
+                R.assemble(gathered, W, H, br, world, out=frame)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            pass
+    sync()
+    elapsed = time.perf_counter() - t0
+    # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region so that
+    # the event queries do not perturb it)
+    for _ in range(min(args.steps, 5)):
+        if world == 1:
+            R.render(app, W, H, t, out=frame)
+        else:
+            R.render_rank(app, W, H, t, br, rank, world, out=slab)
+        kernel_ms.append(R.last_kernel_ms())
+    sync()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        km = torch.tensor([sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device=dev)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kmean = float(km.item())
+    else:
+        kmean = sum(kernel_ms) / len(kernel_ms)
+
+    if rank == 0:
+        pixels = W * H
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = pixels / (ms_per_step * 1e-3) / 1e6
+        ops = OPS_PER_PIXEL.get(app)
+        launch_pixels = pixels if world == 1 else shard.rank_rows(H, br, 0, world) * W
+        roofline = None
+        if ops is not None:
+            achieved = ops * launch_pixels / (kmean * 1e-3) / 1e12
+            roofline = {"bound": "valu", "kernel": "k_" + app, "achieved": round(achieved, 4),
+                        "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5),
+                        "ops_per_pixel": ops, "pixels_per_launch": launch_pixels,
+                        "kernel_ms": round(kmean, 4), "traffic": None,
+                        "hbm": {"achieved": round(16.0 * launch_pixels / (kmean * 1e-3) / 1e9, 2),
+                                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_pixel": 16}}
+        out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(value, 3),
+               "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)"
+                                      % (app.upper(), W, H, t),
+                          "parallelism": "1 GPU, one launch per frame" if world == 1 else
+                                         "cyclic %d-row blocks over %d GPUs + 1 RCCL gather + assemble" % (br, world)},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(app, W, H, t, args.cpu_row_stride)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(app, W, H, t, stride):
+    """The CPU oracle ('port' of the reference path, oracle/) on this host's cores, bounded sample."""
+    from oracle.oracle import APP_IDS, Oracle
+    o = Oracle()
+    rows = list(range(stride // 2, H, stride))
+    cores = os.cpu_count() or 1
+    o.render_rows(APP_IDS[app], W, H, t, rows[:cores], threads=cores)   # warm the threads/caches
+    t0 = time.perf_counter()
+    o.render_rows(APP_IDS[app], W, H, t, rows, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(rows) * W / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d rows (every %dth row) of the same %dx%d frame, %.1f s, g++ -O2 -ffp-contract=off"
+                      % (len(rows), H, stride, W, H, dt)}
+
+
+if __name__ == "__main__":
+    main()

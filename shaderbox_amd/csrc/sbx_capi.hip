@@ -265,6 +265,7 @@ static int check_common(sbx_ctx* ctx, const sbx_uniforms* uni, const float* rgba
 int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int y0, int y1, float* rgba,
                     void* stream) {
     int W, H;
+    if (ctx && uni && y0 == y1 && y0 >= 0 && (float)y0 <= uni->u_res[1]) return SBX_OK;   // empty strip: nothing to write
     int rc = check_common(ctx, uni, rgba, W, H);
     if (rc != SBX_OK) return rc;
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(ctx, SBX_ERR_ARG, "bad row range");
