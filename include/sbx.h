@@ -122,6 +122,11 @@ int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks
 int sbx_set_timing(sbx_ctx* ctx, int enabled);
 int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms);
 
+/* Diagnostic knob: 0 = default kernels; 1 = "per-lane" cross-check kernels where one exists
+ * (APP_CLOUDS: every lane hashes its own lattice corners instead of the wave-cooperative scheme).
+ * Both variants are specified to produce identical bits. */
+int sbx_set_variant(sbx_ctx* ctx, int variant);
+
 /* Device evaluation of the math spec, elementwise over device arrays (for parity tests):
  * fn in {"sin","cos","tan","exp","pow","acos","atan2","hash"}; b may be NULL for unary fns. */
 int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, float* out,

@@ -82,6 +82,7 @@ def load_library(path=None):
     lib.sbx_rank_rows_max.argtypes = [ci, ci, ci]
     lib.sbx_assemble.argtypes = [vp, ci, ci, ci, ci, fp, fp, vp]
     lib.sbx_set_timing.argtypes = [vp, ci]
+    lib.sbx_set_variant.argtypes = [vp, ci]
     lib.sbx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.sbx_math_eval.argtypes = [vp, ctypes.c_char_p, fp, fp, fp, ctypes.c_size_t, vp]
     lib.sbx_last_error.argtypes = [vp]
@@ -185,6 +186,10 @@ class Renderer:
                                           ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
                                           self._stream()))
         return frame
+
+    def set_variant(self, variant):
+        """0 = default kernels, 1 = per-lane cross-check kernels (bit-identical by specification)."""
+        self._check(self.lib.sbx_set_variant(self.ctx, int(variant)))
 
     def set_timing(self, enabled=True):
         self._check(self.lib.sbx_set_timing(self.ctx, 1 if enabled else 0))

@@ -33,7 +33,11 @@ __device__ __forceinline__ float clouds_illuminate(const FrameClouds& F, v3 orig
     return transmittance * F.sun_power * phase;
 }
 
-__global__ void __launch_bounds__(WG_THREADS) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out) {
+// ---------------------------------------------------------------------------------------------
+// variant 1 ("per-lane"): every lane evaluates all 8 lattice hashes of every noise cell itself.
+// Kept as the in-library cross-check of the cooperative kernel below (sbx_set_variant(ctx, 1)).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
@@ -73,8 +77,153 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds(FrameClouds F, RowMap M, 
     store_rgba(out, px.idx, to_srgb(col));
 }
 
-void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_clouds, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+// ---------------------------------------------------------------------------------------------
+// variant 0 (default, "wave-cooperative hashing").
+//
+// hash(n) depends only on the integer lattice index n = p.x + 157 p.y + 113 p.z (noise_iq.h:19), and
+// the 64 rays of an 8x8 pixel tile sample almost the same place: measured on the 3840x2160 frame a
+// wave touches on average 1.07 / 1.18 / 1.49 / 2.25 distinct lattice cells in octaves 0..3 (5.9 cells
+// per density_func, p99 = 24).  So instead of 64 lanes x 4 octaves x 8 corners = 2048 sin evaluations
+// per density_func, the wave
+//   1. finds the distinct cells of each octave with ballot/readlane (leader election per value),
+//   2. evaluates the 8 corner hashes of every distinct cell ONCE, one (cell, corner) task per lane
+//      (typically one pass of <= 64 tasks), into a per-wave LDS table,
+//   3. lets every lane read back the 8 hashes of its own cell (two ds_read_b128, broadcast within the
+//      group) and do its own trilinear blend.
+// Each hash is the same function of the same binary32 argument as in the per-lane variant, so the
+// result is bit-identical by construction; only redundant work is removed.  Control flow around the
+// cross-lane steps is wave-uniform: lanes never exit early, they carry `alive`/`lit` predicates.
+// ---------------------------------------------------------------------------------------------
+constexpr int COOP_MAX_CELLS = 256;                      // 64 lanes x 4 octaves, worst case
+struct alignas(16) WaveScratch {
+    float hashes[COOP_MAX_CELLS * 8];                    // [cell][corner]  corner order: +0,+1,+157,+158,+113,+114,+270,+271
+    float cell_n[COOP_MAX_CELLS];
+};
+
+// leader election: give every active lane the index of its cell in the wave's cell list
+__device__ __forceinline__ int coop_group(float n, bool active, int& C, float* cell_n, int lane) {
+    unsigned long long rem = __ballot(active);
+    const int nb = (int)f2u(n);
+    int mine = 0;
+    while (rem) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const int n0 = __builtin_amdgcn_readlane(nb, leader);
+        const bool same = (nb == n0);
+        if (same) mine = C;
+        if (lane == leader) cell_n[C] = n;
+        ++C;
+        rem &= ~(__ballot(same) | (1ull << leader));
+    }
+    return mine;
+}
+
+__device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, bool active, WaveScratch& S, int lane) {
+    v3 p = (pos_in * .001f) * 2.03f;                     // :66,72
+    float fx[4], fy[4], fz[4];
+    int cell[4];
+    int C = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                        // lattice part of noise_iq.h:14-19 per octave
+        const float px = floor_(p.x), py = floor_(p.y), pz = floor_(p.z);
+        float ax = p.x - px, ay = p.y - py, az = p.z - pz;
+        fx[k] = ax * ax * (3.0f - 2.0f * ax);
+        fy[k] = ay * ay * (3.0f - 2.0f * ay);
+        fz[k] = az * az * (3.0f - 2.0f * az);
+        const float n = px + py * 157.0f + 113.0f * pz;
+        cell[k] = coop_group(n, active, C, S.cell_n, lane);
+        p = p * 2.64f;                                   // fbm.h:6  p *= lacunarity
+    }
+    __builtin_amdgcn_wave_barrier();
+    // one (cell, corner) hash task per lane
+    const int corner = lane & 7;
+    const float off = (corner & 1 ? 1.0f : 0.0f) + (corner & 2 ? 157.0f : 0.0f) + (corner & 4 ? 113.0f : 0.0f);
+    const int tasks = C * 8;
+    for (int base = 0; base < tasks; base += 64) {
+        const int tau = base + lane;
+        if (tau < tasks) S.hashes[tau] = hash1(S.cell_n[tau >> 3] + off);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float t = 0.f, H = .5f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                        // blend part of noise_iq.h:20-23
+        const float4 lo = *reinterpret_cast<const float4*>(&S.hashes[cell[k] * 8]);
+        const float4 hi = *reinterpret_cast<const float4*>(&S.hashes[cell[k] * 8 + 4]);
+        const float gx = 1.0f - fx[k], gy = 1.0f - fy[k], gz = 1.0f - fz[k];
+        const float a = lo.x * gx + lo.y * fx[k];
+        const float b = lo.z * gx + lo.w * fx[k];
+        const float c = hi.x * gx + hi.y * fx[k];
+        const float d = hi.z * gx + hi.w * fx[k];
+        const float ab = a * gy + b * fy[k];
+        const float cd = c * gy + d * fy[k];
+        t += (ab * gz + cd * fz[k]) * H;
+        H *= .5f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return t * smoothstep_(F.cov, F.cov_hi, t);          // :83-84
+}
+
+__global__ void __launch_bounds__(WG_THREADS) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out) {
+    __shared__ WaveScratch scratch[WG_THREADS / 64];
+    const int lane = threadIdx.x & 63;
+    WaveScratch& S = scratch[threadIdx.x >> 6];
+    const Pixel px = pixel_of_thread(M);
+    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 dir = primary_dir(F.cam, pc);
+
+    // render_sky_color :36-46
+    float sun_amount = fmax_(dot(dir, F.sun_dir), 0.f);
+    v3 sky = mix3(V3(.0f, .1f, .4f), V3(.3f, .6f, .8f), 1.0f - dir.y);
+    sky = sky + F.sun_color * fmin_(pow_(sun_amount, 1500.0f) * 5.0f, 1.0f);
+    sky = sky + F.sun_color * fmin_(pow_(sun_amount, 10.0f) * .6f, 1.0f);
+    sky = abs3(sky);
+
+    const float cutoff = dot(dir, V3(0, 1, 0));
+    const bool marches = px.valid && !(cutoff < 0.05f);       // :212
+    bool alive = marches;
+    float transmittance = 1.f, radiance = 0.f, alpha = 0.f;
+    if (__ballot(alive)) {                                    // wave-uniform
+        const v3 projection = dir / dir.y;                    // render_clouds :153-202
+        const v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
+        const float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
+        const v3 lstep = F.sun_dir * F.dt;
+        float t = 0.f;
+        for (int i = 0; i < F.steps; ++i) {
+            if (!__ballot(alive)) break;
+            const v3 pos = origin + t * projection;
+            t += F.dt;
+            const float density = coop_density(F, pos, alive, S, lane);
+            const bool lit = alive && !(density < .005f);     // integrate_volume :132
+            if (__ballot(lit)) {
+                const float T_i = exp_(-density * F.sigma * F.dt);
+                v3 lp = pos + lstep;                           // illuminate_volume :91-123
+                float ltrans = 1.f;
+                for (int j = 0; j < F.lsteps; ++j) {
+                    const float d = coop_density(F, lp, lit, S, lane);
+                    ltrans *= exp_(-d * F.sigma * F.dt);
+                    lp = lp + lstep;
+                }
+                const float illum = ltrans * F.sun_power * phase;
+                if (lit) {
+                    transmittance *= T_i;
+                    radiance += (density * F.sigma) * illum * transmittance * F.dt;
+                    alpha += (1.f - T_i) * (1.f - alpha);
+                }
+            }
+            if (alpha > .999f) alive = false;                 // :197
+        }
+    }
+    if (!px.valid) return;
+    v3 col = sky;
+    if (marches) {
+        const float a = alpha * smoothstep_(.0f, .2f, cutoff);
+        col = abs3(mix3(sky, V3s(radiance), a));               // :215-217
+    }
+    store_rgba(out, px.idx, to_srgb(col));
+}
+
+void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant) {
+    if (variant == 1) hipLaunchKernelGGL(k_clouds_perlane, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_clouds, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

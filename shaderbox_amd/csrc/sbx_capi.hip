@@ -16,6 +16,7 @@ using namespace sbx;
 struct sbx_ctx {
     int device = 0;
     bool timing = false;
+    int variant = 0;
     bool have_events = false;
     hipEvent_t ev0{}, ev1{};
     std::string err;
@@ -231,7 +232,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         sbx_aux_clouds A;
         if (aux) A = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&A);
         if (A.cld_march_steps < 0 || A.illum_march_steps < 0) return fail(ctx, SBX_ERR_ARG, "negative march steps");
-        launch_clouds(build_clouds(*uni, A), M, rgba, s);
+        launch_clouds(build_clouds(*uni, A), M, rgba, s, ctx->variant);
         break;
     }
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s); break;
@@ -314,6 +315,12 @@ int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks
     return SBX_OK;
 }
 
+int sbx_set_variant(sbx_ctx* ctx, int variant) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (variant < 0 || variant > 1) return fail(ctx, SBX_ERR_ARG, "unknown kernel variant");
+    ctx->variant = variant;
+    return SBX_OK;
+}
 int sbx_set_timing(sbx_ctx* ctx, int enabled) {
     if (!ctx) return SBX_ERR_ARG;
     ctx->timing = enabled != 0;

@@ -123,3 +123,16 @@ def test_error_codes(renderer):
         renderer.render("egg", 64, 64, 0.0, rows=(10, 80))
     assert e.value.code == shaderbox_amd.SBX_ERR_ARG
     assert renderer.render("egg", 64, 64, 0.0, rows=(5, 5)).shape[0] == 0
+
+
+def test_clouds_cooperative_equals_perlane_full_size(renderer):
+    """BASELINE size (3840x2160): the wave-cooperative CLOUDS kernel is bit-identical to the per-lane
+    cross-check kernel, which the small-frame tests above tie to the oracle."""
+    import torch
+    for (w, h, t, mouse) in [(3840, 2160, 0.37, (0.0, 0.0)), (1920, 1080, 2.5, (0.0, 0.0)), (1283, 721, 100.0, (2.0, 0.0))]:
+        renderer.set_variant(0)
+        a = renderer.render("clouds", w, h, t, mouse=mouse)
+        renderer.set_variant(1)
+        b = renderer.render("clouds", w, h, t, mouse=mouse)
+        renderer.set_variant(0)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (w, h, t)
