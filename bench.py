@@ -84,17 +84,12 @@ def main():
         def step():
             R.render(app, W, H, t, out=frame)
     else:
-        rmax = shard.rank_rows_max(H, br, world)
-        slab = torch.zeros((rmax, W, 4), dtype=torch.float32, device=dev)
-        gathered = torch.empty((world, rmax, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
-        glist = [gathered[i] for i in range(world)] if rank == 0 else None
-        frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
+        from shaderbox_amd.distributed import FramePlan
+        plan = FramePlan(R, dist, W, H, br)
+        slab = plan.slab
 
         def step():
-            R.render_rank(app, W, H, t, br, rank, world, out=slab)
-            dist.gather(slab, glist, dst=0)          # the single RCCL collective of the path
-            if rank == 0:
-                R.assemble(gathered, W, H, br, world, out=frame)
+            plan.render(app, t)      # render_rank + the single RCCL gather + assemble on rank 0
 
     def sync():
         if dist is not None:

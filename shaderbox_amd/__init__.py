@@ -154,6 +154,11 @@ class Renderer:
     def _auxp(aux):
         return ctypes.cast(ctypes.byref(aux), ctypes.c_void_p) if aux is not None else None
 
+    def empty(self, shape, zero=False):
+        """float32 device buffer (used by distributed.FramePlan)"""
+        f = self.torch.zeros if zero else self.torch.empty
+        return f(tuple(shape), dtype=self.torch.float32, device=self.tdev)
+
     def _buffer(self, rows, width, out):
         if out is None:
             return self.torch.empty((rows, width, 4), dtype=self.torch.float32, device=self.tdev)

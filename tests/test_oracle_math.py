@@ -1,0 +1,53 @@
+"""Accuracy of the oracle's statement of the sbx math spec (oracle/sbx_math_ref.h).
+
+Spec: transcendentals are evaluated in binary64 and rounded once to binary32, i.e. they are the
+correctly rounded binary32 results (up to ties closer than ~2^-28 ulp).  sin on integer arguments
+|n| <= 2^21 — the whole domain of the noise hash — is checked EXHAUSTIVELY; the others on dense samples.
+Reference values: numpy float64 libm rounded to float32 (its error, <1 ulp of double, is 2^-29 ulp of
+float, so it decides correct rounding except on near-ties, of which we allow a vanishing fraction)."""
+import numpy as np
+
+
+def _mismatch(got, want64):
+    want = want64.astype(np.float32)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    return int((~same).sum())
+
+
+def test_sin_is_correctly_rounded_on_all_hash_arguments(oracle):
+    n = np.arange(-(1 << 21), (1 << 21) + 1, dtype=np.float32)
+    assert _mismatch(oracle.math("sin", n), np.sin(n.astype(np.float64))) == 0
+    assert _mismatch(oracle.math("cos", n), np.cos(n.astype(np.float64))) == 0
+
+
+def test_transcendentals_are_correctly_rounded_on_samples(oracle):
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal(2_000_000) * 2000).astype(np.float32)
+    assert _mismatch(oracle.math("sin", x), np.sin(x.astype(np.float64))) <= 2
+    assert _mismatch(oracle.math("cos", x), np.cos(x.astype(np.float64))) <= 2
+    x = rng.uniform(-1.5, 1.5, 1_000_000).astype(np.float32)
+    assert _mismatch(oracle.math("tan", x), np.tan(x.astype(np.float64))) <= 2
+    x = rng.uniform(-87, 88, 2_000_000).astype(np.float32)
+    assert _mismatch(oracle.math("exp", x), np.exp(x.astype(np.float64))) <= 2
+    x = np.abs(rng.standard_normal(2_000_000)).astype(np.float32) * 3
+    for y in (1 / 2.2, 1.5, 10.0, 30.0, 1500.0):
+        yy = np.float32(y)
+        w = np.power(x.astype(np.float64), np.float64(yy))
+        ok = np.isfinite(w) & (w > 1e-37)
+        assert _mismatch(oracle.math("pow", x, yy)[ok], w[ok]) <= 2
+    x = rng.uniform(-1, 1, 1_000_000).astype(np.float32)
+    assert _mismatch(oracle.math("acos", x), np.arccos(x.astype(np.float64))) <= 2
+    a, b = rng.standard_normal(1_000_000).astype(np.float32), rng.standard_normal(1_000_000).astype(np.float32)
+    assert _mismatch(oracle.math("atan2", a, b), np.arctan2(a.astype(np.float64), b.astype(np.float64))) <= 2
+
+
+def test_special_values(oracle):
+    f = np.float32
+    assert oracle.math("exp", np.array([0, -np.inf, np.inf, 89, -104], f)).tolist() == [1.0, 0.0, np.inf, np.inf, 0.0]
+    assert np.isnan(oracle.math("exp", np.array([np.nan], f))[0])
+    assert np.isnan(oracle.math("sin", np.array([np.inf], f))[0])
+    p = oracle.math("pow", np.array([0, 0, 2, -1, 1, np.nan, 0.5], f), np.array([1.5, 0, 0, .5, 1500, 1, 1500], f))
+    assert p[0] == 0 and p[1] == 1 and p[2] == 1 and np.isnan(p[3]) and p[4] == 1 and np.isnan(p[5]) and p[6] == 0
+    assert [float(v) for v in oracle.math("pow", np.array([2, 2, 2, 2, 2], f), np.array([1, 2, 3, 4, 5], f))] == [2, 4, 8, 16, 32]
+    a = oracle.math("acos", np.array([1, -1, 1.5, -3.2], f))
+    assert a[0] == 0 and a[1] == f(np.pi) and np.isnan(a[2]) and np.isnan(a[3])   # NaN dir -> black (App. B3)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz: small float32 RGBA frames of every app at the canonical times.
+
+The reference ships no golden images; these fixtures are outputs of the CPU oracle
+(oracle/, itself pinned against SURVEY.md Appendix C by tests/test_oracle_kat.py), committed so that
+(a) the oracle cannot drift silently and (b) the GPU parity tests have a fixed target that does not
+depend on rebuilding the oracle on the GPU box.  Re-run after any deliberate change of the math spec:
+    python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.oracle import APP_IDS, Oracle  # noqa: E402
+
+CASES = {"egg": (64, 64), "clouds": (96, 54), "raytracer": (64, 64), "atmosphere": (64, 36),
+         "sdf_ao": (64, 36), "planet": (64, 36)}
+TIMES = (0.0, 0.37, 2.5)
+
+if __name__ == "__main__":
+    o = Oracle(rebuild=True)
+    out = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out, exist_ok=True)
+    for app, (w, h) in CASES.items():
+        frames = {"t%g" % t: o.render(APP_IDS[app], w, h, t) for t in TIMES}
+        np.savez_compressed(os.path.join(out, "%s_%dx%d.npz" % (app, w, h)), **frames)
+        print(app, w, h, {k: float(np.nanmean(v[..., :3])) for k, v in frames.items()})
