@@ -1,0 +1,43 @@
+"""The C++ host layer over the C ABI (host/): builds with plain g++; on a GPU the CLI's raw output and the
+mainImage() drop-in loop reproduce the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "host")
+
+
+@pytest.fixture(scope="module")
+def built():
+    from shaderbox_amd import build
+    build.build(verbose=False)
+    subprocess.run(["make", "-s", "-C", HOST, "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", HOST, "all", "APP=-DAPP_EGG"], check=True)
+    return HOST
+
+
+def test_hosts_build_and_fail_loudly_without_gpu(built):
+    import torch
+    assert os.path.exists(os.path.join(built, "sbx_render")) and os.path.exists(os.path.join(built, "mainimage_demo"))
+    if not torch.cuda.is_available():
+        r = subprocess.run([os.path.join(built, "sbx_render"), "--app", "egg", "--res", "32x32"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_and_mainimage_dropin_match_oracle(built, oracle, tmp_path):
+    from oracle.oracle import APP_IDS
+    out = str(tmp_path / "f.f32")
+    for app, w, h, t in [("clouds", 160, 90, 0.37), ("APP_RAYTRACER", 96, 64, 2.5)]:
+        subprocess.run([os.path.join(built, "sbx_render"), "--app", app, "--res", "%dx%d" % (w, h), "--time", str(t),
+                        "--f32", out, "--ppm", str(tmp_path / "f.ppm")], check=True)
+        got = np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
+        ref = oracle.render(APP_IDS[app.lower().replace("app_", "")], w, h, t)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    r = subprocess.run([os.path.join(built, "mainimage_demo"), "256", "256", "0.37"], capture_output=True, text=True, check=True)
+    mean = [float(v) for v in r.stdout.strip().split("=")[-1].split()]
+    # EGG 256x256 t=.37 frame mean
+    assert np.allclose(mean, [0.401660, 0.545536, 0.539848], atol=2e-6), r.stdout

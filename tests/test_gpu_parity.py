@@ -153,7 +153,6 @@ def test_clouds_4k_against_survey_pixels_and_oracle_rows(renderer, oracle):
         assert np.max(np.abs(img[y, x, :3].astype(np.float64) - np.array(rgb))) <= 1e-4, (x, y, img[y, x])
     mean = img[..., :3].reshape(-1, 3).mean(0, dtype=np.float64)
     assert np.max(np.abs(mean - np.array([0.608542, 0.746136, 0.861747]))) <= 2e-6, mean
-    assert np.all(img[:550, :, :3] == img[:550, :1, :3].repeat(W, 1)) or True   # rows < 550 never march (sky only)
     rows = [0, 549, 550, 551, 700, 1080, 1500, 1999, 2159]
     ref = oracle.render_rows(APP_CLOUDS, W, H, T, rows)
     maxd, nbits = compare(img[rows], ref)
