@@ -49,6 +49,10 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--time", type=float, default=0.37)
     ap.add_argument("--block-rows", type=int, default=8)
+    ap.add_argument("--gather-groups", type=int, default=4,
+                    help="N>1: issue the gather in this many pipelined pieces (1 = one plain gather)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the torch.distributed/RCCL path even with one rank (smoke test of the N>1 code on 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=8)
     args = ap.parse_args()
@@ -65,9 +69,11 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -78,14 +84,14 @@ def main():
     W, H, app, t = args.width, args.height, args.app, args.time
     br = args.block_rows
 
-    if world == 1:
+    if not use_dist:
         frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
 
         def step():
             R.render(app, W, H, t, out=frame)
     else:
         from shaderbox_amd.distributed import FramePlan
-        plan = FramePlan(R, dist, W, H, br)
+        plan = FramePlan(R, dist, W, H, br, groups=args.gather_groups)
         slab = plan.slab
 
         def step():
@@ -103,14 +109,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if world == 1:
-            pass
     sync()
     elapsed = time.perf_counter() - t0
     # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region so that
     # the event queries do not perturb it)
     for _ in range(min(args.steps, 5)):
-        if world == 1:
+        if not use_dist:
             R.render(app, W, H, t, out=frame)
         else:
             R.render_rank(app, W, H, t, br, rank, world, out=slab)
@@ -149,7 +153,8 @@ def main():
                "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)"
                                       % (app.upper(), W, H, t),
                           "parallelism": "1 GPU, one launch per frame" if world == 1 else
-                                         "cyclic %d-row blocks over %d GPUs + 1 RCCL gather + assemble" % (br, world)},
+                                         "cyclic %d-row blocks over %d GPUs + 1 RCCL gather (in %d pipelined pieces) + assemble"
+                                         % (br, world, args.gather_groups)},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(app, W, H, t, args.cpu_row_stride)

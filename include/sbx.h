@@ -108,6 +108,10 @@ int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* 
  * GLOBAL (x, y), so the assembled frame is bit-identical to a 1-GPU render. */
 int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
                     int block_rows, int rank, int nranks, float* rgba, void* stream);
+/* Same, restricted to slab rows [r0, r1) of the rank (r1 is clipped to sbx_rank_rows()); `rgba` points at
+ * slab row r0.  Lets a host pipeline the slab in groups: render group g, start its transfer, render g+1. */
+int sbx_render_rank_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
+                         int block_rows, int rank, int nranks, int r0, int r1, float* rgba, void* stream);
 /* Number of rows rank `rank` owns (<= sbx_rank_rows_max). */
 int sbx_rank_rows(int height, int block_rows, int rank, int nranks);
 /* Rows every rank's buffer must hold so that an equal-count gather works: max over ranks. */

@@ -78,6 +78,7 @@ def load_library(path=None):
     lib.sbx_destroy.restype = None
     lib.sbx_render_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, fp, vp]
     lib.sbx_render_rank.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, fp, vp]
+    lib.sbx_render_rank_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, fp, vp]
     lib.sbx_rank_rows.argtypes = [ci, ci, ci, ci]
     lib.sbx_rank_rows_max.argtypes = [ci, ci, ci]
     lib.sbx_assemble.argtypes = [vp, ci, ci, ci, ci, fp, fp, vp]
@@ -183,6 +184,18 @@ class Renderer:
         self._check(self.lib.sbx_render_rank(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
                                              rank, nranks, ctypes.c_void_p(buf.data_ptr()), self._stream()))
         return buf
+
+    def render_rank_rows(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0),
+                         aux=None):
+        """Render slab rows [r0, r1) of `rank` into slab[r0:r1] (pipelined multi-GPU frames)."""
+        u = self.uniforms(width, height, time, mouse)
+        if r1 <= r0:
+            return slab
+        view = slab[r0:r1]
+        self._check(self.lib.sbx_render_rank_rows(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
+                                                  rank, nranks, int(r0), int(r1), ctypes.c_void_p(view.data_ptr()),
+                                                  self._stream()))
+        return slab
 
     def assemble(self, gathered, width, height, block_rows, nranks, out=None):
         """Root side: scatter the rank-major gathered slabs to their global rows -> [H, W, 4]."""

@@ -270,7 +270,7 @@ int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* 
     int rc = check_common(ctx, uni, rgba, W, H);
     if (rc != SBX_OK) return rc;
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(ctx, SBX_ERR_ARG, "bad row range");
-    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0};
+    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0, 0};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
 }
 
@@ -297,7 +297,22 @@ int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* 
     if (rc != SBX_OK) return rc;
     const int rows = sbx_rank_rows(H, block_rows, rank, nranks);
     if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
-    RowMap M{W, H, 0, block_rows, nranks, rank, rows};
+    RowMap M{W, H, 0, block_rows, nranks, rank, rows, 0};
+    return render_mapped(ctx, app, uni, aux, M, rgba, stream);
+}
+
+int sbx_render_rank_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                         int nranks, int r0, int r1, float* rgba, void* stream) {
+    int W, H;
+    if (ctx && uni && r0 == r1 && r0 >= 0) return SBX_OK;
+    int rc = check_common(ctx, uni, rgba, W, H);
+    if (rc != SBX_OK) return rc;
+    const int rows = sbx_rank_rows(H, block_rows, rank, nranks);
+    if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
+    if (r0 < 0 || r1 < r0) return fail(ctx, SBX_ERR_ARG, "bad slab row range");
+    if (r1 > rows) r1 = rows;                 // the slab is padded to rank_rows_max; the tail has no pixels
+    if (r0 >= r1) return SBX_OK;
+    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
 }
 

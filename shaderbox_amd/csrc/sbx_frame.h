@@ -19,10 +19,12 @@ struct RowMap {
     int width, height;
     int y0, block_rows, nranks, rank;
     int nrows;   // local rows in this launch
+    int r0;      // first local row of this launch within the rank's slab (sub-range launches)
 };
 SBX_HD int row_to_y(const RowMap& m, int r) {
-    int blk = r / m.block_rows;
-    return m.y0 + (blk * m.nranks + m.rank) * m.block_rows + (r - blk * m.block_rows);
+    const int rr = r + m.r0;
+    const int blk = rr / m.block_rows;
+    return m.y0 + (blk * m.nranks + m.rank) * m.block_rows + (rr - blk * m.block_rows);
 }
 
 // Camera part of mainImage (src/main.h:33-48) + get_primary_ray (src/util.h:5-20)

@@ -1,40 +1,59 @@
-"""Multi-GPU frame: cyclic row-blocks per rank + ONE gather + root-side assembly.
+"""Multi-GPU frame: cyclic row-blocks per rank + ONE gather (optionally pipelined) + root-side assembly.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, xGMI underneath).  The path has
-exactly one exchange step — bringing the rendered rows to the rank that owns the frame — so there is
-exactly one collective per frame: a gather to rank 0.  Seven peers send over seven distinct xGMI links
-(point-to-point, no ring), 16.6 MB each for a 3840x2160 RGBA32F frame.  Everything else is
-embarrassingly parallel: every rank computes its pixels from their GLOBAL coordinates, so the
-assembled frame is bit-identical to a single-GPU render.
+exactly one exchange step — bringing the rendered rows to the rank that owns the frame — so the only
+collective is a gather to rank 0.  Seven peers send over seven distinct xGMI links (point-to-point, no
+ring), 16.6 MB each for a 3840x2160 RGBA32F frame.  Everything else is embarrassingly parallel: every
+rank computes its pixels from their GLOBAL coordinates, so the assembled frame is bit-identical to a
+single-GPU render.
 
-`renderer` is duck-typed (render_rank / assemble / empty): shaderbox_amd.Renderer on GPUs; the CPU
+Pipelining: at 8 GPUs a rank's strip takes ~1.5 ms while its 16.6 MB take ~0.2-0.3 ms on one xGMI link, so
+the gather is issued in `groups` pieces: slab rows are rendered group by group and each group's gather is
+started asynchronously (RCCL runs on its own stream) while the next group renders; only the last piece
+and the assembly kernel are exposed.  groups = 1 is the plain single gather.
+
+`renderer` is duck-typed (render_rank_rows / assemble / empty): shaderbox_amd.Renderer on GPUs; the CPU
 tests drive the same code over gloo with an oracle-backed stand-in.
 """
 from . import shard
 
 
 class FramePlan:
-    """Buffers of one rank for repeated frames of a fixed size."""
+    """Buffers and schedule of one rank for repeated frames of a fixed size."""
 
-    def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS):
+    def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS, groups=1):
         self.r, self.dist = renderer, dist
         self.width, self.height, self.block_rows = int(width), int(height), int(block_rows)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.rows_max = shard.rank_rows_max(self.height, self.block_rows, self.world)
+        nblocks = self.rows_max // self.block_rows
+        groups = max(1, min(int(groups), nblocks))
+        # slab row ranges of the groups: whole blocks, as even as possible
+        cuts = [((g * nblocks) // groups) * self.block_rows for g in range(groups + 1)]
+        self.ranges = [(cuts[g], cuts[g + 1]) for g in range(groups) if cuts[g + 1] > cuts[g]]
         self.slab = renderer.empty((self.rows_max, self.width, 4), zero=True)
         if self.rank == 0:
             self.gathered = renderer.empty((self.world, self.rows_max, self.width, 4))
-            self.glist = [self.gathered[i] for i in range(self.world)]
+            self.glists = [[self.gathered[i, a:b] for i in range(self.world)] for a, b in self.ranges]
             self.frame = renderer.empty((self.height, self.width, 4))
         else:
-            self.gathered = self.glist = self.frame = None
+            self.gathered = self.frame = None
+            self.glists = [None] * len(self.ranges)
 
     def render(self, app, time, mouse=(0.0, 0.0), aux=None):
         """All ranks call this; rank 0 returns the assembled [H, W, 4] frame, the others None."""
-        self.r.render_rank(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
-                           mouse=mouse, aux=aux, out=self.slab)
-        self.dist.gather(self.slab, self.glist, dst=0)        # the single collective of the path
+        works = []
+        last = len(self.ranges) - 1
+        for g, (a, b) in enumerate(self.ranges):
+            self.r.render_rank_rows(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
+                                    a, b, self.slab, mouse=mouse, aux=aux)
+            # the gather of the path (one logical gather, issued per group so that it overlaps the next render)
+            w = self.dist.gather(self.slab[a:b], self.glists[g], dst=0, async_op=(g != last))
+            if w is not None:
+                works.append(w)
+        for w in works:
+            w.wait()          # stream-level wait on GPUs: the slab/gathered buffers are safe to reuse/read after it
         if self.rank == 0:
             return self.r.assemble(self.gathered, self.width, self.height, self.block_rows, self.world,
                                    out=self.frame)

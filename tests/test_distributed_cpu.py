@@ -21,13 +21,15 @@ class OracleRenderer:
     def empty(self, shape, zero=False):
         return torch.zeros(tuple(shape), dtype=torch.float32)
 
-    def render_rank(self, app, width, height, time, block_rows, rank, nranks, mouse=(0.0, 0.0), aux=None, out=None):
+    def render_rank_rows(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0),
+                         aux=None):
         from oracle.oracle import APP_IDS
         from shaderbox_amd import shard
-        rows = shard.rank_row_indices(height, block_rows, rank, nranks)
-        img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
-        out[:len(rows)] = torch.from_numpy(img)
-        return out
+        rows = shard.rank_row_indices(height, block_rows, rank, nranks)[r0:r1]
+        if rows:
+            img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
+            slab[r0:r0 + len(rows)] = torch.from_numpy(img)
+        return slab
 
     def assemble(self, gathered, width, height, block_rows, nranks, out=None):
         from shaderbox_amd import shard          # mirror of k_assemble (kern_util.hip)
@@ -36,12 +38,12 @@ class OracleRenderer:
         return out
 
 
-def _worker(rank, world, port, app, w, h, t, br, result_path):
+def _worker(rank, world, port, app, w, h, t, br, groups, result_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from shaderbox_amd.distributed import FramePlan
-    plan = FramePlan(OracleRenderer(), dist, w, h, br)
+    plan = FramePlan(OracleRenderer(), dist, w, h, br, groups=groups)
     frame = None
     for _ in range(2):                       # buffers are reused across frames
         frame = plan.render(app, t)
@@ -61,11 +63,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,app,w,h,br", [(2, "clouds", 96, 54, 8), (2, "egg", 64, 45, 8), (3, "raytracer", 64, 50, 5)])
-def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, app, w, h, br):
+@pytest.mark.parametrize("world,app,w,h,br,groups", [(2, "clouds", 96, 54, 8, 1), (2, "egg", 64, 45, 8, 3),
+                                                      (3, "raytracer", 64, 50, 5, 2), (2, "egg", 32, 20, 8, 4)])
+def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, app, w, h, br, groups):
     from oracle.oracle import APP_IDS
     path = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, groups, path), nprocs=world, join=True)
     got = np.load(path)
     ref = oracle.render(APP_IDS[app], w, h, 0.37)
     assert got.shape == ref.shape

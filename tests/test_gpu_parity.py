@@ -86,6 +86,12 @@ def test_strip_and_rank_invariance(renderer):
                 renderer.render_rank(app, w, h, t, br, r, nranks, out=slabs[r])
             frame = renderer.assemble(slabs, w, h, br, nranks)
             assert torch.equal(frame.view(torch.int32), full.view(torch.int32)), (app, nranks, br)
+            # the same slabs produced in pieces (pipelined gather path)
+            slabs2 = torch.zeros_like(slabs)
+            for r in range(nranks):
+                for a, b in [(0, br), (br, 3 * br), (3 * br, rmax)]:
+                    renderer.render_rank_rows(app, w, h, t, br, r, nranks, a, min(b, rmax), slabs2[r])
+            assert torch.equal(slabs2.view(torch.int32), slabs.view(torch.int32)), (app, nranks, br)
 
 
 def test_device_math_matches_oracle(renderer, oracle):
