@@ -6,6 +6,7 @@
 // henyey_greenstein_phase_func src/volumetric.h:27-33 with hg_g = .2 (:5).
 #include "sbx_device.h"
 #include "sbx_noise.h"
+#include <cstdlib>
 
 namespace sbx {
 
@@ -78,94 +79,112 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, Ro
 }
 
 // ---------------------------------------------------------------------------------------------
-// variant 0 (default, "wave-cooperative hashing").
+// variant 0 (default): per-wave lattice-hash cache in LDS.
 //
 // hash(n) depends only on the integer lattice index n = p.x + 157 p.y + 113 p.z (noise_iq.h:19), and
 // the 64 rays of an 8x8 pixel tile sample almost the same place: measured on the 3840x2160 frame a
-// wave touches on average 1.07 / 1.18 / 1.49 / 2.25 distinct lattice cells in octaves 0..3 (5.9 cells
-// per density_func, p99 = 24).  So instead of 64 lanes x 4 octaves x 8 corners = 2048 sin evaluations
-// per density_func, the wave
-//   1. finds the distinct cells of each octave with ballot/readlane (leader election per value),
-//   2. evaluates the 8 corner hashes of every distinct cell ONCE, one (cell, corner) task per lane
-//      (typically one pass of <= 64 tasks), into a per-wave LDS table,
-//   3. lets every lane read back the 8 hashes of its own cell (two ds_read_b128, broadcast within the
-//      group) and do its own trilinear blend.
+// wave touches on average 1.07 / 1.18 / 1.49 / 2.25 distinct lattice cells in octaves 0..3 per sample,
+// and consecutive samples along the march (and the six light samples of a lit step) mostly stay in the
+// cells of the previous sample.  So the 8 corner hashes of a cell are computed ONCE per wave and kept
+// in a small direct-mapped table in LDS (per octave 64 slots of {tag = bits of n, 8 hashes}, 9 KB per
+// wave), keyed by slot = int(n) & 63:
+//   hit  (the common case): one ds_read_b32 for the tag, a compare, two ds_read_b128 for the 8 hashes
+//         (lanes of a tile mostly read the same slot: LDS broadcast), then the lane's own blend;
+//   miss: the missing cells are inserted by the wave together — leader election over the missing lanes
+//         with ballot/readlane (one cell per slot per round), then ONE pass in which lane (r, c)
+//         evaluates corner c of pending cell r (8 cells x 8 corners = 64 lanes) — and the lookup repeats.
+//         A lane always reads its hashes before a later insertion can evict them.
 // Each hash is the same function of the same binary32 argument as in the per-lane variant, so the
-// result is bit-identical by construction; only redundant work is removed.  Control flow around the
+// result is bit-identical by construction; only redundant evaluations are removed (on the 4K frame the
+// per-lane variant evaluates 32 sin per lane per density_func; this one ~0.1).  Control flow around the
 // cross-lane steps is wave-uniform: lanes never exit early, they carry `alive`/`lit` predicates.
+// (The first cooperative version re-elected the distinct cells of every sample: 11.6 ms per 4K frame,
+// of which 2.3 ms election and 2.0 ms hash passes)
 // ---------------------------------------------------------------------------------------------
-constexpr int COOP_MAX_CELLS = 256;                      // 64 lanes x 4 octaves, worst case
-struct alignas(16) WaveScratch {
-    float hashes[COOP_MAX_CELLS * 8];                    // [cell][corner]  corner order: +0,+1,+157,+158,+113,+114,+270,+271
-    float cell_n[COOP_MAX_CELLS];
+constexpr int HC_SLOTS = 64;
+struct alignas(16) WaveCache {
+    float h[4][HC_SLOTS][8];          // corner order: +0,+1,+157,+158,+113,+114,+270,+271
+    unsigned tag[4][HC_SLOTS];        // bits of n; 0x7fc00001 (a NaN) = empty
+    unsigned ins_tag[8], ins_slot[8]; // cells being inserted in the current pass
 };
 
-// leader election: give every active lane the index of its cell in the wave's cell list
-__device__ __forceinline__ int coop_group(float n, bool active, int& C, float* cell_n, int lane) {
-    unsigned long long rem = __ballot(active);
-    const int nb = (int)f2u(n);
-    int mine = 0;
-    while (rem) {
-        const int leader = __ffsll((long long)rem) - 1;
-        const int n0 = __builtin_amdgcn_readlane(nb, leader);
-        const bool same = (nb == n0);
-        if (same) mine = C;
-        if (lane == leader) cell_n[C] = n;
-        ++C;
-        rem &= ~(__ballot(same) | (1ull << leader));
-    }
-    return mine;
-}
-
-__device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, bool active, WaveScratch& S, int lane) {
-    v3 p = (pos_in * .001f) * 2.03f;                     // :66,72
-    float fx[4], fy[4], fz[4];
-    int cell[4];
-    int C = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                        // lattice part of noise_iq.h:14-19 per octave
-        const float px = floor_(p.x), py = floor_(p.y), pz = floor_(p.z);
-        float ax = p.x - px, ay = p.y - py, az = p.z - pz;
-        fx[k] = ax * ax * (3.0f - 2.0f * ax);
-        fy[k] = ay * ay * (3.0f - 2.0f * ay);
-        fz[k] = az * az * (3.0f - 2.0f * az);
-        const float n = px + py * 157.0f + 113.0f * pz;
-        cell[k] = coop_group(n, active, C, S.cell_n, lane);
-        p = p * 2.64f;                                   // fbm.h:6  p *= lacunarity
-    }
-    __builtin_amdgcn_wave_barrier();
-    // one (cell, corner) hash task per lane
+// miss path, one octave: the lanes in `need` lack their cell.  Leaders (one per distinct slot) are
+// elected with ballot/readlane, up to 8 cells per pass; lane (r, c) evaluates corner c of pending cell r.
+__device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, int slot, bool need, int lane) {
     const int corner = lane & 7;
     const float off = (corner & 1 ? 1.0f : 0.0f) + (corner & 2 ? 157.0f : 0.0f) + (corner & 4 ? 113.0f : 0.0f);
-    const int tasks = C * 8;
-    for (int base = 0; base < tasks; base += 64) {
-        const int tau = base + lane;
-        if (tau < tasks) S.hashes[tau] = hash1(S.cell_n[tau >> 3] + off);
+    unsigned long long m = __ballot(need);
+    while (m) {
+        int cnt = 0;
+        while (m && cnt < 8) {
+            const int leader = __ffsll((long long)m) - 1;
+            const unsigned n0 = (unsigned)__builtin_amdgcn_readlane((int)nbits, leader);
+            const int s0 = __builtin_amdgcn_readlane(slot, leader);
+            if (lane == cnt) { S.ins_tag[cnt] = n0; S.ins_slot[cnt] = (unsigned)s0; }
+            m &= ~__ballot(slot == s0);          // one cell per slot per call; losers are served in the next round
+            ++cnt;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt * 8) {
+            const int r = lane >> 3;
+            const unsigned n0 = S.ins_tag[r];
+            const int s0 = (int)S.ins_slot[r];
+            S.h[k][s0][corner] = hash1(u2f(n0) + off);
+            if (corner == 0) S.tag[k][s0] = n0;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, bool active, WaveCache& S, int lane) {
+    v3 p = (pos_in * .001f) * 2.03f;                     // :66,72
     float t = 0.f, H = .5f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                        // blend part of noise_iq.h:20-23
-        const float4 lo = *reinterpret_cast<const float4*>(&S.hashes[cell[k] * 8]);
-        const float4 hi = *reinterpret_cast<const float4*>(&S.hashes[cell[k] * 8 + 4]);
-        const float gx = 1.0f - fx[k], gy = 1.0f - fy[k], gz = 1.0f - fz[k];
-        const float a = lo.x * gx + lo.y * fx[k];
-        const float b = lo.z * gx + lo.w * fx[k];
-        const float c = hi.x * gx + hi.y * fx[k];
-        const float d = hi.z * gx + hi.w * fx[k];
-        const float ab = a * gy + b * fy[k];
-        const float cd = c * gy + d * fy[k];
-        t += (ab * gz + cd * fz[k]) * H;
+    for (int k = 0; k < 4; ++k) {
+        // lattice part of noise_iq.h:14-19
+        const float px = floor_(p.x), py = floor_(p.y), pz = floor_(p.z);
+        const float ax = p.x - px, ay = p.y - py, az = p.z - pz;
+        const float fx = ax * ax * (3.0f - 2.0f * ax);
+        const float fy = ay * ay * (3.0f - 2.0f * ay);
+        const float fz = az * az * (3.0f - 2.0f * az);
+        const float n = px + py * 157.0f + 113.0f * pz;
+        const unsigned nbits = f2u(n);
+        const int slot = (int)n & (HC_SLOTS - 1);
+        const float* src = &S.h[k][slot][0];
+        // `need` is the only per-lane state the miss loop tests: keeping the loop condition free of
+        // loop-invariant divergent terms stops the optimizer from unswitching the loop on them, which
+        // would make the cross-lane steps inside run with some lanes masked off.
+        bool need = active && (S.tag[k][slot] != nbits);
+        float4 lo = *reinterpret_cast<const float4*>(src);
+        float4 hi = *reinterpret_cast<const float4*>(src + 4);
+        while (__ballot(need)) {                         // wave-uniform and rare: insert, then latch
+            hc_insert(S, k, nbits, slot, need, lane);
+            if (need && S.tag[k][slot] == nbits) {       // a lane keeps what it has read: later insertions
+                lo = *reinterpret_cast<const float4*>(src);       // into the same slot cannot take it away
+                hi = *reinterpret_cast<const float4*>(src + 4);
+                need = false;
+            }
+        }
+        // blend part of noise_iq.h:20-23
+        const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+        const float a = lo.x * gx + lo.y * fx;
+        const float b = lo.z * gx + lo.w * fx;
+        const float c = hi.x * gx + hi.y * fx;
+        const float d = hi.z * gx + hi.w * fx;
+        const float ab = a * gy + b * fy;
+        const float cd = c * gy + d * fy;
+        t += (ab * gz + cd * fz) * H;
         H *= .5f;
+        p = p * 2.64f;                                   // fbm.h:6  p *= lacunarity
     }
-    __builtin_amdgcn_wave_barrier();
     return t * smoothstep_(F.cov, F.cov_hi, t);          // :83-84
 }
 
 __global__ void __launch_bounds__(WG_THREADS) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out) {
-    __shared__ WaveScratch scratch[WG_THREADS / 64];
+    __shared__ WaveCache cache[WG_THREADS / 64];
     const int lane = threadIdx.x & 63;
-    WaveScratch& S = scratch[threadIdx.x >> 6];
+    WaveCache& S = cache[threadIdx.x >> 6];
+    for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
+    __builtin_amdgcn_wave_barrier();
     const Pixel px = pixel_of_thread(M);
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 dir = primary_dir(F.cam, pc);
@@ -223,7 +242,10 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds(FrameClouds F, RowMap M, 
 
 void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant) {
     if (variant == 1) hipLaunchKernelGGL(k_clouds_perlane, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
-    else hipLaunchKernelGGL(k_clouds, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else {
+        static const int pad = getenv("SBX_CLOUDS_LDS_PAD") ? atoi(getenv("SBX_CLOUDS_LDS_PAD")) : 0;   // occupancy experiments
+        hipLaunchKernelGGL(k_clouds, grid_for(M), dim3(WG_THREADS), pad, s, F, M, out);
+    }
 }
 
 }  // namespace sbx

@@ -56,19 +56,40 @@ constexpr double D_PI_LO = 0x1.1a62633145c07p-53;
 constexpr double D_PIO2 = 0x1.921fb54442d18p+0;
 constexpr double D_INV_PI = 0x1.45f306dc9c883p-2;
 
+// Polynomial coefficients of the binary64 cores.  On the device they are read from __constant__
+// memory (scalar loads -> SGPR pairs, which v_fma_f64 takes directly as its addend): written as
+// literals the compiler materialises every one of them in a VGPR pair and keeps ~40 VGPRs alive across
+// the hot loops, which costs a wave of occupancy in k_clouds.  Host code reads the same list from a
+// constexpr array; both arrays are initialised from the single list below, so the values are identical.
+#define SBX_SIN_COEFS                                                                                  \
+    0x1.71b8ef6dcf572p-66, -0x1.2f49b46814157p-57, 0x1.952c77030ad4ap-49, -0x1.ae7f3e733b81fp-41,     \
+    0x1.6124613a86d09p-33, -0x1.ae64567f544e4p-26, 0x1.71de3a556c734p-19, -0x1.a01a01a01a01ap-13,      \
+    0x1.1111111111111p-7, -0x1.5555555555555p-3
+#define SBX_EXP_COEFS                                                                                  \
+    0x1.6124613a86d09p-33, 0x1.1eed8eff8d898p-29, 0x1.ae64567f544e4p-26, 0x1.27e4fb7789f5cp-22,        \
+    0x1.71de3a556c734p-19, 0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-13, 0x1.6c16c16c16c17p-10,        \
+    0x1.1111111111111p-7, 0x1.5555555555555p-5, 0x1.5555555555555p-3, 0x1.0000000000000p-1
+#if defined(__HIP_DEVICE_COMPILE__)
+__constant__ const double kSinCoef[10] = {SBX_SIN_COEFS};
+__constant__ const double kExpCoef[12] = {SBX_EXP_COEFS};
+#else
+constexpr double kSinCoef[10] = {SBX_SIN_COEFS};
+constexpr double kExpCoef[12] = {SBX_EXP_COEFS};
+#endif
+
 // sin r, |r| <= pi/2: r + r^3 * (Taylor in r^2 up to r^21)
 SBX_HD double d_sin_poly(double r) {
     double s = r * r;
-    double p = 0x1.71b8ef6dcf572p-66;
-    p = __builtin_fma(p, s, -0x1.2f49b46814157p-57);
-    p = __builtin_fma(p, s, 0x1.952c77030ad4ap-49);
-    p = __builtin_fma(p, s, -0x1.ae7f3e733b81fp-41);
-    p = __builtin_fma(p, s, 0x1.6124613a86d09p-33);
-    p = __builtin_fma(p, s, -0x1.ae64567f544e4p-26);
-    p = __builtin_fma(p, s, 0x1.71de3a556c734p-19);
-    p = __builtin_fma(p, s, -0x1.a01a01a01a01ap-13);
-    p = __builtin_fma(p, s, 0x1.1111111111111p-7);
-    p = __builtin_fma(p, s, -0x1.5555555555555p-3);
+    double p = kSinCoef[0];                           //  1/21!
+    p = __builtin_fma(p, s, kSinCoef[1]);             // -1/19!
+    p = __builtin_fma(p, s, kSinCoef[2]);             //  1/17!
+    p = __builtin_fma(p, s, kSinCoef[3]);             // -1/15!
+    p = __builtin_fma(p, s, kSinCoef[4]);             //  1/13!
+    p = __builtin_fma(p, s, kSinCoef[5]);             // -1/11!
+    p = __builtin_fma(p, s, kSinCoef[6]);             //  1/9!
+    p = __builtin_fma(p, s, kSinCoef[7]);             // -1/7!
+    p = __builtin_fma(p, s, kSinCoef[8]);             //  1/5!
+    p = __builtin_fma(p, s, kSinCoef[9]);             // -1/3!
     return __builtin_fma(r * s, p, r);
 }
 SBX_HD double d_sin(double x) {
@@ -118,18 +139,18 @@ SBX_HD double d_exp2(double t) {
     int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
     kd = kd - D_MAGIC;
     double u = (t - kd) * D_LN2;
-    double p = 0x1.6124613a86d09p-33;
-    p = __builtin_fma(p, u, 0x1.1eed8eff8d898p-29);
-    p = __builtin_fma(p, u, 0x1.ae64567f544e4p-26);
-    p = __builtin_fma(p, u, 0x1.27e4fb7789f5cp-22);
-    p = __builtin_fma(p, u, 0x1.71de3a556c734p-19);
-    p = __builtin_fma(p, u, 0x1.a01a01a01a01ap-16);
-    p = __builtin_fma(p, u, 0x1.a01a01a01a01ap-13);
-    p = __builtin_fma(p, u, 0x1.6c16c16c16c17p-10);
-    p = __builtin_fma(p, u, 0x1.1111111111111p-7);
-    p = __builtin_fma(p, u, 0x1.5555555555555p-5);
-    p = __builtin_fma(p, u, 0x1.5555555555555p-3);
-    p = __builtin_fma(p, u, 0x1.0000000000000p-1);
+    double p = kExpCoef[0];                           // 1/13!
+    p = __builtin_fma(p, u, kExpCoef[1]);             // 1/12!
+    p = __builtin_fma(p, u, kExpCoef[2]);
+    p = __builtin_fma(p, u, kExpCoef[3]);
+    p = __builtin_fma(p, u, kExpCoef[4]);
+    p = __builtin_fma(p, u, kExpCoef[5]);
+    p = __builtin_fma(p, u, kExpCoef[6]);
+    p = __builtin_fma(p, u, kExpCoef[7]);
+    p = __builtin_fma(p, u, kExpCoef[8]);
+    p = __builtin_fma(p, u, kExpCoef[9]);
+    p = __builtin_fma(p, u, kExpCoef[10]);            // 1/3!
+    p = __builtin_fma(p, u, kExpCoef[11]);            // 1/2!
     p = __builtin_fma(p, u, 1.0);
     p = __builtin_fma(p, u, 1.0);
     double sc = u2d((uint64_t)(int64_t)(ki + 1023) << 52);
