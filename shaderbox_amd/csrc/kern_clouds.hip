@@ -135,46 +135,72 @@ __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, i
         __builtin_amdgcn_wave_barrier();
     }
 }
+// trilinear blend of the 8 corner hashes (noise_iq.h:20-23)
+__device__ __forceinline__ float hc_blend(float4 lo, float4 hi, float fx, float fy, float fz) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+    const float a = lo.x * gx + lo.y * fx;
+    const float b = lo.z * gx + lo.w * fx;
+    const float c = hi.x * gx + hi.y * fx;
+    const float d = hi.z * gx + hi.w * fx;
+    const float ab = a * gy + b * fy;
+    const float cd = c * gy + d * fy;
+    return ab * gz + cd * fz;
+}
+
 __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, bool active, WaveCache& S, int lane) {
     v3 p = (pos_in * .001f) * 2.03f;                     // :66,72
-    float t = 0.f, H = .5f;
+    float fx[4], fy[4], fz[4];
+    unsigned nbits[4];
+    int slot[4];
+    bool miss = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        // lattice part of noise_iq.h:14-19
+    for (int k = 0; k < 4; ++k) {                        // lattice part of noise_iq.h:14-19, all octaves first
         const float px = floor_(p.x), py = floor_(p.y), pz = floor_(p.z);
         const float ax = p.x - px, ay = p.y - py, az = p.z - pz;
-        const float fx = ax * ax * (3.0f - 2.0f * ax);
-        const float fy = ay * ay * (3.0f - 2.0f * ay);
-        const float fz = az * az * (3.0f - 2.0f * az);
+        fx[k] = ax * ax * (3.0f - 2.0f * ax);
+        fy[k] = ay * ay * (3.0f - 2.0f * ay);
+        fz[k] = az * az * (3.0f - 2.0f * az);
         const float n = px + py * 157.0f + 113.0f * pz;
-        const unsigned nbits = f2u(n);
-        const int slot = (int)n & (HC_SLOTS - 1);
-        const float* src = &S.h[k][slot][0];
-        // `need` is the only per-lane state the miss loop tests: keeping the loop condition free of
-        // loop-invariant divergent terms stops the optimizer from unswitching the loop on them, which
-        // would make the cross-lane steps inside run with some lanes masked off.
-        bool need = active && (S.tag[k][slot] != nbits);
-        float4 lo = *reinterpret_cast<const float4*>(src);
-        float4 hi = *reinterpret_cast<const float4*>(src + 4);
-        while (__ballot(need)) {                         // wave-uniform and rare: insert, then latch
-            hc_insert(S, k, nbits, slot, need, lane);
-            if (need && S.tag[k][slot] == nbits) {       // a lane keeps what it has read: later insertions
-                lo = *reinterpret_cast<const float4*>(src);       // into the same slot cannot take it away
-                hi = *reinterpret_cast<const float4*>(src + 4);
-                need = false;
-            }
-        }
-        // blend part of noise_iq.h:20-23
-        const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-        const float a = lo.x * gx + lo.y * fx;
-        const float b = lo.z * gx + lo.w * fx;
-        const float c = hi.x * gx + hi.y * fx;
-        const float d = hi.z * gx + hi.w * fx;
-        const float ab = a * gy + b * fy;
-        const float cd = c * gy + d * fy;
-        t += (ab * gz + cd * fz) * H;
-        H *= .5f;
+        nbits[k] = f2u(n);
+        slot[k] = (int)n & (HC_SLOTS - 1);
+        miss = miss || (S.tag[k][slot[k]] != nbits[k]);  // the four tag reads issue back to back
         p = p * 2.64f;                                   // fbm.h:6  p *= lacunarity
+    }
+    float t = 0.f, H = .5f;
+    if (!__ballot(active && miss)) {
+        // every active lane finds all four cells cached: straight-line reads + blends
+        float4 lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+            hi[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t += hc_blend(lo[k], hi[k], fx[k], fy[k], fz[k]) * H;
+            H *= .5f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* src = &S.h[k][slot[k]][0];
+            // `need` is the only per-lane state the miss loop tests: keeping the loop condition free of
+            // loop-invariant divergent terms stops the optimizer from unswitching the loop on them, which
+            // would make the cross-lane steps inside run with some lanes masked off.
+            bool need = active && (S.tag[k][slot[k]] != nbits[k]);
+            float4 lo = *reinterpret_cast<const float4*>(src);
+            float4 hi = *reinterpret_cast<const float4*>(src + 4);
+            while (__ballot(need)) {                     // insert the missing cells, then latch
+                hc_insert(S, k, nbits[k], slot[k], need, lane);
+                if (need && S.tag[k][slot[k]] == nbits[k]) {   // a lane keeps what it has read: later insertions
+                    lo = *reinterpret_cast<const float4*>(src);   // into the same slot cannot take it away
+                    hi = *reinterpret_cast<const float4*>(src + 4);
+                    need = false;
+                }
+            }
+            t += hc_blend(lo, hi, fx[k], fy[k], fz[k]) * H;
+            H *= .5f;
+        }
     }
     return t * smoothstep_(F.cov, F.cov_hi, t);          // :83-84
 }
