@@ -10,6 +10,20 @@
 
 namespace sbx {
 
+// "does any lane of the wave have x?" as an OPAQUE wave-uniform value.  Every branch and loop that
+// encloses cross-lane steps (ballot/readlane leader election, the 64-lane hash pass) must stay
+// wave-uniform with all lanes enabled.  Written as `if (__ballot(x))` / `while (__ballot(x))` the
+// optimizer is free to fold the test back to the per-lane condition x and to unswitch or re-nest the
+// region on per-lane terms; the region then runs with lanes masked off and the cooperative steps
+// silently lose their workers (observed: endless miss loops).  Passing the mask through an empty asm
+// with an SGPR constraint keeps the value uniform and hides its origin.
+__device__ __forceinline__ bool wave_any(bool x) {
+    const unsigned long long m = __ballot(x);
+    unsigned any = (unsigned)m | (unsigned)(m >> 32);
+    asm volatile("" : "+s"(any));
+    return any != 0;
+}
+
 __device__ __forceinline__ float clouds_density(const FrameClouds& F, v3 pos_in) {
     v3 pos = pos_in * .001f;                                   // cld_noise_factor, :20,66
     float shape = fbm<4>(pos * 2.03f, 2.64f, .5f, .5f, [](v3 p) { return noise_iq(p); });   // :72
@@ -135,6 +149,31 @@ __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, i
         __builtin_amdgcn_wave_barrier();
     }
 }
+// Slow path of one octave, out of line on purpose: called only when some active lane misses.  Inserts
+// the missing cells round by round (one cell per slot per round) and hands every active lane the 8
+// hashes of its cell BY VALUE: a lane latches its hashes as soon as its cell is present, so a later
+// round that reuses the slot cannot take them away.  Kept in its own function, with a single read site
+// and an opaque wave-uniform loop test (wave_any), because inlined into the callers the optimizer merged
+// the latch with the caller's pre-loop read and turned the loop into a per-lane (divergent) one — the
+// hash pass then ran with its worker lanes masked off and the loop never finished.
+struct H8 { float4 lo, hi; };
+__device__ __forceinline__ H8 hc_slow(WaveCache& S, int k, unsigned nbits, int slot, bool active, int lane) {
+    H8 r;
+    r.lo = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.hi = r.lo;
+    bool need = active;
+    for (int round = 0; round < 4096; ++round) {          // bounded on principle; needs <= 64 rounds
+        if (need && S.tag[k][slot] == nbits) {
+            r.lo = *reinterpret_cast<const float4*>(&S.h[k][slot][0]);
+            r.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
+            need = false;
+        }
+        if (!wave_any(need)) break;
+        hc_insert(S, k, nbits, slot, need, lane);
+    }
+    return r;
+}
+
 // trilinear blend of the 8 corner hashes (noise_iq.h:20-23)
 __device__ __forceinline__ float hc_blend(float4 lo, float4 hi, float fx, float fy, float fz) {
     const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
@@ -152,6 +191,7 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
     float fx[4], fy[4], fz[4];
     unsigned nbits[4];
     int slot[4];
+    bool ne[4];
     bool miss = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                        // lattice part of noise_iq.h:14-19, all octaves first
@@ -163,11 +203,12 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
         const float n = px + py * 157.0f + 113.0f * pz;
         nbits[k] = f2u(n);
         slot[k] = (int)n & (HC_SLOTS - 1);
-        miss = miss || (S.tag[k][slot[k]] != nbits[k]);  // the four tag reads issue back to back
+        ne[k] = (S.tag[k][slot[k]] != nbits[k]);         // the four tag reads issue back to back
+        miss |= ne[k];
         p = p * 2.64f;                                   // fbm.h:6  p *= lacunarity
     }
     float t = 0.f, H = .5f;
-    if (!__ballot(active && miss)) {
+    if (!wave_any(active && miss)) {
         // every active lane finds all four cells cached: straight-line reads + blends
         float4 lo[4], hi[4];
 #pragma unroll
@@ -183,29 +224,114 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float* src = &S.h[k][slot[k]][0];
-            // `need` is the only per-lane state the miss loop tests: keeping the loop condition free of
-            // loop-invariant divergent terms stops the optimizer from unswitching the loop on them, which
-            // would make the cross-lane steps inside run with some lanes masked off.
-            bool need = active && (S.tag[k][slot[k]] != nbits[k]);
-            float4 lo = *reinterpret_cast<const float4*>(src);
-            float4 hi = *reinterpret_cast<const float4*>(src + 4);
-            while (__ballot(need)) {                     // insert the missing cells, then latch
-                hc_insert(S, k, nbits[k], slot[k], need, lane);
-                if (need && S.tag[k][slot[k]] == nbits[k]) {   // a lane keeps what it has read: later insertions
-                    lo = *reinterpret_cast<const float4*>(src);   // into the same slot cannot take it away
-                    hi = *reinterpret_cast<const float4*>(src + 4);
-                    need = false;
-                }
+            H8 h;
+            if (wave_any(active && ne[k])) {
+                h = hc_slow(S, k, nbits[k], slot[k], active, lane);
+            } else {
+                h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+                h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
             }
-            t += hc_blend(lo, hi, fx[k], fy[k], fz[k]) * H;
+            t += hc_blend(h.lo, h.hi, fx[k], fy[k], fz[k]) * H;
             H *= .5f;
         }
     }
     return t * smoothstep_(F.cov, F.cov_hi, t);          // :83-84
 }
 
-__global__ void __launch_bounds__(WG_THREADS) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out) {
+// x/y half of the trilinear blend (the four x-mixes and two y-mixes of noise_iq.h:20-23)
+__device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, float fy, float& ab, float& cd) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const float a = lo.x * gx + lo.y * fx;
+    const float b = lo.z * gx + lo.w * fx;
+    const float c = hi.x * gx + hi.y * fx;
+    const float d = hi.z * gx + hi.w * fx;
+    ab = a * gy + b * fy;
+    cd = c * gy + d * fy;
+}
+
+// illuminate_volume's march (:106-113) when the light step L*dt has no x and no y component — the
+// reference's default sun_dir (0,0,-1), src/uniform_buffer.h:42.  Then pos.x + 0 and pos.y + 0 never change
+// along the light march, so for every octave floor/fract/smoothstep of x and y, the partial lattice index
+// p.x + 157 p.y, and — as long as the sample stays in the same lattice cell — the x- and y-mixes of the
+// blend are the SAME binary32 values for all light samples of the step.  They are computed once; per
+// sample only the z terms, the cell lookup and the final z-mix remain.  Every value is produced by the
+// same operations on the same inputs as in the general path, hence identical bits.
+__device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, WaveCache& S, int lane) {
+    float fx[4], fy[4], nxy[4], ab[4], cd[4];
+    unsigned cur[4];
+    {
+        float qx = (lp.x * .001f) * 2.03f, qy = (lp.y * .001f) * 2.03f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float px = floor_(qx), py = floor_(qy);
+            const float ax = qx - px, ay = qy - py;
+            fx[k] = ax * ax * (3.0f - 2.0f * ax);
+            fy[k] = ay * ay * (3.0f - 2.0f * ay);
+            nxy[k] = px + py * 157.0f;
+            cur[k] = 0x7fc00001u;
+            ab[k] = cd[k] = 0.f;
+            qx = qx * 2.64f; qy = qy * 2.64f;
+        }
+    }
+    float ltrans = 1.f;
+    for (int j = 0; j < F.lsteps; ++j) {
+        float fz[4];
+        unsigned nbits[4];
+        int slot[4];
+        bool ne[4];
+        bool miss = false;
+        float qz = (lp.z * .001f) * 2.03f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float pz = floor_(qz);
+            const float az = qz - pz;
+            fz[k] = az * az * (3.0f - 2.0f * az);
+            const float n = nxy[k] + 113.0f * pz;
+            nbits[k] = f2u(n);
+            slot[k] = (int)n & (HC_SLOTS - 1);
+            ne[k] = (S.tag[k][slot[k]] != nbits[k]);
+            miss |= ne[k];
+            qz = qz * 2.64f;
+        }
+        if (wave_any(lit && miss)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                H8 h;
+                if (wave_any(lit && ne[k])) {
+                    h = hc_slow(S, k, nbits[k], slot[k], lit, lane);
+                } else {
+                    h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+                    h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+                }
+                hc_blend_xy(h.lo, h.hi, fx[k], fy[k], ab[k], cd[k]);
+                cur[k] = nbits[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (wave_any(lit && nbits[k] != cur[k])) {   // some lit lane entered another cell in this octave
+                    const float4 lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+                    const float4 hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+                    hc_blend_xy(lo, hi, fx[k], fy[k], ab[k], cd[k]);
+                    cur[k] = nbits[k];
+                }
+            }
+        }
+        float t = 0.f, H = .5f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gz = 1.0f - fz[k];
+            t += (ab[k] * gz + cd[k] * fz[k]) * H;
+            H *= .5f;
+        }
+        const float d = t * smoothstep_(F.cov, F.cov_hi, t);
+        ltrans *= exp_(-d * F.sigma * F.dt);
+        lp = lp + lstep;
+    }
+    return ltrans;
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out) {
     __shared__ WaveCache cache[WG_THREADS / 64];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
@@ -226,26 +352,30 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds(FrameClouds F, RowMap M, 
     const bool marches = px.valid && !(cutoff < 0.05f);       // :212
     bool alive = marches;
     float transmittance = 1.f, radiance = 0.f, alpha = 0.f;
-    if (__ballot(alive)) {                                    // wave-uniform
+    if (wave_any(alive)) {                                    // wave-uniform
         const v3 projection = dir / dir.y;                    // render_clouds :153-202
         const v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
         const float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
         const v3 lstep = F.sun_dir * F.dt;
         float t = 0.f;
         for (int i = 0; i < F.steps; ++i) {
-            if (!__ballot(alive)) break;
+            if (!wave_any(alive)) break;
             const v3 pos = origin + t * projection;
             t += F.dt;
             const float density = coop_density(F, pos, alive, S, lane);
             const bool lit = alive && !(density < .005f);     // integrate_volume :132
-            if (__ballot(lit)) {
+            if (wave_any(lit)) {
                 const float T_i = exp_(-density * F.sigma * F.dt);
                 v3 lp = pos + lstep;                           // illuminate_volume :91-123
                 float ltrans = 1.f;
-                for (int j = 0; j < F.lsteps; ++j) {
-                    const float d = coop_density(F, lp, lit, S, lane);
-                    ltrans *= exp_(-d * F.sigma * F.dt);
-                    lp = lp + lstep;
+                if (lstep.x == 0.f && lstep.y == 0.f) {        // uniform (kernel argument): z-only light step
+                    ltrans = light_march_z(F, lp, lstep, lit, S, lane);
+                } else {
+                    for (int j = 0; j < F.lsteps; ++j) {
+                        const float d = coop_density(F, lp, lit, S, lane);
+                        ltrans *= exp_(-d * F.sigma * F.dt);
+                        lp = lp + lstep;
+                    }
                 }
                 const float illum = ltrans * F.sun_power * phase;
                 if (lit) {
