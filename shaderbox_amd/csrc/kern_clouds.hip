@@ -331,66 +331,78 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
     return ltrans;
 }
 
+// sky colour of a view direction (render_sky_color :36-46)
+__device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
+    float sun_amount = fmax_(dot(dir, F.sun_dir), 0.f);
+    v3 sky = mix3(V3(.0f, .1f, .4f), V3(.3f, .6f, .8f), 1.0f - dir.y);
+    sky = sky + F.sun_color * fmin_(pow_(sun_amount, 1500.0f) * 5.0f, 1.0f);
+    sky = sky + F.sun_color * fmin_(pow_(sun_amount, 10.0f) * .6f, 1.0f);
+    return abs3(sky);
+}
+
 __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out) {
     __shared__ WaveCache cache[WG_THREADS / 64];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
     __builtin_amdgcn_wave_barrier();
-    const Pixel px = pixel_of_thread(M);
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
-    const v3 dir = primary_dir(F.cam, pc);
 
-    // render_sky_color :36-46
-    float sun_amount = fmax_(dot(dir, F.sun_dir), 0.f);
-    v3 sky = mix3(V3(.0f, .1f, .4f), V3(.3f, .6f, .8f), 1.0f - dir.y);
-    sky = sky + F.sun_color * fmin_(pow_(sun_amount, 1500.0f) * 5.0f, 1.0f);
-    sky = sky + F.sun_color * fmin_(pow_(sun_amount, 10.0f) * .6f, 1.0f);
-    sky = abs3(sky);
-
-    const float cutoff = dot(dir, V3(0, 1, 0));
-    const bool marches = px.valid && !(cutoff < 0.05f);       // :212
-    bool alive = marches;
     float transmittance = 1.f, radiance = 0.f, alpha = 0.f;
-    if (wave_any(alive)) {                                    // wave-uniform
-        const v3 projection = dir / dir.y;                    // render_clouds :153-202
-        const v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
-        const float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
-        const v3 lstep = F.sun_dir * F.dt;
-        float t = 0.f;
-        for (int i = 0; i < F.steps; ++i) {
-            if (!wave_any(alive)) break;
-            const v3 pos = origin + t * projection;
-            t += F.dt;
-            const float density = coop_density(F, pos, alive, S, lane);
-            const bool lit = alive && !(density < .005f);     // integrate_volume :132
-            if (wave_any(lit)) {
-                const float T_i = exp_(-density * F.sigma * F.dt);
-                v3 lp = pos + lstep;                           // illuminate_volume :91-123
-                float ltrans = 1.f;
-                if (lstep.x == 0.f && lstep.y == 0.f) {        // uniform (kernel argument): z-only light step
-                    ltrans = light_march_z(F, lp, lstep, lit, S, lane);
-                } else {
-                    for (int j = 0; j < F.lsteps; ++j) {
-                        const float d = coop_density(F, lp, lit, S, lane);
-                        ltrans *= exp_(-d * F.sigma * F.dt);
-                        lp = lp + lstep;
+    bool marches;
+    {
+        // Only what the march needs stays live across it (origin, projection, phase): the view direction
+        // and the sky colour are recomputed in the epilogue from the pixel coordinates — same operations,
+        // same bits — which keeps the register budget of the march at 4 waves per SIMD without spills.
+        const Pixel px = pixel_of_thread(M);
+        const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+        const v3 dir = primary_dir(F.cam, pc);
+        const float cutoff = dot(dir, V3(0, 1, 0));
+        marches = px.valid && !(cutoff < 0.05f);                  // :212
+        bool alive = marches;
+        if (wave_any(alive)) {                                    // wave-uniform
+            const v3 projection = dir / dir.y;                    // render_clouds :153-202
+            const v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
+            const float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
+            const v3 lstep = F.sun_dir * F.dt;
+            float t = 0.f;
+            for (int i = 0; i < F.steps; ++i) {
+                if (!wave_any(alive)) break;
+                const v3 pos = origin + t * projection;
+                t += F.dt;
+                const float density = coop_density(F, pos, alive, S, lane);
+                const bool lit = alive && !(density < .005f);     // integrate_volume :132
+                if (wave_any(lit)) {
+                    const float T_i = exp_(-density * F.sigma * F.dt);
+                    v3 lp = pos + lstep;                           // illuminate_volume :91-123
+                    float ltrans = 1.f;
+                    if (lstep.x == 0.f && lstep.y == 0.f) {        // uniform (kernel argument): z-only light step
+                        ltrans = light_march_z(F, lp, lstep, lit, S, lane);
+                    } else {
+                        for (int j = 0; j < F.lsteps; ++j) {
+                            const float d = coop_density(F, lp, lit, S, lane);
+                            ltrans *= exp_(-d * F.sigma * F.dt);
+                            lp = lp + lstep;
+                        }
+                    }
+                    const float illum = ltrans * F.sun_power * phase;
+                    if (lit) {
+                        transmittance *= T_i;
+                        radiance += (density * F.sigma) * illum * transmittance * F.dt;
+                        alpha += (1.f - T_i) * (1.f - alpha);
                     }
                 }
-                const float illum = ltrans * F.sun_power * phase;
-                if (lit) {
-                    transmittance *= T_i;
-                    radiance += (density * F.sigma) * illum * transmittance * F.dt;
-                    alpha += (1.f - T_i) * (1.f - alpha);
-                }
+                if (alpha > .999f) alive = false;                 // :197
             }
-            if (alpha > .999f) alive = false;                 // :197
         }
     }
+    const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 dir = primary_dir(F.cam, pc);
+    const v3 sky = clouds_sky(F, dir);
     v3 col = sky;
     if (marches) {
-        const float a = alpha * smoothstep_(.0f, .2f, cutoff);
+        const float a = alpha * smoothstep_(.0f, .2f, dot(dir, V3(0, 1, 0)));
         col = abs3(mix3(sky, V3s(radiance), a));               // :215-217
     }
     store_rgba(out, px.idx, to_srgb(col));
