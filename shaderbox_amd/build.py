@@ -18,13 +18,16 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "lib", "libsbx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fno-slp-vectorize",
          "-fno-gpu-flush-denormals-to-zero", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mfma",
          "-Wall", "-Wno-unused-function"]
 SOURCES = ["kern_clouds.hip", "kern_egg.hip", "kern_raytracer.hip", "kern_atmosphere.hip", "kern_sdf_ao.hip",
            "kern_planet.hip", "kern_util.hip", "sbx_capi.hip"]
-# per-file extra flags.  kern_clouds: without the SLP vectoriser (v_pk_*_f32 need their constants in VGPR
-# pairs, ~20 extra live registers) the kernel fits 4 waves/SIMD with a handful of spills instead of 45.
-EXTRA = {"kern_clouds.hip": ["-fno-slp-vectorize"]}
+# -fno-slp-vectorize: measured on MI355X, the SLP vectoriser's v_pk_{mul,add}_f32 are a net loss for every
+# kernel here (CLOUDS 8.7 -> 6.5 ms, PLANET 57 -> 41 ms, SDF_AO 1.75 -> 1.37 ms at 4K/8K): a packed op issues
+# in ~4.7 cycles against 2 x 2.9 for the scalar pair (profiles/r01_ubench_valu.txt), needs its constants in
+# VGPR pairs (no literals), and the extra live registers cost a wave of occupancy.
+EXTRA = {}
 HEADERS = ["sbx_math.h", "sbx_vec.h", "sbx_frame.h", "sbx_device.h", "sbx_noise.h", "../../include/sbx.h"]
 
 
