@@ -35,6 +35,9 @@ sys.path.insert(0, ROOT)
 # transcendental counted as ONE op), measured at the listed resolution
 OPS_PER_PIXEL = {"clouds": 60248.0, "egg": 15276.0, "raytracer": 564.0, "atmosphere": 2493.0,
                  "planet": 21253.0, "sdf_ao": 7255.0}
+# HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (WRITE_SIZE + 2 x FETCH_SIZE,
+# KB -> bytes, per MI355X_MICROARCH.md), for the default workload only; see DESIGN.md §6
+MEASURED_TRAFFIC_BYTES = {("clouds", 3840, 2160): int(136373 * 1024 + 2 * 2715.58 * 1024)}   # profiles/r01_clouds_v5_*
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0
 
@@ -54,7 +57,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the torch.distributed/RCCL path even with one rank (smoke test of the N>1 code on 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-row-stride", type=int, default=8)
+    ap.add_argument("--cpu-row-stride", type=int, default=0,
+                    help="cpu_baseline renders every k-th row of the frame (0 = pick from the core count: ~10 s of wall time)")
     args = ap.parse_args()
 
     import torch
@@ -143,7 +147,8 @@ def main():
                         "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5),
                         "ops_per_pixel": ops, "pixels_per_launch": launch_pixels,
-                        "kernel_ms": round(kmean, 4), "traffic": None,
+                        "kernel_ms": round(kmean, 4),
+                        "traffic": MEASURED_TRAFFIC_BYTES.get((app, W, H)) if world == 1 else None,
                         "hbm": {"achieved": round(16.0 * launch_pixels / (kmean * 1e-3) / 1e9, 2),
                                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_pixel": 16}}
         out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(value, 3),
@@ -168,8 +173,10 @@ def cpu_baseline(app, W, H, t, stride):
     """The CPU oracle ('port' of the reference path, oracle/) on this host's cores, bounded sample."""
     from oracle.oracle import APP_IDS, Oracle
     o = Oracle()
-    rows = list(range(stride // 2, H, stride))
     cores = os.cpu_count() or 1
+    if stride <= 0:
+        stride = 8 if cores <= 16 else (4 if cores <= 64 else 2)
+    rows = list(range(stride // 2, H, stride))
     o.render_rows(APP_IDS[app], W, H, t, rows[:cores], threads=cores)   # warm the threads/caches
     t0 = time.perf_counter()
     o.render_rows(APP_IDS[app], W, H, t, rows, threads=cores)
