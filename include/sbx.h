@@ -136,6 +136,17 @@ int sbx_set_variant(sbx_ctx* ctx, int variant);
 int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, float* out,
                   size_t n, void* stream);
 
+/* The noise library as standalone functions over n points (xyz interleaved, device arrays), 3 floats out
+ * per point: "noise_iq" (src/noise_iq.h:11-29, out[0]); "hash_w" (src/noise_worley.h:5-17);
+ * "noise_w" (:20-51; params[0] = domain_repeat; out = sqrt F1, sqrt F2, |cell id|);
+ * "fbm_worley_tile" (src/fbm.h:8 as instantiated at util/ddsvolgen/src/ddsvolgen.cpp:52;
+ * params = lacunarity, init_gain, gain; out[0]). */
+int sbx_noise_eval(sbx_ctx* ctx, const char* fn, const float* xyz, const float* params, float* out,
+                   size_t n, void* stream);
+/* The size^3 RGBA32F noise volume util/ddsvolgen bakes (ddsvolgen.cpp:101-117): R =
+ * fbm_worley_tile((xyz + .5)/size, 2, 1, .5), G = B = A = 0, x fastest.  `rgba`: size^3 * 4 floats. */
+int sbx_worley_volume(sbx_ctx* ctx, int size, float* rgba, void* stream);
+
 const char* sbx_last_error(sbx_ctx* ctx);
 const char* sbx_version(void);
 

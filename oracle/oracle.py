@@ -35,6 +35,8 @@ class Oracle:
                                               ctypes.c_int, fp, ctypes.c_int]
         self.lib.sbxo_math.argtypes = [ctypes.c_char_p, fp, fp, fp, ctypes.c_long]
         self.lib.sbxo_kat.argtypes = [ctypes.c_char_p, fp, fp]
+        self.lib.sbxo_noise.argtypes = [ctypes.c_char_p, fp, fp, fp, ctypes.c_long]
+        self.lib.sbxo_worley_volume.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
 
     @staticmethod
     def _uni(width, height, time, mouse):
@@ -86,6 +88,21 @@ class Oracle:
         rc = self.lib.sbxo_math(fn.encode(), self._fp(a), self._fp(b), self._fp(out), a.size)
         if rc != 0:
             raise ValueError("oracle: unknown math function %r" % fn)
+        return out
+
+    def noise(self, fn, xyz, par=(0.0, 0.0, 0.0)):
+        """library noise functions over points xyz[n,3] -> float32 [n,3]"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        par = np.ascontiguousarray(np.asarray(par, dtype=np.float32))
+        out = np.zeros_like(xyz)
+        if self.lib.sbxo_noise(fn.encode(), self._fp(xyz), self._fp(par), self._fp(out), len(xyz)) != 0:
+            raise ValueError("oracle: unknown noise function %r" % fn)
+        return out
+
+    def worley_volume(self, size, z0=0, z1=None):
+        z1 = size if z1 is None else z1
+        out = np.zeros((z1 - z0, size, size, 4), dtype=np.float32)
+        self.lib.sbxo_worley_volume(int(size), int(z0), int(z1), self._fp(out))
         return out
 
     def kat(self, name, args, nout):

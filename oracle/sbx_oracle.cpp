@@ -115,6 +115,39 @@ int sbxo_math(const char* fn, const float* a, const float* b, float* out, long n
     return 0;
 }
 
+/* elementwise library noise functions over n points (xyz interleaved); out has 3 floats per point.
+ * fn: "noise_iq" (out[0]), "hash_w", "noise_w" (par[0] = domain_repeat), "fbm_worley_tile"
+ * (par = lacunarity, init_gain, gain; out[0]) */
+int sbxo_noise(const char* fn, const float* xyz, const float* par, float* out, long n) {
+    std::string f(fn);
+    for (long i = 0; i < n; ++i) {
+        vec3 p(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        vec3 r(0, 0, 0);
+        if (f == "noise_iq") r.x = noise_iq(p);
+        else if (f == "hash_w") r = hash_w(p);
+        else if (f == "noise_w") r = noise_w(p, par[0]);
+        else if (f == "fbm_worley_tile") r.x = fbm_worley_tile(p, par[0], par[1], par[2]);
+        else return -1;
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+    return 0;
+}
+
+/* The noise volume of util/ddsvolgen (/root/reference/util/ddsvolgen/src/ddsvolgen.cpp:101-117):
+ * size^3 voxels, RGBA32F, R = fbm_worley_tile((xyz + .5)/size, 2, 1, .5) (:52-61), G = B = A = 0,
+ * x fastest.  Slices [z0, z1). */
+int sbxo_worley_volume(int size, int z0, int z1, float* out) {
+    for (int z = z0; z < z1; ++z)
+        for (int y = 0; y < size; ++y)
+            for (int x = 0; x < size; ++x) {
+                vec3 pos = (vec3((float)x, (float)y, (float)z) + .5f) / (float)size;
+                float* o = out + (((size_t)(z - z0) * size + y) * size + x) * 4;
+                o[0] = fbm_worley_tile(pos, 2.f, 1.f, .5f);
+                o[1] = o[2] = o[3] = 0.f;
+            }
+    return 0;
+}
+
 /* Known-answer hooks: evaluate one library/app function on explicit arguments.
  * `in` / `out` are flat float arrays; meaning per name is listed in tests/test_oracle_kat.py.
  * Uniform-dependent functions take {W, H, mouse.x, mouse.y, time} as the first 5 inputs. */

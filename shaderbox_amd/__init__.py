@@ -86,6 +86,8 @@ def load_library(path=None):
     lib.sbx_set_variant.argtypes = [vp, ci]
     lib.sbx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.sbx_math_eval.argtypes = [vp, ctypes.c_char_p, fp, fp, fp, ctypes.c_size_t, vp]
+    lib.sbx_noise_eval.argtypes = [vp, ctypes.c_char_p, fp, fp, fp, ctypes.c_size_t, vp]
+    lib.sbx_worley_volume.argtypes = [vp, ci, fp, vp]
     lib.sbx_last_error.argtypes = [vp]
     lib.sbx_last_error.restype = ctypes.c_char_p
     lib.sbx_version.restype = ctypes.c_char_p
@@ -216,6 +218,22 @@ class Renderer:
         ms = ctypes.c_float()
         self._check(self.lib.sbx_last_kernel_ms(self.ctx, ctypes.byref(ms)))
         return ms.value
+
+    def noise(self, fn, xyz, params=(0.0, 0.0, 0.0)):
+        """Library noise functions (noise_iq / hash_w / noise_w / fbm_worley_tile) over points xyz[n,3] -> [n,3]."""
+        xyz = xyz.to(self.tdev, self.torch.float32).contiguous().view(-1, 3)
+        par = (ctypes.c_float * 3)(*[float(v) for v in params])
+        out = self.torch.empty_like(xyz)
+        self._check(self.lib.sbx_noise_eval(self.ctx, fn.encode(), ctypes.c_void_p(xyz.data_ptr()),
+                                            ctypes.cast(par, ctypes.c_void_p), ctypes.c_void_p(out.data_ptr()),
+                                            xyz.shape[0], self._stream()))
+        return out
+
+    def worley_volume(self, size=128):
+        """The ddsvolgen noise volume: float32 [size, size, size, 4] (z, y, x, rgba)."""
+        out = self.torch.empty((size, size, size, 4), dtype=self.torch.float32, device=self.tdev)
+        self._check(self.lib.sbx_worley_volume(self.ctx, int(size), ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
 
     def math(self, fn, a, b=None):
         """Evaluate the device math spec elementwise (parity tests)."""

@@ -368,6 +368,36 @@ int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, 
     return SBX_OK;
 }
 
+int sbx_noise_eval(sbx_ctx* ctx, const char* fn, const float* xyz, const float* params, float* out, size_t n,
+                   void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!fn || !xyz || !out) return fail(ctx, SBX_ERR_ARG, "NULL argument");
+    static const char* names[] = {"noise_iq", "hash_w", "noise_w", "fbm_worley_tile"};
+    int id = -1;
+    for (int i = 0; i < 4; ++i) if (std::strcmp(fn, names[i]) == 0) id = i;
+    if (id < 0) return fail(ctx, SBX_ERR_ARG, "unknown noise function");
+    const float zero[3] = {0.f, 0.f, 0.f};
+    if (id >= 2 && !params) return fail(ctx, SBX_ERR_ARG, "noise_w / fbm_worley_tile need params");
+    if (n == 0) return SBX_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    launch_noise_eval(id, xyz, params ? params : zero, out, n, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "noise_eval launch", e);
+    return SBX_OK;
+}
+
+int sbx_worley_volume(sbx_ctx* ctx, int size, float* rgba, void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!rgba || size <= 0 || size > 1024) return fail(ctx, SBX_ERR_ARG, "bad volume arguments");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    launch_worley_volume(size, rgba, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "worley_volume launch", e);
+    return SBX_OK;
+}
+
 const char* sbx_last_error(sbx_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 const char* sbx_version(void) { return "libsbx 0.1 (gfx950, ABI 1)"; }
 

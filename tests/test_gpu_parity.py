@@ -179,3 +179,23 @@ def test_full_size_rows_match_oracle(renderer, oracle, app, w, h, rows):
     maxd, nbits = compare(got, ref)
     print("%s %dx%d rows %s: max|diff|=%.3g differing pixels=%d" % (app, w, h, rows, maxd, nbits))
     assert maxd <= 1e-4 and nbits == 0
+
+
+def test_noise_library_matches_oracle(renderer, oracle):
+    """noise_iq / hash_w / noise_w / fbm_worley_tile as library functions, and the
+    ddsvolgen volume; bit-for-bit against the oracle (which test_oracle_kat pins to Appendix C)."""
+    import torch
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-20, 20, (20000, 3)), rng.uniform(0, 1, (20000, 3)),
+                          [[.1, .2, .3], [.77, .01, .5], [1, 2, 3], [0, 0, 0], [-7.25, 40.5, 113.125]]]).astype(np.float32)
+    for fn, par in [("noise_iq", (0, 0, 0)), ("hash_w", (0, 0, 0)), ("noise_w", (4, 0, 0)), ("noise_w", (8, 0, 0)),
+                    ("fbm_worley_tile", (2, 1, .5)), ("fbm_worley_tile", (4, 1, .5))]:
+        got = renderer.noise(fn, torch.from_numpy(pts), par).cpu().numpy()
+        want = oracle.noise(fn, pts, par)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (fn, par)
+    vol = renderer.worley_volume(128)
+    ref = oracle.worley_volume(128, 0, 2)
+    assert np.array_equal(vol[:2].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    ref = oracle.worley_volume(128, 77, 78)
+    assert np.array_equal(vol[77:78].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert abs(float(vol[0, 0, 0, 0]) - 1.35212326) < 2e-2          # Appendix C: ddsvolgen voxel (0,0,0)
