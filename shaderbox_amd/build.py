@@ -28,7 +28,7 @@ SOURCES = ["kern_clouds.hip", "kern_egg.hip", "kern_raytracer.hip", "kern_atmosp
 # in ~4.7 cycles against 2 x 2.9 for the scalar pair (profiles/r01_ubench_valu.txt), needs its constants in
 # VGPR pairs (no literals), and the extra live registers cost a wave of occupancy.
 EXTRA = {}
-HEADERS = ["sbx_math.h", "sbx_vec.h", "sbx_frame.h", "sbx_device.h", "sbx_noise.h", "../../include/sbx.h"]
+HEADERS = ["sbx_math.h", "sbx_vec.h", "sbx_frame.h", "sbx_device.h", "sbx_noise.h", "sbx_hashcache.h", "../../include/sbx.h"]
 
 
 def _newer(target, deps):

@@ -6,23 +6,10 @@
 // henyey_greenstein_phase_func src/volumetric.h:27-33 with hg_g = .2 (:5).
 #include "sbx_device.h"
 #include "sbx_noise.h"
+#include "sbx_hashcache.h"
 #include <cstdlib>
 
 namespace sbx {
-
-// "does any lane of the wave have x?" as an OPAQUE wave-uniform value.  Every branch and loop that
-// encloses cross-lane steps (ballot/readlane leader election, the 64-lane hash pass) must stay
-// wave-uniform with all lanes enabled.  Written as `if (__ballot(x))` / `while (__ballot(x))` the
-// optimizer is free to fold the test back to the per-lane condition x and to unswitch or re-nest the
-// region on per-lane terms; the region then runs with lanes masked off and the cooperative steps
-// silently lose their workers (observed: endless miss loops).  Passing the mask through an empty asm
-// with an SGPR constraint keeps the value uniform and hides its origin.
-__device__ __forceinline__ bool wave_any(bool x) {
-    const unsigned long long m = __ballot(x);
-    unsigned any = (unsigned)m | (unsigned)(m >> 32);
-    asm volatile("" : "+s"(any));
-    return any != 0;
-}
 
 __device__ __forceinline__ float clouds_density(const FrameClouds& F, v3 pos_in) {
     v3 pos = pos_in * .001f;                                   // cld_noise_factor, :20,66
@@ -115,77 +102,6 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, Ro
 // (The first cooperative version re-elected the distinct cells of every sample: 11.6 ms per 4K frame,
 // of which 2.3 ms election and 2.0 ms hash passes)
 // ---------------------------------------------------------------------------------------------
-constexpr int HC_SLOTS = 64;
-struct alignas(16) WaveCache {
-    float h[4][HC_SLOTS][8];          // corner order: +0,+1,+157,+158,+113,+114,+270,+271
-    unsigned tag[4][HC_SLOTS];        // bits of n; 0x7fc00001 (a NaN) = empty
-    unsigned ins_tag[8], ins_slot[8]; // cells being inserted in the current pass
-};
-
-// miss path, one octave: the lanes in `need` lack their cell.  Leaders (one per distinct slot) are
-// elected with ballot/readlane, up to 8 cells per pass; lane (r, c) evaluates corner c of pending cell r.
-__device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, int slot, bool need, int lane) {
-    const int corner = lane & 7;
-    const float off = (corner & 1 ? 1.0f : 0.0f) + (corner & 2 ? 157.0f : 0.0f) + (corner & 4 ? 113.0f : 0.0f);
-    unsigned long long m = __ballot(need);
-    while (m) {
-        int cnt = 0;
-        while (m && cnt < 8) {
-            const int leader = __ffsll((long long)m) - 1;
-            const unsigned n0 = (unsigned)__builtin_amdgcn_readlane((int)nbits, leader);
-            const int s0 = __builtin_amdgcn_readlane(slot, leader);
-            if (lane == cnt) { S.ins_tag[cnt] = n0; S.ins_slot[cnt] = (unsigned)s0; }
-            m &= ~__ballot(slot == s0);          // one cell per slot per call; losers are served in the next round
-            ++cnt;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < cnt * 8) {
-            const int r = lane >> 3;
-            const unsigned n0 = S.ins_tag[r];
-            const int s0 = (int)S.ins_slot[r];
-            S.h[k][s0][corner] = hash1(u2f(n0) + off);
-            if (corner == 0) S.tag[k][s0] = n0;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-// Slow path of one octave, out of line on purpose: called only when some active lane misses.  Inserts
-// the missing cells round by round (one cell per slot per round) and hands every active lane the 8
-// hashes of its cell BY VALUE: a lane latches its hashes as soon as its cell is present, so a later
-// round that reuses the slot cannot take them away.  Kept in its own function, with a single read site
-// and an opaque wave-uniform loop test (wave_any), because inlined into the callers the optimizer merged
-// the latch with the caller's pre-loop read and turned the loop into a per-lane (divergent) one — the
-// hash pass then ran with its worker lanes masked off and the loop never finished.
-struct H8 { float4 lo, hi; };
-__device__ __forceinline__ H8 hc_slow(WaveCache& S, int k, unsigned nbits, int slot, bool active, int lane) {
-    H8 r;
-    r.lo = make_float4(0.f, 0.f, 0.f, 0.f);
-    r.hi = r.lo;
-    bool need = active;
-    for (int round = 0; round < 4096; ++round) {          // bounded on principle; needs <= 64 rounds
-        if (need && S.tag[k][slot] == nbits) {
-            r.lo = *reinterpret_cast<const float4*>(&S.h[k][slot][0]);
-            r.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
-            need = false;
-        }
-        if (!wave_any(need)) break;
-        hc_insert(S, k, nbits, slot, need, lane);
-    }
-    return r;
-}
-
-// trilinear blend of the 8 corner hashes (noise_iq.h:20-23)
-__device__ __forceinline__ float hc_blend(float4 lo, float4 hi, float fx, float fy, float fz) {
-    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-    const float a = lo.x * gx + lo.y * fx;
-    const float b = lo.z * gx + lo.w * fx;
-    const float c = hi.x * gx + hi.y * fx;
-    const float d = hi.z * gx + hi.w * fx;
-    const float ab = a * gy + b * fy;
-    const float cd = c * gy + d * fy;
-    return ab * gz + cd * fz;
-}
-
 __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, bool active, WaveCache& S, int lane) {
     v3 p = (pos_in * .001f) * 2.03f;                     // :66,72
     float fx[4], fy[4], fz[4];

@@ -9,6 +9,12 @@
 // flows to the framebuffer exactly as IEEE arithmetic dictates.
 #include "sbx_device.h"
 #include "sbx_noise.h"
+#include "sbx_hashcache.h"
+
+// All noise_iq evaluations go through the per-wave lattice-hash cache (sbx_hashcache.h): octave k of any fBm
+// uses table k & 3.  The cross-lane steps of the cache need wave-uniform control flow, so lanes never leave
+// a loop early; they carry predicates (`tm` terrain march, `cm` cloud march, `hitl` ground hit) and the loops
+// test wave_any().  A predicated-off lane still evaluates the arithmetic (harmlessly) but commits nothing.
 
 namespace sbx {
 
@@ -21,25 +27,74 @@ __device__ __forceinline__ Vol make_vol(v3 o) { return Vol{o, o, 0.f, 1.f, 0.f, 
 __device__ __forceinline__ float band(float start, float peak, float end, float t) {   // util.h:103-112
     return smoothstep_(start, peak, t) * (1.f - smoothstep_(peak, end, t));
 }
-__device__ __forceinline__ float anoise(v3 p) { return abs_(noise_iq(p) * 2.f - 1.f); }          // :65
-__device__ __forceinline__ float rnoise(v3 p) { return 1.f - abs_(noise_iq(p) * 2.f - 1.f); }    // :167
 
-__device__ __forceinline__ void clouds_map(Vol& c, float t_step) {                     // :102-119 + :79-100
-    float dens = fbm<4>(c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f), 2.0276f, .5f, .5f, anoise);
+// DECL_FBM_FUNC(name, OCT, basis(noise_iq(p)))  fbm.h:6 — the OCT noise values come from one cooperative batch
+// MODE 0: noise(p)   1: anoise = |2 noise - 1| (:65)   2: rnoise = 1 - |2 noise - 1| (:167)
+template <int MODE>
+__device__ __forceinline__ float pl_basis(float n) {
+    if (MODE == 0) return n;
+    if (MODE == 1) return abs_(n * 2.f - 1.f);
+    return 1.f - abs_(n * 2.f - 1.f);
+}
+template <int OCT, int MODE>
+__device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_gain, float gain) {
+    float H = init_gain, t = 0.f;
+#pragma unroll
+    for (int i = 0; i < OCT; ++i) {
+        t += pl_basis<MODE>(nz[i]) * H;
+        H *= gain;
+    }
+    return t;
+}
+
+// fBm over the cached noise: octaves are fetched in cooperative batches of <= 4 (register budget), the sum
+// runs in octave order exactly as fbm.h:6 (t += basis * H; p *= lacunarity; H *= gain)
+template <int OCT, int MODE>
+__device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, float init_gain, float gain, bool on, int lane) {
+    float H = init_gain, t = 0.f;
+#pragma unroll
+    for (int base = 0; base < OCT; base += 4) {
+        constexpr int REM = OCT;   // (constexpr arithmetic below)
+        if (base + 4 <= OCT) {
+            v3 p[4]; int tab[4]; float nz[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
+            coop_noise_n<4>(S, p, tab, on, lane, nz);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
+        } else {
+            constexpr int R = REM % 4;
+            v3 p[R > 0 ? R : 1]; int tab[R > 0 ? R : 1]; float nz[R > 0 ? R : 1];
+#pragma unroll
+            for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
+            coop_noise_n<(R > 0 ? R : 1)>(S, p, tab, on, lane, nz);
+#pragma unroll
+            for (int i = 0; i < R; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
+        }
+    }
+    return t;
+}
+
+// clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
+__device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, bool on, int lane) {
+    float dens = coop_fbm<4, 1>(S, c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f), 2.0276f, .5f, .5f, on, lane);
     const float cov = .29475675f, fuzzy = .0335f;
     dens *= smoothstep_(cov, cov + fuzzy, dens);
     dens *= band(.2f, .35f, .65f, c.height);
     const float T_i = exp_(-30.034f * dens * t_step);
-    c.transmittance *= T_i;
-    c.radiance += dens * (exp_(c.height) / .055f) * c.transmittance * t_step;
-    c.alpha += (1.f - T_i) * (1.f - c.alpha);
+    if (on) {
+        c.transmittance *= T_i;
+        c.radiance += dens * (exp_(c.height) / .055f) * c.transmittance * t_step;
+        c.alpha += (1.f - T_i) * (1.f - c.alpha);
+    }
 }
 
+// sdf_terrain_map / sdf_terrain_map_detail :175-199
 template <int OCT>
-__device__ __forceinline__ v2 terrain_map(v3 pos) {                                    // :175-199
-    const float h0 = fbm<OCT>(pos * 2.0987f, 2.0244f, .454f, .454f, [](v3 p) { return noise_iq(p); });
+__device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lane) {
+    const float h0 = coop_fbm<OCT, 0>(S, pos * 2.0987f, 2.0244f, .454f, .454f, on, lane);
     const float n0 = smoothstep_(.35f, 1.f, h0);
-    const float h1 = fbm<OCT>(pos * 1.50987f + V3(1.9489f, 2.435f, .5483f), 2.0244f, .454f, .454f, rnoise);
+    const float h1 = coop_fbm<OCT, 2>(S, pos * 1.50987f + V3(1.9489f, 2.435f, .5483f), 2.0244f, .454f, .454f, on, lane);
     const float n1 = smoothstep_(.6f, 1.f, h1);
     const float n = n0 + n1;
     return V2(length(pos) - 1.f - n * PL_MAX_HEIGHT, n / PL_MAX_HEIGHT);
@@ -64,9 +119,12 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
     return abs3(sky);
 }
 
-__global__ void __launch_bounds__(WG_THREADS) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
+__global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
+    __shared__ WaveCache cache[WG_THREADS / 64];
+    const int lane = threadIdx.x & 63;
+    WaveCache& S = cache[threadIdx.x >> 6];
+    hc_init(S, lane);
     const Pixel px = pixel_of_thread(M);
-    if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
 
@@ -89,44 +147,60 @@ __global__ void __launch_bounds__(WG_THREADS) k_planet(FramePlanet F, RowMap M, 
             }
         }
     }
-    v3 col;
-    if (!hit_atm) {
-        col = planet_background(rd);                              // :316-318
-    } else {
+    hit_atm = hit_atm && px.valid;
+    v3 col = V3(0, 0, 0);
+    if (wave_any(hit_atm)) {
+        // terrain march :328-342
         float t = 0.f;
         v2 df = V2(1, PL_MAX_HEIGHT);
         v3 pos = V3(0, 0, 0);
         float max_cld = PL_MAX_RAY_DIST;
-        for (int i = 0; i < 120; ++i) {                           // :328-342
-            if (t > PL_MAX_RAY_DIST) break;
+        bool tm = hit_atm;
+        for (int i = 0; i < 120; ++i) {
+            if (tm && t > PL_MAX_RAY_DIST) tm = false;           // `if (t > max_ray_dist) break;`
+            if (!wave_any(tm)) break;
             const v3 o = hit_o + t * rd;
-            pos = mul(F.rot, o - V3(0, 0, 0));
-            df = terrain_map<3>(pos);
-            if (df.x < .005f) { max_cld = t; break; }
-            t += df.x * .4567f;
+            const v3 p = mul(F.rot, o - V3(0, 0, 0));
+            const v2 d = terrain_map<3>(S, p, tm, lane);
+            if (tm) {
+                pos = p;
+                df = d;
+                if (df.x < .005f) { max_cld = t; tm = false; }
+                else t += df.x * .4567f;
+            }
         }
-        Vol cloud = make_vol(hit_o);                              // :345-346, clouds_march :121-141
+        // clouds_march :121-141 on construct_volume(hit.origin)
+        Vol cloud = make_vol(hit_o);
         {
             const float t_step = PL_MAX_RAY_DIST / 75.f;
             float tc = 0.f;
+            bool cm = hit_atm;
             for (int i = 0; i < 75; ++i) {
-                if (tc > max_cld || cloud.alpha >= 1.f) break;
+                if (cm && (tc > max_cld || cloud.alpha >= 1.f)) cm = false;   // `return` of clouds_march
+                if (!wave_any(cm)) break;
                 const v3 o = cloud.origin + tc * rd;
-                cloud.pos = mul(F.rot_cloud, o - V3(0, 0, 0));
-                cloud.height = (length(cloud.pos) - 1.f) / PL_MAX_HEIGHT;
+                const v3 cp = mul(F.rot_cloud, o - V3(0, 0, 0));
+                const float ch = (length(cp) - 1.f) / PL_MAX_HEIGHT;
+                if (cm) { cloud.pos = cp; cloud.height = ch; }
                 tc += t_step;
-                clouds_map(cloud, t_step);
+                clouds_map(S, cloud, t_step, cm, lane);
             }
         }
-        if (df.x < .005f) {                                       // :349-363
+        const bool hitl = hit_atm && (df.x < .005f);              // :349
+        v3 c_hit = V3(0, 0, 0);
+        if (wave_any(hitl)) {
             // illuminate :238-298
             const float h = df.y;
             const v3 w_normal = normalize(pos);
             const float e = 0.001f;
-            const v3 normal = normalize(V3(                        // sdf_terrain_normal :201-212
-                terrain_map<7>(pos + V3(e, 0, 0)).x - terrain_map<7>(pos - V3(e, 0, 0)).x,
-                terrain_map<7>(pos + V3(0, e, 0)).x - terrain_map<7>(pos - V3(0, e, 0)).x,
-                terrain_map<7>(pos + V3(0, 0, e)).x - terrain_map<7>(pos - V3(0, 0, e)).x));
+            float g[3];                                            // sdf_terrain_normal :201-212
+#pragma unroll 1
+            for (int ax = 0; ax < 3; ++ax) {                       // one code copy for the three central differences
+                const v3 d = V3(ax == 0 ? e : 0.f, ax == 1 ? e : 0.f, ax == 2 ? e : 0.f);
+                const float v = terrain_map<7>(S, pos + d, hitl, lane).x - terrain_map<7>(S, pos - d, hitl, lane).x;
+                if (ax == 0) g[0] = v; else if (ax == 1) g[1] = v; else g[2] = v;
+            }
+            const v3 normal = normalize(V3(g[0], g[1], g[2]));
             const float N = dot(normal, w_normal);
             const v3 c_water = V3(.015f, .110f, .455f), c_grass = V3(.086f, .132f, .018f),
                      c_beach = V3(.153f, .172f, .121f), c_rock = V3(.080f, .050f, .030f),
@@ -154,15 +228,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_planet(FramePlanet F, RowMap M, 
                     sh.pos = mul(F.rot_cloud, o - V3(0, 0, 0));
                     sh.height = (length(sh.pos) - 1.f) / PL_MAX_HEIGHT;
                     ts += t_step;
-                    clouds_map(sh, t_step);
+                    clouds_map(S, sh, t_step, hitl, lane);
                 }
             }
             const float shadow = mix_(.7f, 1.f, step_(sh.alpha, 0.33f));
-            col = abs3(mix3(c_terr * shadow, V3s(c_cld), alpha));
-        } else {
-            col = abs3(mix3(planet_background(rd), V3s(cloud.radiance), cloud.alpha));   // :364-366
+            c_hit = abs3(mix3(c_terr * shadow, V3s(c_cld), alpha));
         }
+        col = hitl ? c_hit : abs3(mix3(planet_background(rd), V3s(cloud.radiance), cloud.alpha));   // :364-366
     }
+    if (!px.valid) return;
+    if (!hit_atm) col = planet_background(rd);                   // :316-318
     store_rgba(out, px.idx, to_srgb(col));
 }
 
