@@ -7,6 +7,10 @@ Workload (BASELINE.json `metric`): APP_CLOUDS, 3840x2160, canonical frame u_time
 default aux uniforms.  One "step" = one whole frame rendered into an RGBA32F framebuffer resident in
 HBM (nothing crosses PCIe inside the timed region).
 
+Frames are independent, so consecutive frames are pipelined over two HIP streams (double-buffered
+framebuffers, --streams): the drain of one frame's kernel (its last, longest waves) overlaps the start of
+the next frame.  The timed region still runs from the first launch to the completion of all K frames.
+
 N = 1 : the frame is one kernel launch.
 N > 1 : one process per GPU (torch.distributed / RCCL).  The SAME frame is sharded as cyclic 8-row
         blocks (shaderbox_amd/shard.py), every rank renders its blocks, ONE gather over xGMI brings the
@@ -52,8 +56,11 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--time", type=float, default=0.37)
     ap.add_argument("--block-rows", type=int, default=8)
-    ap.add_argument("--gather-groups", type=int, default=4,
+    ap.add_argument("--gather-groups", type=int, default=1,
                     help="N>1: issue the gather in this many pipelined pieces (1 = one plain gather)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="frames in flight: consecutive frames alternate over this many HIP streams, each with its own "
+                         "framebuffers, so the drain of one frame's kernel overlaps the next frame (1 = strictly serial)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the torch.distributed/RCCL path even with one rank (smoke test of the N>1 code on 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,31 +95,36 @@ def main():
     W, H, app, t = args.width, args.height, args.app, args.time
     br = args.block_rows
 
+    ns = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)] if ns > 1 else [torch.cuda.current_stream(dev)]
     if not use_dist:
-        frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
+        frame = frames[0]
 
-        def step():
-            R.render(app, W, H, t, out=frame)
+        def step(i=0):
+            with torch.cuda.stream(streams[i % ns]):
+                R.render(app, W, H, t, out=frames[i % ns])
     else:
         from shaderbox_amd.distributed import FramePlan
-        plan = FramePlan(R, dist, W, H, br, groups=args.gather_groups)
-        slab = plan.slab
+        plans = [FramePlan(R, dist, W, H, br, groups=args.gather_groups) for _ in range(ns)]
+        slab = plans[0].slab
 
-        def step():
-            plan.render(app, t)      # render_rank + the single RCCL gather + assemble on rank 0
+        def step(i=0):
+            with torch.cuda.stream(streams[i % ns]):
+                plans[i % ns].render(app, t)      # render_rank + the single RCCL gather + assemble on rank 0
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     sync()
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     sync()
     elapsed = time.perf_counter() - t0
     # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region so that
@@ -157,6 +169,7 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)"
                                       % (app.upper(), W, H, t),
+                          "frames_in_flight": ns,
                           "parallelism": "1 GPU, one launch per frame" if world == 1 else
                                          "cyclic %d-row blocks over %d GPUs + 1 RCCL gather (in %d pipelined pieces) + assemble"
                                          % (br, world, args.gather_groups)},

@@ -31,3 +31,25 @@ for br in (8, 16):
         ts = [timed(lambda r=r: R.render_rank(app, W, H, 0.37, br, r, n, out=slab)) for r in range(n)]
         print("  block_rows=%2d N=%d: per-rank ms min %.3f max %.3f  -> compute-only speed-up %.2fx (ideal %d)"
               % (br, n, min(ts), max(ts), t1 / max(ts), n))
+
+# throughput with frames pipelined over 2 streams (what bench.py does): ms per frame of one rank's share
+import time
+for n in (1, 2, 4, 8):
+    slabs = [torch.empty((shard.rank_rows_max(H, 8, n), W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    worst = 0.0
+    for r in range(n):
+        for i in range(6):
+            with torch.cuda.stream(streams[i % 2]):
+                R.render_rank(app, W, H, 0.37, 8, r, n, out=slabs[i % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K = 40
+        for i in range(K):
+            with torch.cuda.stream(streams[i % 2]):
+                R.render_rank(app, W, H, 0.37, 8, r, n, out=slabs[i % 2])
+        torch.cuda.synchronize()
+        worst = max(worst, (time.perf_counter() - t0) * 1e3 / K)
+    if n == 1:
+        base = worst
+    print("  2 streams, N=%d: slowest rank %.3f ms/frame -> compute-only speed-up %.2fx" % (n, worst, base / worst))
