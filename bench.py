@@ -18,6 +18,7 @@ N > 1 : one process per GPU (torch.distributed / RCCL).  The SAME frame is shard
         "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
 
 Extra objects on the JSON line:
+  roofline_hbm : the same kernel against HBM (16 B/pixel written once): far from the bound by design.
   roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel
                  of HBM traffic), so bound = "valu": achieved = algorithmic scalar fp ops per launch
                  (SURVEY.md §8d per-pixel count x pixels) / mean launch duration measured with HIP events on
@@ -160,9 +161,11 @@ def main():
                         "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5),
                         "ops_per_pixel": ops, "pixels_per_launch": launch_pixels,
                         "kernel_ms": round(kmean, 4),
-                        "traffic": MEASURED_TRAFFIC_BYTES.get((app, W, H)) if world == 1 else None,
-                        "hbm": {"achieved": round(16.0 * launch_pixels / (kmean * 1e-3) / 1e9, 2),
-                                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "bytes_per_pixel": 16}}
+                        "traffic": MEASURED_TRAFFIC_BYTES.get((app, W, H)) if world == 1 else None}
+            hbm = 16.0 * launch_pixels / (kmean * 1e-3) / 1e9
+            roofline_hbm = {"bound": "hbm", "kernel": "k_" + app, "achieved": round(hbm, 2), "peak": PEAK_HBM_GBPS,
+                            "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBPS, 5), "bytes_per_pixel": 16,
+                            "traffic": MEASURED_TRAFFIC_BYTES.get((app, W, H)) if world == 1 else None}
         out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(value, 3),
                "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
@@ -173,7 +176,7 @@ def main():
                           "parallelism": "1 GPU, one launch per frame" if world == 1 else
                                          "cyclic %d-row blocks over %d GPUs + 1 RCCL gather (in %d pipelined pieces) + assemble"
                                          % (br, world, args.gather_groups)},
-               "roofline": roofline}
+               "roofline": roofline, "roofline_hbm": roofline_hbm if ops is not None else None}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(app, W, H, t, args.cpu_row_stride)
         print(json.dumps(out))

@@ -199,3 +199,13 @@ def test_noise_library_matches_oracle(renderer, oracle):
     ref = oracle.worley_volume(128, 77, 78)
     assert np.array_equal(vol[77:78].cpu().numpy().view(np.uint32), ref.view(np.uint32))
     assert abs(float(vol[0, 0, 0, 0]) - 1.35212326) < 2e-2          # Appendix C: ddsvolgen voxel (0,0,0)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (33, 9), (8, 64), (257, 2)])
+def test_tiny_and_ragged_frames(renderer, oracle, w, h):
+    """sizes that do not fill a wave tile / workgroup: every app, bit-for-bit"""
+    from oracle.oracle import APP_IDS
+    for app in ("egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet"):
+        ref = oracle.render(APP_IDS[app], w, h, 0.37, threads=4)
+        gpu = renderer.render(app, w, h, 0.37).cpu().numpy()
+        assert compare(gpu, ref) == (0.0, 0), (app, w, h)
