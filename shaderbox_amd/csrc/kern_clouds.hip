@@ -222,15 +222,15 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
                 hc_blend_xy(h.lo, h.hi, fx[k], fy[k], ab[k], cd[k]);
                 cur[k] = nbits[k];
             }
-        } else {
+        } else if (wave_any(lit && ((nbits[0] != cur[0]) | (nbits[1] != cur[1]) | (nbits[2] != cur[2]) | (nbits[3] != cur[3])))) {
+            // some lit lane entered another cell in some octave: refresh all four x/y blends (one uniform
+            // branch per sample costs less than one per octave)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (wave_any(lit && nbits[k] != cur[k])) {   // some lit lane entered another cell in this octave
-                    const float4 lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
-                    const float4 hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
-                    hc_blend_xy(lo, hi, fx[k], fy[k], ab[k], cd[k]);
-                    cur[k] = nbits[k];
-                }
+                const float4 lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+                const float4 hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+                hc_blend_xy(lo, hi, fx[k], fy[k], ab[k], cd[k]);
+                cur[k] = nbits[k];
             }
         }
         float t = 0.f, H = .5f;
