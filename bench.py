@@ -18,6 +18,10 @@ N > 1 : one process per GPU (torch.distributed / RCCL).  The SAME frame is shard
         "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
 
 Extra objects on the JSON line:
+                 kernel_ms is the duration of an un-overlapped launch (measured after the timed region, one launch at a
+                 time); the committed rocprofv3 summary (profiles/r01_clouds_final_rocprof_summary.txt) is of this
+                 command with --streams 1 — with two frames in flight the per-kernel durations rocprof reports are
+                 stretched by the overlap.
   roofline_hbm : the same kernel against HBM (16 B/pixel written once): far from the bound by design.
   roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel
                  of HBM traffic), so bound = "valu": achieved = algorithmic scalar fp ops per launch
@@ -42,7 +46,7 @@ OPS_PER_PIXEL = {"clouds": 60248.0, "egg": 15276.0, "raytracer": 564.0, "atmosph
                  "planet": 21253.0, "sdf_ao": 7255.0}
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (WRITE_SIZE + 2 x FETCH_SIZE,
 # KB -> bytes, per MI355X_MICROARCH.md), for the default workload only; see DESIGN.md §6
-MEASURED_TRAFFIC_BYTES = {("clouds", 3840, 2160): int(136373 * 1024 + 2 * 2715.58 * 1024)}   # profiles/r01_clouds_v5_*
+MEASURED_TRAFFIC_BYTES = {("clouds", 3840, 2160): int(136019 * 1024 + 2 * 2715.82 * 1024)}   # profiles/r01_clouds_final_*
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0
 
