@@ -41,3 +41,23 @@ def test_cli_and_mainimage_dropin_match_oracle(built, oracle, tmp_path):
     mean = [float(v) for v in r.stdout.strip().split("=")[-1].split()]
     # EGG 256x256 t=.37 frame mean
     assert np.allclose(mean, [0.401660, 0.545536, 0.539848], atol=2e-6), r.stdout
+
+
+def test_inclxpnd_flattens_includes(built, tmp_path):
+    (tmp_path / "sub").mkdir()
+    (tmp_path / "a.h").write_text('#include "sub/b.h"\nint a;\n#include <math.h>\n  #  include "missing.h"\n')
+    (tmp_path / "sub" / "b.h").write_text('#include "c.h"\nint b;\n')
+    (tmp_path / "sub" / "c.h").write_text('int c;\n#include "b.h"\n')          # cycle back to b.h
+    r = subprocess.run([os.path.join(built, "inclxpnd"), str(tmp_path / "a.h")], capture_output=True, text=True, check=True)
+    assert r.stdout.splitlines() == ["int c;", "int b;", "int a;", "#include <math.h>", '  #  include "missing.h"']
+
+
+def test_bench_cpu_baseline_leg(oracle):
+    """the cpu_baseline object of bench.py (oracle timed on the host cores) on a tiny frame"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cb = bench.cpu_baseline("egg", 64, 36, 0.37, 4)
+    assert cb["kind"] == "port" and cb["unit"] == "Mpixels/s" and cb["cores"] >= 1 and cb["value"] > 0
+    assert set(bench.OPS_PER_PIXEL) == {"clouds", "egg", "raytracer", "atmosphere", "planet", "sdf_ao"}
