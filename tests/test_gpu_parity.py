@@ -209,3 +209,15 @@ def test_tiny_and_ragged_frames(renderer, oracle, w, h):
         ref = oracle.render(APP_IDS[app], w, h, 0.37, threads=4)
         gpu = renderer.render(app, w, h, 0.37).cpu().numpy()
         assert compare(gpu, ref) == (0.0, 0), (app, w, h)
+
+
+def test_late_time_and_mouse_against_oracle(renderer, oracle):
+    """large lattice indices (wind offset at t = 100: |n| up to ~9e4) and an orbiting camera, vs the oracle"""
+    from oracle.oracle import APP_CLOUDS, APP_PLANET
+    for t, mouse in [(100.0, (0.0, 0.0)), (37.5, (2.5, 0.0))]:
+        ref = oracle.render(APP_CLOUDS, 160, 90, t, mouse=mouse)
+        gpu = renderer.render("clouds", 160, 90, t, mouse=mouse).cpu().numpy()
+        assert compare(gpu, ref) == (0.0, 0), (t, mouse)
+    ref = oracle.render(APP_PLANET, 128, 72, 41.0)
+    gpu = renderer.render("planet", 128, 72, 41.0).cpu().numpy()
+    assert compare(gpu, ref) == (0.0, 0)
