@@ -61,3 +61,21 @@ def test_bench_cpu_baseline_leg(oracle):
     cb = bench.cpu_baseline("egg", 64, 36, 0.37, 4)
     assert cb["kind"] == "port" and cb["unit"] == "Mpixels/s" and cb["cores"] >= 1 and cb["value"] > 0
     assert set(bench.OPS_PER_PIXEL) == {"clouds", "egg", "raytracer", "atmosphere", "planet", "sdf_ao"}
+
+
+@pytest.mark.gpu
+def test_ddsvolgen_writes_the_volume(built, oracle, tmp_path):
+    """host/sbx_ddsvolgen: DX10 volume DDS whose texels are the oracle's fbm_worley_tile volume"""
+    import struct
+    out = str(tmp_path / "n.dds")
+    subprocess.run([os.path.join(built, "sbx_ddsvolgen"), "--size", "32", "--out", out], check=True)
+    raw = open(out, "rb").read()
+    assert len(raw) == 4 + 124 + 20 + 32 ** 3 * 16
+    magic, size, flags, height, width, pitch, depth = struct.unpack_from("<7I", raw, 0)
+    assert magic == 0x20534444 and size == 124 and (height, width, depth) == (32, 32, 32) and flags & 0x800000
+    fourcc = struct.unpack_from("<I", raw, 4 + 76 + 8)[0]
+    dxgi, dim = struct.unpack_from("<2I", raw, 4 + 124)
+    assert fourcc == 0x30315844 and dxgi == 2 and dim == 4
+    vox = np.frombuffer(raw, dtype=np.float32, offset=148).reshape(32, 32, 32, 4)
+    ref = oracle.worley_volume(32, 0, 3)
+    assert np.array_equal(vox[:3].view(np.uint32), ref.view(np.uint32))
