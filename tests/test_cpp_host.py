@@ -73,7 +73,7 @@ def test_ddsvolgen_writes_the_volume(built, oracle, tmp_path):
     assert len(raw) == 4 + 124 + 20 + 32 ** 3 * 16
     magic, size, flags, height, width, pitch, depth = struct.unpack_from("<7I", raw, 0)
     assert magic == 0x20534444 and size == 124 and (height, width, depth) == (32, 32, 32) and flags & 0x800000
-    fourcc = struct.unpack_from("<I", raw, 4 + 76 + 8)[0]
+    fourcc = struct.unpack_from("<I", raw, 4 + 72 + 8)[0]
     dxgi, dim = struct.unpack_from("<2I", raw, 4 + 124)
     assert fourcc == 0x30315844 and dxgi == 2 and dim == 4
     vox = np.frombuffer(raw, dtype=np.float32, offset=148).reshape(32, 32, 32, 4)
