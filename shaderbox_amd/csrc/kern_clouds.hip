@@ -102,6 +102,39 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, Ro
 // (The first cooperative version re-elected the distinct cells of every sample: 11.6 ms per 4K frame,
 // of which 2.3 ms election and 2.0 ms hash passes)
 // ---------------------------------------------------------------------------------------------
+// ---- y terms of the main march --------------------------------------------------------------------
+// render_clouds marches along projection = dir / dir.y (:165), whose y component is dir.y / dir.y = 1 exactly,
+// from origin.y = (eye.y + 150) + wind.y — the same for every pixel.  So the sample height of march step i,
+// pos.y = origin.y + t_i, is a frame constant, and with it, per octave, floor/fract/smoothstep of y and the
+// term 157 * floor(y) of the lattice index.  They are computed once per frame by k_clouds_ytab (one thread
+// per step, the same operations a lane would do) into a small table that the march reads with scalar loads:
+// the values arrive in SGPRs and ~9 VALU instructions per octave per sample disappear from every lane.
+// The z light march of a lit step (x, y unchanged) uses the same row.
+struct YRow { float4 fy, gy, py157; };     // per march step: 4 octaves each
+
+__global__ void __launch_bounds__(64) k_clouds_ytab(FrameClouds F, YRow* __restrict__ tab) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= F.steps) return;
+    float t = 0.f;
+    for (int j = 0; j < i; ++j) t += F.dt;                    // t after i steps of `t += dt` (:186)
+    const float origin_y = (F.cam.eye.y + 1.0f * 150.f) + F.wind_off.y;   // :166-167 with projection.y = 1
+    const float y = origin_y + t * 1.0f;                      // :185
+    float q = (y * .001f) * 2.03f;                            // :66,72
+    float fy[4], gy[4], p157[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float py = floor_(q);
+        const float ay = q - py;
+        fy[k] = ay * ay * (3.0f - 2.0f * ay);
+        gy[k] = 1.0f - fy[k];
+        p157[k] = py * 157.0f;
+        q = q * 2.64f;
+    }
+    tab[i].fy = make_float4(fy[0], fy[1], fy[2], fy[3]);
+    tab[i].gy = make_float4(gy[0], gy[1], gy[2], gy[3]);
+    tab[i].py157 = make_float4(p157[0], p157[1], p157[2], p157[3]);
+}
+
 __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, bool active, WaveCache& S, int lane) {
     v3 p = (pos_in * .001f) * 2.03f;                     // :66,72
     float fx[4], fy[4], fz[4];
@@ -155,14 +188,73 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
 }
 
 // x/y half of the trilinear blend (the four x-mixes and two y-mixes of noise_iq.h:20-23)
-__device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, float fy, float& ab, float& cd) {
-    const float gx = 1.0f - fx, gy = 1.0f - fy;
+__device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, float fy, float gy, float& ab, float& cd) {
+    const float gx = 1.0f - fx;
     const float a = lo.x * gx + lo.y * fx;
     const float b = lo.z * gx + lo.w * fx;
     const float c = hi.x * gx + hi.y * fx;
     const float d = hi.z * gx + hi.w * fx;
     ab = a * gy + b * fy;
     cd = c * gy + d * fy;
+}
+
+// density_func of a MAIN march sample with the y terms of its step taken from the frame table (SGPRs)
+__device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
+                                                  WaveCache& S, int lane) {
+    float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
+    const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
+    const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
+    const float rpy[4] = {row.py157.x, row.py157.y, row.py157.z, row.py157.w};
+    float fx[4], fz[4];
+    unsigned nbits[4];
+    int slot[4];
+    bool ne[4];
+    bool miss = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float px = floor_(qx), pz = floor_(qz);
+        const float ax = qx - px, az = qz - pz;
+        fx[k] = ax * ax * (3.0f - 2.0f * ax);
+        fz[k] = az * az * (3.0f - 2.0f * az);
+        const float n = px + rpy[k] + 113.0f * pz;       // p.x + p.y*157 + 113*p.z, noise_iq.h:19
+        nbits[k] = f2u(n);
+        slot[k] = (int)n & (HC_SLOTS - 1);
+        ne[k] = (S.tag[k][slot[k]] != nbits[k]);
+        miss |= ne[k];
+        qx = qx * 2.64f; qz = qz * 2.64f;
+    }
+    float t = 0.f, H = .5f;
+    if (!wave_any(active && miss)) {
+        float4 lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+            hi[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float ab, cd;
+            hc_blend_xy(lo[k], hi[k], fx[k], rfy[k], rgy[k], ab, cd);
+            t += (ab * (1.0f - fz[k]) + cd * fz[k]) * H;
+            H *= .5f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            H8 h;
+            if (wave_any(active && ne[k])) {
+                h = hc_slow(S, k, nbits[k], slot[k], active, lane);
+            } else {
+                h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+                h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+            }
+            float ab, cd;
+            hc_blend_xy(h.lo, h.hi, fx[k], rfy[k], rgy[k], ab, cd);
+            t += (ab * (1.0f - fz[k]) + cd * fz[k]) * H;
+            H *= .5f;
+        }
+    }
+    return t * smoothstep_(F.cov, F.cov_hi, t);          // :83-84
 }
 
 // illuminate_volume's march (:106-113) when the light step L*dt has no x and no y component — the
@@ -172,18 +264,31 @@ __device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, floa
 // blend are the SAME binary32 values for all light samples of the step.  They are computed once; per
 // sample only the z terms, the cell lookup and the final z-mix remain.  Every value is produced by the
 // same operations on the same inputs as in the general path, hence identical bits.
-__device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, WaveCache& S, int lane) {
-    float fx[4], fy[4], nxy[4], ab[4], cd[4];
+template <bool YTAB>
+__device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, WaveCache& S, int lane,
+                                               const YRow& row) {
+    float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4];
     unsigned cur[4];
     {
+        const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
+        const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
+        const float rpy[4] = {row.py157.x, row.py157.y, row.py157.z, row.py157.w};
         float qx = (lp.x * .001f) * 2.03f, qy = (lp.y * .001f) * 2.03f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float px = floor_(qx), py = floor_(qy);
-            const float ax = qx - px, ay = qy - py;
+            const float px = floor_(qx);
+            const float ax = qx - px;
             fx[k] = ax * ax * (3.0f - 2.0f * ax);
-            fy[k] = ay * ay * (3.0f - 2.0f * ay);
-            nxy[k] = px + py * 157.0f;
+            if (YTAB) {                                   // lp.y = pos.y + 0: the step's own row
+                fy[k] = rfy[k]; gy[k] = rgy[k];
+                nxy[k] = px + rpy[k];
+            } else {
+                const float py = floor_(qy);
+                const float ay = qy - py;
+                fy[k] = ay * ay * (3.0f - 2.0f * ay);
+                gy[k] = 1.0f - fy[k];
+                nxy[k] = px + py * 157.0f;
+            }
             cur[k] = 0x7fc00001u;
             ab[k] = cd[k] = 0.f;
             qx = qx * 2.64f; qy = qy * 2.64f;
@@ -219,7 +324,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
                     h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
                     h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
                 }
-                hc_blend_xy(h.lo, h.hi, fx[k], fy[k], ab[k], cd[k]);
+                hc_blend_xy(h.lo, h.hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
                 cur[k] = nbits[k];
             }
         } else if (wave_any(lit && ((nbits[0] != cur[0]) | (nbits[1] != cur[1]) | (nbits[2] != cur[2]) | (nbits[3] != cur[3])))) {
@@ -229,7 +334,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             for (int k = 0; k < 4; ++k) {
                 const float4 lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
                 const float4 hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
-                hc_blend_xy(lo, hi, fx[k], fy[k], ab[k], cd[k]);
+                hc_blend_xy(lo, hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
                 cur[k] = nbits[k];
             }
         }
@@ -256,7 +361,9 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
     return abs3(sky);
 }
 
-__global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out) {
+template <bool YTAB>
+__global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out,
+                                                          const YRow* __restrict__ ytab) {
     __shared__ WaveCache cache[WG_THREADS / 64];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
@@ -285,14 +392,17 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
                 if (!wave_any(alive)) break;
                 const v3 pos = origin + t * projection;
                 t += F.dt;
-                const float density = coop_density(F, pos, alive, S, lane);
+                YRow row;
+                if (YTAB) row = ytab[i];                          // uniform index: scalar loads
+                const float density = YTAB ? coop_density_row(F, pos, row, alive, S, lane)
+                                           : coop_density(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 if (wave_any(lit)) {
                     const float T_i = exp_(-density * F.sigma * F.dt);
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
                     if (lstep.x == 0.f && lstep.y == 0.f) {        // uniform (kernel argument): z-only light step
-                        ltrans = light_march_z(F, lp, lstep, lit, S, lane);
+                        ltrans = light_march_z<YTAB>(F, lp, lstep, lit, S, lane, row);
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
                             const float d = coop_density(F, lp, lit, S, lane);
@@ -324,11 +434,15 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
     store_rgba(out, px.idx, to_srgb(col));
 }
 
-void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant) {
-    if (variant == 1) hipLaunchKernelGGL(k_clouds_perlane, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
-    else {
-        static const int pad = getenv("SBX_CLOUDS_LDS_PAD") ? atoi(getenv("SBX_CLOUDS_LDS_PAD")) : 0;   // occupancy experiments
-        hipLaunchKernelGGL(k_clouds, grid_for(M), dim3(WG_THREADS), pad, s, F, M, out);
+void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows) {
+    if (variant == 1) {
+        hipLaunchKernelGGL(k_clouds_perlane, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    } else if (ytab && F.steps <= ytab_rows && F.steps > 0) {
+        YRow* tab = reinterpret_cast<YRow*>(ytab);
+        hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
+        hipLaunchKernelGGL(k_clouds<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out, (const YRow*)tab);
+    } else {
+        hipLaunchKernelGGL(k_clouds<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out, (const YRow*)nullptr);
     }
 }
 

@@ -17,6 +17,8 @@ struct sbx_ctx {
     int device = 0;
     bool timing = false;
     int variant = 0;
+    char* ytab = nullptr;      // CLOUDS_YTAB_RING tables of CLOUDS_YTAB_BYTES, device memory
+    unsigned ytab_next = 0;
     bool have_events = false;
     hipEvent_t ev0{}, ev1{};
     std::string err;
@@ -203,12 +205,18 @@ int sbx_create(int device, sbx_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SBX_ERR_NO_DEVICE;   // kernels exist for gfx950 only
     sbx_ctx* ctx = new sbx_ctx();
     ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipMalloc((void**)&ctx->ytab, (size_t)CLOUDS_YTAB_RING * CLOUDS_YTAB_BYTES) != hipSuccess) {
+        delete ctx;
+        return SBX_ERR_HIP;
+    }
     *out = ctx;
     return SBX_OK;
 }
 
 void sbx_destroy(sbx_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->ytab) (void)hipFree(ctx->ytab);
     if (ctx->have_events) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
     delete ctx;
 }
@@ -232,7 +240,8 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         sbx_aux_clouds A;
         if (aux) A = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&A);
         if (A.cld_march_steps < 0 || A.illum_march_steps < 0) return fail(ctx, SBX_ERR_ARG, "negative march steps");
-        launch_clouds(build_clouds(*uni, A), M, rgba, s, ctx->variant);
+        void* ytab = ctx->ytab + (size_t)(ctx->ytab_next++ % CLOUDS_YTAB_RING) * CLOUDS_YTAB_BYTES;
+        launch_clouds(build_clouds(*uni, A), M, rgba, s, ctx->variant, ytab, CLOUDS_YTAB_ROWS);
         break;
     }
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s); break;

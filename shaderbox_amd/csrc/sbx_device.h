@@ -34,7 +34,10 @@ __device__ __forceinline__ void store_rgba(float* out, size_t idx, v3 c) {
 }
 
 // launchers (one per app), defined next to their kernels
-void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant);
+void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows);
+constexpr int CLOUDS_YTAB_ROWS = 1024;      // march steps covered by the per-frame y table
+constexpr int CLOUDS_YTAB_BYTES = CLOUDS_YTAB_ROWS * 48;
+constexpr int CLOUDS_YTAB_RING = 8;         // tables in flight (one per launch, round robin)
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s);
 void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s);
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s);
