@@ -11,6 +11,7 @@
 namespace sbx {
 
 constexpr float ATM_EARTH_R = 6360e3f, ATM_ATMOS_R = 6420e3f, ATM_HR = 7994.0f, ATM_HM = 1200.0f;   // :34-38
+constexpr double ATM_HR_RD = 1.0 / (double)ATM_HR, ATM_HM_RD = 1.0 / (double)ATM_HM;   // exact division by constants (sbx_math.h div_by)
 
 // isect_sphere with the atmosphere sphere (origin 0)                        :15-26
 __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
@@ -32,8 +33,8 @@ __device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM) 
         const v3 s = ro + rd * (march_pos + 0.5f * march_step);
         const float height = length(s) - ATM_EARTH_R;
         if (height < 0.f) return false;
-        odR += exp_(-height / ATM_HR) * march_step;
-        odM += exp_(-height / ATM_HM) * march_step;
+        odR += exp_(div_by(-height, ATM_HR_RD)) * march_step;
+        odM += exp_(div_by(-height, ATM_HM_RD)) * march_step;
         march_pos += march_step;
     }
     return true;
@@ -65,8 +66,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, Ro
         for (int i = 0; i < 16; ++i) {
             const v3 s = ro + rd * (march_pos + 0.5f * march_step);
             const float height = length(s) - ATM_EARTH_R;
-            const float hr = exp_(-height / ATM_HR) * march_step;
-            const float hm = exp_(-height / ATM_HM) * march_step;
+            const float hr = exp_(div_by(-height, ATM_HR_RD)) * march_step;
+            const float hm = exp_(div_by(-height, ATM_HM_RD)) * march_step;
             odR += hr;
             odM += hm;
             float lR = 0.f, lM = 0.f;

@@ -14,7 +14,7 @@ namespace sbx {
 __device__ __forceinline__ float clouds_density(const FrameClouds& F, v3 pos_in) {
     v3 pos = pos_in * .001f;                                   // cld_noise_factor, :20,66
     float shape = fbm<4>(pos * 2.03f, 2.64f, .5f, .5f, [](v3 p) { return noise_iq(p); });   // :72
-    return shape * smoothstep_(F.cov, F.cov_hi, shape);        // :83-84
+    return shape * smoothstep_(F.cov, F.cov_hi, shape);        // :83-84 (per-lane cross-check kernel keeps the IEEE division)
 }
 
 __device__ __forceinline__ float hg_phase(float mu, float g) {  // volumetric.h:27-33, note (4 + PI)
@@ -184,7 +184,7 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
             H *= .5f;
         }
     }
-    return t * smoothstep_(F.cov, F.cov_hi, t);          // :83-84
+    return t * smoothstep_rd(F.cov, F.cov_rd, t);        // :83-84
 }
 
 // x/y half of the trilinear blend (the four x-mixes and two y-mixes of noise_iq.h:20-23)
@@ -254,7 +254,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
             H *= .5f;
         }
     }
-    return t * smoothstep_(F.cov, F.cov_hi, t);          // :83-84
+    return t * smoothstep_rd(F.cov, F.cov_rd, t);        // :83-84
 }
 
 // illuminate_volume's march (:106-113) when the light step L*dt has no x and no y component — the
@@ -345,7 +345,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             t += (ab[k] * gz + cd[k] * fz[k]) * H;
             H *= .5f;
         }
-        const float d = t * smoothstep_(F.cov, F.cov_hi, t);
+        const float d = t * smoothstep_rd(F.cov, F.cov_rd, t);
         ltrans *= exp_(-d * F.sigma * F.dt);
         lp = lp + lstep;
     }

@@ -24,8 +24,10 @@ constexpr float PL_MAX_RAY_DIST = PL_MAX_HEIGHT * 4.f;  // :21
 struct Vol { v3 origin, pos; float height, transmittance, radiance, alpha; };   // volumetric.h:47-68 (radiance r=g=b)
 __device__ __forceinline__ Vol make_vol(v3 o) { return Vol{o, o, 0.f, 1.f, 0.f, 0.f}; }
 
-__device__ __forceinline__ float band(float start, float peak, float end, float t) {   // util.h:103-112
-    return smoothstep_(start, peak, t) * (1.f - smoothstep_(peak, end, t));
+// smoothstep with literal edges: the division by (e1 - e0) is an exact multiply by its binary64 reciprocal
+#define SMOOTHSTEP_K(e0, e1, x) smoothstep_rd((e0), 1.0 / (double)((e1) - (e0)), (x))
+__device__ __forceinline__ float band(float t) {                     // band(.2, .35, .65, t)  util.h:103-112
+    return SMOOTHSTEP_K(.2f, .35f, t) * (1.f - SMOOTHSTEP_K(.35f, .65f, t));
 }
 
 // DECL_FBM_FUNC(name, OCT, basis(noise_iq(p)))  fbm.h:6 — the OCT noise values come from one cooperative batch
@@ -79,12 +81,12 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
 __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, bool on, int lane) {
     float dens = coop_fbm<4, 1>(S, c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f), 2.0276f, .5f, .5f, on, lane);
     const float cov = .29475675f, fuzzy = .0335f;
-    dens *= smoothstep_(cov, cov + fuzzy, dens);
-    dens *= band(.2f, .35f, .65f, c.height);
+    dens *= SMOOTHSTEP_K(cov, cov + fuzzy, dens);
+    dens *= band(c.height);
     const float T_i = exp_(-30.034f * dens * t_step);
     if (on) {
         c.transmittance *= T_i;
-        c.radiance += dens * (exp_(c.height) / .055f) * c.transmittance * t_step;
+        c.radiance += dens * div_by(exp_(c.height), 1.0 / (double).055f) * c.transmittance * t_step;
         c.alpha += (1.f - T_i) * (1.f - c.alpha);
     }
 }
@@ -93,11 +95,11 @@ __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, b
 template <int OCT>
 __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lane) {
     const float h0 = coop_fbm<OCT, 0>(S, pos * 2.0987f, 2.0244f, .454f, .454f, on, lane);
-    const float n0 = smoothstep_(.35f, 1.f, h0);
+    const float n0 = SMOOTHSTEP_K(.35f, 1.f, h0);
     const float h1 = coop_fbm<OCT, 2>(S, pos * 1.50987f + V3(1.9489f, 2.435f, .5483f), 2.0244f, .454f, .454f, on, lane);
-    const float n1 = smoothstep_(.6f, 1.f, h1);
+    const float n1 = SMOOTHSTEP_K(.6f, 1.f, h1);
     const float n = n0 + n1;
-    return V2(length(pos) - 1.f - n * PL_MAX_HEIGHT, n / PL_MAX_HEIGHT);
+    return V2(length(pos) - 1.f - n * PL_MAX_HEIGHT, div_by(n, 1.0 / (double)PL_MAX_HEIGHT));
 }
 
 __device__ __forceinline__ v3 setup_lights(v3 L, v3 normal) {                          // :217-236
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap 
                 if (!wave_any(cm)) break;
                 const v3 o = cloud.origin + tc * rd;
                 const v3 cp = mul(F.rot_cloud, o - V3(0, 0, 0));
-                const float ch = (length(cp) - 1.f) / PL_MAX_HEIGHT;
+                const float ch = div_by(length(cp) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
                 if (cm) { cloud.pos = cp; cloud.height = ch; }
                 tc += t_step;
                 clouds_map(S, cloud, t_step, cm, lane);
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap 
                 for (int i = 0; i < 5; ++i) {
                     const v3 o = sh.origin + ts * local_up;
                     sh.pos = mul(F.rot_cloud, o - V3(0, 0, 0));
-                    sh.height = (length(sh.pos) - 1.f) / PL_MAX_HEIGHT;
+                    sh.height = div_by(length(sh.pos) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
                     ts += t_step;
                     clouds_map(S, sh, t_step, hitl, lane);
                 }

@@ -69,6 +69,7 @@ struct FrameClouds {
     int steps, lsteps;
     float dt;             // cld_thick / float(cld_march_steps)         app_clouds.h:98,180
     float cov, cov_hi;    // 1 - cld_coverage, cov + .0135              app_clouds.h:83-84
+    double cov_rd;        // recip64(cov_hi - cov): the smoothstep division becomes an exact multiply
 };
 
 // ---- APP_EGG (src/app_egg.h) ----------------------------------------------------------------

@@ -44,6 +44,24 @@ SBX_HD float smoothstep_(float e0, float e1, float x) {
     return (t * t) * (3.0f - 2.0f * t);
 }
 SBX_HD float radians_(float deg) { return deg * 0.017453292519943295f; }
+
+// Exact binary32 division by a denominator whose binary64 reciprocal is already known (a frame constant or
+// a literal): n / d == (float)((double)n * RN64(1 / (double)d)) for ALL binary32 n, d, bit for bit with the
+// IEEE quotient.  Proof sketch: the exact quotient Q of two 24-bit significands is never a rounding midpoint
+// of binary32 (m * d with m an odd 25-bit integer has >= 25 significant bits) and, unless it is exactly
+// representable, lies at relative distance >= 2^-49 from the nearest midpoint; the computed product carries a
+// relative error < 2^-51.9 (one rounding in the reciprocal, one in the product), less than half that gap, so
+// rounding it to binary32 gives RN32(Q).  Zeros, infinities, NaNs and denormals follow the same rules on
+// both sides.  On MI355X this is v_cvt_f64_f32 + v_mul_f64 + v_cvt_f32_f64 (~13 issue cycles) against ~42
+// for the v_div_scale/v_rcp/v_fma.../v_div_fixup sequence (profiles/r01_ubench_valu.txt).  The oracle keeps
+// the plain division; tests/test_gpu_parity.py::test_division_by_reciprocal_is_exact checks the identity.
+SBX_HD double recip64(float d) { return 1.0 / (double)d; }
+SBX_HD float div_by(float n, double rd) { return (float)((double)n * rd); }
+// smoothstep(e0, e1, x) with rd = recip64(e1 - e0)
+SBX_HD float smoothstep_rd(float e0, double rd, float x) {
+    float t = clamp_(div_by(x - e0, rd), 0.0f, 1.0f);
+    return (t * t) * (3.0f - 2.0f * t);
+}
 SBX_HD float sqrt_(float x) { return __builtin_sqrtf(x); }
 
 // ---- binary64 cores ------------------------------------------------------------------------

@@ -221,3 +221,30 @@ def test_late_time_and_mouse_against_oracle(renderer, oracle):
     ref = oracle.render(APP_PLANET, 128, 72, 41.0)
     gpu = renderer.render("planet", 128, 72, 41.0).cpu().numpy()
     assert compare(gpu, ref) == (0.0, 0)
+
+
+def test_division_by_reciprocal_is_exact(renderer):
+    """sbx_math.h div_by(): (float)((double)n * RN64(1/d)) is the IEEE binary32 quotient n/d for every n, d —
+    checked on the device: all 2^24 significand patterns x several exponents against the denominators the
+    kernels use, random pairs over the whole range, and the special values."""
+    import torch
+    rng = np.random.default_rng(5)
+    dens = np.array([.0135, 7994.0, 1200.0, .4, .055, .0335, .65, .15, .3, 1.0 - .465], dtype=np.float32)
+    dens = np.concatenate([dens, np.float32(1.0 - .535) + np.float32(.0135) - np.float32(1.0 - .535) * np.ones(1, np.float32)])
+    mant = np.arange(1 << 24, dtype=np.uint32)
+    for d in dens:
+        for e in (100, 126, 127, 140):                     # n = 1.m * 2^(e-127)
+            n = ((np.uint32(e) << 23) | (mant & 0x7fffff)).view(np.float32)
+            n = np.where(mant & 0x800000, -n, n).astype(np.float32)
+            a = torch.from_numpy(n)
+            b = torch.full_like(a, float(d))
+            q0 = renderer.math("div", a, b)
+            q1 = renderer.math("div_rd", a, b)
+            assert torch.equal(q0.view(torch.int32), q1.view(torch.int32)), (d, e)
+    bits = rng.integers(0, 1 << 32, size=(2, 1 << 23), dtype=np.uint64).astype(np.uint32)
+    a, b = torch.from_numpy(bits[0].view(np.float32).copy()), torch.from_numpy(bits[1].view(np.float32).copy())
+    sp = torch.tensor([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, 1.17549435e-38, 1.0], dtype=torch.float32)
+    a = torch.cat([a, sp.repeat_interleave(len(sp))]); b = torch.cat([b, sp.repeat(len(sp))])
+    q0 = renderer.math("div", a, b).cpu().numpy(); q1 = renderer.math("div_rd", a, b).cpu().numpy()
+    same = (q0.view(np.uint32) == q1.view(np.uint32)) | (np.isnan(q0) & np.isnan(q1))
+    assert same.all(), (a.numpy()[~same][:5], b.numpy()[~same][:5], q0[~same][:5], q1[~same][:5])
