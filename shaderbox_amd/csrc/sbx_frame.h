@@ -33,12 +33,14 @@ struct Camera {
     float aspect_x;   // u_res.x / u_res.y
     float fov;
     v3 eye, fwd, up, right;
+    double rres_x, rres_y;   // recip64(u_res): fragCoord / u_res as an exact multiply (sbx_math.h div_by)
 };
 SBX_HD Camera make_camera(float res_x, float res_y, float fov, v3 eye, v3 look_at) {
     Camera c;
     c.res_x = res_x; c.res_y = res_y;
     c.aspect_x = res_x / res_y;            // main.h:33
     c.fov = fov;
+    c.rres_x = recip64(res_x); c.rres_y = recip64(res_y);
     c.eye = eye;
     c.fwd = normalize(look_at - eye);      // util.h:10
     v3 up = V3(0, 1, 0);
@@ -48,7 +50,7 @@ SBX_HD Camera make_camera(float res_x, float res_y, float fov, v3 eye, v3 look_a
 }
 // point_cam.xy for fragCoord (main.h:40,44-46); point_cam.z = -1
 SBX_HD v2 point_cam(const Camera& c, float fx, float fy) {
-    float nx = fx / c.res_x, ny = fy / c.res_y;
+    float nx = div_by(fx, c.rres_x), ny = div_by(fy, c.rres_y);   // main.h:40
     return V2(((2.0f * nx - 1.0f) * c.aspect_x) * c.fov, ((2.0f * ny - 1.0f) * 1.0f) * c.fov);
 }
 SBX_HD v3 primary_dir(const Camera& c, v2 pc) {
