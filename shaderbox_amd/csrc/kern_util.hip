@@ -46,13 +46,14 @@ __global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restri
     case 7: r = hash1(x); break;
     case 8: r = x / y; break;                       // IEEE division
     case 9: r = div_by(x, recip64(y)); break;       // the same through the binary64 reciprocal (sbx_math.h)
+    case 10: r = exp_spec_(x); break;               // exp with the spec's guards (exp_ uses cheaper, equivalent ones)
     default: r = 0.f;
     }
     out[i] = r;
 }
 
 int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t n, hipStream_t s) {
-    if (fn < 0 || fn > 9) return -1;
+    if (fn < 0 || fn > 10) return -1;
     hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, a, b, out, n);
     return 0;
 }

@@ -174,11 +174,20 @@ SBX_HD double d_exp2(double t) {
     double sc = u2d((uint64_t)(int64_t)(ki + 1023) << 52);
     return p * sc;
 }
-SBX_HD float exp_(float x) {
+// exp as the spec writes it (oracle/sbx_math_ref.h m_exp): NaN check, binary64 clamp of t
+SBX_HD float exp_spec_(float x) {
     if (x != x) return x;
     double t = (double)x * D_INV_LN2;
     if (t < -160.0) t = -160.0;
     if (t > 136.0) t = 136.0;
+    return (float)d_exp2(t);
+}
+// Same function, cheaper guards: clamping x to [-104, 89] in binary32 gives the same result as the spec's
+// binary64 clamp of t for every input (below -104 both round to 0, above 89 both overflow to +inf, in
+// between neither clamps), and a NaN input propagates through the arithmetic to a NaN result without a test.
+// tests/test_gpu_parity.py::test_exp_guards_are_equivalent compares the two on all 2^32 inputs on the device.
+SBX_HD float exp_(float x) {
+    const double t = (double)clamp_(x, -104.0f, 89.0f) * D_INV_LN2;
     return (float)d_exp2(t);
 }
 SBX_HD float pow_(float x, float y) {

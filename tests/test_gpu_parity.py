@@ -248,3 +248,16 @@ def test_division_by_reciprocal_is_exact(renderer):
     q0 = renderer.math("div", a, b).cpu().numpy(); q1 = renderer.math("div_rd", a, b).cpu().numpy()
     same = (q0.view(np.uint32) == q1.view(np.uint32)) | (np.isnan(q0) & np.isnan(q1))
     assert same.all(), (a.numpy()[~same][:5], b.numpy()[~same][:5], q0[~same][:5], q1[~same][:5])
+
+
+def test_exp_guards_are_equivalent(renderer):
+    """exp_ (binary32 clamp, no NaN test) == exp_spec_ (the spec's guards) on ALL 2^32 binary32 inputs"""
+    import torch
+    step = 1 << 26
+    for lo in range(0, 1 << 32, step):
+        bits = torch.arange(lo, lo + step, dtype=torch.int64, device="cuda").to(torch.int32)   # wraps to all patterns
+        x = bits.view(torch.float32)
+        a = renderer.math("exp", x)
+        b = renderer.math("exp_spec", x)
+        same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+        assert bool(same.all()), lo
