@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 # algorithmic scalar fp ops per pixel at the canonical frame (every
 # transcendental counted as ONE op), measured at the listed resolution
 OPS_PER_PIXEL = {"clouds": 60248.0, "egg": 15276.0, "raytracer": 564.0, "atmosphere": 2493.0,
-                 "planet": 21253.0, "sdf_ao": 7255.0}
+                 "planet": 21253.0, "sdf_ao": 7255.0}       # (no survey count for vinyl: roofline is omitted there)
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (WRITE_SIZE + 2 x FETCH_SIZE,
 # KB -> bytes, per MI355X_MICROARCH.md), for the default workload only; see DESIGN.md §6
 MEASURED_TRAFFIC_BYTES = {("clouds", 3840, 2160): int(136019 * 1024 + 2 * 2715.82 * 1024)}   # profiles/r01_clouds_final_*

@@ -38,7 +38,7 @@ extern "C" {
 typedef enum sbx_app {
     SBX_APP_PLANET = 0,
     SBX_APP_CLOUDS = 1,
-    SBX_APP_VINYL = 2,      /* not on the accelerated path: returns SBX_ERR_UNSUPPORTED */
+    SBX_APP_VINYL = 2,      /* C++-build semantics: 60 march steps (src/app_vinyl.h:411-416) */
     SBX_APP_EGG = 3,
     SBX_APP_RAYTRACER = 4,
     SBX_APP_ATMOSPHERE = 5,

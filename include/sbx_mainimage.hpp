@@ -38,9 +38,9 @@
 #elif defined(APP_SDF_AO)
 #define SBX_SELECTED_APP SBX_APP_SDF_AO
 #elif defined(APP_VINYL)
-#error "APP_VINYL is not on the accelerated path (DESIGN.md §1)"
+#define SBX_SELECTED_APP SBX_APP_VINYL
 #else
-#error "define one of APP_PLANET APP_CLOUDS APP_EGG APP_RAYTRACER APP_ATMOSPHERE APP_SDF_AO"
+#error "define one of APP_PLANET APP_CLOUDS APP_VINYL APP_EGG APP_RAYTRACER APP_ATMOSPHERE APP_SDF_AO"
 #endif
 
 namespace sbx_host {

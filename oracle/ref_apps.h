@@ -867,5 +867,248 @@ struct AppPlanet {
     }
 };
 
+/* =================================================================================== */
+/* APP_VINYL — src/app_vinyl.h (C++ build: 60 march steps, :411-416; SHADERTOY undefined)  */
+/* SURVEY.md §8f row 4 ("remaining apps").  The reference gives no known answers for it.   */
+/* =================================================================================== */
+struct AppVinyl {
+    uniforms_t U;
+    enum { num_materials = 8, mat_debug = 0, mat_groove = 1, mat_dead_wax, mat_label, mat_logo, mat_shiny }; /* :20-24 */
+    material_t materials[num_materials];                     /* material.h:17 */
+    mat3 platter_rot;                                        /* :66 (_mutable, assigned in render before use) */
+    vec3 sun_dir = normalize(vec3(-1, 4, -3));               /* :285-286 */
+
+    float fov() const { return 1.f; }                        /* :459 */
+    vec3 background(const ray_t&) const { return vec3(1, 1, 1); }   /* :15-18 */
+    material_t get_material(int index) const {               /* material.h:19-36 */
+        material_t mat;
+        for (int i = 0; i < num_materials; ++i) if (i == index) { mat = materials[i]; break; }
+        return mat;
+    }
+    static void setup_mat(material_t& mat, vec3 diffuse, float metallic, float roughness) {   /* :26-38 */
+        mat.base_color = diffuse; mat.metallic = metallic; mat.roughness = roughness;
+        mat.ior = 1.f; mat.reflectivity = 0.f; mat.translucency = 0.f;
+    }
+    void setup_scene() {                                     /* :40-54 */
+        setup_mat(materials[mat_debug], vec3(1, 1, 1), .0f, .0f);
+        setup_mat(materials[mat_groove], vec3(.01f, .01f, .01f), .0f, .013f);
+        setup_mat(materials[mat_dead_wax], vec3(.05f, .05f, .05f), .0f, .005f);
+        setup_mat(materials[mat_label], vec3(.5f, .5f, .0f), .0f, .5f);
+        setup_mat(materials[mat_logo], vec3(0, 0, .7f), .0f, .5f);
+        setup_mat(materials[mat_shiny], vec3(.7f, .7f, .7f), 1.f, .01f);
+    }
+    void setup_camera(vec3& eye, vec3& look_at) const {       /* :56-64 */
+        eye = vec3(0, 5.75f, 6.75f);
+        look_at = vec3(0, -2.5f, 0);
+    }
+    /* :68-85 */
+    static float sdf_logo(vec3 pos, float thick) {
+        vec3 b = vec3(.25f, thick, 1.2f);
+        vec3 d = vec3(.7f, 0, 0);
+        vec3 p = mul(pos, rotate_around_y(30.f));
+        float v1 = sd_box(p - d, b);
+        p = mul(pos, rotate_around_y(-30.f));
+        float v2 = sd_box(p + d, b);
+        float x = sd_box(pos, vec3(1.5f, thick, 1.35f));
+        float v = op_add(v1, v2);
+        return op_intersect(v, x);
+    }
+    /* :87-125 */
+    static vec2 sdf_platter(vec3 p) {
+        const float thick = .1f;
+        vec2 lead_in = vec2(sd_y_cylinder(p, 6.f, thick - .05f), (float)mat_dead_wax);
+        vec2 groove = vec2(sd_y_cylinder(p, 5.9f, thick), (float)mat_groove);
+        vec2 dead_wax = vec2(sd_y_cylinder(p, 3.f, thick), (float)mat_dead_wax);
+        vec2 label = vec2(sd_y_cylinder(p, 2.f, thick), (float)mat_label);
+        vec2 logo = vec2(sdf_logo(p, thick - .0175f), (float)mat_logo);
+        float spc = sd_y_cylinder(p, .10f, .6f);
+        float sps = sd_sphere(p - vec3(0, .3f, 0), .10f);
+        vec2 spindle = vec2(op_add(spc, sps), (float)mat_shiny);
+        vec2 d0 = op_add(groove, lead_in);
+        vec2 d1 = op_add(d0, dead_wax);
+        vec2 d2 = op_add(label, logo);
+        vec2 d3 = op_add(d1, d2);
+        vec2 d4 = op_add(d3, spindle);
+        float defect1 = sd_sphere(p + vec3(6.05f, 0, 0), .1f);
+        float defect2 = sd_sphere(p + vec3(-6.05f, 0, 0), .1f);
+        float defect = op_add(defect1, defect2);
+        return vec2(op_sub(d4.x, defect), d4.y);
+    }
+    /* :127-255 */
+    vec2 sdf_tonearm(vec3 pos) const {
+        vec3 base_p = vec3(-7, 0, -5);
+        float platter = sd_y_cylinder(pos, 6.25f, 1.f);
+        float base_0 = sd_y_cylinder(pos - base_p, 3.f, .25f);
+        float base_1 = op_sub(base_0, platter);
+        float base_2 = sd_y_cylinder(pos - base_p, 1.25f, 1.f);
+        float base_12 = op_add(base_1, base_2);
+        vec2 base_a = vec2(base_12, (float)mat_shiny);
+        vec2 base_b = vec2(sd_y_cylinder(pos - base_p, 0.5f, 2.5f), (float)mat_shiny);
+        vec2 base = op_add(base_a, base_b);
+
+        vec3 p = mul(pos, rotate_around_x(m_sin(U.u_time * 3.6758f) * .1f));
+
+        const float R = .1f;
+        const float H = .8f;
+        vec3 a1 = vec3(-6, H, -3);
+        vec3 a11 = vec3(-4.25f, H, 2);
+        vec3 a2 = vec3(-4.1f, H, 2.45f);
+        vec3 a33 = vec3(-3.5f, H, 3);
+        vec3 a3 = vec3(-2, H, 4);
+        float arm1 = sd_capsule(p, base_p + vec3(-1, H, -2), a1, R);
+        float arm2 = sd_capsule(p, a1, a11, R);
+        float arm3 = sd_capsule(p, a33, a3, R);
+        vec2 armb = sd_bezier(a11, a2, a33, p, R);
+        float arm_link1 = op_add(arm1, arm2);
+        float arm_link2 = op_add(arm_link1, arm3);
+        vec2 arm = vec2(op_add(arm_link2, armb.x), (float)mat_shiny);
+
+        vec3 arm_fwd = normalize(a3 - a33);
+        vec3 arm_up = vec3(0, 1, 0);
+        vec3 arm_right = cross(arm_fwd, arm_up);
+        mat3 arm_xform;
+        arm_xform.c[0] = arm_fwd; arm_xform.c[1] = arm_up; arm_xform.c[2] = arm_right;   /* mat3(col, col, col) */
+
+        vec3 clr_p = p - a3;
+        float clr_r = R * 1.5f;
+        float collar = sd_cylinder(clr_p, vec3(0, 0, 0), vec3(0, 0, 0) + arm_fwd * .05f, clr_r);
+
+        const float fl_w = .045f;
+        const float fl_h = .020f;
+        float fl_len1 = clr_r * 1.f;
+        float fl_len2 = fl_len1 * 1.2f;
+        mat3 fl_rot = mul(arm_xform, rotate_around_x(45.f));
+        vec3 fl_p = mul(clr_p - arm_right * clr_r - arm_up * clr_r, fl_rot);
+        float fl1 = sd_box(fl_p, vec3(fl_w, fl_h, fl_len1));
+        mat3 fl_rot2 = rotate_around_x(-45.f);
+        float fl2 = sd_box(mul(fl_p - vec3(0, 0, fl_len1), fl_rot2) - vec3(0, 0, fl_len2), vec3(fl_w, fl_h, fl_len2));
+        float finger_lift = op_add(fl1, fl2);
+        vec2 headshell = vec2(op_add(collar, finger_lift), (float)mat_shiny);
+
+        const float ctg_w = .05f;
+        const float ctg_h = .05f;
+        float ctg_len1 = .3f;
+        float ctg_len2 = .5f;
+        vec3 ctg_p = mul(clr_p, arm_xform);
+        float ctg1 = sd_box(ctg_p, vec3(ctg_len1, ctg_h, ctg_w));
+        mat3 ctg_rot = rotate_around_z(44.f);
+        vec3 ctg2_p = mul(ctg_p - vec3(ctg_len1, 0, 0), ctg_rot) - vec3(ctg_len2 - 0.03f, -.01f, 0);
+        float ctg2 = sd_box(ctg2_p, vec3(ctg_len2, ctg_h, ctg_w));
+        float cut = sd_box(mul(mul(ctg2_p, rotate_around_x(10.f)) - vec3(0, .05f, .175f), rotate_around_y(-5.f)),
+                           vec3(ctg_len2 * 2.f, ctg_h * 3.f, ctg_w * 3.2f));
+        float cut2 = sd_box(mul(ctg2_p - vec3(.3f, .2f, 0), rotate_around_z(10.f)), vec3(.4f, .2f, .3f));
+        float ctg12 = op_add(ctg1, ctg2);
+        float ctg12c = op_sub(ctg12, cut);
+        vec2 cartridge = vec2(op_sub(ctg12c, cut2), (float)mat_shiny);
+
+        vec2 tone1 = op_add(base, arm);
+        vec2 tone2 = op_add(headshell, cartridge);
+        return op_add(tone1, tone2);
+    }
+    /* :257-265 */
+    vec2 sdf(vec3 pos) const {
+        vec3 p = mul(pos, platter_rot);
+        vec2 plat = sdf_platter(p);
+        vec2 arm = sdf_tonearm(pos);
+        return op_add(plat, arm);
+    }
+    /* :267-278 */
+    vec3 sdf_normal(vec3 p) const {
+        float dt = 0.001f;
+        vec3 x = vec3(dt, 0, 0), y = vec3(0, dt, 0), z = vec3(0, 0, dt);
+        return normalize(vec3(sdf(p + x).x - sdf(p - x).x, sdf(p + y).x - sdf(p - y).x, sdf(p + z).x - sdf(p - z).x));
+    }
+    static float saw(float x) { return x - m_floor(x); }           /* :280-283 */
+    static float pulse(float x) { return saw(x + .5f) - saw(x); }  /* :285-288 */
+    /* :293-377 */
+    vec3 illuminate(vec3 eye, hit_t& hit) const {
+        vec3 L = sun_dir;
+        vec3 V = normalize(eye - hit.origin);
+        material_t mat = get_material(hit.material_id);
+        if (hit.material_id == mat_groove || hit.material_id == mat_dead_wax) {
+            hit.origin = mul(hit.origin, platter_rot);
+            L = mul(L, platter_rot);
+            V = mul(V, platter_rot);
+            float r = length(hit.origin);
+            vec3 B = hit.origin / r;
+            vec3 N = vec3(0, 1, 0);
+            if (hit.material_id == mat_groove) {
+                float rr = r + .07575f * noise_iq(hit.origin * 2.456f);
+                float s = pulse(rr * 24.f);
+                if (s > 0.f) {
+                    N = normalize(N + B);
+                    N = reflect(N, vec3(0, 1, 0));
+                }
+            }
+            if (hit.material_id == mat_dead_wax) {
+                float s = saw(r * 4.f);
+                N = normalize(N + B * (float)(s > .9f));
+            }
+            vec3 T = cross(B, N);
+            const float ro_diff = 1.f;
+            const float ro_spec = .0725f;
+            const float a_x = .025f;
+            const float a_y = .5f;
+            vec3 H = normalize(V + L);
+            float dotLN = dot(L, N);
+            vec3 diffuse = mat.base_color * (ro_diff / PI) * m_max(0.f, dotLN);
+            float spec_a = ro_spec / m_sqrt(dotLN * dot(V, N));
+            float spec_b = 1.f / (4.f * PI * a_x * a_y);
+            float ht = dot(H, T) / a_x;
+            float hb = dot(H, B) / a_y;
+            float spec_c = -2.f * (ht * ht + hb * hb) / (1.f + dot(H, N));
+            vec3 specular = vec3(1, 1, 1) * spec_a * spec_b * m_exp(spec_c);
+            return diffuse + specular;
+        } else {
+            hit.normal = sdf_normal(hit.origin);
+            vec3 diffuse = mat.base_color * m_max(0.f, dot(L, hit.normal));
+            vec3 H = normalize(V + L);
+            vec3 specular = m_pow(m_max(0.f, dot(H, hit.normal)), 50.f) * vec3(1, 1, 1);
+            return diffuse + specular;
+        }
+    }
+    /* :379-404 */
+    float sdf_shadow(const ray_t& ray) const {
+        const int steps = 20;
+        const float end = 5.f;
+        const float penumbra_factor = 16.f;
+        const float darkest = .05f;
+        float t = 0.f;
+        float umbra = 1.f;
+        for (int i = 0; i < steps; i++) {
+            vec3 p = ray.origin + ray.direction * t;
+            vec2 d = sdf(p);
+            if (t > end) break;
+            if (d.x < .005f) return darkest;
+            t += d.x;
+            umbra = m_min(umbra, penumbra_factor * d.x / t);
+        }
+        return umbra;
+    }
+    /* :406-457 */
+    vec3 render(const ray_t& ray, vec3 /*point_cam*/) {
+        const int steps = 60;                                 /* the __cplusplus value, :411-416 */
+        const float end = 40.f;
+        float rot = U.u_time * 200.f;
+        platter_rot = mul(rotate_around_y(rot), rotate_around_x(m_sin(U.u_time) * .1f));
+        float t = 0.f;
+        for (int i = 0; i < steps; i++) {
+            vec3 p = ray.origin + ray.direction * t;
+            vec2 d = sdf(p);
+            if (t > end) break;
+            if (d.x < .005f) {
+                hit_t h;
+                h.t = t; h.material_id = (int)d.y; h.normal = vec3(0, 1, 0); h.origin = p;
+                float sh = 1.f;
+                ray_t sh_ray; sh_ray.origin = p + sun_dir * 0.05f; sh_ray.direction = sun_dir;
+                sh = sdf_shadow(sh_ray);
+                return illuminate(ray.origin, h) * sh;
+            }
+            t += d.x;
+        }
+        return background(ray);
+    }
+};
+
 } /* namespace sbxref */
 #endif

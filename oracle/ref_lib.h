@@ -182,6 +182,15 @@ static inline vec2 sd_bezier(vec3 a, vec3 b, vec3 c, vec3 p, float thickness) {
     return vec2(0.85f * (m_sqrt(dot(cp.xy(), cp.xy()) + p3.z * p3.z) - thickness), cp.z);
 }
 
+/* sdf.h:30-36 */
+static inline float op_intersect(float d1, float d2) { return m_max(d1, d2); }
+/* sdf.h:162-171 */
+static inline float sd_capsule(vec3 p, vec3 a, vec3 b, float r) {
+    vec3 ab = b - a;
+    float t = m_clamp(dot(p - a, ab) / dot(ab, ab), 0.f, 1.f);
+    return length((ab * t + a) - p) - r;
+}
+
 /* ---- src/IK.h ------------------------------------------------------------------- */
 /* IK.h:5-42 (the law-of-cosines branch, the one compiled) */
 static inline vec3 ik_2_bone_centered_solver(vec3 goal, float L1, float L2) {

@@ -59,6 +59,7 @@ static bool pixel(int app, const uniforms_t& U, const void* aux, float fx, float
     case APP_ATMOSPHERE: { AppAtmosphere a; a.U = U; c = main_image(a, fc); break; }
     case APP_SDF_AO: { AppSdfAo a; a.U = U; a.A = parse_sdf_ao_aux(aux); c = main_image(a, fc); break; }
     case APP_PLANET: { AppPlanet a; a.U = U; c = main_image(a, fc); break; }
+    case APP_VINYL: { AppVinyl a; a.U = U; c = main_image(a, fc); break; }
     default: return false;
     }
     out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;

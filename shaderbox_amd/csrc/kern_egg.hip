@@ -8,47 +8,9 @@
 // runs per march step.  `depth` (a _mutable global, :188) is a per-thread register that starts
 // at -max_dist for every pixel = GLSL per-invocation semantics.
 #include "sbx_device.h"
+#include "sbx_sdf.h"
 
 namespace sbx {
-
-__device__ __forceinline__ float op_blend(float a, float b, float k) {      // sdf.h:38-47
-    float h = clamp_(0.5f + 0.5f * (b - a) / k, 0.0f, 1.0f);
-    return mix_(b, a, h) - k * h * (1.0f - h);
-}
-__device__ __forceinline__ float det2(v2 a, v2 b) { return a.x * b.y - b.x * a.y; }   // sdf.h:114-119
-
-// sd_bezier, point-dependent part                                          sdf.h:120-159
-__device__ __forceinline__ float sd_bezier_x(const BezierFrame& B, v3 p, float thickness) {
-    const v3 q = p - B.b;
-    const v3 p3 = V3(dot(q, B.u), dot(q, B.v), dot(q, B.w));
-    const v2 pxy = V2(p3.x, p3.y);
-    const v2 b0 = B.a2 - pxy, b1 = V2(0.f, 0.f) - pxy, b2 = B.c2 - pxy;
-    // sd_bezier_get_closest :120-139
-    const float a = det2(b0, b2);
-    const float b = 2.0f * det2(b1, b0);
-    const float d = 2.0f * det2(b2, b1);
-    const float f = b * d - a * a;
-    const v2 d21 = b2 - b1, d10 = b1 - b0, d20 = b2 - b0;
-    v2 gf = 2.0f * (b * d21 + d * d10 + a * d20);
-    gf = V2(gf.y, -gf.x);
-    const v2 pp = (-f * gf) / dot(gf, gf);
-    const v2 d0p = b0 - pp;
-    const float ap = det2(d0p, d20);
-    const float bp = 2.0f * det2(d10, d0p);
-    const float t = clamp_((ap + bp) / (2.0f * a + b + d), 0.0f, 1.0f);
-    const v2 cp = mix2(mix2(b0, b1, t), mix2(b1, b2, t), t);
-    return 0.85f * (sqrt_(dot(cp, cp) + p3.z * p3.z) - thickness);
-}
-// sd_cylinder(P, 0, P1, R), point-dependent part                            sdf.h:95-109
-__device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) {
-    const float dist = length(cross(C.dir, P - V3(0.f, 0.f, 0.f)));
-    const float plane_1 = dot(C.dir, P) + C.len1;
-    const float plane_2 = dot(-C.dir, P) + (-C.len0);
-    return fmax_(fmax_(dist, -plane_1), -plane_2) - R;           // op_sub(op_sub(dist,p1),p2) - R
-}
-
-struct D2 { float d, m; };   // (distance, material id) pairs; op_add keeps the nearer   sdf.h:5-11
-__device__ __forceinline__ D2 op_add2(D2 a, D2 b) { return a.d < b.d ? a : b; }
 
 __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
     const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                         // :40-41

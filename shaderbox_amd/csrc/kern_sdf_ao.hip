@@ -5,17 +5,9 @@
 // render (height fog) :287-311; SDF primitives from src/sdf.h.  The two constant-angle rotations
 // (rotate_around_x(-90), rotate_around_y(180)) and normalize(1,2,1) are frame constants.
 #include "sbx_device.h"
+#include "sbx_sdf.h"
 
 namespace sbx {
-
-struct D2 { float d, m; };
-__device__ __forceinline__ D2 op_add2(D2 a, D2 b) { return a.d < b.d ? a : b; }                  // sdf.h:5-11
-__device__ __forceinline__ float sd_box(v3 p, v3 b) {                                            // sdf.h:67-73
-    return fmax_(abs_(p.x) - b.x, fmax_(abs_(p.y) - b.y, abs_(p.z) - b.z));
-}
-__device__ __forceinline__ float sd_y_cylinder(v3 p, float r, float h) {                          // sdf.h:85-93
-    return fmax_(length(V2(p.x, p.z)) - r, abs_(p.y) - h / 2.f);
-}
 
 __device__ __forceinline__ D2 ao_sdf_pipe(const FrameSdfAo& F, v3 pos) {                          // :54-113
     const v3 size = V3(1.3f, 1.f, 1.25f);                                                          // :52

@@ -1,0 +1,198 @@
+// shaderbox_amd/csrc/kern_vinyl.hip — APP_VINYL: turntable SDF with anisotropic (Ward-like) vinyl shading.
+//
+// Follows /root/reference/src/app_vinyl.h with the C++ build's 60 march steps (:411-416; GLSL uses 180),
+// SHADERTOY undefined: sdf_logo :68-85, sdf_platter :87-125, sdf_tonearm :127-255, sdf :257-265, sdf_normal
+// :267-278, illuminate :293-377, sdf_shadow :379-404, render :406-457.  Everything that depends only on u_time
+// (platter and wobble rotations, the tonearm's constant-angle rotations, capsule/Bezier/cylinder frames) is in
+// FrameVinyl.  SURVEY.md §8f row 4; the reference has no known answers for this app (parity vs oracle only).
+#include "sbx_device.h"
+#include "sbx_sdf.h"
+#include "sbx_noise.h"
+
+namespace sbx {
+
+__device__ __forceinline__ float vinyl_logo(const FrameVinyl& F, v3 pos, float thick) {       // :68-85
+    const v3 b = V3(.25f, thick, 1.2f), d = V3(.7f, 0, 0);
+    v3 p = mul(pos, F.ry30);
+    const float v1 = sd_box(p - d, b);
+    p = mul(pos, F.rym30);
+    const float v2 = sd_box(p + d, b);
+    const float x = sd_box(pos, V3(1.5f, thick, 1.35f));
+    return fmax_(fmin_(v1, v2), x);                              // op_intersect(op_add(v1, v2), x)
+}
+__device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {                       // :87-125
+    const float thick = .1f;
+    const D2 lead_in = {sd_y_cylinder(p, 6.f, thick - .05f), 2.f};
+    const D2 groove = {sd_y_cylinder(p, 5.9f, thick), 1.f};
+    const D2 dead_wax = {sd_y_cylinder(p, 3.f, thick), 2.f};
+    const D2 label = {sd_y_cylinder(p, 2.f, thick), 3.f};
+    const D2 logo = {vinyl_logo(F, p, thick - .0175f), 4.f};
+    const float spc = sd_y_cylinder(p, .10f, .6f);
+    const float sps = length(p - V3(0, .3f, 0)) - .10f;
+    const D2 spindle = {fmin_(spc, sps), 5.f};
+    const D2 d0 = op_add2(groove, lead_in);
+    const D2 d1 = op_add2(d0, dead_wax);
+    const D2 d2 = op_add2(label, logo);
+    const D2 d3 = op_add2(d1, d2);
+    const D2 d4 = op_add2(d3, spindle);
+    const float defect1 = length(p + V3(6.05f, 0, 0)) - .1f;
+    const float defect2 = length(p + V3(-6.05f, 0, 0)) - .1f;
+    const float defect = fmin_(defect1, defect2);
+    return D2{fmax_(d4.d, -defect), d4.m};                       // op_sub
+}
+__device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos) {                     // :127-255
+    const v3 base_p = V3(-7, 0, -5);
+    const float platter = sd_y_cylinder(pos, 6.25f, 1.f);
+    const float base_0 = sd_y_cylinder(pos - base_p, 3.f, .25f);
+    const float base_1 = fmax_(base_0, -platter);
+    const float base_2 = sd_y_cylinder(pos - base_p, 1.25f, 1.f);
+    const float base_12 = fmin_(base_1, base_2);
+    const D2 base_a = {base_12, 5.f};
+    const D2 base_b = {sd_y_cylinder(pos - base_p, 0.5f, 2.5f), 5.f};
+    const D2 base = op_add2(base_a, base_b);
+
+    const v3 p = mul(pos, F.wobble);
+    const float R = .1f;
+    const float arm1 = sd_capsule_f(p, F.arm1.a, F.arm1.ab, F.arm1.rd, R);
+    const float arm2 = sd_capsule_f(p, F.arm2.a, F.arm2.ab, F.arm2.rd, R);
+    const float arm3 = sd_capsule_f(p, F.arm3.a, F.arm3.ab, F.arm3.rd, R);
+    const float armb = sd_bezier_x(F.armb, p, R);
+    const float arm_link1 = fmin_(arm1, arm2);
+    const float arm_link2 = fmin_(arm_link1, arm3);
+    const D2 arm = {fmin_(arm_link2, armb), 5.f};
+
+    const v3 clr_p = p - F.a3;
+    const float clr_r = R * 1.5f;
+    const float collar = sd_cylinder0(F.collar, clr_p, clr_r);
+    const float fl_w = .045f, fl_h = .020f;
+    const float fl_len1 = clr_r * 1.f;
+    const float fl_len2 = fl_len1 * 1.2f;
+    const v3 fl_p = mul(clr_p - F.fl_sub1 - F.fl_sub2, F.fl_rot);
+    const float fl1 = sd_box(fl_p, V3(fl_w, fl_h, fl_len1));
+    const float fl2 = sd_box(mul(fl_p - V3(0, 0, fl_len1), F.fl_rot2) - V3(0, 0, fl_len2), V3(fl_w, fl_h, fl_len2));
+    const float finger_lift = fmin_(fl1, fl2);
+    const D2 headshell = {fmin_(collar, finger_lift), 5.f};
+
+    const float ctg_w = .05f, ctg_h = .05f, ctg_len1 = .3f, ctg_len2 = .5f;
+    const v3 ctg_p = mul(clr_p, F.arm_xform);
+    const float ctg1 = sd_box(ctg_p, V3(ctg_len1, ctg_h, ctg_w));
+    const v3 ctg2_p = mul(ctg_p - V3(ctg_len1, 0, 0), F.ctg_rot) - V3(ctg_len2 - 0.03f, -.01f, 0);
+    const float ctg2 = sd_box(ctg2_p, V3(ctg_len2, ctg_h, ctg_w));
+    const float cut = sd_box(mul(mul(ctg2_p, F.cut_rx10) - V3(0, .05f, .175f), F.cut_rym5),
+                             V3(ctg_len2 * 2.f, ctg_h * 3.f, ctg_w * 3.2f));
+    const float cut2 = sd_box(mul(ctg2_p - V3(.3f, .2f, 0), F.cut2_rz10), V3(.4f, .2f, .3f));
+    const float ctg12 = fmin_(ctg1, ctg2);
+    const float ctg12c = fmax_(ctg12, -cut);
+    const D2 cartridge = {fmax_(ctg12c, -cut2), 5.f};
+
+    const D2 tone1 = op_add2(base, arm);
+    const D2 tone2 = op_add2(headshell, cartridge);
+    return op_add2(tone1, tone2);
+}
+__device__ __forceinline__ D2 vinyl_sdf(const FrameVinyl& F, v3 pos) {                         // :257-265
+    const D2 plat = vinyl_platter(F, mul(pos, F.platter_rot));
+    const D2 arm = vinyl_tonearm(F, pos);
+    return op_add2(plat, arm);
+}
+__device__ __forceinline__ float saw(float x) { return x - floor_(x); }                        // :280-283
+__device__ __forceinline__ float pulse(float x) { return saw(x + .5f) - saw(x); }              // :285-288
+
+__device__ __forceinline__ v3 vinyl_base_color(int mat) {                                       // setup_scene :40-54
+    switch (mat) {
+    case 0: return V3(1, 1, 1);
+    case 1: return V3(.01f, .01f, .01f);
+    case 2: return V3(.05f, .05f, .05f);
+    case 3: return V3(.5f, .5f, .0f);
+    case 4: return V3(0, 0, .7f);
+    case 5: return V3(.7f, .7f, .7f);
+    default: return V3(0, 0, 0);                                 // unset material slots are zero (App. B5)
+    }
+}
+
+__global__ void __launch_bounds__(WG_THREADS) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
+    const Pixel px = pixel_of_thread(M);
+    if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
+
+    v3 color = V3(1, 1, 1);                                     // background :15-18
+    float t = 0.f;
+    for (int i = 0; i < 60; ++i) {                              // render :427-455
+        const v3 p = ro + rd * t;
+        const D2 d = vinyl_sdf(F, p);
+        if (t > 40.f) break;
+        if (d.d < .005f) {
+            const int mat = (int)d.m;
+            // sdf_shadow :379-404
+            float sh = 1.f;
+            {
+                const v3 so = p + F.sun_dir * 0.05f;
+                float ts = 0.f;
+                for (int k = 0; k < 20; ++k) {
+                    const D2 ds = vinyl_sdf(F, so + F.sun_dir * ts);
+                    if (ts > 5.f) break;
+                    if (ds.d < .005f) { sh = .05f; break; }
+                    ts += ds.d;
+                    sh = fmin_(sh, 16.f * ds.d / ts);
+                }
+            }
+            // illuminate :293-377
+            v3 L = F.sun_dir;
+            v3 V = normalize(ro - p);
+            const v3 base = vinyl_base_color(mat);
+            v3 lit;
+            if (mat == 1 || mat == 2) {
+                const v3 ho = mul(p, F.platter_rot);
+                L = mul(L, F.platter_rot);
+                V = mul(V, F.platter_rot);
+                const float r = length(ho);
+                const v3 B = ho / r;
+                v3 N = V3(0, 1, 0);
+                if (mat == 1) {
+                    const float rr = r + .07575f * noise_iq(ho * 2.456f);
+                    const float s = pulse(rr * 24.f);
+                    if (s > 0.f) {
+                        N = normalize(N + B);
+                        N = N - 2.f * dot(V3(0, 1, 0), N) * V3(0, 1, 0);      // reflect(N, (0,1,0))
+                    }
+                }
+                if (mat == 2) {
+                    const float s = saw(r * 4.f);
+                    N = normalize(N + B * ((s > .9f) ? 1.f : 0.f));
+                }
+                const v3 T = cross(B, N);
+                const float ro_diff = 1.f, ro_spec = .0725f, a_x = .025f, a_y = .5f;
+                const v3 H = normalize(V + L);
+                const float dotLN = dot(L, N);
+                const v3 diffuse = base * (ro_diff / 3.14159265359f) * fmax_(0.f, dotLN);
+                const float spec_a = ro_spec / sqrt_(dotLN * dot(V, N));
+                const float spec_b = 1.f / (4.f * 3.14159265359f * a_x * a_y);
+                const float ht = dot(H, T) / a_x;
+                const float hb = dot(H, B) / a_y;
+                const float spec_c = -2.f * (ht * ht + hb * hb) / (1.f + dot(H, N));
+                const v3 specular = V3(1, 1, 1) * spec_a * spec_b * exp_(spec_c);
+                lit = diffuse + specular;
+            } else {
+                const float e = 0.001f;                              // sdf_normal :267-278
+                const v3 n = normalize(V3(
+                    vinyl_sdf(F, p + V3(e, 0, 0)).d - vinyl_sdf(F, p - V3(e, 0, 0)).d,
+                    vinyl_sdf(F, p + V3(0, e, 0)).d - vinyl_sdf(F, p - V3(0, e, 0)).d,
+                    vinyl_sdf(F, p + V3(0, 0, e)).d - vinyl_sdf(F, p - V3(0, 0, e)).d));
+                const v3 diffuse = base * fmax_(0.f, dot(L, n));
+                const v3 H = normalize(V + L);
+                const v3 specular = pow_(fmax_(0.f, dot(H, n)), 50.f) * V3(1, 1, 1);
+                lit = diffuse + specular;
+            }
+            color = lit * sh;
+            break;
+        }
+        t += d.d;
+    }
+    store_rgba(out, px.idx, to_srgb(color));
+}
+
+void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_vinyl, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+}
+
+}  // namespace sbx

@@ -159,6 +159,48 @@ static FrameSdfAo build_sdf_ao(const sbx_uniforms& U, const sbx_aux_sdf_ao& A) {
     return F;
 }
 
+static Capsule capsule(v3 a, v3 b) {                                   // sdf.h:168-169
+    Capsule c;
+    c.a = a;
+    c.ab = b - a;
+    c.rd = recip64(dot(c.ab, c.ab));
+    return c;
+}
+static FrameVinyl build_vinyl(const sbx_uniforms& U) {
+    FrameVinyl F;
+    const float t = U.u_time;
+    F.cam = make_camera(U.u_res[0], U.u_res[1], 1.f, V3(0, 5.75f, 6.75f), V3(0, -2.5f, 0));   // app_vinyl.h:56-64,459
+    F.platter_rot = mul(rotate_around_y(t * 200.f), rotate_around_x(sin_(t) * .1f));          // :417,424-426
+    F.sun_dir = normalize(V3(-1, 4, -3));
+    F.ry30 = rotate_around_y(30.f);
+    F.rym30 = rotate_around_y(-30.f);
+    F.wobble = rotate_around_x(sin_(t * 3.6758f) * .1f);
+    const float R = .1f, H = .8f;
+    const v3 base_p = V3(-7, 0, -5);
+    const v3 a1 = V3(-6, H, -3), a11 = V3(-4.25f, H, 2), a2 = V3(-4.1f, H, 2.45f), a33 = V3(-3.5f, H, 3), a3 = V3(-2, H, 4);
+    F.arm1 = capsule(base_p + V3(-1, H, -2), a1);
+    F.arm2 = capsule(a1, a11);
+    F.arm3 = capsule(a33, a3);
+    F.armb = bezier_frame(a11, a2, a33);
+    F.a3 = a3;
+    const v3 arm_fwd = normalize(a3 - a33);
+    const v3 arm_up = V3(0, 1, 0);
+    const v3 arm_right = cross(arm_fwd, arm_up);
+    F.arm_xform = m3{arm_fwd, arm_up, arm_right};
+    const float clr_r = R * 1.5f;
+    F.collar = cyl_frame(V3(0, 0, 0), V3(0, 0, 0) + arm_fwd * .05f);
+    F.fl_rot = mul(F.arm_xform, rotate_around_x(45.f));
+    F.fl_sub1 = arm_right * clr_r;
+    F.fl_sub2 = arm_up * clr_r;
+    F.fl_rot2 = rotate_around_x(-45.f);
+    F.ctg_rot = rotate_around_z(44.f);
+    F.cut_rx10 = rotate_around_x(10.f);
+    F.cut_rym5 = rotate_around_y(-5.f);
+    F.cut2_rz10 = rotate_around_z(10.f);
+    (void)R;
+    return F;
+}
+
 static FramePlanet build_planet(const sbx_uniforms& U) {
     FramePlanet F;
     F.cam = make_camera(U.u_res[0], U.u_res[1], tan_(radians_(30.f)), V3(0, 0, -2.5f), V3(0, 0, 2));   // app_planet.h:47-58,368
@@ -255,6 +297,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         break;
     }
     case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s); break;
+    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s); break;
     default: return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
     }
     if (ctx->timing) (void)hipEventRecord(ctx->ev1, s);

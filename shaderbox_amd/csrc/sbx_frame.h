@@ -125,4 +125,20 @@ struct FramePlanet {
     v3 L;                       // rot * normalize(1,1,0)   app_planet.h:289
 };
 
+// ---- APP_VINYL (src/app_vinyl.h; C++ build) -------------------------------------------------
+struct Capsule { v3 a, ab; double rd; };   // sd_capsule(p, a, b, r): ab = b - a, rd = recip64(dot(ab, ab))
+struct FrameVinyl {
+    Camera cam;
+    m3 platter_rot;            // rotate_around_y(200 t) * rotate_around_x(sin(t) * .1)      app_vinyl.h:424-426
+    v3 sun_dir;                // normalize(-1, 4, -3)                                        :285-286
+    m3 ry30, rym30;            // logo                                                        :74,77
+    m3 wobble;                 // rotate_around_x(sin(3.6758 t) * .1)                         :141-142
+    Capsule arm1, arm2, arm3;  //                                                             :151-153
+    BezierFrame armb;          // sd_bezier(a11, a2, a33, ., R)                               :154
+    v3 a3;                     //                                                             :150
+    m3 arm_xform, fl_rot, fl_rot2, ctg_rot, cut_rx10, cut_rym5, cut2_rz10;   // :163-232
+    v3 fl_sub1, fl_sub2;       // arm_right * clr_r, arm_up * clr_r                           :191-193
+    CylFrame collar;           // sd_cylinder(., 0, arm_fwd * .05, .)                         :173-176
+};
+
 }  // namespace sbx

@@ -1,0 +1,57 @@
+// shaderbox_amd/csrc/sbx_sdf.h — the SDF library of /root/reference/src/sdf.h for the kernels, with the
+// point-independent part of the costly primitives split off into per-frame "frames" (host-evaluated).
+#pragma once
+#include "sbx_frame.h"
+
+namespace sbx {
+
+struct D2 { float d, m; };   // (distance, material id); op_add keeps the nearer              sdf.h:5-11
+__device__ __forceinline__ D2 op_add2(D2 a, D2 b) { return a.d < b.d ? a : b; }
+
+__device__ __forceinline__ float op_blend(float a, float b, float k) {                         // sdf.h:38-47
+    float h = clamp_(0.5f + 0.5f * (b - a) / k, 0.0f, 1.0f);
+    return mix_(b, a, h) - k * h * (1.0f - h);
+}
+__device__ __forceinline__ float sd_box(v3 p, v3 b) {                                          // sdf.h:67-73
+    return fmax_(abs_(p.x) - b.x, fmax_(abs_(p.y) - b.y, abs_(p.z) - b.z));
+}
+__device__ __forceinline__ float sd_y_cylinder(v3 p, float r, float h) {                        // sdf.h:85-93
+    return fmax_(length(V2(p.x, p.z)) - r, abs_(p.y) - h / 2.f);
+}
+__device__ __forceinline__ float det2(v2 a, v2 b) { return a.x * b.y - b.x * a.y; }             // sdf.h:114-119
+
+// sd_bezier(a, b, c, p, thickness).x, point-dependent part (frame = bezier_frame(a, b, c))    sdf.h:120-159
+__device__ __forceinline__ float sd_bezier_x(const BezierFrame& B, v3 p, float thickness) {
+    const v3 q = p - B.b;
+    const v3 p3 = V3(dot(q, B.u), dot(q, B.v), dot(q, B.w));
+    const v2 pxy = V2(p3.x, p3.y);
+    const v2 b0 = B.a2 - pxy, b1 = V2(0.f, 0.f) - pxy, b2 = B.c2 - pxy;
+    const float a = det2(b0, b2);                                // sd_bezier_get_closest :120-139
+    const float b = 2.0f * det2(b1, b0);
+    const float d = 2.0f * det2(b2, b1);
+    const float f = b * d - a * a;
+    const v2 d21 = b2 - b1, d10 = b1 - b0, d20 = b2 - b0;
+    v2 gf = 2.0f * (b * d21 + d * d10 + a * d20);
+    gf = V2(gf.y, -gf.x);
+    const v2 pp = (-f * gf) / dot(gf, gf);
+    const v2 d0p = b0 - pp;
+    const float ap = det2(d0p, d20);
+    const float bp = 2.0f * det2(d10, d0p);
+    const float t = clamp_((ap + bp) / (2.0f * a + b + d), 0.0f, 1.0f);
+    const v2 cp = mix2(mix2(b0, b1, t), mix2(b1, b2, t), t);
+    return 0.85f * (sqrt_(dot(cp, cp) + p3.z * p3.z) - thickness);
+}
+// sd_cylinder(P, 0, P1, R), point-dependent part (frame = cyl_frame(0, P1))                    sdf.h:95-109
+__device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) {
+    const float dist = length(cross(C.dir, P - V3(0.f, 0.f, 0.f)));
+    const float plane_1 = dot(C.dir, P) + C.len1;
+    const float plane_2 = dot(-C.dir, P) + (-C.len0);
+    return fmax_(fmax_(dist, -plane_1), -plane_2) - R;           // op_sub(op_sub(dist, p1), p2) - R
+}
+// sd_capsule(p, a, b, r) with ab = b - a and rd = recip64(dot(ab, ab)) from the frame         sdf.h:162-171
+__device__ __forceinline__ float sd_capsule_f(v3 p, v3 a, v3 ab, double rd, float r) {
+    const float t = clamp_(div_by(dot(p - a, ab), rd), 0.f, 1.f);
+    return length((ab * t + a) - p) - r;
+}
+
+}  // namespace sbx

@@ -17,6 +17,7 @@ CASES = [
     ("atmosphere", 256, 144),
     ("sdf_ao", 256, 144),
     ("planet", 256, 144),
+    ("vinyl", 256, 144), ("vinyl", 160, 160),
 ]
 TIMES = [0.0, 0.37, 2.5]
 
@@ -123,7 +124,7 @@ def test_device_math_matches_oracle(renderer, oracle):
 def test_error_codes(renderer):
     import shaderbox_amd
     with pytest.raises(shaderbox_amd.SbxError) as e:
-        renderer.render("APP_VINYL", 64, 64, 0.0)
+        renderer.render(7, 64, 64, 0.0)
     assert e.value.code == shaderbox_amd.SBX_ERR_UNSUPPORTED
     with pytest.raises(shaderbox_amd.SbxError) as e:
         renderer.render("egg", 64, 64, 0.0, rows=(10, 80))
@@ -169,7 +170,8 @@ def test_clouds_4k_against_survey_pixels_and_oracle_rows(renderer, oracle):
                                           ("raytracer", 3840, 2160, [0, 500, 1080, 1600, 2159]),
                                           ("atmosphere", 7680, 4320, [0, 1000, 2160, 3000, 4319]),
                                           ("planet", 7680, 4320, [2160, 2600]),
-                                          ("sdf_ao", 1920, 1080, [0, 400, 800, 1079])])
+                                          ("sdf_ao", 1920, 1080, [0, 400, 800, 1079]),
+                                          ("vinyl", 1920, 1080, [100, 540, 900])])
 def test_full_size_rows_match_oracle(renderer, oracle, app, w, h, rows):
     """BASELINE.json config sizes (C2 EGG 1920x1080, C3 RAYTRACER 3840x2160, C5 7680x4320): full-width rows
     of the full-size frame, rendered as one-row strips on the GPU, equal the oracle bit-for-bit."""
@@ -205,7 +207,7 @@ def test_noise_library_matches_oracle(renderer, oracle):
 def test_tiny_and_ragged_frames(renderer, oracle, w, h):
     """sizes that do not fill a wave tile / workgroup: every app, bit-for-bit"""
     from oracle.oracle import APP_IDS
-    for app in ("egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet"):
+    for app in ("egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet", "vinyl"):
         ref = oracle.render(APP_IDS[app], w, h, 0.37, threads=4)
         gpu = renderer.render(app, w, h, 0.37).cpu().numpy()
         assert compare(gpu, ref) == (0.0, 0), (app, w, h)
