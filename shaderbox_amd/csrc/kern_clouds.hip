@@ -200,7 +200,7 @@ __device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, floa
 
 // density_func of a MAIN march sample with the y terms of its step taken from the frame table (SGPRs)
 __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
-                                                  WaveCache& S, int lane) {
+                                                  unsigned long long active_mask, WaveCache& S, int lane) {
     float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
     const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
     const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
@@ -209,7 +209,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
     unsigned nbits[4];
     int slot[4];
     bool ne[4];
-    bool miss = false;
+    unsigned long long miss_mask = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float px = floor_(qx), pz = floor_(qz);
@@ -220,11 +220,11 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
         nbits[k] = f2u(n);
         slot[k] = (int)n & (HC_SLOTS - 1);
         ne[k] = (S.tag[k][slot[k]] != nbits[k]);
-        miss |= ne[k];
+        miss_mask |= wave_mask(ne[k]);
         qx = qx * 2.64f; qz = qz * 2.64f;
     }
     float t = 0.f, H = .5f;
-    if (!wave_any(active && miss)) {
+    if (!wave_any_mask(miss_mask & active_mask)) {
         float4 lo[4], hi[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -265,8 +265,8 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 // sample only the z terms, the cell lookup and the final z-mix remain.  Every value is produced by the
 // same operations on the same inputs as in the general path, hence identical bits.
 template <bool YTAB>
-__device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, WaveCache& S, int lane,
-                                               const YRow& row) {
+__device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
+                                               WaveCache& S, int lane, const YRow& row) {
     float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4];
     unsigned cur[4];
     {
@@ -300,7 +300,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
         unsigned nbits[4];
         int slot[4];
         bool ne[4];
-        bool miss = false;
+        unsigned long long miss_mask = 0, moved_mask = 0;
         float qz = (lp.z * .001f) * 2.03f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -311,10 +311,11 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             nbits[k] = f2u(n);
             slot[k] = (int)n & (HC_SLOTS - 1);
             ne[k] = (S.tag[k][slot[k]] != nbits[k]);
-            miss |= ne[k];
+            miss_mask |= wave_mask(ne[k]);
+            moved_mask |= wave_mask(nbits[k] != cur[k]);
             qz = qz * 2.64f;
         }
-        if (wave_any(lit && miss)) {
+        if (wave_any_mask(miss_mask & lit_mask)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 H8 h;
@@ -327,7 +328,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
                 hc_blend_xy(h.lo, h.hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
                 cur[k] = nbits[k];
             }
-        } else if (wave_any(lit && ((nbits[0] != cur[0]) | (nbits[1] != cur[1]) | (nbits[2] != cur[2]) | (nbits[3] != cur[3])))) {
+        } else if (wave_any_mask(moved_mask & lit_mask)) {
             // some lit lane entered another cell in some octave: refresh all four x/y blends (one uniform
             // branch per sample costs less than one per octave)
 #pragma unroll
@@ -388,21 +389,23 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
             const float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
             const v3 lstep = F.sun_dir * F.dt;
             float t = 0.f;
+            unsigned long long alive_mask = wave_mask(alive);
             for (int i = 0; i < F.steps; ++i) {
-                if (!wave_any(alive)) break;
+                if (!wave_any_mask(alive_mask)) break;
                 const v3 pos = origin + t * projection;
                 t += F.dt;
                 YRow row;
                 if (YTAB) row = ytab[i];                          // uniform index: scalar loads
-                const float density = YTAB ? coop_density_row(F, pos, row, alive, S, lane)
+                const float density = YTAB ? coop_density_row(F, pos, row, alive, alive_mask, S, lane)
                                            : coop_density(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
-                if (wave_any(lit)) {
+                const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
+                if (wave_any_mask(lit_mask)) {
                     const float T_i = exp_(-density * F.sigma * F.dt);
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
                     if (lstep.x == 0.f && lstep.y == 0.f) {        // uniform (kernel argument): z-only light step
-                        ltrans = light_march_z<YTAB>(F, lp, lstep, lit, S, lane, row);
+                        ltrans = light_march_z<YTAB>(F, lp, lstep, lit, lit_mask, S, lane, row);
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
                             const float d = coop_density(F, lp, lit, S, lane);
@@ -418,6 +421,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
                     }
                 }
                 if (alpha > .999f) alive = false;                 // :197
+                alive_mask &= ~wave_mask(alpha > .999f);
             }
         }
     }

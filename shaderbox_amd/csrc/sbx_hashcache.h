@@ -22,8 +22,16 @@ namespace sbx {
 // region on per-lane terms; the region then runs with lanes masked off and the cooperative steps
 // silently lose their workers (observed: endless miss loops).  Passing the mask through an empty asm
 // with an SGPR constraint keeps the value uniform and hides its origin.
+// ballot of a comparison is the comparison's own SGPR result; ballots of combined predicates cost a
+// v_cndmask + v_cmp round trip, so hot tests OR/AND the 64-bit masks of the individual comparisons instead
+__device__ __forceinline__ unsigned long long wave_mask(bool x) { return __builtin_amdgcn_ballot_w64(x); }
+__device__ __forceinline__ bool wave_any_mask(unsigned long long m) {
+    unsigned any = (unsigned)m | (unsigned)(m >> 32);
+    asm volatile("" : "+s"(any));
+    return any != 0;
+}
 __device__ __forceinline__ bool wave_any(bool x) {
-    const unsigned long long m = __ballot(x);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(x);    // the i1 mask itself, no 0/1 round trip through a VGPR
     unsigned any = (unsigned)m | (unsigned)(m >> 32);
     asm volatile("" : "+s"(any));
     return any != 0;
@@ -41,7 +49,7 @@ struct alignas(16) WaveCache {
 __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, int slot, bool need, int lane) {
     const int corner = lane & 7;
     const float off = (corner & 1 ? 1.0f : 0.0f) + (corner & 2 ? 157.0f : 0.0f) + (corner & 4 ? 113.0f : 0.0f);
-    unsigned long long m = __ballot(need);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(need);
     while (m) {
         int cnt = 0;
         while (m && cnt < 8) {
@@ -49,7 +57,7 @@ __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, i
             const unsigned n0 = (unsigned)__builtin_amdgcn_readlane((int)nbits, leader);
             const int s0 = __builtin_amdgcn_readlane(slot, leader);
             if (lane == cnt) { S.ins_tag[cnt] = n0; S.ins_slot[cnt] = (unsigned)s0; }
-            m &= ~__ballot(slot == s0);          // one cell per slot per call; losers are served in the next round
+            m &= ~__builtin_amdgcn_ballot_w64(slot == s0);          // one cell per slot per call; losers are served in the next round
             ++cnt;
         }
         __builtin_amdgcn_wave_barrier();
