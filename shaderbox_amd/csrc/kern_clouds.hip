@@ -40,7 +40,7 @@ __device__ __forceinline__ float clouds_illuminate(const FrameClouds& F, v3 orig
 // Kept as the in-library cross-check of the cooperative kernel below (sbx_set_variant(ctx, 1)).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, RowMap M, float* __restrict__ out) {
-    const Pixel px = pixel_of_thread(M);
+    const Pixel px = pixel_of_thread<32>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 dir = primary_dir(F.cam, pc);
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
         // Only what the march needs stays live across it (origin, projection, phase): the view direction
         // and the sky colour are recomputed in the epilogue from the pixel coordinates — same operations,
         // same bits — which keeps the register budget of the march at 4 waves per SIMD without spills.
-        const Pixel px = pixel_of_thread(M);
+        const Pixel px = pixel_of_thread<32>(M);
         const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
         const v3 dir = primary_dir(F.cam, pc);
         const float cutoff = dot(dir, V3(0, 1, 0));
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
             }
         }
     }
-    const Pixel px = pixel_of_thread(M);
+    const Pixel px = pixel_of_thread<32>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 dir = primary_dir(F.cam, pc);
@@ -440,13 +440,13 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
 
 void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows) {
     if (variant == 1) {
-        hipLaunchKernelGGL(k_clouds_perlane, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+        hipLaunchKernelGGL(k_clouds_perlane, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out);
     } else if (ytab && F.steps <= ytab_rows && F.steps > 0) {
         YRow* tab = reinterpret_cast<YRow*>(ytab);
         hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
-        hipLaunchKernelGGL(k_clouds<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out, (const YRow*)tab);
+        hipLaunchKernelGGL(k_clouds<true>, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out, (const YRow*)tab);
     } else {
-        hipLaunchKernelGGL(k_clouds<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out, (const YRow*)nullptr);
+        hipLaunchKernelGGL(k_clouds<false>, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out, (const YRow*)nullptr);
     }
 }
 

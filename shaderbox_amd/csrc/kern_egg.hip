@@ -55,7 +55,7 @@ __device__ __forceinline__ float egg_shadowmarch(const FrameEgg& F, v3 ro, v3 rd
 }
 
 __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float* __restrict__ out) {
-    const Pixel px = pixel_of_thread(M);
+    const Pixel px = pixel_of_thread<16>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float*
 }
 
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_egg, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    hipLaunchKernelGGL(k_egg, grid_for<16>(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

@@ -1,33 +1,39 @@
 // shaderbox_amd/csrc/sbx_device.h — thread->pixel mapping and framebuffer store shared by the kernels.
 //
-// One thread per pixel.  A workgroup is 256 threads = 4 wave64; each wave owns an 8x8 pixel tile
-// (lane = ly*8 + lx) so that the rays of a wave stay coherent (same lattice cells, same march
-// exits) and so that a tile of 8 rows lines up with the 8-row cyclic blocks of the multi-GPU
-// split; the workgroup covers 32x8 pixels.  Every lane stores one float4 (16 B): a wave writes
-// eight 128-byte row segments, fully coalesced.
+// One thread per pixel.  A workgroup is 256 threads = 4 wave64; each wave owns a small pixel tile
+// (8x8 by default, lane = ly*TW + lx) so that the rays of a wave stay coherent (same lattice cells,
+// same march exits); the workgroup covers 4 tiles side by side.  Every lane stores one float4 (16 B):
+// a wave writes full 128..512-byte row segments, fully coalesced.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "sbx_frame.h"
 
 namespace sbx {
 
-constexpr int TILE_W = 8, TILE_H = 8, WG_TILES_X = 4;
-constexpr int WG_W = TILE_W * WG_TILES_X, WG_H = TILE_H, WG_THREADS = 256;
+// Tile shape of a wave (TW x 64/TW pixels) is chosen per kernel from measurements on MI355X
+// (profiles/r01_tile_shapes.txt): wide tiles suit APP_CLOUDS (a pixel row shares dir.y, hence march
+// length and lit pattern), 16x4 suits APP_EGG, 8x8 the others.  Tile heights divide the 8-row blocks of the
+// multi-GPU split.
+constexpr int WG_TILES_X = 4, WG_THREADS = 256;
 
 struct Pixel { int x, y; size_t idx; bool valid; };
 
+template <int TW = 8>
 __device__ __forceinline__ Pixel pixel_of_thread(const RowMap& M) {
+    constexpr int TH = 64 / TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Pixel p;
-    p.x = blockIdx.x * WG_W + wave * TILE_W + (lane & 7);
-    const int r = blockIdx.y * WG_H + (lane >> 3);
+    p.x = blockIdx.x * (TW * WG_TILES_X) + wave * TW + (lane % TW);
+    const int r = blockIdx.y * TH + (lane / TW);
     p.valid = (p.x < M.width) && (r < M.nrows);
     p.y = row_to_y(M, r);
     p.idx = (size_t)r * M.width + p.x;
     return p;
 }
+template <int TW = 8>
 inline dim3 grid_for(const RowMap& M) {
-    return dim3((M.width + WG_W - 1) / WG_W, (M.nrows + WG_H - 1) / WG_H);
+    constexpr int TH = 64 / TW, W = TW * WG_TILES_X;
+    return dim3((M.width + W - 1) / W, (M.nrows + TH - 1) / TH);
 }
 __device__ __forceinline__ void store_rgba(float* out, size_t idx, v3 c) {
     reinterpret_cast<float4*>(out)[idx] = make_float4(c.x, c.y, c.z, 1.0f);   // main.h:52
