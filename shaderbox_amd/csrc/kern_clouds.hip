@@ -362,10 +362,16 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
     return abs3(sky);
 }
 
+// Waves per workgroup. Waves never talk to each other (one LDS cache per wave), so the workgroup is only a
+// scheduling unit: measured at 4K, 1 wave/WG 5.26 ms, 2 5.57 ms, 4 5.48 ms per launch (profiles/r01_tile_shapes.txt);
+// single-wave workgroups also drain best at the end of a launch (8-rank strips 0.63 vs 0.71 ms/frame pipelined).
+#ifndef CL_TX
+#define CL_TX 1
+#endif
 template <bool YTAB>
-__global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out,
+__global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out,
                                                           const YRow* __restrict__ ytab) {
-    __shared__ WaveCache cache[WG_THREADS / 64];
+    __shared__ WaveCache cache[CL_TX];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
@@ -377,7 +383,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
         // Only what the march needs stays live across it (origin, projection, phase): the view direction
         // and the sky colour are recomputed in the epilogue from the pixel coordinates — same operations,
         // same bits — which keeps the register budget of the march at 4 waves per SIMD without spills.
-        const Pixel px = pixel_of_thread<32>(M);
+        const Pixel px = pixel_of_thread<32, CL_TX>(M);
         const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
         const v3 dir = primary_dir(F.cam, pc);
         const float cutoff = dot(dir, V3(0, 1, 0));
@@ -425,7 +431,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
             }
         }
     }
-    const Pixel px = pixel_of_thread<32>(M);
+    const Pixel px = pixel_of_thread<32, CL_TX>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 dir = primary_dir(F.cam, pc);
@@ -438,15 +444,16 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_clouds(FrameClouds F, RowMap 
     store_rgba(out, px.idx, to_srgb(col));
 }
 
-void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows) {
+void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows,
+                   bool build_table) {
     if (variant == 1) {
         hipLaunchKernelGGL(k_clouds_perlane, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out);
     } else if (ytab && F.steps <= ytab_rows && F.steps > 0) {
         YRow* tab = reinterpret_cast<YRow*>(ytab);
-        hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
-        hipLaunchKernelGGL(k_clouds<true>, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out, (const YRow*)tab);
+        if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
+        hipLaunchKernelGGL(k_clouds<true>, (grid_for<32, CL_TX>(M)), dim3(64 * CL_TX), 0, s, F, M, out, (const YRow*)tab);
     } else {
-        hipLaunchKernelGGL(k_clouds<false>, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out, (const YRow*)nullptr);
+        hipLaunchKernelGGL(k_clouds<false>, (grid_for<32, CL_TX>(M)), dim3(64 * CL_TX), 0, s, F, M, out, (const YRow*)nullptr);
     }
 }
 

@@ -19,6 +19,15 @@ struct sbx_ctx {
     int variant = 0;
     char* ytab = nullptr;      // CLOUDS_YTAB_RING tables of CLOUDS_YTAB_BYTES, device memory
     unsigned ytab_next = 0;
+    // the table depends only on (eye.y + wind.y, dt, steps): it is rebuilt, into the next ring slot, only when that
+    // key or the stream changes (default wind has no y component, so an animation reuses one table)
+    bool ytab_valid = false;
+    float ytab_key[3] = {0, 0, 0};
+    int ytab_steps = 0;
+    hipStream_t ytab_stream = nullptr;
+    void* ytab_cur = nullptr;
+    hipEvent_t ytab_ready{};
+    bool have_ytab_event = false;
     bool have_events = false;
     hipEvent_t ev0{}, ev1{};
     std::string err;
@@ -260,6 +269,7 @@ int sbx_create(int device, sbx_ctx** out) {
 void sbx_destroy(sbx_ctx* ctx) {
     if (!ctx) return;
     if (ctx->ytab) (void)hipFree(ctx->ytab);
+    if (ctx->have_ytab_event) (void)hipEventDestroy(ctx->ytab_ready);
     if (ctx->have_events) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
     delete ctx;
 }
@@ -283,8 +293,26 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         sbx_aux_clouds A;
         if (aux) A = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&A);
         if (A.cld_march_steps < 0 || A.illum_march_steps < 0) return fail(ctx, SBX_ERR_ARG, "negative march steps");
-        void* ytab = ctx->ytab + (size_t)(ctx->ytab_next++ % CLOUDS_YTAB_RING) * CLOUDS_YTAB_BYTES;
-        launch_clouds(build_clouds(*uni, A), M, rgba, s, ctx->variant, ytab, CLOUDS_YTAB_ROWS);
+        const FrameClouds F = build_clouds(*uni, A);
+        const float key[3] = {F.cam.eye.y, F.wind_off.y, F.dt};
+        bool rebuild = !ctx->ytab_valid || F.steps != ctx->ytab_steps ||
+                       std::memcmp(key, ctx->ytab_key, sizeof(key)) != 0;
+        if (!ctx->have_ytab_event) {
+            if (hipEventCreateWithFlags(&ctx->ytab_ready, hipEventDisableTiming) != hipSuccess)
+                return fail(ctx, SBX_ERR_HIP, "hipEventCreate");
+            ctx->have_ytab_event = true;
+        }
+        if (rebuild) {
+            ctx->ytab_cur = ctx->ytab + (size_t)(ctx->ytab_next++ % CLOUDS_YTAB_RING) * CLOUDS_YTAB_BYTES;
+            std::memcpy(ctx->ytab_key, key, sizeof(key));
+            ctx->ytab_steps = F.steps;
+            ctx->ytab_valid = true;
+            ctx->ytab_stream = s;
+        } else if (s != ctx->ytab_stream) {
+            (void)hipStreamWaitEvent(s, ctx->ytab_ready, 0);      // table was built on another stream
+        }
+        launch_clouds(F, M, rgba, s, ctx->variant, ctx->ytab_cur, CLOUDS_YTAB_ROWS, rebuild);
+        if (rebuild) (void)hipEventRecord(ctx->ytab_ready, s);
         break;
     }
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s); break;

@@ -14,25 +14,28 @@ namespace sbx {
 // (profiles/r01_tile_shapes.txt): wide tiles suit APP_CLOUDS (a pixel row shares dir.y, hence march
 // length and lit pattern), 16x4 suits APP_EGG, 8x8 the others.  Tile heights divide the 8-row blocks of the
 // multi-GPU split.
-constexpr int WG_TILES_X = 4, WG_THREADS = 256;
+#ifndef SBX_WG_WAVES
+#define SBX_WG_WAVES 4
+#endif
+constexpr int WG_TILES_X = SBX_WG_WAVES, WG_THREADS = 64 * SBX_WG_WAVES;
 
 struct Pixel { int x, y; size_t idx; bool valid; };
 
-template <int TW = 8>
+template <int TW = 8, int TX = WG_TILES_X>
 __device__ __forceinline__ Pixel pixel_of_thread(const RowMap& M) {
     constexpr int TH = 64 / TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Pixel p;
-    p.x = blockIdx.x * (TW * WG_TILES_X) + wave * TW + (lane % TW);
+    p.x = blockIdx.x * (TW * TX) + wave * TW + (lane % TW);
     const int r = blockIdx.y * TH + (lane / TW);
     p.valid = (p.x < M.width) && (r < M.nrows);
     p.y = row_to_y(M, r);
     p.idx = (size_t)r * M.width + p.x;
     return p;
 }
-template <int TW = 8>
+template <int TW = 8, int TX = WG_TILES_X>
 inline dim3 grid_for(const RowMap& M) {
-    constexpr int TH = 64 / TW, W = TW * WG_TILES_X;
+    constexpr int TH = 64 / TW, W = TW * TX;
     return dim3((M.width + W - 1) / W, (M.nrows + TH - 1) / TH);
 }
 __device__ __forceinline__ void store_rgba(float* out, size_t idx, v3 c) {
@@ -40,7 +43,8 @@ __device__ __forceinline__ void store_rgba(float* out, size_t idx, v3 c) {
 }
 
 // launchers (one per app), defined next to their kernels
-void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows);
+void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows,
+                   bool build_table);
 constexpr int CLOUDS_YTAB_ROWS = 1024;      // march steps covered by the per-frame y table
 constexpr int CLOUDS_YTAB_BYTES = CLOUDS_YTAB_ROWS * 48;
 constexpr int CLOUDS_YTAB_RING = 8;         // tables in flight (one per launch, round robin)
