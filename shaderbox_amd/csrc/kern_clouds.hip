@@ -267,8 +267,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 template <bool YTAB>
 __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                WaveCache& S, int lane, const YRow& row) {
-    float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4];
-    unsigned cur[4];
+    float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4], curz[4];
     {
         const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
         const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
@@ -289,54 +288,62 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
                 gy[k] = 1.0f - fy[k];
                 nxy[k] = px + py * 157.0f;
             }
-            cur[k] = 0x7fc00001u;
+            curz[k] = u2f(0x7fc00001u);
             ab[k] = cd[k] = 0.f;
             qx = qx * 2.64f; qy = qy * 2.64f;
         }
     }
     float ltrans = 1.f;
     for (int j = 0; j < F.lsteps; ++j) {
-        float fz[4];
-        unsigned nbits[4];
-        int slot[4];
-        bool ne[4];
-        unsigned long long miss_mask = 0, moved_mask = 0;
+        // z terms of the sample.  The cell of octave k is the one of the previous sample iff floor(z) is (nxy is
+        // fixed), and then ab/cd still hold its x/y blends whatever happened to the cache since: no lookup at all.
+        float fz[4], pzv[4];
+        unsigned long long moved_mask = 0;
         float qz = (lp.z * .001f) * 2.03f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float pz = floor_(qz);
             const float az = qz - pz;
             fz[k] = az * az * (3.0f - 2.0f * az);
-            const float n = nxy[k] + 113.0f * pz;
-            nbits[k] = f2u(n);
-            slot[k] = (int)n & (HC_SLOTS - 1);
-            ne[k] = (S.tag[k][slot[k]] != nbits[k]);
-            miss_mask |= wave_mask(ne[k]);
-            moved_mask |= wave_mask(nbits[k] != cur[k]);
+            pzv[k] = pz;
+            moved_mask |= wave_mask(pz != curz[k]);       // first sample: curz is NaN, always true
             qz = qz * 2.64f;
         }
-        if (wave_any_mask(miss_mask & lit_mask)) {
+        if (wave_any_mask(moved_mask & lit_mask)) {
+            // some lit lane entered another cell in some octave: look all four up again (one uniform branch
+            // per sample costs less than one per octave) and redo the x/y blends
+            unsigned nbits[4];
+            int slot[4];
+            bool ne[4];
+            unsigned long long miss_mask = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                H8 h;
-                if (wave_any(lit && ne[k])) {
-                    h = hc_slow(S, k, nbits[k], slot[k], lit, lane);
-                } else {
-                    h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
-                    h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
-                }
-                hc_blend_xy(h.lo, h.hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
-                cur[k] = nbits[k];
+                const float n = nxy[k] + 113.0f * pzv[k];
+                nbits[k] = f2u(n);
+                slot[k] = (int)n & (HC_SLOTS - 1);
+                ne[k] = (S.tag[k][slot[k]] != nbits[k]);
+                miss_mask |= wave_mask(ne[k]);
+                curz[k] = pzv[k];
             }
-        } else if (wave_any_mask(moved_mask & lit_mask)) {
-            // some lit lane entered another cell in some octave: refresh all four x/y blends (one uniform
-            // branch per sample costs less than one per octave)
+            if (wave_any_mask(miss_mask & lit_mask)) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
-                const float4 hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
-                hc_blend_xy(lo, hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
-                cur[k] = nbits[k];
+                for (int k = 0; k < 4; ++k) {
+                    H8 h;
+                    if (wave_any(lit && ne[k])) {
+                        h = hc_slow(S, k, nbits[k], slot[k], lit, lane);
+                    } else {
+                        h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+                        h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+                    }
+                    hc_blend_xy(h.lo, h.hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+                    const float4 hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+                    hc_blend_xy(lo, hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
+                }
             }
         }
         float t = 0.f, H = .5f;
@@ -379,6 +386,9 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
 
     float transmittance = 1.f, radiance = 0.f, alpha = 0.f;
     bool marches;
+#ifdef SBX_CL_STATS
+    float st_steps = 0.f, st_lit = 0.f, st_alive = 0.f, st_litl = 0.f;
+#endif
     {
         // Only what the march needs stays live across it (origin, projection, phase): the view direction
         // and the sky colour are recomputed in the epilogue from the pixel coordinates — same operations,
@@ -398,6 +408,9 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
             unsigned long long alive_mask = wave_mask(alive);
             for (int i = 0; i < F.steps; ++i) {
                 if (!wave_any_mask(alive_mask)) break;
+#ifdef SBX_CL_STATS
+                st_steps += 1.f; st_alive += (float)__builtin_popcountll(alive_mask);
+#endif
                 const v3 pos = origin + t * projection;
                 t += F.dt;
                 YRow row;
@@ -407,6 +420,9 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
                 if (wave_any_mask(lit_mask)) {
+#ifdef SBX_CL_STATS
+                    st_lit += 1.f; st_litl += (float)__builtin_popcountll(lit_mask);
+#endif
                     const float T_i = exp_(-density * F.sigma * F.dt);
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
@@ -441,6 +457,10 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
         const float a = alpha * smoothstep_(.0f, .2f, dot(dir, V3(0, 1, 0)));
         col = abs3(mix3(sky, V3s(radiance), a));               // :215-217
     }
+#ifdef SBX_CL_STATS
+    reinterpret_cast<float4*>(out)[px.idx] = make_float4(st_steps, st_lit, st_alive, st_litl);
+    return;
+#endif
     store_rgba(out, px.idx, to_srgb(col));
 }
 
