@@ -200,12 +200,13 @@ __device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, floa
 
 // density_func of a MAIN march sample with the y terms of its step taken from the frame table (SGPRs)
 __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
-                                                  unsigned long long active_mask, WaveCache& S, int lane) {
+                                                  unsigned long long active_mask, WaveCache& S, int lane,
+                                                  float (&fx)[4], float (&nxy)[4]) {
     float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
     const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
     const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
     const float rpy[4] = {row.py157.x, row.py157.y, row.py157.z, row.py157.w};
-    float fx[4], fz[4];
+    float fz[4];
     unsigned nbits[4];
     int slot[4];
     bool ne[4];
@@ -216,7 +217,8 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
         const float ax = qx - px, az = qz - pz;
         fx[k] = ax * ax * (3.0f - 2.0f * ax);
         fz[k] = az * az * (3.0f - 2.0f * az);
-        const float n = px + rpy[k] + 113.0f * pz;       // p.x + p.y*157 + 113*p.z, noise_iq.h:19
+        nxy[k] = px + rpy[k];
+        const float n = nxy[k] + 113.0f * pz;            // p.x + p.y*157 + 113*p.z, noise_iq.h:19
         nbits[k] = f2u(n);
         slot[k] = (int)n & (HC_SLOTS - 1);
         ne[k] = (S.tag[k][slot[k]] != nbits[k]);
@@ -266,28 +268,33 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 // same operations on the same inputs as in the general path, hence identical bits.
 template <bool YTAB>
 __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
-                                               WaveCache& S, int lane, const YRow& row) {
+                                               WaveCache& S, int lane, const YRow& row, const float (&mfx)[4],
+                                               const float (&mnxy)[4]) {
     float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4], curz[4];
-    {
+    if (YTAB) {
+        // lp.x = pos.x + 0 and lp.y = pos.y + 0: the x terms are the main sample's own (same operations on
+        // the same value; a -0 turned +0 by the addition changes no result bit), the y terms
+        // are the step's row of the frame table.
         const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
         const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
-        const float rpy[4] = {row.py157.x, row.py157.y, row.py157.z, row.py157.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            fx[k] = mfx[k]; fy[k] = rfy[k]; gy[k] = rgy[k]; nxy[k] = mnxy[k];
+            curz[k] = u2f(0x7fc00001u);
+            ab[k] = cd[k] = 0.f;
+        }
+    } else {
         float qx = (lp.x * .001f) * 2.03f, qy = (lp.y * .001f) * 2.03f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float px = floor_(qx);
             const float ax = qx - px;
             fx[k] = ax * ax * (3.0f - 2.0f * ax);
-            if (YTAB) {                                   // lp.y = pos.y + 0: the step's own row
-                fy[k] = rfy[k]; gy[k] = rgy[k];
-                nxy[k] = px + rpy[k];
-            } else {
-                const float py = floor_(qy);
-                const float ay = qy - py;
-                fy[k] = ay * ay * (3.0f - 2.0f * ay);
-                gy[k] = 1.0f - fy[k];
-                nxy[k] = px + py * 157.0f;
-            }
+            const float py = floor_(qy);
+            const float ay = qy - py;
+            fy[k] = ay * ay * (3.0f - 2.0f * ay);
+            gy[k] = 1.0f - fy[k];
+            nxy[k] = px + py * 157.0f;
             curz[k] = u2f(0x7fc00001u);
             ab[k] = cd[k] = 0.f;
             qx = qx * 2.64f; qy = qy * 2.64f;
@@ -415,7 +422,8 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
                 t += F.dt;
                 YRow row;
                 if (YTAB) row = ytab[i];                          // uniform index: scalar loads
-                const float density = YTAB ? coop_density_row(F, pos, row, alive, alive_mask, S, lane)
+                float mfx[4] = {0.f, 0.f, 0.f, 0.f}, mnxy[4] = {0.f, 0.f, 0.f, 0.f};
+                const float density = YTAB ? coop_density_row(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy)
                                            : coop_density(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
@@ -427,7 +435,7 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
                     if (lstep.x == 0.f && lstep.y == 0.f) {        // uniform (kernel argument): z-only light step
-                        ltrans = light_march_z<YTAB>(F, lp, lstep, lit, lit_mask, S, lane, row);
+                        ltrans = light_march_z<YTAB>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy);
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
                             const float d = coop_density(F, lp, lit, S, lane);
