@@ -317,6 +317,9 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             qz = qz * 2.64f;
         }
         if (wave_any_mask(moved_mask & lit_mask)) {
+#ifdef SBX_CL_STATS
+            if (lane == 0) S.stat[3] += 1.f;
+#endif
             // some lit lane entered another cell in some octave: look all four up again (one uniform branch
             // per sample costs less than one per octave) and redo the x/y blends
             unsigned nbits[4];
@@ -389,6 +392,9 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
+#ifdef SBX_CL_STATS
+    if (lane < 4) S.stat[lane] = 0.f;
+#endif
     __builtin_amdgcn_wave_barrier();
 
     float transmittance = 1.f, radiance = 0.f, alpha = 0.f;
@@ -466,6 +472,8 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
         col = abs3(mix3(sky, V3s(radiance), a));               // :215-217
     }
 #ifdef SBX_CL_STATS
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 1) { st_steps = S.stat[0]; st_lit = S.stat[1]; st_alive = S.stat[2]; st_litl = S.stat[3]; }
     reinterpret_cast<float4*>(out)[px.idx] = make_float4(st_steps, st_lit, st_alive, st_litl);
     return;
 #endif
