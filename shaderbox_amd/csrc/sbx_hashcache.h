@@ -42,6 +42,9 @@ struct alignas(16) WaveCache {
     float h[4][HC_SLOTS][8];          // corner order: +0,+1,+157,+158,+113,+114,+270,+271
     unsigned tag[4][HC_SLOTS];        // bits of n; 0x7fc00001 (a NaN) = empty
     unsigned ins_tag[8], ins_slot[8]; // cells being inserted in the current pass
+#ifdef SBX_CL_STATS
+    float stat[4];                    // census build only (tools/clouds_census.py): slow calls, passes, cells, re-lookups
+#endif
 };
 
 // miss path, one octave: the lanes in `need` lack their cell.  Leaders (one per distinct slot) are
@@ -61,6 +64,9 @@ __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, i
             ++cnt;
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef SBX_CL_STATS
+        if (lane == 0) { S.stat[1] += 1.f; S.stat[2] += (float)cnt; }
+#endif
         if (lane < cnt * 8) {
             const int r = lane >> 3;
             const unsigned n0 = S.ins_tag[r];
@@ -84,6 +90,9 @@ __device__ __forceinline__ H8 hc_slow(WaveCache& S, int k, unsigned nbits, int s
     r.lo = make_float4(0.f, 0.f, 0.f, 0.f);
     r.hi = r.lo;
     bool need = active;
+#ifdef SBX_CL_STATS
+    if (lane == 0) S.stat[0] += 1.f;
+#endif
     for (int round = 0; round < 4096; ++round) {          // bounded on principle; needs <= 64 rounds
         if (need && S.tag[k][slot] == nbits) {
             r.lo = *reinterpret_cast<const float4*>(&S.h[k][slot][0]);
