@@ -17,12 +17,13 @@
 #include "../include/sbx.h"
 
 static int app_from_name(const std::string& s) {
-    const char* names[] = {"planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao"};
-    for (int i = 0; i < 7; ++i)
+    const char* names[] = {"planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best"};
+    const int n = 8;
+    for (int i = 0; i < n; ++i)
         if (s == names[i] || s == std::string("APP_") + names[i]) return i;
     std::string up;
     for (char c : s) up += (char)tolower(c);
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < n; ++i)
         if (up == names[i] || up == std::string("app_") + names[i]) return i;
     return -1;
 }

@@ -42,7 +42,10 @@ typedef enum sbx_app {
     SBX_APP_EGG = 3,
     SBX_APP_RAYTRACER = 4,
     SBX_APP_ATMOSPHERE = 5,
-    SBX_APP_SDF_AO = 6
+    SBX_APP_SDF_AO = 6,
+    /* not an APP_* define of the reference: the stand-alone shader src/app_clouds_best.h (own mainImage :669-696),
+       numbered after the reference's apps */
+    SBX_APP_CLOUDS_BEST = 7
 } sbx_app;
 
 typedef enum sbx_status {

@@ -39,6 +39,8 @@
 #define SBX_SELECTED_APP SBX_APP_SDF_AO
 #elif defined(APP_VINYL)
 #define SBX_SELECTED_APP SBX_APP_VINYL
+#elif defined(APP_CLOUDS_BEST)   /* src/app_clouds_best.h, the stand-alone shader (no APP_* define in the reference) */
+#define SBX_SELECTED_APP SBX_APP_CLOUDS_BEST
 #else
 #error "define one of APP_PLANET APP_CLOUDS APP_VINYL APP_EGG APP_RAYTRACER APP_ATMOSPHERE APP_SDF_AO"
 #endif

@@ -11,9 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO = range(7)
+APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST = range(8)
 APP_IDS = {"planet": APP_PLANET, "clouds": APP_CLOUDS, "egg": APP_EGG, "raytracer": APP_RAYTRACER,
-           "atmosphere": APP_ATMOSPHERE, "sdf_ao": APP_SDF_AO, "vinyl": APP_VINYL}
+           "atmosphere": APP_ATMOSPHERE, "sdf_ao": APP_SDF_AO, "vinyl": APP_VINYL, "clouds_best": APP_CLOUDS_BEST}
 
 
 def build(variant=""):

@@ -1110,5 +1110,90 @@ struct AppVinyl {
     }
 };
 
+/* =================================================================================== */
+/* "clouds_best" — src/app_clouds_best.h, the stand-alone (flattened) cloud shader; SURVEY.md §8f row 4. */
+/* Not selected by an APP_* define in the reference: it is a complete shader with its own mainImage      */
+/* (:669-696, identical to src/main.h) and FOV 1 (:663).  C++ branch of its macros (:31-40).             */
+/* =================================================================================== */
+struct AppCloudsBest {
+    uniforms_t U;
+    static constexpr int cld_march_steps = 50;                 /* :410 */
+    static constexpr float cld_coverage = .3125f;              /* :411 */
+    static constexpr float cld_thick = 90.f;                   /* :412 */
+    static constexpr float cld_absorb_coeff = 1.f;             /* :413 */
+    vec3 cld_wind_dir() const { return vec3(0, 0, -U.u_time * .2f); }         /* :414 */
+    static vec3 cld_sun_dir() { return normalize(vec3(0, 0, -1)); }           /* :415 */
+
+    struct volume_t {                                          /* :362-372 */
+        vec3 origin, pos;
+        float height = 0.f, coeff_absorb = 0.f, T = 1.f;
+        vec3 C;
+        float alpha = 0.f;
+    };
+    float fov() const { return 1.f; }                          /* :663 */
+    void setup_scene() {}                                      /* :643-645 */
+    void setup_camera(vec3& eye, vec3& look_at) const {        /* :635-641 */
+        eye = vec3(0, 1.f, 0);
+        look_at = vec3(0, 1.6f, -1);
+    }
+    /* :562 DECL_FBM_FUNC(fbm_clouds, 5, abs(noise(p))) with noise = snoise (:552) */
+    static float fbm_clouds(vec3 pos, float lacunarity, float init_gain, float gain) {
+        return fbm_generic<5>(pos, lacunarity, init_gain, gain, [](vec3 p) { return m_abs(snoise(p)); });
+    }
+    /* :564-575 */
+    vec3 render_sky_color(vec3 eye_dir) const {
+        const vec3 sun_color = vec3(1.f, .7f, .55f);
+        float sun_amount = m_max(dot(eye_dir, cld_sun_dir()), 0.f);
+        vec3 sky = vmix(vec3(.0f, .1f, .4f), vec3(.3f, .6f, .8f), 1.0f - eye_dir.y);
+        sky += sun_color * m_min(m_pow(sun_amount, 1500.0f) * 5.0f, 1.0f);
+        sky += sun_color * m_min(m_pow(sun_amount, 10.0f) * .6f, 1.0f);
+        return sky;
+    }
+    /* :577-589 */
+    float density_func(vec3 pos, float /*h*/) const {
+        vec3 p = pos * .001f + cld_wind_dir();
+        float dens = fbm_clouds(p * 2.032f, 2.6434f, .5f, .5f);
+        dens *= m_smoothstep(cld_coverage, cld_coverage + .035f, dens);
+        return dens;
+    }
+    /* :591-597 */
+    static float illuminate_volume(const volume_t& cloud) { return m_exp(cloud.height) / 1.95f; }
+    /* :392-407 */
+    static void integrate_volume(volume_t& vol, float density, float dt) {
+        float T_i = m_exp(-vol.coeff_absorb * density * dt);
+        vol.T *= T_i;
+        vol.C += vol.T * illuminate_volume(vol) * density * dt;
+        vol.alpha += (1.f - T_i) * (1.f - vol.alpha);
+    }
+    /* :599-633 */
+    vec4 render_clouds(const ray_t& eye) const {
+        const int steps = cld_march_steps;
+        const float march_step = cld_thick / float(steps);
+        vec3 projection = eye.direction / eye.direction.y;
+        vec3 iter = projection * march_step;
+        float cutoff = dot(eye.direction, vec3(0, 1, 0));
+        volume_t cloud;                                        /* begin_volume :374-384 */
+        cloud.origin = eye.origin + projection * 100.f;
+        cloud.pos = cloud.origin;
+        cloud.coeff_absorb = cld_absorb_coeff;
+        for (int i = 0; i < steps; i++) {
+            cloud.height = (cloud.pos.y - cloud.origin.y) / cld_thick;
+            float dens = density_func(cloud.pos, cloud.height);
+            integrate_volume(cloud, dens, march_step);
+            cloud.pos += iter;
+            if (cloud.alpha > .999f) break;
+        }
+        return vec4(cloud.C, cloud.alpha * m_smoothstep(.0f, .2f, cutoff));
+    }
+    /* :647-661 */
+    vec3 render(const ray_t& eye_ray, vec3 /*point_cam*/) const {
+        vec3 sky = render_sky_color(eye_ray.direction);
+        if (dot(eye_ray.direction, vec3(0, 1, 0)) < 0.05f) return sky;
+        vec4 cld = render_clouds(eye_ray);
+        vec3 col = vmix(sky, cld.rgb(), cld.w);
+        return col;
+    }
+};
+
 } /* namespace sbxref */
 #endif

@@ -289,6 +289,71 @@ static inline float fbm_generic(vec3 pos, float lacunarity, float init_gain, flo
     return t;
 }
 
+/* ---- src/app_clouds_best.h:460-552 : Ashima simplex noise as flattened into the stand-alone cloud shader ---- */
+/* app_clouds_best.h:460-466 : x - floor(x * (1.0 / 289.0)) * 289.0 */
+static inline float sn_mod289(float x) { return x - m_floor(x * (1.0f / 289.0f)) * 289.0f; }
+/* :469-471 */
+static inline float sn_permute(float x) { return sn_mod289(((x * 34.0f) + 1.0f) * x); }
+/* :478-551.  vec4 quantities are arrays of 4; every vector operation is done component-wise in the order written. */
+static inline float snoise(vec3 v) {
+    const float Cx = 1.0f / 6.0f, Cy = 1.0f / 3.0f;                       /* :480 */
+    /* first corner :484-485 */
+    const float s = dot(v, vec3(Cy, Cy, Cy));
+    vec3 i = vfloor(v + s);
+    const float t = dot(i, vec3(Cx, Cx, Cx));
+    vec3 x0 = (v - i) + t;
+    /* other corners :488-491 */
+    vec3 g = vec3(m_step(x0.y, x0.x), m_step(x0.z, x0.y), m_step(x0.x, x0.z));   /* step(x0.yzx, x0.xyz) */
+    vec3 l = vec3(1.0f - g.x, 1.0f - g.y, 1.0f - g.z);
+    vec3 i1 = vec3(m_min(g.x, l.z), m_min(g.y, l.x), m_min(g.z, l.y));            /* min(g.xyz, l.zxy) */
+    vec3 i2 = vec3(m_max(g.x, l.z), m_max(g.y, l.x), m_max(g.z, l.y));
+    /* :497-499 */
+    vec3 x1 = (x0 - i1) + Cx;
+    vec3 x2 = (x0 - i2) + Cy;
+    vec3 x3 = x0 - vec3(0.5f, 0.5f, 0.5f);
+    /* permutations :502-506 */
+    i = vec3(sn_mod289(i.x), sn_mod289(i.y), sn_mod289(i.z));
+    const float oz[4] = {0.0f, i1.z, i2.z, 1.0f}, oy[4] = {0.0f, i1.y, i2.y, 1.0f}, ox[4] = {0.0f, i1.x, i2.x, 1.0f};
+    float p[4];
+    for (int k = 0; k < 4; k++)
+        p[k] = sn_permute((sn_permute((sn_permute(i.z + oz[k]) + i.y) + oy[k]) + i.x) + ox[k]);
+    /* gradients :510-531 */
+    const float n_ = 0.142857142857f;
+    const float nsx = n_ * 2.0f - 0.0f, nsy = n_ * 0.5f - 1.0f, nsz = n_ * 1.0f - 0.0f;   /* n_ * D.wyz - D.xzx */
+    float gx[4], gy[4], h[4];
+    for (int k = 0; k < 4; k++) {
+        const float j = p[k] - 49.0f * m_floor(p[k] * nsz * nsz);
+        const float x_ = m_floor(j * nsz);
+        const float y_ = m_floor(j - 7.0f * x_);
+        gx[k] = x_ * nsx + nsy;
+        gy[k] = y_ * nsx + nsy;
+        h[k] = 1.0f - m_abs(gx[k]) - m_abs(gy[k]);
+    }
+    const float b0[4] = {gx[0], gx[1], gy[0], gy[1]}, b1[4] = {gx[2], gx[3], gy[2], gy[3]};
+    float s0[4], s1[4], sh[4];
+    for (int k = 0; k < 4; k++) {
+        s0[k] = m_floor(b0[k]) * 2.0f + 1.0f;
+        s1[k] = m_floor(b1[k]) * 2.0f + 1.0f;
+        sh[k] = -m_step(h[k], 0.0f);
+    }
+    /* a0 = b0.xzyw + s0.xzyw*sh.xxyy ; a1 = b1.xzyw + s1.xzyw*sh.zzww  :533-534 */
+    const float a0[4] = {b0[0] + s0[0] * sh[0], b0[2] + s0[2] * sh[0], b0[1] + s0[1] * sh[1], b0[3] + s0[3] * sh[1]};
+    const float a1[4] = {b1[0] + s1[0] * sh[2], b1[2] + s1[2] * sh[2], b1[1] + s1[1] * sh[3], b1[3] + s1[3] * sh[3]};
+    vec3 p0 = vec3(a0[0], a0[1], h[0]), p1 = vec3(a0[2], a0[3], h[1]);
+    vec3 p2 = vec3(a1[0], a1[1], h[2]), p3 = vec3(a1[2], a1[3], h[3]);
+    /* normalise gradients :473-476, 542-546 */
+    p0 *= 1.79284291400159f - 0.85373472095314f * dot(p0, p0);
+    p1 *= 1.79284291400159f - 0.85373472095314f * dot(p1, p1);
+    p2 *= 1.79284291400159f - 0.85373472095314f * dot(p2, p2);
+    p3 *= 1.79284291400159f - 0.85373472095314f * dot(p3, p3);
+    /* mix :549-551 */
+    float m[4] = {m_max(0.6f - dot(x0, x0), 0.0f), m_max(0.6f - dot(x1, x1), 0.0f),
+                  m_max(0.6f - dot(x2, x2), 0.0f), m_max(0.6f - dot(x3, x3), 0.0f)};
+    for (int k = 0; k < 4; k++) m[k] = m[k] * m[k];
+    const float d[4] = {dot(p0, x0), dot(p1, x1), dot(p2, x2), dot(p3, x3)};
+    return 42.0f * ((((m[0] * m[0]) * d[0] + (m[1] * m[1]) * d[1]) + (m[2] * m[2]) * d[2]) + (m[3] * m[3]) * d[3]);
+}
+
 /* ---- src/noise_worley.h --------------------------------------------------------- */
 /* noise_worley.h:5-17 */
 static inline vec3 hash_w(vec3 x) {

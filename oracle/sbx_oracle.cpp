@@ -19,7 +19,8 @@
 using namespace sbxref;
 
 /* app ids: same order as the README table (/root/reference/README.md:15-22) + SDF_AO */
-enum { APP_PLANET = 0, APP_CLOUDS = 1, APP_VINYL = 2, APP_EGG = 3, APP_RAYTRACER = 4, APP_ATMOSPHERE = 5, APP_SDF_AO = 6 };
+enum { APP_PLANET = 0, APP_CLOUDS = 1, APP_VINYL = 2, APP_EGG = 3, APP_RAYTRACER = 4, APP_ATMOSPHERE = 5, APP_SDF_AO = 6,
+       APP_CLOUDS_BEST = 7 /* src/app_clouds_best.h: not an APP_* define of the reference, numbered after them */ };
 
 /* aux blocks arrive as the 16-byte-register images of src/uniform_buffer.h:39-60 */
 static clouds_aux_t parse_clouds_aux(const void* aux) {
@@ -60,6 +61,7 @@ static bool pixel(int app, const uniforms_t& U, const void* aux, float fx, float
     case APP_SDF_AO: { AppSdfAo a; a.U = U; a.A = parse_sdf_ao_aux(aux); c = main_image(a, fc); break; }
     case APP_PLANET: { AppPlanet a; a.U = U; c = main_image(a, fc); break; }
     case APP_VINYL: { AppVinyl a; a.U = U; c = main_image(a, fc); break; }
+    case APP_CLOUDS_BEST: { AppCloudsBest a; a.U = U; c = main_image(a, fc); break; }
     default: return false;
     }
     out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
@@ -159,6 +161,8 @@ int sbxo_kat(const char* name, const float* in, float* out) {
     auto uni = [&]() { uniforms_t U; U.u_res = vec2(in[0], in[1]); U.u_mouse = vec2(in[2], in[3]); U.u_time = in[4]; return U; };
 
     if (f == "hash") { out[0] = hash(in[0]); return 0; }
+    if (f == "snoise") { out[0] = snoise(V3(0)); return 0; }
+    if (f == "clouds_best.fbm_clouds") { out[0] = AppCloudsBest::fbm_clouds(V3(0), in[3], in[4], in[5]); return 0; }
     if (f == "noise_iq") { out[0] = noise_iq(V3(0)); return 0; }
     if (f == "clouds.fbm") { out[0] = AppClouds::fbm(V3(0), in[3], in[4], in[5]); return 0; }
     if (f == "clouds.density_func") { AppClouds a; out[0] = a.density_func(V3(0), in[3]); return 0; }

@@ -17,9 +17,10 @@ from . import shard  # noqa: F401  (pure-python row-block arithmetic, no GPU nee
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsbx.so")
 
-APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO = range(7)
+APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST = range(8)
 APPS = {"APP_PLANET": APP_PLANET, "APP_CLOUDS": APP_CLOUDS, "APP_VINYL": APP_VINYL, "APP_EGG": APP_EGG,
-        "APP_RAYTRACER": APP_RAYTRACER, "APP_ATMOSPHERE": APP_ATMOSPHERE, "APP_SDF_AO": APP_SDF_AO}
+        "APP_RAYTRACER": APP_RAYTRACER, "APP_ATMOSPHERE": APP_ATMOSPHERE, "APP_SDF_AO": APP_SDF_AO,
+        "APP_CLOUDS_BEST": APP_CLOUDS_BEST}    # src/app_clouds_best.h (stand-alone shader, not an APP_* define)
 
 SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 

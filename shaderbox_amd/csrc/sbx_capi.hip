@@ -221,6 +221,29 @@ static FramePlanet build_planet(const sbx_uniforms& U) {
     return F;
 }
 
+static FrameCloudsBest build_clouds_best(const sbx_uniforms& U) {
+    FrameCloudsBest F;
+    F.cam = make_camera(U.u_res[0], U.u_res[1], 1.f, V3(0, 1.f, 0), V3(0, 1.6f, -1));   // app_clouds_best.h:635-641,663
+    F.sun_dir = normalize(V3(0, 0, -1));                               // :415
+    F.wind_z = -U.u_time * .2f;                                        // :414
+    const float cld_thick = 90.f;                                      // :412
+    F.march_step = cld_thick / float(CB_STEPS);                        // :603
+    F.cov = .3125f;                                                    // :411
+    F.cov_rd = recip64((F.cov + .035f) - F.cov);                       // smoothstep(cov, cov + .035, dens) :583
+    // y of the march: projection.y = dir.y / dir.y = 1, so origin.y = eye.y + 1 * 100 and iter.y = 1 * march_step
+    const float origin_y = F.cam.eye.y + 1.0f * 100.f;                 // :611
+    const float iter_y = 1.0f * F.march_step;                          // :606
+    float pos_y = origin_y;
+    for (int i = 0; i < CB_STEPS; ++i) {
+        const float height = (pos_y - origin_y) / cld_thick;           // :619-620
+        F.row[i].illum = exp_(height) / 1.95f;                         // illuminate_volume :591-597
+        float q = (pos_y * .001f + 0.f) * 2.032f;                      // density_func :581-582 (wind.y = 0)
+        for (int k = 0; k < 5; ++k) { F.row[i].qy[k] = q; q = q * 2.6434f; }   // fbm: p *= lacunarity
+        pos_y = pos_y + iter_y;                                        // :628
+    }
+    return F;
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -326,6 +349,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     }
     case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s); break;
     case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s); break;
+    case SBX_APP_CLOUDS_BEST: launch_clouds_best(build_clouds_best(*uni), M, rgba, s); break;
     default: return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
     }
     if (ctx->timing) (void)hipEventRecord(ctx->ev1, s);

@@ -53,6 +53,7 @@ void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipS
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s);
 void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s);
 void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s);
+void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, hipStream_t s);
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s);
 void launch_assemble(int width, int height, int block_rows, int nranks, int rows_max,
                      const float* gathered, float* frame, hipStream_t s);

@@ -125,6 +125,22 @@ struct FramePlanet {
     v3 L;                       // rot * normalize(1,1,0)   app_planet.h:289
 };
 
+// ---- "clouds_best" (src/app_clouds_best.h, the stand-alone cloud shader) ------
+// The march runs along projection = dir / dir.y, whose y component is exactly 1, from origin.y = eye.y + 100:
+// sample height, `cloud.height`, illuminate_volume() = exp(height)/1.95 and the y coordinate of the five
+// noise octaves are the same for every pixel.  One row per march step, built on the host with the math spec.
+constexpr int CB_STEPS = 50;                                   // cld_march_steps :410
+struct CBRow { float qy[5]; float illum; };
+struct FrameCloudsBest {
+    Camera cam;
+    v3 sun_dir;               // normalize(0, 0, -1)                                          :415
+    float wind_z;             // -u_time * .2                                                 :414
+    float march_step;         // cld_thick / float(steps)                                     :603
+    float cov;                // cld_coverage                                                 :411
+    double cov_rd;            // recip64((cov + .035) - cov)                                  :583
+    CBRow row[CB_STEPS];
+};
+
 // ---- APP_VINYL (src/app_vinyl.h; C++ build) -------------------------------------------------
 struct Capsule { v3 a, ab; double rd; };   // sd_capsule(p, a, b, r): ab = b - a, rd = recip64(dot(ab, ab))
 struct FrameVinyl {

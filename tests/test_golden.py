@@ -22,7 +22,7 @@ def _same(a, b):
 
 
 def test_golden_set_is_complete():
-    assert {c[1] for c in _cases()} == {"egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet", "vinyl"}
+    assert {c[1] for c in _cases()} == {"egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet", "vinyl", "clouds_best"}
 
 
 @pytest.mark.parametrize("path,app,w,h", list(_cases()))

@@ -18,6 +18,7 @@ CASES = [
     ("sdf_ao", 256, 144),
     ("planet", 256, 144),
     ("vinyl", 256, 144), ("vinyl", 160, 160),
+    ("clouds_best", 256, 144), ("clouds_best", 160, 160),
 ]
 TIMES = [0.0, 0.37, 2.5]
 
@@ -124,7 +125,7 @@ def test_device_math_matches_oracle(renderer, oracle):
 def test_error_codes(renderer):
     import shaderbox_amd
     with pytest.raises(shaderbox_amd.SbxError) as e:
-        renderer.render(7, 64, 64, 0.0)
+        renderer.render(99, 64, 64, 0.0)
     assert e.value.code == shaderbox_amd.SBX_ERR_UNSUPPORTED
     with pytest.raises(shaderbox_amd.SbxError) as e:
         renderer.render("egg", 64, 64, 0.0, rows=(10, 80))
@@ -171,7 +172,8 @@ def test_clouds_4k_against_survey_pixels_and_oracle_rows(renderer, oracle):
                                           ("atmosphere", 7680, 4320, [0, 1000, 2160, 3000, 4319]),
                                           ("planet", 7680, 4320, [2160, 2600]),
                                           ("sdf_ao", 1920, 1080, [0, 400, 800, 1079]),
-                                          ("vinyl", 1920, 1080, [100, 540, 900])])
+                                          ("vinyl", 1920, 1080, [100, 540, 900]),
+                                          ("clouds_best", 3840, 2160, [1100, 1500, 2159])])
 def test_full_size_rows_match_oracle(renderer, oracle, app, w, h, rows):
     """BASELINE.json config sizes (C2 EGG 1920x1080, C3 RAYTRACER 3840x2160, C5 7680x4320): full-width rows
     of the full-size frame, rendered as one-row strips on the GPU, equal the oracle bit-for-bit."""
@@ -207,7 +209,7 @@ def test_noise_library_matches_oracle(renderer, oracle):
 def test_tiny_and_ragged_frames(renderer, oracle, w, h):
     """sizes that do not fill a wave tile / workgroup: every app, bit-for-bit"""
     from oracle.oracle import APP_IDS
-    for app in ("egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet", "vinyl"):
+    for app in ("egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet", "vinyl", "clouds_best"):
         ref = oracle.render(APP_IDS[app], w, h, 0.37, threads=4)
         gpu = renderer.render(app, w, h, 0.37).cpu().numpy()
         assert compare(gpu, ref) == (0.0, 0), (app, w, h)
