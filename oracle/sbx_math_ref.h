@@ -161,12 +161,42 @@ static inline double d_exp2(double t) {
     return p * sc;
 }
 
+/* exp: x = (k/32) ln2 + r, |r| <= ln2/64; exp(x) = 2^(k>>5) * 2^((k&31)/32) * exp(r).
+ * k by the 1.5*2^52 trick on fma(x, 32/ln2, magic); r by a two-term Cody-Waite reduction (the high part of
+ * ln2/32 has 38 significant bits, so k*hi is exact for |k| < 2^14); exp(r) by the degree-6 Taylor polynomial
+ * (remainder < 3.5e-18 relative); 2^(j/32) from a table of correctly rounded doubles (tools/gen_math_coeffs.py).
+ * The binary64 value is within ~1.2e-16 relative of exp(x) and is rounded once to binary32.
+ * (The 13-term form in d_exp2, which this replaced as the definition of exp, gives the same binary32 result on
+ * all 2^32 inputs but one, x = -89.45233 (0xc2b2e798), where it misrounds a denormal by an ulp and this one does
+ * not — tests/test_gpu_parity.py::test_exp_table_vs_horner.)  pow keeps d_exp2. */
+static const double SBX_EXP2_TAB[32] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
 static inline float m_exp(float x) {
     if (x != x) return x;
-    double t = (double)x * SBX_D_INV_LN2;
-    if (t < -160.0) t = -160.0;
-    if (t > 136.0) t = 136.0;
-    return (float)d_exp2(t);
+    if (x < -104.0f) x = -104.0f;            /* below: rounds to 0 either way; above 89: overflows to +inf */
+    if (x > 89.0f) x = 89.0f;
+    const double xd = (double)x;
+    double kd = fma(xd, 0x1.71547652b82fep+5 /* 32/ln2 */, SBX_D_MAGIC);
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - SBX_D_MAGIC;
+    double r = fma(kd, -0x1.62e42fefa0000p-6 /* ln2/32, high 38 bits */, xd);
+    r = fma(kd, -0x1.cf79abc9e3b3ap-45 /* ln2/32 - high */, r);
+    double p = 0x1.6c16c16c16c17p-10;            /* 1/6! */
+    p = fma(p, r, 0x1.1111111111111p-7);         /* 1/5! */
+    p = fma(p, r, 0x1.5555555555555p-5);         /* 1/4! */
+    p = fma(p, r, 0x1.5555555555555p-3);         /* 1/3! */
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double y = p * SBX_EXP2_TAB[ki & 31];
+    return (float)u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
 }
 
 static inline float m_pow(float x, float y) {

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restri
     case 7: r = hash1(x); break;
     case 8: r = x / y; break;                       // IEEE division
     case 9: r = div_by(x, recip64(y)); break;       // the same through the binary64 reciprocal (sbx_math.h)
-    case 10: r = exp_spec_(x); break;               // exp with the spec's guards (exp_ uses cheaper, equivalent ones)
+    case 10: r = exp_h13_(x); break;                // the former 13-term exp (equivalence test against the table form)
     default: r = 0.f;
     }
     out[i] = r;

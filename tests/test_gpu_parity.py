@@ -254,14 +254,23 @@ def test_division_by_reciprocal_is_exact(renderer):
     assert same.all(), (a.numpy()[~same][:5], b.numpy()[~same][:5], q0[~same][:5], q1[~same][:5])
 
 
-def test_exp_guards_are_equivalent(renderer):
-    """exp_ (binary32 clamp, no NaN test) == exp_spec_ (the spec's guards) on ALL 2^32 binary32 inputs"""
+def test_exp_table_vs_horner(renderer):
+    """exp (table form: the spec, oracle m_exp) against the former 13-term form on ALL 2^32 binary32 inputs:
+    equal everywhere except x = -89.45233 (0xc2b2e798), whose exact result 1011149.5000000046 * 2^-149 sits
+    4.6e-9 of a denormal ulp above a tie: the table form returns the correctly rounded 0x000f6dce, the 13-term
+    form 0x000f6dcd.  NaN inputs give NaN in both (the binary32 clamp lets them through)."""
     import torch
     step = 1 << 26
+    odd = []
     for lo in range(0, 1 << 32, step):
         bits = torch.arange(lo, lo + step, dtype=torch.int64, device="cuda").to(torch.int32)   # wraps to all patterns
         x = bits.view(torch.float32)
         a = renderer.math("exp", x)
-        b = renderer.math("exp_spec", x)
+        b = renderer.math("exp_h13", x)
         same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
-        assert bool(same.all()), lo
+        assert bool((torch.isnan(a) == torch.isnan(x)).all()), lo
+        if not bool(same.all()):
+            d = ~same
+            odd += [(int(p) & 0xffffffff, int(q) & 0xffffffff, int(r) & 0xffffffff) for p, q, r in
+                    zip(bits[d].cpu().tolist(), a[d].view(torch.int32).cpu().tolist(), b[d].view(torch.int32).cpu().tolist())]
+    assert odd == [(0xc2b2e798, 0x000f6dce, 0x000f6dcd)], odd

@@ -6,6 +6,7 @@ correctly rounded binary32 results (up to ties closer than ~2^-28 ulp).  sin on 
 Reference values: numpy float64 libm rounded to float32 (its error, <1 ulp of double, is 2^-29 ulp of
 float, so it decides correct rounding except on near-ties, of which we allow a vanishing fraction)."""
 import numpy as np
+import pytest
 
 
 def _mismatch(got, want64):
@@ -51,3 +52,27 @@ def test_special_values(oracle):
     assert [float(v) for v in oracle.math("pow", np.array([2, 2, 2, 2, 2], f), np.array([1, 2, 3, 4, 5], f))] == [2, 4, 8, 16, 32]
     a = oracle.math("acos", np.array([1, -1, 1.5, -3.2], f))
     assert a[0] == 0 and a[1] == f(np.pi) and np.isnan(a[2]) and np.isnan(a[3])   # NaN dir -> black (App. B3)
+
+
+def test_exp_is_correctly_rounded_against_mpmath(oracle):
+    """m_exp (table form) against exp() in 200-bit arithmetic, rounded once to binary32 — over the whole result
+    range including denormal results, and on the one input where the former 13-term form misrounded."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-104, 89, 6000), rng.uniform(-1, 1, 2000), rng.uniform(-104, -87, 2000)]).astype(np.float32)
+    x = np.concatenate([x, np.array([0xc2b2e798], np.uint32).view(np.float32)])
+    got = oracle.math("exp", x)
+
+    def rn32(v):                      # round-to-nearest-even of a positive mpf to binary32, denormals included
+        if v >= mp.mpf(2) ** 128:
+            return np.float32(np.inf)
+        e = max(int(mp.floor(mp.log(v, 2))), -126)
+        q = v / mp.mpf(2) ** (e - 23)
+        n = int(mp.floor(q)); f = q - n
+        if f > 0.5 or (f == 0.5 and n & 1):
+            n += 1
+        return np.float32(float(mp.mpf(n) * mp.mpf(2) ** (e - 23)))
+    want = np.array([rn32(mp.exp(mp.mpf(float(v)))) for v in x], np.float32)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all(), (x[got != want][:5], got[got != want][:5], want[got != want][:5])
+    assert got[-1].view(np.uint32) == 0x000f6dce

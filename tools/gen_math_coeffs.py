@@ -120,3 +120,23 @@ if __name__ == "__main__":
     lo = np.float32(float(ln2 - mp.mpf(float(hi))))
     print("  LN2_HI = %s, LN2_LO = %s, LOG2E = %s" % (hexf(hi), hexf(lo), hexf(float(1 / ln2))))
     print("  (double) 1/ln2 = %s ; ln2 = %s" % (float(1 / ln2).hex(), float(ln2).hex()))
+
+
+def exp_table():
+    """Constants of the table form of exp (sbx_math.h exp_, oracle m_exp): 2^(j/32) correctly rounded to
+    binary64, 32/ln2, and ln2/32 split into a 38-bit high part (k*hi exact for |k| < 2^14) and the rest."""
+    import struct
+    tab = [float(mp.mpf(2) ** (mp.mpf(j) / 32)) for j in range(32)]
+    c = mp.log(2) / 32
+    b = struct.unpack("<Q", struct.pack("<d", float(c)))[0] & ~((1 << 15) - 1)
+    hi = struct.unpack("<d", struct.pack("<Q", b))[0]
+    lo = float(c - mp.mpf(hi))
+    print("// 2^(j/32), j = 0..31")
+    for i in range(0, 32, 4):
+        print("    " + ", ".join(float.hex(v) for v in tab[i:i + 4]) + ",")
+    print("// 32/ln2 = %s ; ln2/32 = %s + %s" % (float.hex(float(32 / mp.log(2))), float.hex(hi), float.hex(lo)))
+    print("// 1/n!, n = 2..6: " + ", ".join(float.hex(float(1 / mp.factorial(n))) for n in range(2, 7)))
+
+
+if __name__ == "__main__" and "--exp-table" in __import__("sys").argv:
+    exp_table()
