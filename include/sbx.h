@@ -105,6 +105,15 @@ void sbx_destroy(sbx_ctx* ctx);
 int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
                     int y0, int y1, float* rgba, void* stream);
 
+/* The reference's own per-pixel entry, for hosts that keep their pixel loop:
+ *     void mainImage(out vec4 fragColor, in vec2 fragCoord)            src/main.h:6-9
+ * (what the absent VML/SDL harness calls per pixel, src/Makefile:21).  The first call for a given
+ * (app, uniforms, aux) renders the whole frame on the GPU with one launch and copies it to the host;
+ * later calls read their pixel.  fragCoord is a pixel centre (x + .5, y + .5), y = 0 at the bottom
+ * row; coordinates outside the frame are clamped to it.  One caller per context. */
+int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
+                   const float fragCoord[2], float fragColor[4]);
+
 /* Render the cyclic row-blocks owned by one rank of an N-way split: blocks of
  * `block_rows` rows, rank r owns blocks r, r+N, r+2N, ...  The rank's rows are written densely,
  * in increasing y, into `rgba` (capacity sbx_rank_rows() rows).  Each pixel is computed from its

@@ -79,6 +79,8 @@ def load_library(path=None):
     lib.sbx_destroy.restype = None
     lib.sbx_render_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, fp, vp]
     lib.sbx_render_rank.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, fp, vp]
+    lib.sbx_main_image.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ctypes.POINTER(ctypes.c_float * 2),
+                                   ctypes.POINTER(ctypes.c_float * 4)]
     lib.sbx_render_rank_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, fp, vp]
     lib.sbx_rank_rows.argtypes = [ci, ci, ci, ci]
     lib.sbx_rank_rows_max.argtypes = [ci, ci, ci]
@@ -187,6 +189,17 @@ class Renderer:
         self._check(self.lib.sbx_render_rank(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
                                              rank, nranks, ctypes.c_void_p(buf.data_ptr()), self._stream()))
         return buf
+
+    def main_image(self, app, width, height, time, frag_coord, mouse=(0.0, 0.0), aux=None):
+        """void mainImage(out vec4 fragColor, in vec2 fragCoord) (src/main.h:6-9) for hosts that loop over the
+        pixels themselves: returns the RGBA tuple of the pixel whose centre is frag_coord.  The first call for a
+        frame renders all of it on the GPU; later calls read from the host copy."""
+        u = self.uniforms(width, height, time, mouse)
+        fc = (ctypes.c_float * 2)(float(frag_coord[0]), float(frag_coord[1]))
+        out = (ctypes.c_float * 4)()
+        self._check(self.lib.sbx_main_image(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), ctypes.byref(fc),
+                                            ctypes.byref(out)))
+        return tuple(out)
 
     def render_rank_rows(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0),
                          aux=None):

@@ -274,3 +274,27 @@ def test_exp_table_vs_horner(renderer):
             odd += [(int(p) & 0xffffffff, int(q) & 0xffffffff, int(r) & 0xffffffff) for p, q, r in
                     zip(bits[d].cpu().tolist(), a[d].view(torch.int32).cpu().tolist(), b[d].view(torch.int32).cpu().tolist())]
     assert odd == [(0xc2b2e798, 0x000f6dce, 0x000f6dcd)], odd
+
+
+def test_per_pixel_main_image_entry(renderer):
+    """sbx_main_image — the reference's own per-pixel entry (src/main.h:6-9) — returns the pixels of the frame,
+    re-renders when app / uniforms / aux change, clamps coordinates outside the frame."""
+    import shaderbox_amd
+    W, H = 96, 54
+    frame = renderer.render("clouds", W, H, 0.37).cpu().numpy()
+    for (x, y) in [(0, 0), (95, 53), (17, 40), (50, 27)]:
+        px = np.array(renderer.main_image("clouds", W, H, 0.37, (x + .5, y + .5)), np.float32)
+        assert (px.view(np.uint32) == frame[y, x].view(np.uint32)).all()
+    frame2 = renderer.render("clouds", W, H, 2.5).cpu().numpy()
+    px = np.array(renderer.main_image("clouds", W, H, 2.5, (50.5, 40.5)), np.float32)
+    assert (px.view(np.uint32) == frame2[40, 50].view(np.uint32)).all()
+    aux = shaderbox_amd.clouds_defaults(renderer.lib)           # an aux block is part of the cache key
+    aux.cld_coverage = 0.6
+    frame3 = renderer.render("clouds", W, H, 2.5, aux=aux).cpu().numpy()
+    px = np.array(renderer.main_image("clouds", W, H, 2.5, (50.5, 40.5), aux=aux), np.float32)
+    assert (px.view(np.uint32) == frame3[40, 50].view(np.uint32)).all() and not (frame3[40, 50] == frame2[40, 50]).all()
+    egg = renderer.render("egg", 64, 64, 0.0).cpu().numpy()
+    px = np.array(renderer.main_image("egg", 64, 64, 0.0, (-3.0, 1000.0)), np.float32)      # clamped to (0, 63)
+    assert (px.view(np.uint32) == egg[63, 0].view(np.uint32)).all()
+    with pytest.raises(shaderbox_amd.SbxError):
+        renderer.main_image(99, 64, 64, 0.0, (.5, .5))
