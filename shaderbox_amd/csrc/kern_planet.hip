@@ -79,10 +79,16 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
 
 // clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
 __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, bool on, int lane) {
+    // The cloud shell is the height band (.2, .65): outside it band() is exactly +0, so dens = fbm * 0 = +0,
+    // T_i = exp(-0) = 1, and the three updates below are `*= 1`, `+= 0`, `+= 0 * (1 - alpha)`: nothing changes.
+    // When that holds for every committing lane of the wave the noise is not evaluated at all (most steps of the
+    // 75-step march and 2-3 of the 5 shadow steps).  A NaN height compares unequal and takes the full path.
+    const float bd = band(c.height);
+    if (!wave_any(on && bd != 0.f)) return;
     float dens = coop_fbm<4, 1>(S, c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f), 2.0276f, .5f, .5f, on, lane);
     const float cov = .29475675f, fuzzy = .0335f;
     dens *= SMOOTHSTEP_K(cov, cov + fuzzy, dens);
-    dens *= band(c.height);
+    dens *= bd;
     const float T_i = exp_(-30.034f * dens * t_step);
     if (on) {
         c.transmittance *= T_i;
