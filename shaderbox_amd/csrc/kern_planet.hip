@@ -49,14 +49,12 @@ __device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_
     return t;
 }
 
-// fBm over the cached noise: octaves are fetched in cooperative batches of <= 4 (register budget), the sum
-// runs in octave order exactly as fbm.h:6 (t += basis * H; p *= lacunarity; H *= gain)
-template <int OCT, int MODE>
-__device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, float init_gain, float gain, bool on, int lane) {
-    float H = init_gain, t = 0.f;
+// fBm over the cached noise: octaves START..OCT-1 are fetched in cooperative batches of <= 4 (register budget) and
+// added to (t, H, q) in octave order exactly as fbm.h:6 (t += basis * H; p *= lacunarity; H *= gain)
+template <int OCT, int MODE, int START>
+__device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacunarity, float& H, float gain, float& t, bool on, int lane) {
 #pragma unroll
-    for (int base = 0; base < OCT; base += 4) {
-        constexpr int REM = OCT;   // (constexpr arithmetic below)
+    for (int base = START; base < OCT; base += 4) {
         if (base + 4 <= OCT) {
             v3 p[4]; int tab[4]; float nz[4];
 #pragma unroll
@@ -65,7 +63,7 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         } else {
-            constexpr int R = REM % 4;
+            constexpr int R = (OCT - START) % 4;
             v3 p[R > 0 ? R : 1]; int tab[R > 0 ? R : 1]; float nz[R > 0 ? R : 1];
 #pragma unroll
             for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
@@ -74,6 +72,11 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
             for (int i = 0; i < R; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         }
     }
+}
+template <int OCT, int MODE>
+__device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, float init_gain, float gain, bool on, int lane) {
+    float H = init_gain, t = 0.f;
+    coop_fbm_range<OCT, MODE, 0>(S, q, lacunarity, H, gain, t, on, lane);
     return t;
 }
 
@@ -102,8 +105,19 @@ template <int OCT>
 __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lane) {
     const float h0 = coop_fbm<OCT, 0>(S, pos * 2.0987f, 2.0244f, .454f, .454f, on, lane);
     const float n0 = SMOOTHSTEP_K(.35f, 1.f, h0);
-    const float h1 = coop_fbm<OCT, 2>(S, pos * 1.50987f + V3(1.9489f, 2.435f, .5483f), 2.0244f, .454f, .454f, on, lane);
-    const float n1 = SMOOTHSTEP_K(.6f, 1.f, h1);
+    // Second fBm (ridged basis, values in [0, 1]): n1 = smoothstep(.6, 1, h1) is exactly +0 whenever h1 < .6.
+    // After the first octave, h1 <= t + (.454^2 + ... + .454^OCT); when that bound is below .6 for every
+    // committing lane of the wave the remaining octaves cannot change n1 = +0 and are not evaluated.
+    v3 q = pos * 1.50987f + V3(1.9489f, 2.435f, .5483f);
+    float H = .454f, h1 = 0.f;
+    coop_fbm_range<1, 2, 0>(S, q, 2.0244f, H, .454f, h1, on, lane);
+    constexpr float TAIL = (OCT == 3) ? .2998f : .3745f;       // sum of .454^k, k = 2..OCT, rounded up (OCT = 3 or 7)
+    static_assert(OCT == 3 || OCT == 7, "tail bound tabulated for 3 and 7 octaves");
+    float n1 = 0.f;
+    if (wave_any(on && !(h1 + TAIL * 1.0001f < .6f))) {
+        coop_fbm_range<OCT, 2, 1>(S, q, 2.0244f, H, .454f, h1, on, lane);
+        n1 = SMOOTHSTEP_K(.6f, 1.f, h1);
+    }
     const float n = n0 + n1;
     return V2(length(pos) - 1.f - n * PL_MAX_HEIGHT, div_by(n, 1.0 / (double)PL_MAX_HEIGHT));
 }
