@@ -198,21 +198,18 @@ __device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, floa
     cd = c * gy + d * fy;
 }
 
-// density_func of a MAIN march sample with the y terms of its step taken from the frame table (SGPRs)
-__device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
-                                                  unsigned long long active_mask, WaveCache& S, int lane,
-                                                  float (&fx)[4], float (&nxy)[4]) {
-    float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
-    const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
-    const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
-    const float rpy[4] = {row.py157.x, row.py157.y, row.py157.z, row.py157.w};
+// Octaves [K0, K1) of a main sample's fBm: lattice terms, tag checks, ONE wave-uniform all-hit test, reads, blends.
+template <int K0, int K1>
+__device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (&rgy)[4], const float (&rpy)[4], float& qx, float& qz,
+                                            float& t, float& H, bool active, unsigned long long active_mask, WaveCache& S,
+                                            int lane, float (&fx)[4], float (&nxy)[4]) {
     float fz[4];
     unsigned nbits[4];
     int slot[4];
     bool ne[4];
     unsigned long long miss_mask = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = K0; k < K1; ++k) {
         const float px = floor_(qx), pz = floor_(qz);
         const float ax = qx - px, az = qz - pz;
         fx[k] = ax * ax * (3.0f - 2.0f * ax);
@@ -225,16 +222,15 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
         miss_mask |= wave_mask(ne[k]);
         qx = qx * 2.64f; qz = qz * 2.64f;
     }
-    float t = 0.f, H = .5f;
     if (!wave_any_mask(miss_mask & active_mask)) {
         float4 lo[4], hi[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = K0; k < K1; ++k) {
             lo[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
             hi[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = K0; k < K1; ++k) {
             float ab, cd;
             hc_blend_xy(lo[k], hi[k], fx[k], rfy[k], rgy[k], ab, cd);
             t += (ab * (1.0f - fz[k]) + cd * fz[k]) * H;
@@ -242,7 +238,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = K0; k < K1; ++k) {
             H8 h;
             if (wave_any(active && ne[k])) {
                 h = hc_slow(S, k, nbits[k], slot[k], active, lane);
@@ -256,6 +252,28 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
             H *= .5f;
         }
     }
+}
+
+// density_func of a MAIN march sample with the y terms of its step taken from the frame table (SGPRs).
+// The value is only used when it is >= .005 (integrate_volume :132), and shape * smoothstep(cov, cov + .0135, shape)
+// is exactly +0 for shape <= cov.  The noise of an octave lies in [0, 1], so after octaves 0-1 the full sum is at
+// most t + .125 + .0625 and after octave 2 at most t + .0625 (plus rounding, covered by the margins): when that
+// bound is below cov for EVERY alive lane of the wave the sample cannot be lit and the remaining octaves are not
+// evaluated (54 % / 73 % of the main samples of the 4K frame; the skipped octaves are the ones that miss most).
+// A skipped sample returns 0, which integrate_volume treats exactly like the true value.
+__device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
+                                                  unsigned long long active_mask, WaveCache& S, int lane,
+                                                  float (&fx)[4], float (&nxy)[4]) {
+    float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
+    const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
+    const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
+    const float rpy[4] = {row.py157.x, row.py157.y, row.py157.z, row.py157.w};
+    float t = 0.f, H = .5f;
+    row_octaves<0, 2>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
+    if (!wave_any_mask(active_mask & wave_mask(!(t + .1876f < F.cov)))) return 0.f;      // NaN compares false: goes on
+    row_octaves<2, 3>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
+    if (!wave_any_mask(active_mask & wave_mask(!(t + .06255f < F.cov)))) return 0.f;
+    row_octaves<3, 4>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
     return t * smoothstep_rd(F.cov, F.cov_rd, t);        // :83-84
 }
 
