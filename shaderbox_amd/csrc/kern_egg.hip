@@ -24,8 +24,6 @@ __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
     const D2 egg = {egg_2, mat_egg};
 
     const float thick = .05f;
-    const D2 legs = op_add2(D2{sd_bezier_x(F.leg_l, p, thick), mat_egg},      // :102-118
-                            D2{sd_bezier_x(F.leg_r, p, thick), mat_egg});
     const D2 left_foot = {sd_cylinder0(F.foot_l, p + F.left_foot, thick), mat_egg};    // :120-123
     const D2 right_foot = {sd_cylinder0(F.foot_r, p + F.right_foot, thick), mat_egg};  // :125-128
     const D2 feet = op_add2(left_foot, right_foot);
@@ -37,6 +35,13 @@ __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
 
     const D2 _1 = op_add2(feet, bike);
     const D2 _2 = op_add2(egg, _1);
+    // The two leg tubes (half of the cost of sdf()) are evaluated only where they can matter: a tube whose bounding
+    // sphere is farther than the distance the other members already give enters the union as +inf (bezier_far).
+    const float dmin = fmin_(ground.d, _2.d);
+    const float inf = u2f(0x7f800000u);
+    const float leg_l = bezier_far(F.leg_l, p, thick, dmin) ? inf : sd_bezier_x(F.leg_l, p, thick);     // :102-118
+    const float leg_r = bezier_far(F.leg_r, p, thick, dmin) ? inf : sd_bezier_x(F.leg_r, p, thick);
+    const D2 legs = op_add2(D2{leg_l, mat_egg}, D2{leg_r, mat_egg});
     const D2 _3 = op_add2(legs, _2);
     return op_add2(ground, _3);
 }

@@ -85,6 +85,8 @@ static BezierFrame bezier_frame(v3 a, v3 b, v3 c) {                    // sdf.h:
     B.v = normalize(cross(B.w, B.u));
     B.a2 = V2(dot(a - b, B.u), dot(a - b, B.v));
     B.c2 = V2(dot(c - b, B.u), dot(c - b, B.v));
+    B.bc = (a + b + c) * (1.f / 3.f);              // any point works; the radius below is measured from it
+    B.br = fmax_(fmax_(length(a - B.bc), length(b - B.bc)), length(c - B.bc)) * 1.001f + 1e-4f;
     return B;
 }
 static CylFrame cyl_frame(v3 P0, v3 P1) {                              // sdf.h:104,106-107

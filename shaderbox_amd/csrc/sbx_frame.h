@@ -78,6 +78,7 @@ struct FrameClouds {
 struct BezierFrame {      // the P-independent part of sd_bezier (src/sdf.h:147-153)
     v3 b, u, v, w;
     v2 a2, c2;
+    v3 bc; float br;      // a sphere around the control triangle (hence around the curve), radius rounded up: sbx_sdf.h bezier_far
 };
 struct CylFrame {         // the P-independent part of sd_cylinder with P0 = 0 (src/sdf.h:104,106-107)
     v3 dir;

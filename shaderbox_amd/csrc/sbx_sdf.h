@@ -41,6 +41,17 @@ __device__ __forceinline__ float sd_bezier_x(const BezierFrame& B, v3 p, float t
     const v2 cp = mix2(mix2(b0, b1, t), mix2(b1, b2, t), t);
     return 0.85f * (sqrt_(dot(cp, cp) + p3.z * p3.z) - thickness);
 }
+// Can the tube be left out of a union whose other members already give distance dmin >= 0 at p?  sd_bezier returns
+// .85 * (D - thickness) with D the distance from p to a point of the curve, and the curve lies inside the sphere
+// (bc, br) around its control triangle, so D >= |p - bc| - br.  With K = 1.18 (dmin + 1e-3) + 1.002 thickness +
+// br + 1e-3, |p - bc| > K implies .85 * (D - thickness) > dmin + 1e-3 with room for every rounding on the way
+// (1.18 > 1 / .85; br is already rounded up by .1 %; scene scale ~10): the tube cannot be the minimum, and a
+// union (op_add2: `a.d < b.d ? a : b`) that gets +inf instead returns the same member.  NaN compares false.
+__device__ __forceinline__ bool bezier_far(const BezierFrame& B, v3 p, float thickness, float dmin) {
+    const v3 q = p - B.bc;
+    const float K = (dmin + 1e-3f) * 1.18f + (thickness * 1.002f + B.br + 1e-3f);
+    return dmin >= 0.f && dot(q, q) > K * K;
+}
 // sd_cylinder(P, 0, P1, R), point-dependent part (frame = cyl_frame(0, P1))                    sdf.h:95-109
 __device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) {
     const float dist = length(cross(C.dir, P - V3(0.f, 0.f, 0.f)));
