@@ -12,9 +12,22 @@
 
 namespace sbx {
 
+// Is everything but the ground plane farther away than the ground?  Every other member of the union is
+// >= .7 * (|p - oc| - orad) (FrameEgg, built in sbx_capi.hip), so with K = 1.43 (ground + 1e-3) + orad (1.43 > 1/.7),
+// |p - oc| > K puts all of them strictly above the ground's distance: sdf() is the ground plane, exactly.
+__device__ __forceinline__ bool egg_far(const FrameEgg& F, v3 p, float ground_d) {
+    const v3 q = p - F.oc;
+    const float K = (ground_d + 1e-3f) * 1.43f + F.orad;
+    return ground_d >= 0.f && dot(q, q) > K * K;
+}
+
 __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
     const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                         // :40-41
     const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
+    {
+        const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};       // sd_plane :136-138
+        if (egg_far(F, p, ground.d)) return ground;
+    }
     const float egg_y = 0.65f;
     const float egg_m = length(p - V3(0, egg_y, 0)) - 0.475f;                  // :47-49
     const float egg_b = length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;

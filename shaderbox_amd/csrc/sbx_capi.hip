@@ -125,6 +125,21 @@ static FrameEgg build_egg(const sbx_uniforms& U) {
     const v3 right_toe = normalize(V3(F.right_foot.y - knee_r.y, knee_r.x - F.right_foot.x, 0));  // :125
     F.foot_l = cyl_frame(zero, left_toe / 8.f);
     F.foot_r = cyl_frame(zero, right_toe / 8.f);
+    // Bounding sphere of the egg, legs, feet and wheel (everything but the ground), see kern_egg.hip egg_far: each
+    // member m has a centre c and a radius rho such that its sdf value is >= .7 * (|p - c| - rho) wherever that is
+    // positive: egg spheres r + .36 (two smooth-mins of k = .5 lower the union by <= .25), tubes br + .061 (the .85
+    // factor and the thickness), toe cylinders .161 around their midpoint (max(axis, slabs) >= |.|/sqrt2 - 1/16),
+    // wheel 1.03.
+    const float egg_y = 0.65f;
+    const v3 cs[8] = {V3(0, egg_y, 0), V3(0, egg_y - 0.45f, 0), V3(0, egg_y + 0.45f, 0), F.leg_l.bc, F.leg_r.bc,
+                      -F.left_foot + left_toe * (-1.f / 16.f), -F.right_foot + right_toe * (-1.f / 16.f), -wheel_pos};
+    const float rs[8] = {.475f + .36f, .25f + .36f, .25f + .36f, F.leg_l.br + .061f, F.leg_r.br + .061f, .161f, .161f, 1.03f};
+    v3 c = V3(0, 0, 0);
+    for (int i = 0; i < 8; ++i) c = c + cs[i] * .125f;
+    float R = 0.f;
+    for (int i = 0; i < 8; ++i) R = fmax_(R, length(cs[i] - c) + rs[i]);
+    F.oc = c;
+    F.orad = R * 1.001f + 1e-3f;
     return F;
 }
 
