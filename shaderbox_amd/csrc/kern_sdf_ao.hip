@@ -41,18 +41,37 @@ __device__ __forceinline__ D2 ao_sdf_pipe(const FrameSdfAo& F, v3 pos) {        
     return op_add2(pipe, deck);
 }
 
+// The reference's sd_box is the max-norm distance max_i(|p_i| - b_i) (sdf.h:67-73) and sd_y_cylinder is
+// max(length(p.xz) - r, |p.y| - h/2) >= the max-norm distance to the cylinder's own bounding box; `max(box, -cylinder)`
+// >= the box.  Every member of sdf_pipe lies inside the axis-aligned box x [-1.325, 1.3], y [0, 2.3], z [-1.275, 1.275]
+// of the pipe's own coordinates (ramp block, coping, rail, bars; :54-113), and for nested intervals
+// |p_i - c_member| - b_member >= |p_i - C| - H on every axis, so sdf_pipe(s) >= the max-norm distance from s to that box
+// (taken .01 larger).  Where this exceeds what ground, reference pole and bottom slab already give, the pipe cannot be
+// the minimum of the union and enters it as +inf — same result as evaluating it (op_add2 is a strict `<`).  The two
+// ramps' boxes are .65 apart, so near any surface at least one ramp (10 primitives) is skipped.
+__device__ __forceinline__ bool ao_pipe_far(v3 s, float dmin) {
+    const v3 c = V3(-.0125f, 1.15f, 0.f), h = V3(1.3225f + .01f, 1.15f + .01f, 1.275f + .01f);
+    const float lb = fmax_(abs_(s.x - c.x) - h.x, fmax_(abs_(s.y - c.y) - h.y, abs_(s.z - c.z) - h.z));
+    return dmin >= 0.f && lb > dmin * 1.001f + 2e-3f;
+}
+
 __device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos) {                                // :115-150
     const v3 size = V3(1.3f, 1.f, 1.25f);
     const float B = .15f;
     v3 p = pos - V3(0, B, 0);
     const D2 bottom = {sd_box(p, V3(2.25f * size.x, B, size.z)), 3.f};                             // mat_bottom
-    const D2 pipe1 = ao_sdf_pipe(F, p + V3(1.25f * size.x, 0, 0));
-    p = p - V3(1.25f * size.x, 0, 0);
-    p = mul(p, F.ry_180);
-    const D2 pipe2 = ao_sdf_pipe(F, p);
-    const D2 pipe = op_add2(pipe1, pipe2);
     const D2 ref = {sd_box(pos, V3(.025f, 15, .025f)), 0.f};                                       // mat_debug
     const D2 ground = {dot(V3(0, 1, 0), pos) + 0.f, 1.f};                                          // sd_plane, mat_ground
+    const float dmin = fmin_(fmin_(ground.d, ref.d), bottom.d);
+    const float inf = u2f(0x7f800000u);
+    const v3 s1 = p + V3(1.25f * size.x, 0, 0);
+    D2 pipe1 = {inf, 2.f};
+    if (!ao_pipe_far(s1, dmin)) pipe1 = ao_sdf_pipe(F, s1);
+    p = p - V3(1.25f * size.x, 0, 0);
+    p = mul(p, F.ry_180);
+    D2 pipe2 = {inf, 2.f};
+    if (!ao_pipe_far(p, dmin)) pipe2 = ao_sdf_pipe(F, p);
+    const D2 pipe = op_add2(pipe1, pipe2);
     const D2 g = op_add2(ground, ref);
     const D2 b = op_add2(pipe, bottom);
     return op_add2(b, g);

@@ -298,3 +298,16 @@ def test_per_pixel_main_image_entry(renderer):
     assert (px.view(np.uint32) == egg[63, 0].view(np.uint32)).all()
     with pytest.raises(shaderbox_amd.SbxError):
         renderer.main_image(99, 64, 64, 0.0, (.5, .5))
+
+
+@pytest.mark.parametrize("app,w,h", [("egg", 200, 112), ("sdf_ao", 200, 112), ("planet", 160, 90), ("clouds", 160, 90)])
+def test_exact_skips_over_many_times(renderer, oracle, app, w, h):
+    """The kernels leave work out where they can prove it cannot change the result (EGG/SDF_AO: members of the
+    union behind a bounding volume; PLANET: noise outside the cloud band / below a smoothstep edge; CLOUDS: octaves of
+    samples that cannot be lit).  The bounds move with the frame (feet, knees, sun, wind), so sweep the time."""
+    from oracle.oracle import APP_IDS
+    for t in (0.1, 0.77, 1.3, 3.9, 7.7, 12.34, 31.0):
+        ref = oracle.render(APP_IDS[app], w, h, t)
+        gpu = renderer.render(app, w, h, t).cpu().numpy()
+        maxd, nbits = compare(gpu, ref)
+        assert nbits == 0 and maxd == 0.0, (app, t, maxd, nbits)
