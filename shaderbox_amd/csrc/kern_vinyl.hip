@@ -40,26 +40,53 @@ __device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {        
     const float defect = fmin_(defect1, defect2);
     return D2{fmax_(d4.d, -defect), d4.m};                       // op_sub
 }
-__device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos) {                     // :127-255
+// Exact culling (as in kern_egg.hip): `dmin` is the distance the platter already gives at pos; a group of the tonearm
+// whose lower bound exceeds the running minimum cannot be returned by the union and enters it as +inf.
+//  * base: three y-cylinders around base_p (max(.., -platter) >= its first argument); a y-cylinder is
+//    max(length(xz) - r, |y| - h/2) >= the max-norm distance to its own bounding box, all inside x,z in base_p +- 3,
+//    |y| <= 1.25;
+//  * the Bezier link: bezier_far (sbx_sdf.h);
+//  * headshell + cartridge: collar, finger lift and cartridge boxes all lie within 1.3 of a3 in the wobbled frame
+//    (offsets and half-sizes of :163-232 added up); a box evaluated in a rotated frame is a max-norm distance
+//    >= Euclidean / sqrt3, the collar's max(axis, slabs) form >= Euclidean / sqrt2 minus its size, and max(x, -cut) >= x:
+//    every member is >= .577 (|p - a3| - 1.3) - so with K = 1.74 (dmin + 1e-3) + 1.35, |p - a3| > K puts them all above dmin.
+__device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float dmin) {        // :127-255
+    const float inf = u2f(0x7f800000u);
     const v3 base_p = V3(-7, 0, -5);
-    const float platter = sd_y_cylinder(pos, 6.25f, 1.f);
-    const float base_0 = sd_y_cylinder(pos - base_p, 3.f, .25f);
-    const float base_1 = fmax_(base_0, -platter);
-    const float base_2 = sd_y_cylinder(pos - base_p, 1.25f, 1.f);
-    const float base_12 = fmin_(base_1, base_2);
-    const D2 base_a = {base_12, 5.f};
-    const D2 base_b = {sd_y_cylinder(pos - base_p, 0.5f, 2.5f), 5.f};
-    const D2 base = op_add2(base_a, base_b);
+    D2 base = {inf, 5.f};
+    {
+        const v3 q = pos - base_p;
+        const float lb = fmax_(abs_(q.x) - 3.01f, fmax_(abs_(q.y) - 1.26f, abs_(q.z) - 3.01f));
+        if (!(dmin >= 0.f && lb > dmin * 1.001f + 2e-3f)) {
+            const float platter = sd_y_cylinder(pos, 6.25f, 1.f);
+            const float base_0 = sd_y_cylinder(pos - base_p, 3.f, .25f);
+            const float base_1 = fmax_(base_0, -platter);
+            const float base_2 = sd_y_cylinder(pos - base_p, 1.25f, 1.f);
+            const float base_12 = fmin_(base_1, base_2);
+            const D2 base_a = {base_12, 5.f};
+            const D2 base_b = {sd_y_cylinder(pos - base_p, 0.5f, 2.5f), 5.f};
+            base = op_add2(base_a, base_b);
+        }
+    }
 
     const v3 p = mul(pos, F.wobble);
     const float R = .1f;
     const float arm1 = sd_capsule_f(p, F.arm1.a, F.arm1.ab, F.arm1.rd, R);
     const float arm2 = sd_capsule_f(p, F.arm2.a, F.arm2.ab, F.arm2.rd, R);
     const float arm3 = sd_capsule_f(p, F.arm3.a, F.arm3.ab, F.arm3.rd, R);
-    const float armb = sd_bezier_x(F.armb, p, R);
     const float arm_link1 = fmin_(arm1, arm2);
     const float arm_link2 = fmin_(arm_link1, arm3);
+    const float dmin2 = fmin_(fmin_(dmin, base.d), arm_link2);
+    const float armb = bezier_far(F.armb, p, R, dmin2) ? inf : sd_bezier_x(F.armb, p, R);
     const D2 arm = {fmin_(arm_link2, armb), 5.f};
+    {
+        const v3 q = p - F.a3;
+        const float K = (dmin2 + 1e-3f) * 1.74f + 1.35f;
+        if (dmin2 >= 0.f && dot(q, q) > K * K) {
+            const D2 tone1 = op_add2(base, arm);
+            return op_add2(tone1, D2{inf, 5.f});
+        }
+    }
 
     const v3 clr_p = p - F.a3;
     const float clr_r = R * 1.5f;
@@ -91,7 +118,7 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos) {      
 }
 __device__ __forceinline__ D2 vinyl_sdf(const FrameVinyl& F, v3 pos) {                         // :257-265
     const D2 plat = vinyl_platter(F, mul(pos, F.platter_rot));
-    const D2 arm = vinyl_tonearm(F, pos);
+    const D2 arm = vinyl_tonearm(F, pos, plat.d);
     return op_add2(plat, arm);
 }
 __device__ __forceinline__ float saw(float x) { return x - floor_(x); }                        // :280-283

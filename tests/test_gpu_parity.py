@@ -300,7 +300,7 @@ def test_per_pixel_main_image_entry(renderer):
         renderer.main_image(99, 64, 64, 0.0, (.5, .5))
 
 
-@pytest.mark.parametrize("app,w,h", [("egg", 200, 112), ("sdf_ao", 200, 112), ("planet", 160, 90), ("clouds", 160, 90)])
+@pytest.mark.parametrize("app,w,h", [("egg", 200, 112), ("sdf_ao", 200, 112), ("vinyl", 200, 112), ("planet", 160, 90), ("clouds", 160, 90)])
 def test_exact_skips_over_many_times(renderer, oracle, app, w, h):
     """The kernels leave work out where they can prove it cannot change the result (EGG/SDF_AO: members of the
     union behind a bounding volume; PLANET: noise outside the cloud band / below a smoothstep edge; CLOUDS: octaves of
