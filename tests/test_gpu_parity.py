@@ -311,3 +311,24 @@ def test_exact_skips_over_many_times(renderer, oracle, app, w, h):
         gpu = renderer.render(app, w, h, t).cpu().numpy()
         maxd, nbits = compare(gpu, ref)
         assert nbits == 0 and maxd == 0.0, (app, t, maxd, nbits)
+
+
+def test_clouds_aux_corners(renderer, oracle):
+    """APP_CLOUDS run-time parameters that switch code paths: more march steps than the per-frame y table holds
+    (general main sample), a wind with a y component (table key), coverage extremes (the stage bounds of the main
+    sample compare against 1 - coverage), a sun that is not along -z (general light march)."""
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS
+    W, H = 96, 54
+    cases = []
+    a = shaderbox_amd.clouds_defaults(); a.cld_march_steps = 1100; a.cld_thick = 137.5; cases.append((a, 0.37))
+    a = shaderbox_amd.clouds_defaults(); a.wind_dir[1] = .05; a.wind_dir[0] = -.1; cases.append((a, 1.7))
+    a = shaderbox_amd.clouds_defaults(); a.cld_coverage = .95; cases.append((a, 0.37))
+    a = shaderbox_amd.clouds_defaults(); a.cld_coverage = .05; cases.append((a, 0.37))
+    a = shaderbox_amd.clouds_defaults(); a.cld_coverage = 1.5; a.sigma_scattering = .4; cases.append((a, 2.5))
+    a = shaderbox_amd.clouds_defaults(); a.sun_dir[0], a.sun_dir[1], a.sun_dir[2] = .3, .2, -.9; a.illum_march_steps = 9; cases.append((a, 0.9))
+    a = shaderbox_amd.clouds_defaults(); a.illum_march_steps = 0; cases.append((a, 0.37))
+    for aux, t in cases:
+        ref = oracle.render(APP_CLOUDS, W, H, t, aux=aux)
+        gpu = renderer.render("clouds", W, H, t, aux=aux).cpu().numpy()
+        assert compare(gpu, ref) == (0.0, 0), (t, aux.cld_march_steps, aux.cld_coverage)
