@@ -403,6 +403,9 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
 #ifndef CL_TX
 #define CL_TX 1
 #endif
+#ifndef CL_TW
+#define CL_TW 32          // wave tile CL_TW x 64/CL_TW pixels (profiles/r01_tile_shapes.txt)
+#endif
 template <bool YTAB>
 __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out,
                                                           const YRow* __restrict__ ytab) {
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
         // Only what the march needs stays live across it (origin, projection, phase): the view direction
         // and the sky colour are recomputed in the epilogue from the pixel coordinates — same operations,
         // same bits — which keeps the register budget of the march at 4 waves per SIMD without spills.
-        const Pixel px = pixel_of_thread<32, CL_TX>(M);
+        const Pixel px = pixel_of_thread<CL_TW, CL_TX>(M);
         const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
         const v3 dir = primary_dir(F.cam, pc);
         const float cutoff = dot(dir, V3(0, 1, 0));
@@ -479,7 +482,7 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
             }
         }
     }
-    const Pixel px = pixel_of_thread<32, CL_TX>(M);
+    const Pixel px = pixel_of_thread<CL_TW, CL_TX>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 dir = primary_dir(F.cam, pc);
@@ -505,9 +508,9 @@ void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_
     } else if (ytab && F.steps <= ytab_rows && F.steps > 0) {
         YRow* tab = reinterpret_cast<YRow*>(ytab);
         if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
-        hipLaunchKernelGGL(k_clouds<true>, (grid_for<32, CL_TX>(M)), dim3(64 * CL_TX), 0, s, F, M, out, (const YRow*)tab);
+        hipLaunchKernelGGL(k_clouds<true>, (grid_for<CL_TW, CL_TX>(M)), dim3(64 * CL_TX), 0, s, F, M, out, (const YRow*)tab);
     } else {
-        hipLaunchKernelGGL(k_clouds<false>, (grid_for<32, CL_TX>(M)), dim3(64 * CL_TX), 0, s, F, M, out, (const YRow*)nullptr);
+        hipLaunchKernelGGL(k_clouds<false>, (grid_for<CL_TW, CL_TX>(M)), dim3(64 * CL_TX), 0, s, F, M, out, (const YRow*)nullptr);
     }
 }
 
