@@ -332,3 +332,16 @@ def test_clouds_aux_corners(renderer, oracle):
         ref = oracle.render(APP_CLOUDS, W, H, t, aux=aux)
         gpu = renderer.render("clouds", W, H, t, aux=aux).cpu().numpy()
         assert compare(gpu, ref) == (0.0, 0), (t, aux.cld_march_steps, aux.cld_coverage)
+
+
+@pytest.mark.timeout(300)
+def test_non_finite_uniforms_do_not_hang(renderer):
+    """NaN / inf / huge u_time and u_mouse flow through as data (the reference has no error path); in particular the
+    cooperative miss loops of the hash cache must terminate when lattice indices are NaN or inf."""
+    import torch
+    for app in ("clouds", "planet", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best"):
+        for t in (float("nan"), float("inf"), 1e30, -1e9, 1e-30):
+            for mouse in ((0.0, 0.0), (float("nan"), 5.0), (1e20, -3.0)):
+                f = renderer.render(app, 96, 54, t, mouse=mouse)
+                torch.cuda.synchronize()
+                assert tuple(f.shape) == (54, 96, 4)
