@@ -88,10 +88,21 @@ __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, b
     // 75-step march and 2-3 of the 5 shadow steps).  A NaN height compares unequal and takes the full path.
     const float bd = band(c.height);
     if (!wave_any(on && bd != 0.f)) return;
-    float dens = coop_fbm<4, 1>(S, c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f), 2.0276f, .5f, .5f, on, lane);
+    // fbm of |2 noise - 1| in [0, 1], gains .5 .25 .125 .0625: evaluated in stages {0,1}, {2}, {3}; once the part so far
+    // plus the largest possible rest is below the coverage edge for every committing lane, smoothstep(cov, ..) is
+    // exactly 0, the density +0, and nothing below would change anything.
     const float cov = .29475675f, fuzzy = .0335f;
+    v3 q = c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f);
+    float H = .5f, dens = 0.f;
+    coop_fbm_range<2, 1, 0>(S, q, 2.0276f, H, .5f, dens, on, lane);
+    if (!wave_any(on && !(dens + .1876f < cov))) return;
+    coop_fbm_range<3, 1, 2>(S, q, 2.0276f, H, .5f, dens, on, lane);
+    if (!wave_any(on && !(dens + .06255f < cov))) return;
+    coop_fbm_range<4, 1, 3>(S, q, 2.0276f, H, .5f, dens, on, lane);
     dens *= SMOOTHSTEP_K(cov, cov + fuzzy, dens);
     dens *= bd;
+    // dens is exactly +0 below the coverage edge as well (smoothstep = 0): same identities, skip the two exp
+    if (!wave_any(on && dens != 0.f)) return;
     const float T_i = exp_(-30.034f * dens * t_step);
     if (on) {
         c.transmittance *= T_i;
@@ -201,6 +212,14 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap 
                 if (cm && (tc > max_cld || cloud.alpha >= 1.f)) cm = false;   // `return` of clouds_march
                 if (!wave_any(cm)) break;
                 const v3 o = cloud.origin + tc * rd;
+                // The band (.2, .65) of height = (|p| - 1) / .4 is the shell 1.08 < |p| < 1.26.  |o|^2 outside
+                // (1.166, 1.5885) puts the rotated point outside it with a margin (3e-4 relative) far above the rounding
+                // of rotation, sqrt and division, so clouds_map() would find band() == +0 and change nothing: when that
+                // holds for every committing lane the step is only `tc += t_step` (most steps of the march).
+                {
+                    const float d2 = dot(o, o);
+                    if (!wave_any(cm && !(d2 > 1.5885f || d2 < 1.166f))) { tc += t_step; continue; }
+                }
                 const v3 cp = mul(F.rot_cloud, o - V3(0, 0, 0));
                 const float ch = div_by(length(cp) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
                 if (cm) { cloud.pos = cp; cloud.height = ch; }
