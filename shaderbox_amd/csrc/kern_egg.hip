@@ -10,6 +10,10 @@
 #include "sbx_device.h"
 #include "sbx_sdf.h"
 
+#ifndef EGG_TW
+#define EGG_TW 16          // wave tile EGG_TW x 64/EGG_TW pixels (profiles/r01_tile_shapes.txt)
+#endif
+
 namespace sbx {
 
 // Is everything but the ground plane farther away than the ground?  Every other member of the union is
@@ -73,7 +77,7 @@ __device__ __forceinline__ float egg_shadowmarch(const FrameEgg& F, v3 ro, v3 rd
 }
 
 __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float* __restrict__ out) {
-    const Pixel px = pixel_of_thread<16>(M);
+    const Pixel px = pixel_of_thread<EGG_TW>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float*
 }
 
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_egg, grid_for<16>(M), dim3(WG_THREADS), 0, s, F, M, out);
+    hipLaunchKernelGGL(k_egg, grid_for<EGG_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx
