@@ -345,3 +345,34 @@ def test_non_finite_uniforms_do_not_hang(renderer):
                 f = renderer.render(app, 96, 54, t, mouse=mouse)
                 torch.cuda.synchronize()
                 assert tuple(f.shape) == (54, 96, 4)
+
+
+def test_clouds_random_sweep_default_equals_perlane(renderer):
+    """The shipped k_clouds (hash cache, y table, z-only light march, staged main sample, no-lookup light samples)
+    against the plain per-lane kernel (sbx_set_variant 1: none of those) on random uniforms and aux blocks: identical
+    bits.  The per-lane kernel itself is checked against the oracle by the other tests."""
+    import shaderbox_amd
+    import torch
+    rng = np.random.default_rng(123)
+    try:
+        for i in range(120):
+            aux = shaderbox_amd.clouds_defaults(renderer.lib)
+            t = float(rng.uniform(0, 50)) if i % 3 else float(rng.uniform(0, 3))
+            mouse = (float(rng.uniform(0, 6.3)), 0.0) if i % 2 else (0.0, 0.0)
+            aux.cld_coverage = float(rng.uniform(0.2, 0.9))
+            aux.cld_march_steps = int(rng.integers(10, 160))
+            aux.illum_march_steps = int(rng.integers(0, 9))
+            aux.cld_thick = float(rng.uniform(40, 300))
+            aux.sigma_scattering = float(rng.uniform(.02, .6))
+            if i % 5 == 0:
+                aux.wind_dir[0], aux.wind_dir[1], aux.wind_dir[2] = [float(x) for x in rng.uniform(-.3, .3, 3)]
+            if i % 7 == 0:
+                d = rng.standard_normal(3); d /= np.linalg.norm(d)
+                aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = [float(x) for x in d]
+            W, H = (640, 360) if i % 4 else (333, 187)
+            renderer.set_variant(0); a = renderer.render("clouds", W, H, t, mouse=mouse, aux=aux).clone()
+            renderer.set_variant(1); b = renderer.render("clouds", W, H, t, mouse=mouse, aux=aux)
+            same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+            assert bool(same.all()), (i, t, mouse, aux.cld_coverage, aux.cld_march_steps, int((~same).sum()))
+    finally:
+        renderer.set_variant(0)
