@@ -138,9 +138,10 @@ int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks
 int sbx_set_timing(sbx_ctx* ctx, int enabled);
 int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms);
 
-/* Diagnostic knob: 0 = default kernels; 1 = "per-lane" cross-check kernels where one exists
- * (APP_CLOUDS: every lane hashes its own lattice corners instead of the wave-cooperative scheme).
- * Both variants are specified to produce identical bits. */
+/* Diagnostic knob: 0 = default kernels; 1 = the plain cross-check kernels where one exists: APP_CLOUDS with every
+ * lane hashing its own lattice corners (no cache, no staging, no tables); APP_EGG / APP_SDF_AO / APP_VINYL with every
+ * member of the SDF union evaluated everywhere (no culling); APP_PLANET without its exact skips.
+ * Both variants are specified to produce identical bits (tests/test_gpu_parity.py sweeps them against each other). */
 int sbx_set_variant(sbx_ctx* ctx, int variant);
 
 /* Device evaluation of the math spec, elementwise over device arrays (for parity tests):

@@ -25,12 +25,14 @@ __device__ __forceinline__ bool egg_far(const FrameEgg& F, v3 p, float ground_d)
     return ground_d >= 0.f && dot(q, q) > K * K;
 }
 
+// CULL = false (sbx_set_variant 1) evaluates every member everywhere: the reference form, kept for the parity sweeps
+template <bool CULL>
 __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
     const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                         // :40-41
     const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
     {
         const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};       // sd_plane :136-138
-        if (egg_far(F, p, ground.d)) return ground;
+        if (CULL && egg_far(F, p, ground.d)) return ground;
     }
     const float egg_y = 0.65f;
     const float egg_m = length(p - V3(0, egg_y, 0)) - 0.475f;                  // :47-49
@@ -56,18 +58,19 @@ __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
     // sphere is farther than the distance the other members already give enters the union as +inf (bezier_far).
     const float dmin = fmin_(ground.d, _2.d);
     const float inf = u2f(0x7f800000u);
-    const float leg_l = bezier_far(F.leg_l, p, thick, dmin) ? inf : sd_bezier_x(F.leg_l, p, thick);     // :102-118
-    const float leg_r = bezier_far(F.leg_r, p, thick, dmin) ? inf : sd_bezier_x(F.leg_r, p, thick);
+    const float leg_l = (CULL && bezier_far(F.leg_l, p, thick, dmin)) ? inf : sd_bezier_x(F.leg_l, p, thick);     // :102-118
+    const float leg_r = (CULL && bezier_far(F.leg_r, p, thick, dmin)) ? inf : sd_bezier_x(F.leg_r, p, thick);
     const D2 legs = op_add2(D2{leg_l, mat_egg}, D2{leg_r, mat_egg});
     const D2 _3 = op_add2(legs, _2);
     return op_add2(ground, _3);
 }
 
+template <bool CULL>
 __device__ __forceinline__ float egg_shadowmarch(const FrameEgg& F, v3 ro, v3 rd) {   // :161-186
     float t = 0.f, umbra = 1.f;
     for (int i = 0; i < 20; ++i) {
         const v3 p = ro + rd * t;
-        const D2 d = egg_sdf(F, p);
+        const D2 d = egg_sdf<CULL>(F, p);
         if (t > 10.f) break;
         if (d.d < 0.001f) return 0.1f;
         t += d.d;
@@ -76,6 +79,7 @@ __device__ __forceinline__ float egg_shadowmarch(const FrameEgg& F, v3 ro, v3 rd
     return umbra;
 }
 
+template <bool CULL>
 __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread<EGG_TW>(M);
     if (!px.valid) return;
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float*
     float t = 0.f;
     for (int i = 0; i < 80; ++i) {                          // render_scene :190-231
         const v3 p = ro + rd * t;
-        const D2 d = egg_sdf(F, p);
+        const D2 d = egg_sdf<CULL>(F, p);
         if (t > 15.f) break;
         if (d.d < 0.001f) {
             const int mat = (int)d.m;
@@ -95,7 +99,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float*
             float s = 1.f;
             if (mat == 3) {
                 const v3 sh_dir = V3(0, 1, 1);
-                s = egg_shadowmarch(F, p + sh_dir * 0.05f, sh_dir);
+                s = egg_shadowmarch<CULL>(F, p + sh_dir * 0.05f, sh_dir);
             }
             v3 base = V3(1, 1, 1);                          // illuminate :29-35
             if (mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
@@ -113,8 +117,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float*
     store_rgba(out, px.idx, to_srgb(color));
 }
 
-void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_egg, grid_for<EGG_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
+void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant) {
+    if (variant == 1) hipLaunchKernelGGL(k_egg<false>, grid_for<EGG_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_egg<true>, grid_for<EGG_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

@@ -81,13 +81,15 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
 }
 
 // clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
+// SKIP = false (sbx_set_variant 1) evaluates everything: the reference form, kept for the parity sweeps
+template <bool SKIP>
 __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, bool on, int lane) {
     // The cloud shell is the height band (.2, .65): outside it band() is exactly +0, so dens = fbm * 0 = +0,
     // T_i = exp(-0) = 1, and the three updates below are `*= 1`, `+= 0`, `+= 0 * (1 - alpha)`: nothing changes.
     // When that holds for every committing lane of the wave the noise is not evaluated at all (most steps of the
     // 75-step march and 2-3 of the 5 shadow steps).  A NaN height compares unequal and takes the full path.
     const float bd = band(c.height);
-    if (!wave_any(on && bd != 0.f)) return;
+    if (SKIP && !wave_any(on && bd != 0.f)) return;
     // fbm of |2 noise - 1| in [0, 1], gains .5 .25 .125 .0625: evaluated in stages {0,1}, {2}, {3}; once the part so far
     // plus the largest possible rest is below the coverage edge for every committing lane, smoothstep(cov, ..) is
     // exactly 0, the density +0, and nothing below would change anything.
@@ -95,14 +97,14 @@ __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, b
     v3 q = c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f);
     float H = .5f, dens = 0.f;
     coop_fbm_range<2, 1, 0>(S, q, 2.0276f, H, .5f, dens, on, lane);
-    if (!wave_any(on && !(dens + .1876f < cov))) return;
+    if (SKIP && !wave_any(on && !(dens + .1876f < cov))) return;
     coop_fbm_range<3, 1, 2>(S, q, 2.0276f, H, .5f, dens, on, lane);
-    if (!wave_any(on && !(dens + .06255f < cov))) return;
+    if (SKIP && !wave_any(on && !(dens + .06255f < cov))) return;
     coop_fbm_range<4, 1, 3>(S, q, 2.0276f, H, .5f, dens, on, lane);
     dens *= SMOOTHSTEP_K(cov, cov + fuzzy, dens);
     dens *= bd;
     // dens is exactly +0 below the coverage edge as well (smoothstep = 0): same identities, skip the two exp
-    if (!wave_any(on && dens != 0.f)) return;
+    if (SKIP && !wave_any(on && dens != 0.f)) return;
     const float T_i = exp_(-30.034f * dens * t_step);
     if (on) {
         c.transmittance *= T_i;
@@ -112,7 +114,7 @@ __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, b
 }
 
 // sdf_terrain_map / sdf_terrain_map_detail :175-199
-template <int OCT>
+template <int OCT, bool SKIP>
 __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lane) {
     const float h0 = coop_fbm<OCT, 0>(S, pos * 2.0987f, 2.0244f, .454f, .454f, on, lane);
     const float n0 = SMOOTHSTEP_K(.35f, 1.f, h0);
@@ -125,7 +127,7 @@ __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lan
     constexpr float TAIL = (OCT == 3) ? .2998f : .3745f;       // sum of .454^k, k = 2..OCT, rounded up (OCT = 3 or 7)
     static_assert(OCT == 3 || OCT == 7, "tail bound tabulated for 3 and 7 octaves");
     float n1 = 0.f;
-    if (wave_any(on && !(h1 + TAIL * 1.0001f < .6f))) {
+    if (!SKIP || wave_any(on && !(h1 + TAIL * 1.0001f < .6f))) {
         coop_fbm_range<OCT, 2, 1>(S, q, 2.0244f, H, .454f, h1, on, lane);
         n1 = SMOOTHSTEP_K(.6f, 1.f, h1);
     }
@@ -152,6 +154,7 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
     return abs3(sky);
 }
 
+template <bool SKIP>
 __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
     __shared__ WaveCache cache[WG_THREADS / 64];
     const int lane = threadIdx.x & 63;
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap 
             if (!wave_any(tm)) break;
             const v3 o = hit_o + t * rd;
             const v3 p = mul(F.rot, o - V3(0, 0, 0));
-            const v2 d = terrain_map<3>(S, p, tm, lane);
+            const v2 d = terrain_map<3, SKIP>(S, p, tm, lane);
             if (tm) {
                 pos = p;
                 df = d;
@@ -218,13 +221,13 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap 
                 // holds for every committing lane the step is only `tc += t_step` (most steps of the march).
                 {
                     const float d2 = dot(o, o);
-                    if (!wave_any(cm && !(d2 > 1.5885f || d2 < 1.166f))) { tc += t_step; continue; }
+                    if (SKIP && !wave_any(cm && !(d2 > 1.5885f || d2 < 1.166f))) { tc += t_step; continue; }
                 }
                 const v3 cp = mul(F.rot_cloud, o - V3(0, 0, 0));
                 const float ch = div_by(length(cp) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
                 if (cm) { cloud.pos = cp; cloud.height = ch; }
                 tc += t_step;
-                clouds_map(S, cloud, t_step, cm, lane);
+                clouds_map<SKIP>(S, cloud, t_step, cm, lane);
             }
         }
         const bool hitl = hit_atm && (df.x < .005f);              // :349
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap 
 #pragma unroll 1
             for (int ax = 0; ax < 3; ++ax) {                       // one code copy for the three central differences
                 const v3 d = V3(ax == 0 ? e : 0.f, ax == 1 ? e : 0.f, ax == 2 ? e : 0.f);
-                const float v = terrain_map<7>(S, pos + d, hitl, lane).x - terrain_map<7>(S, pos - d, hitl, lane).x;
+                const float v = terrain_map<7, SKIP>(S, pos + d, hitl, lane).x - terrain_map<7, SKIP>(S, pos - d, hitl, lane).x;
                 if (ax == 0) g[0] = v; else if (ax == 1) g[1] = v; else g[2] = v;
             }
             const v3 normal = normalize(V3(g[0], g[1], g[2]));
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap 
                     sh.pos = mul(F.rot_cloud, o - V3(0, 0, 0));
                     sh.height = div_by(length(sh.pos) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
                     ts += t_step;
-                    clouds_map(S, sh, t_step, hitl, lane);
+                    clouds_map<SKIP>(S, sh, t_step, hitl, lane);
                 }
             }
             const float shadow = mix_(.7f, 1.f, step_(sh.alpha, 0.33f));
@@ -282,8 +285,9 @@ __global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap 
     store_rgba(out, px.idx, to_srgb(col));
 }
 
-void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_planet, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant) {
+    if (variant == 1) hipLaunchKernelGGL(k_planet<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_planet<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

@@ -55,6 +55,7 @@ __device__ __forceinline__ bool ao_pipe_far(v3 s, float dmin) {
     return dmin >= 0.f && lb > dmin * 1.001f + 2e-3f;
 }
 
+template <bool CULL>   // false (sbx_set_variant 1): both ramps evaluated everywhere, the reference form
 __device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos) {                                // :115-150
     const v3 size = V3(1.3f, 1.f, 1.25f);
     const float B = .15f;
@@ -66,17 +67,18 @@ __device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos) {             
     const float inf = u2f(0x7f800000u);
     const v3 s1 = p + V3(1.25f * size.x, 0, 0);
     D2 pipe1 = {inf, 2.f};
-    if (!ao_pipe_far(s1, dmin)) pipe1 = ao_sdf_pipe(F, s1);
+    if (!(CULL && ao_pipe_far(s1, dmin))) pipe1 = ao_sdf_pipe(F, s1);
     p = p - V3(1.25f * size.x, 0, 0);
     p = mul(p, F.ry_180);
     D2 pipe2 = {inf, 2.f};
-    if (!ao_pipe_far(p, dmin)) pipe2 = ao_sdf_pipe(F, p);
+    if (!(CULL && ao_pipe_far(p, dmin))) pipe2 = ao_sdf_pipe(F, p);
     const D2 pipe = op_add2(pipe1, pipe2);
     const D2 g = op_add2(ground, ref);
     const D2 b = op_add2(pipe, bottom);
     return op_add2(b, g);
 }
 
+template <bool CULL>
 __global__ void __launch_bounds__(WG_THREADS) k_sdf_ao(FrameSdfAo F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
@@ -87,21 +89,21 @@ __global__ void __launch_bounds__(WG_THREADS) k_sdf_ao(FrameSdfAo F, RowMap M, f
     float t = 0.f;
     for (int i = 0; i < 70; ++i) {                                // render_impl :245-285
         const v3 p = ro + rd * t;
-        const D2 d = ao_sdf(F, p);
+        const D2 d = ao_sdf<CULL>(F, p);
         if (t > 20.f) break;
         if (d.d < .005f) {
             const int mat = (int)d.m;
             // sdf_normal :152-163
             const float e = 0.001f;
             const v3 n = normalize(V3(
-                ao_sdf(F, p + V3(e, 0, 0)).d - ao_sdf(F, p - V3(e, 0, 0)).d,
-                ao_sdf(F, p + V3(0, e, 0)).d - ao_sdf(F, p - V3(0, e, 0)).d,
-                ao_sdf(F, p + V3(0, 0, e)).d - ao_sdf(F, p - V3(0, 0, e)).d));
+                ao_sdf<CULL>(F, p + V3(e, 0, 0)).d - ao_sdf<CULL>(F, p - V3(e, 0, 0)).d,
+                ao_sdf<CULL>(F, p + V3(0, e, 0)).d - ao_sdf<CULL>(F, p - V3(0, e, 0)).d,
+                ao_sdf<CULL>(F, p + V3(0, 0, e)).d - ao_sdf<CULL>(F, p - V3(0, 0, e)).d));
             // sdf_ao :165-181
             float occlusion = 0.f;
             for (float k = 1.f; k <= 5.f; k += 1.f) {
                 const v3 q = p + .5f * k * n;
-                const float dd = ao_sdf(F, q).d;
+                const float dd = ao_sdf<CULL>(F, q).d;
                 occlusion += 1.f / pow_(2.f, k) * (.5f * k - dd);
             }
             const float ao = 1.f - clamp_(occlusion, 0.f, 1.f);
@@ -135,8 +137,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_sdf_ao(FrameSdfAo F, RowMap M, f
     store_rgba(out, px.idx, to_srgb(col));
 }
 
-void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_sdf_ao, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant) {
+    if (variant == 1) hipLaunchKernelGGL(k_sdf_ao<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_sdf_ao<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

@@ -50,6 +50,7 @@ __device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {        
 //    (offsets and half-sizes of :163-232 added up); a box evaluated in a rotated frame is a max-norm distance
 //    >= Euclidean / sqrt3, the collar's max(axis, slabs) form >= Euclidean / sqrt2 minus its size, and max(x, -cut) >= x:
 //    every member is >= .577 (|p - a3| - 1.3) - so with K = 1.74 (dmin + 1e-3) + 1.35, |p - a3| > K puts them all above dmin.
+template <bool CULL>   // false (sbx_set_variant 1): no culling, the reference form
 __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float dmin) {        // :127-255
     const float inf = u2f(0x7f800000u);
     const v3 base_p = V3(-7, 0, -5);
@@ -57,7 +58,7 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
     {
         const v3 q = pos - base_p;
         const float lb = fmax_(abs_(q.x) - 3.01f, fmax_(abs_(q.y) - 1.26f, abs_(q.z) - 3.01f));
-        if (!(dmin >= 0.f && lb > dmin * 1.001f + 2e-3f)) {
+        if (!(CULL && dmin >= 0.f && lb > dmin * 1.001f + 2e-3f)) {
             const float platter = sd_y_cylinder(pos, 6.25f, 1.f);
             const float base_0 = sd_y_cylinder(pos - base_p, 3.f, .25f);
             const float base_1 = fmax_(base_0, -platter);
@@ -77,12 +78,12 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
     const float arm_link1 = fmin_(arm1, arm2);
     const float arm_link2 = fmin_(arm_link1, arm3);
     const float dmin2 = fmin_(fmin_(dmin, base.d), arm_link2);
-    const float armb = bezier_far(F.armb, p, R, dmin2) ? inf : sd_bezier_x(F.armb, p, R);
+    const float armb = (CULL && bezier_far(F.armb, p, R, dmin2)) ? inf : sd_bezier_x(F.armb, p, R);
     const D2 arm = {fmin_(arm_link2, armb), 5.f};
     {
         const v3 q = p - F.a3;
         const float K = (dmin2 + 1e-3f) * 1.74f + 1.35f;
-        if (dmin2 >= 0.f && dot(q, q) > K * K) {
+        if (CULL && dmin2 >= 0.f && dot(q, q) > K * K) {
             const D2 tone1 = op_add2(base, arm);
             return op_add2(tone1, D2{inf, 5.f});
         }
@@ -116,9 +117,10 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
     const D2 tone2 = op_add2(headshell, cartridge);
     return op_add2(tone1, tone2);
 }
+template <bool CULL>
 __device__ __forceinline__ D2 vinyl_sdf(const FrameVinyl& F, v3 pos) {                         // :257-265
     const D2 plat = vinyl_platter(F, mul(pos, F.platter_rot));
-    const D2 arm = vinyl_tonearm(F, pos, plat.d);
+    const D2 arm = vinyl_tonearm<CULL>(F, pos, plat.d);
     return op_add2(plat, arm);
 }
 __device__ __forceinline__ float saw(float x) { return x - floor_(x); }                        // :280-283
@@ -136,6 +138,7 @@ __device__ __forceinline__ v3 vinyl_base_color(int mat) {                       
     }
 }
 
+template <bool CULL>
 __global__ void __launch_bounds__(WG_THREADS) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_vinyl(FrameVinyl F, RowMap M, fl
     float t = 0.f;
     for (int i = 0; i < 60; ++i) {                              // render :427-455
         const v3 p = ro + rd * t;
-        const D2 d = vinyl_sdf(F, p);
+        const D2 d = vinyl_sdf<CULL>(F, p);
         if (t > 40.f) break;
         if (d.d < .005f) {
             const int mat = (int)d.m;
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_vinyl(FrameVinyl F, RowMap M, fl
                 const v3 so = p + F.sun_dir * 0.05f;
                 float ts = 0.f;
                 for (int k = 0; k < 20; ++k) {
-                    const D2 ds = vinyl_sdf(F, so + F.sun_dir * ts);
+                    const D2 ds = vinyl_sdf<CULL>(F, so + F.sun_dir * ts);
                     if (ts > 5.f) break;
                     if (ds.d < .005f) { sh = .05f; break; }
                     ts += ds.d;
@@ -202,9 +205,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_vinyl(FrameVinyl F, RowMap M, fl
             } else {
                 const float e = 0.001f;                              // sdf_normal :267-278
                 const v3 n = normalize(V3(
-                    vinyl_sdf(F, p + V3(e, 0, 0)).d - vinyl_sdf(F, p - V3(e, 0, 0)).d,
-                    vinyl_sdf(F, p + V3(0, e, 0)).d - vinyl_sdf(F, p - V3(0, e, 0)).d,
-                    vinyl_sdf(F, p + V3(0, 0, e)).d - vinyl_sdf(F, p - V3(0, 0, e)).d));
+                    vinyl_sdf<CULL>(F, p + V3(e, 0, 0)).d - vinyl_sdf<CULL>(F, p - V3(e, 0, 0)).d,
+                    vinyl_sdf<CULL>(F, p + V3(0, e, 0)).d - vinyl_sdf<CULL>(F, p - V3(0, e, 0)).d,
+                    vinyl_sdf<CULL>(F, p + V3(0, 0, e)).d - vinyl_sdf<CULL>(F, p - V3(0, 0, e)).d));
                 const v3 diffuse = base * fmax_(0.f, dot(L, n));
                 const v3 H = normalize(V + L);
                 const v3 specular = pow_(fmax_(0.f, dot(H, n)), 50.f) * V3(1, 1, 1);
@@ -218,8 +221,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_vinyl(FrameVinyl F, RowMap M, fl
     store_rgba(out, px.idx, to_srgb(color));
 }
 
-void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_vinyl, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant) {
+    if (variant == 1) hipLaunchKernelGGL(k_vinyl<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_vinyl<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

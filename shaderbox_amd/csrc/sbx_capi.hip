@@ -367,17 +367,17 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         if (rebuild) (void)hipEventRecord(ctx->ytab_ready, s);
         break;
     }
-    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s); break;
+    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, ctx->variant); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
     case SBX_APP_SDF_AO: {
         sbx_aux_sdf_ao A;
         if (aux) A = *(const sbx_aux_sdf_ao*)aux; else sbx_aux_sdf_ao_defaults(&A);
-        launch_sdf_ao(build_sdf_ao(*uni, A), M, rgba, s);
+        launch_sdf_ao(build_sdf_ao(*uni, A), M, rgba, s, ctx->variant);
         break;
     }
-    case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s); break;
-    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s); break;
+    case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s, ctx->variant); break;
+    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s, ctx->variant); break;
     case SBX_APP_CLOUDS_BEST: launch_clouds_best(build_clouds_best(*uni), M, rgba, s); break;
     default: return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
     }

@@ -48,13 +48,13 @@ void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_
 constexpr int CLOUDS_YTAB_ROWS = 1024;      // march steps covered by the per-frame y table
 constexpr int CLOUDS_YTAB_BYTES = CLOUDS_YTAB_ROWS * 48;
 constexpr int CLOUDS_YTAB_RING = 8;         // tables in flight (one per launch, round robin)
-void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s);
+void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s);
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s);
-void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s);
-void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s);
+void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant);
+void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, hipStream_t s);
-void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s);
+void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_assemble(int width, int height, int block_rows, int nranks, int rows_max,
                      const float* gathered, float* frame, hipStream_t s);
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);

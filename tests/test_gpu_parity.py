@@ -376,3 +376,24 @@ def test_clouds_random_sweep_default_equals_perlane(renderer):
             assert bool(same.all()), (i, t, mouse, aux.cld_coverage, aux.cld_march_steps, int((~same).sum()))
     finally:
         renderer.set_variant(0)
+
+
+@pytest.mark.parametrize("app", ["egg", "sdf_ao", "vinyl", "planet"])
+def test_random_sweep_culled_equals_plain(renderer, app):
+    """Kernels with exact culling / skips (default) against the same kernels with every member and every octave evaluated
+    (sbx_set_variant 1) on random times and mouse positions: identical bits."""
+    import torch
+    rng = np.random.default_rng(7)
+    try:
+        for i in range(100):
+            t = float(rng.uniform(0, 60)) if i % 3 else float(rng.uniform(0, 3))
+            mouse = (float(rng.uniform(0, 640)), float(rng.uniform(0, 360))) if i % 2 else (0.0, 0.0)
+            W, H = (640, 360) if i % 4 else (333, 187)
+            if app == "planet":
+                W, H = (320, 180) if i % 4 else (201, 113)
+            renderer.set_variant(0); a = renderer.render(app, W, H, t, mouse=mouse).clone()
+            renderer.set_variant(1); b = renderer.render(app, W, H, t, mouse=mouse)
+            same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+            assert bool(same.all()), (app, i, t, mouse, int((~same).sum()))
+    finally:
+        renderer.set_variant(0)
