@@ -34,30 +34,56 @@ __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
         const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};       // sd_plane :136-138
         if (CULL && egg_far(F, p, ground.d)) return ground;
     }
-    const float egg_y = 0.65f;
-    const float egg_m = length(p - V3(0, egg_y, 0)) - 0.475f;                  // :47-49
-    const float egg_b = length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
-    const float egg_t = length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
-    const float egg_1 = op_blend(egg_m, egg_b, .5f);
-    const float egg_2 = op_blend(egg_1, egg_t, .5f);
-    const D2 egg = {egg_2, mat_egg};
-
-    const float thick = .05f;
-    const D2 left_foot = {sd_cylinder0(F.foot_l, p + F.left_foot, thick), mat_egg};    // :120-123
-    const D2 right_foot = {sd_cylinder0(F.foot_r, p + F.right_foot, thick), mat_egg};  // :125-128
-    const D2 feet = op_add2(left_foot, right_foot);
+    // Members are evaluated cheapest first with a running minimum `dmin`; a member whose lower bound exceeds it
+    // cannot be the union's result and enters as +inf (op_add2 is a strict `<`, so the winner and its material
+    // are unchanged).  Lower bounds (all with >= 1e-3 of slack over the rounding of the evaluation itself):
+    //   wheel  : distance to the unit circle - .03             >= |pw| - 1.03
+    //   foot   : max(axis, |u + 1/16| - 1/16) - .05            >= |P - M| / sqrt2 - 1/16 - .05   (M = midpoint)
+    //   egg    : two smooth-mins (k = .5) of three spheres     >= |p - (0, .65, 0)| - .7 - .25
+    //   leg    : bezier_far (sbx_sdf.h)
+    const float inf = u2f(0x7f800000u);
+    const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};           // sd_plane :136-138
+    float dmin = ground.d;
+    const bool pos_d = CULL && dmin >= 0.f;          // the bounds below assume a non-negative running minimum
 
     const v3 wheel_pos = V3(0, 1.2f, 0);
     const v3 pw = p + wheel_pos;
-    const D2 bike = {length(V2(length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f, mat_bike};   // sd_torus sdf.h:75-83
-    const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};           // sd_plane :136-138
+    D2 bike = {inf, mat_bike};
+    {
+        const float K = dmin * 1.001f + (1.03f + 2e-3f);
+        if (!(pos_d && dot(pw, pw) > K * K))
+            bike.d = length(V2(length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f;              // sd_torus sdf.h:75-83
+    }
+    dmin = fmin_(dmin, bike.d);
+
+    const float thick = .05f;
+    D2 left_foot = {inf, mat_egg}, right_foot = {inf, mat_egg};
+    {
+        const float K = (dmin + (.0625f + .05f + 1e-3f)) * 1.4143f + 1e-3f;
+        const v3 ql = p - F.foot_ml, qr = p - F.foot_mr;
+        if (!(pos_d && dot(ql, ql) > K * K)) left_foot.d = sd_cylinder0(F.foot_l, p + F.left_foot, thick);     // :120-123
+        if (!(pos_d && dot(qr, qr) > K * K)) right_foot.d = sd_cylinder0(F.foot_r, p + F.right_foot, thick);   // :125-128
+    }
+    const D2 feet = op_add2(left_foot, right_foot);
+    dmin = fmin_(dmin, feet.d);
+
+    const float egg_y = 0.65f;
+    D2 egg = {inf, mat_egg};
+    {
+        const v3 qe = p - V3(0, egg_y, 0);
+        const float K = dmin * 1.001f + (.95f + 3e-3f);
+        if (!(pos_d && dot(qe, qe) > K * K)) {
+            const float egg_m = length(p - V3(0, egg_y, 0)) - 0.475f;                  // :47-49
+            const float egg_b = length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
+            const float egg_t = length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
+            const float egg_1 = op_blend(egg_m, egg_b, .5f);
+            egg.d = op_blend(egg_1, egg_t, .5f);
+        }
+    }
+    dmin = fmin_(dmin, egg.d);
 
     const D2 _1 = op_add2(feet, bike);
     const D2 _2 = op_add2(egg, _1);
-    // The two leg tubes (half of the cost of sdf()) are evaluated only where they can matter: a tube whose bounding
-    // sphere is farther than the distance the other members already give enters the union as +inf (bezier_far).
-    const float dmin = fmin_(ground.d, _2.d);
-    const float inf = u2f(0x7f800000u);
     const float leg_l = (CULL && bezier_far(F.leg_l, p, thick, dmin)) ? inf : sd_bezier_x(F.leg_l, p, thick);     // :102-118
     const float leg_r = (CULL && bezier_far(F.leg_r, p, thick, dmin)) ? inf : sd_bezier_x(F.leg_r, p, thick);
     const D2 legs = op_add2(D2{leg_l, mat_egg}, D2{leg_r, mat_egg});

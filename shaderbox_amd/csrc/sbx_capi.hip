@@ -130,6 +130,8 @@ static FrameEgg build_egg(const sbx_uniforms& U) {
     // positive: egg spheres r + .36 (two smooth-mins of k = .5 lower the union by <= .25), tubes br + .061 (the .85
     // factor and the thickness), toe cylinders .161 around their midpoint (max(axis, slabs) >= |.|/sqrt2 - 1/16),
     // wheel 1.03.
+    F.foot_ml = -F.left_foot + left_toe * (-1.f / 16.f);
+    F.foot_mr = -F.right_foot + right_toe * (-1.f / 16.f);
     const float egg_y = 0.65f;
     const v3 cs[8] = {V3(0, egg_y, 0), V3(0, egg_y - 0.45f, 0), V3(0, egg_y + 0.45f, 0), F.leg_l.bc, F.leg_r.bc,
                       -F.left_foot + left_toe * (-1.f / 16.f), -F.right_foot + right_toe * (-1.f / 16.f), -wheel_pos};

@@ -90,6 +90,7 @@ struct FrameEgg {
     v3 left_foot, right_foot;   //                                      app_egg.h:73-77
     BezierFrame leg_l, leg_r;   //                                      app_egg.h:111-116
     CylFrame foot_l, foot_r;    //                                      app_egg.h:120-128
+    v3 foot_ml, foot_mr;        // midpoints of the toe cylinders in p space: -foot - toe/16 (kern_egg.hip)
     v3 oc; float orad;          // sphere around everything but the ground plane, in sdf()'s p space (kern_egg.hip egg_far)
 };
 
