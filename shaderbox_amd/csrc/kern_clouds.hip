@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, Ro
 // variant 0 (default): per-wave lattice-hash cache in LDS.
 //
 // hash(n) depends only on the integer lattice index n = p.x + 157 p.y + 113 p.z (noise_iq.h:19), and
-// the 64 rays of an 8x8 pixel tile sample almost the same place: measured on the 3840x2160 frame a
+// the 64 rays of a wave's pixel tile sample almost the same place: measured on the 3840x2160 frame (8x8 tiles) a
 // wave touches on average 1.07 / 1.18 / 1.49 / 2.25 distinct lattice cells in octaves 0..3 per sample,
 // and consecutive samples along the march (and the six light samples of a lit step) mostly stay in the
 // cells of the previous sample.  So the 8 corner hashes of a cell are computed ONCE per wave and kept
