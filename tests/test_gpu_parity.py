@@ -397,3 +397,19 @@ def test_random_sweep_culled_equals_plain(renderer, app):
             assert bool(same.all()), (app, i, t, mouse, int((~same).sum()))
     finally:
         renderer.set_variant(0)
+
+
+@pytest.mark.parametrize("app,w,h", [("egg", 1920, 1080), ("egg", 3840, 2160), ("sdf_ao", 3840, 2160), ("vinyl", 3840, 2160),
+                                      ("planet", 7680, 4320)])
+def test_full_size_default_equals_plain(renderer, app, w, h):
+    """BASELINE.json frame sizes: the default kernels (exact culling / skips) and the plain ones agree on every pixel."""
+    import torch
+    try:
+        for t in (0.37, 2.5):
+            renderer.set_variant(0); a = renderer.render(app, w, h, t).clone()
+            renderer.set_variant(1); b = renderer.render(app, w, h, t)
+            same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+            assert bool(same.all()), (app, t, int((~same).sum()))
+            del a, b
+    finally:
+        renderer.set_variant(0)
