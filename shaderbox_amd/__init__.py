@@ -68,6 +68,14 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise ImportError("libsbx.so is not built (%s). Run `python -m shaderbox_amd.build`; "
                           "there is no fallback path." % path)
+    # Load order matters: PyTorch brings its own copy of the HIP runtime.  If libsbx.so (linked against the system
+    # libamdhip64) is loaded first and torch afterwards, the process ends up with two runtimes and device enumeration
+    # fails (observed: sbx_create -> SBX_ERR_NO_DEVICE on a GPU box).  torch is this package's device-memory/stream
+    # provider anyway, so import it before the dlopen whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     vp, ci, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
     lib.sbx_aux_clouds_defaults.argtypes = [ctypes.POINTER(AuxClouds)]

@@ -413,3 +413,16 @@ def test_full_size_default_equals_plain(renderer, app, w, h):
             del a, b
     finally:
         renderer.set_variant(0)
+
+
+def test_library_before_torch_in_a_fresh_process():
+    """build() followed by smoke() in one interpreter: the library is asked for before anything imported torch.
+    (Two HIP runtimes in one process made sbx_create report 'no device'; load_library() now imports torch first.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import shaderbox_amd; lib = shaderbox_amd.load_library(); "
+            "r = shaderbox_amd.Renderer(0); f = r.render('egg', 32, 32, 0.0); print(tuple(f.shape))" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "(32, 32, 4)" in out.stdout, out.stderr[-2000:]
