@@ -75,17 +75,18 @@ int main(int argc, char** argv) {
         FILE* fp = fopen(ppm.c_str(), "wb");
         if (!fp) { perror("fopen"); return 1; }
         fprintf(fp, "P6\n%d %d\n255\n", W, H);
-        std::vector<unsigned char> row(W * 3);
-        for (int y = H - 1; y >= 0; --y) {              // framebuffer row 0 is the bottom row
-            for (int x = 0; x < W; ++x)
-                for (int c = 0; c < 3; ++c) {
-                    float v = host[((size_t)y * W + x) * 4 + c];
-                    v = !(v > 0.f) ? 0.f : (v > 1.f ? 1.f : v);   // NaN -> 0
-                    row[x * 3 + c] = (unsigned char)(v * 255.f + .5f);
-                }
-            fwrite(row.data(), 1, row.size(), fp);
-        }
+        // the back-buffer write of hlsltoy (R8G8B8A8_UNORM, top row first) on the device, then 4 B/pixel over PCIe
+        unsigned char* dev8 = nullptr;
+        const size_t npx = (size_t)W * H;
+        if (hipMalloc((void**)&dev8, npx * 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
+        rc = sbx_pack_unorm8(ctx, W, H, dev, dev8, /*flip_y=*/1, nullptr);
+        if (rc != SBX_OK) { fprintf(stderr, "sbx_pack_unorm8: %s\n", sbx_last_error(ctx)); return 1; }
+        std::vector<unsigned char> rgba8(npx * 4), rgb(npx * 3);
+        if (hipMemcpy(rgba8.data(), dev8, npx * 4, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "hipMemcpy failed\n"); return 1; }
+        for (size_t i = 0; i < npx; ++i) { rgb[i * 3] = rgba8[i * 4]; rgb[i * 3 + 1] = rgba8[i * 4 + 1]; rgb[i * 3 + 2] = rgba8[i * 4 + 2]; }
+        fwrite(rgb.data(), 1, rgb.size(), fp);
         fclose(fp);
+        (void)hipFree(dev8);
     }
     (void)hipFree(dev);
     sbx_destroy(ctx);

@@ -133,6 +133,13 @@ int sbx_rank_rows_max(int height, int block_rows, int nranks);
 int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks,
                  const float* gathered, float* frame, void* stream);
 
+/* The write into hlsltoy's DXGI_FORMAT_R8G8B8A8_UNORM back buffer (util/hlsltoy/src/hlsltoy.cpp:79,192): float RGBA
+ * rows -> 8-bit RGBA by the Direct3D float -> UNORM rule (NaN -> 0, clamp to [0, 1], * 255 + .5, truncate).
+ * `rgba` and `out` are device pointers (width * rows pixels each); flip_y != 0 writes the top row first
+ * (D3D / image-file order; the float frame has row 0 at the bottom). */
+int sbx_pack_unorm8(sbx_ctx* ctx, int width, int rows, const float* rgba, unsigned char* out, int flip_y,
+                    void* stream);
+
 /* Per-launch timing: when enabled, every render call brackets its kernel with HIP events on the
  * launch stream; sbx_last_kernel_ms() synchronises on the last pair and returns the duration. */
 int sbx_set_timing(sbx_ctx* ctx, int enabled);

@@ -87,6 +87,7 @@ def load_library(path=None):
     lib.sbx_destroy.restype = None
     lib.sbx_render_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, fp, vp]
     lib.sbx_render_rank.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, fp, vp]
+    lib.sbx_pack_unorm8.argtypes = [vp, ci, ci, fp, vp, ci, vp]
     lib.sbx_main_image.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ctypes.POINTER(ctypes.c_float * 2),
                                    ctypes.POINTER(ctypes.c_float * 4)]
     lib.sbx_render_rank_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, fp, vp]
@@ -197,6 +198,16 @@ class Renderer:
         self._check(self.lib.sbx_render_rank(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
                                              rank, nranks, ctypes.c_void_p(buf.data_ptr()), self._stream()))
         return buf
+
+    def pack_unorm8(self, frame, flip_y=True):
+        """float RGBA rows [rows, W, 4] (device) -> uint8 [rows, W, 4], the R8G8B8A8_UNORM back-buffer write of hlsltoy
+        (Direct3D float -> UNORM rule); flip_y puts the top row first."""
+        assert frame.is_cuda and frame.dtype == self.torch.float32 and frame.is_contiguous() and frame.shape[-1] == 4
+        rows, width = int(frame.shape[0]), int(frame.shape[1])
+        out = self.torch.empty((rows, width, 4), dtype=self.torch.uint8, device=self.tdev)
+        self._check(self.lib.sbx_pack_unorm8(self.ctx, width, rows, ctypes.c_void_p(frame.data_ptr()),
+                                             ctypes.c_void_p(out.data_ptr()), 1 if flip_y else 0, self._stream()))
+        return out
 
     def main_image(self, app, width, height, time, frag_coord, mouse=(0.0, 0.0), aux=None):
         """void mainImage(out vec4 fragColor, in vec2 fragCoord) (src/main.h:6-9) for hosts that loop over the

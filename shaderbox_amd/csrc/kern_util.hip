@@ -28,6 +28,30 @@ void launch_assemble(int width, int height, int block_rows, int nranks, int rows
                        nranks, rows_max, reinterpret_cast<const float4*>(gathered), reinterpret_cast<float4*>(frame));
 }
 
+// float RGBA -> R8G8B8A8_UNORM, the back-buffer write of hlsltoy (util/hlsltoy/src/hlsltoy.cpp:79,192), by the
+// Direct3D float -> UNORM rule: NaN -> 0, clamp to [0, 1], scale by 255, add .5, truncate.  One pixel per thread:
+// a 16-byte load and a 4-byte store, both coalesced.  flip != 0 writes the top row first (D3D / PPM order).
+__global__ void __launch_bounds__(256) k_pack_unorm8(int width, int rows, int flip, const float4* __restrict__ in,
+                                                      unsigned* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)width * rows;
+    if (i >= total) return;
+    const int y = (int)(i / width), x = (int)(i - (size_t)y * width);
+    const float4 c = in[i];
+    auto q = [](float v) -> unsigned {
+        if (!(v > 0.f)) return 0u;                   // NaN, -x, -0, +0
+        if (v > 1.f) v = 1.f;
+        return (unsigned)(v * 255.f + .5f);
+    };
+    const size_t o = (size_t)(flip ? rows - 1 - y : y) * width + x;
+    out[o] = q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
+}
+void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s) {
+    const size_t total = (size_t)width * rows;
+    hipLaunchKernelGGL(k_pack_unorm8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, width, rows, flip,
+                       reinterpret_cast<const float4*>(in), reinterpret_cast<unsigned*>(out));
+}
+
 __global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restrict__ a, const float* __restrict__ b,
                                                     float* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

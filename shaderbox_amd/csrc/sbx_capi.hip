@@ -505,6 +505,18 @@ int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks
     return SBX_OK;
 }
 
+int sbx_pack_unorm8(sbx_ctx* ctx, int width, int rows, const float* rgba, unsigned char* out, int flip_y, void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (width <= 0 || rows < 0 || (rows > 0 && (!rgba || !out))) return fail(ctx, SBX_ERR_ARG, "bad pack arguments");
+    if (rows == 0) return SBX_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    launch_pack_unorm8(width, rows, flip_y != 0, rgba, out, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "pack launch", e);
+    return SBX_OK;
+}
+
 int sbx_set_variant(sbx_ctx* ctx, int variant) {
     if (!ctx) return SBX_ERR_ARG;
     if (variant < 0 || variant > 1) return fail(ctx, SBX_ERR_ARG, "unknown kernel variant");

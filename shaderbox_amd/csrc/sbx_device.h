@@ -57,6 +57,7 @@ void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, h
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_assemble(int width, int height, int block_rows, int nranks, int rows_max,
                      const float* gathered, float* frame, hipStream_t s);
+void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);
 void launch_worley_volume(int size, float* out, hipStream_t s);
 int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t n, hipStream_t s);

@@ -37,6 +37,14 @@ def test_cli_and_mainimage_dropin_match_oracle(built, oracle, tmp_path):
         got = np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
         ref = oracle.render(APP_IDS[app.lower().replace("app_", "")], w, h, t)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        # the PPM is the same frame through sbx_pack_unorm8 (R8G8B8A8_UNORM rule), top row first
+        raw = open(str(tmp_path / "f.ppm"), "rb").read()
+        hdr = ("P6\n%d %d\n255\n" % (w, h)).encode()
+        assert raw.startswith(hdr) and len(raw) == len(hdr) + w * h * 3
+        img = np.frombuffer(raw[len(hdr):], dtype=np.uint8).reshape(h, w, 3)
+        c = ref[::-1, :, :3]
+        want = (np.where(np.isnan(c) | ~(c > 0), 0, np.minimum(c, 1)).astype(np.float32) * np.float32(255) + np.float32(.5)).astype(np.uint8)
+        assert np.array_equal(img, want)
     r = subprocess.run([os.path.join(built, "mainimage_demo"), "256", "256", "0.37"], capture_output=True, text=True, check=True)
     mean = [float(v) for v in r.stdout.strip().split("=")[-1].split()]
     # EGG 256x256 t=.37 frame mean

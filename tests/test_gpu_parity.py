@@ -426,3 +426,20 @@ def test_library_before_torch_in_a_fresh_process():
             "r = shaderbox_amd.Renderer(0); f = r.render('egg', 32, 32, 0.0); print(tuple(f.shape))" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "(32, 32, 4)" in out.stdout, out.stderr[-2000:]
+
+
+def test_pack_unorm8(renderer):
+    """sbx_pack_unorm8 = Direct3D float -> R8G8B8A8_UNORM (NaN -> 0, clamp, * 255 + .5, truncate), optional row flip"""
+    import torch
+    rng = np.random.default_rng(9)
+    a = rng.uniform(-.2, 1.2, size=(37, 53, 4)).astype(np.float32)
+    a[0, 0] = [np.nan, -0.0, 1.0, np.inf]; a[1, 1] = [0.5 / 255, 1.5 / 255, 254.5 / 255, -np.inf]
+    a[2, 2] = [0.49999 / 255, 0.50001 / 255, 0.999999, 1e-30]
+    want = np.where(np.isnan(a) | ~(a > 0), 0, np.minimum(a, 1)).astype(np.float32)
+    want = (want * np.float32(255) + np.float32(.5)).astype(np.uint8)
+    t = torch.from_numpy(a).cuda()
+    assert (renderer.pack_unorm8(t, flip_y=False).cpu().numpy() == want).all()
+    assert (renderer.pack_unorm8(t, flip_y=True).cpu().numpy() == want[::-1]).all()
+    f = renderer.render("egg", 64, 48, 0.37)
+    p = renderer.pack_unorm8(f).cpu().numpy()
+    assert p.shape == (48, 64, 4) and (p[..., 3] == 255).all()
