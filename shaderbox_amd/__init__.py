@@ -235,6 +235,11 @@ class Renderer:
     def assemble(self, gathered, width, height, block_rows, nranks, out=None):
         """Root side: scatter the rank-major gathered slabs to their global rows -> [H, W, 4]."""
         frame = self._buffer(int(height), int(width), out)
+        need = int(nranks) * shard.rank_rows_max(int(height), int(block_rows), int(nranks)) * int(width) * 4
+        if not (gathered.is_cuda and gathered.dtype == self.torch.float32 and gathered.is_contiguous()
+                and gathered.numel() >= need):
+            raise ValueError("gathered must be a contiguous float32 device tensor of >= nranks * rows_max * W * 4 = %d floats"
+                             % need)
         self._check(self.lib.sbx_assemble(self.ctx, int(width), int(height), block_rows, nranks,
                                           ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
                                           self._stream()))
