@@ -8,7 +8,9 @@
  * the uniforms of src/uniform_buffer.h uploaded as cbuffers b0/b1, hlsltoy.cpp:402-426,
  * 502-516).  A per-pixel FFI into a GPU is meaningless, so the boundary is frame-granular:
  * one call renders rows of one frame of one app into a caller-owned RGBA32F framebuffer in
- * device memory.  Everything a host needs is plain C: pointers, sizes, POD structs.
+ * device memory (sbx_render_rows); sbx_main_image keeps the per-pixel signature on top of it
+ * for hosts that want their loop unchanged.  Everything a host needs is plain C: pointers,
+ * sizes, POD structs.
  *
  * Conventions (all from the reference):
  *   - framebuffer: row-major float4 RGBA, 16 B/pixel, row 0 = BOTTOM row (main.h:40-43: the
@@ -95,7 +97,8 @@ void sbx_aux_clouds_defaults(sbx_aux_clouds* aux);
 void sbx_aux_sdf_ao_defaults(sbx_aux_sdf_ao* aux);
 
 /* Create / destroy a context bound to HIP device `device`.  Owns only small device scratch
- * (trig tables, timing events); the framebuffer always belongs to the caller. */
+ * (APP_CLOUDS' per-frame y tables, timing events, the cached frame of sbx_main_image); the
+ * framebuffer of the render calls always belongs to the caller. */
 int sbx_create(int device, sbx_ctx** out);
 void sbx_destroy(sbx_ctx* ctx);
 
