@@ -100,11 +100,14 @@ __global__ void __launch_bounds__(WG_THREADS) k_sdf_ao(FrameSdfAo F, RowMap M, f
                 ao_sdf<CULL>(F, p + V3(0, e, 0)).d - ao_sdf<CULL>(F, p - V3(0, e, 0)).d,
                 ao_sdf<CULL>(F, p + V3(0, 0, e)).d - ao_sdf<CULL>(F, p - V3(0, 0, e)).d));
             // sdf_ao :165-181
-            float occlusion = 0.f;
+            float occlusion = 0.f, inv2k = 1.f;
             for (float k = 1.f; k <= 5.f; k += 1.f) {
                 const v3 q = p + .5f * k * n;
                 const float dd = ao_sdf<CULL>(F, q).d;
-                occlusion += 1.f / pow_(2.f, k) * (.5f * k - dd);
+                // pow(2, k) of the math spec is exactly 2^k for k = 1..5 (log2(2) = 1 and 2^integer are exact in its
+                // binary64 sequence), so 1 / pow(2, k) is the exact power of two below
+                inv2k *= .5f;
+                occlusion += inv2k * (.5f * k - dd);
             }
             const float ao = 1.f - clamp_(occlusion, 0.f, 1.f);
             const float sh = 1.f;

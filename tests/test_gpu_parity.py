@@ -443,3 +443,13 @@ def test_pack_unorm8(renderer):
     f = renderer.render("egg", 64, 48, 0.37)
     p = renderer.pack_unorm8(f).cpu().numpy()
     assert p.shape == (48, 64, 4) and (p[..., 3] == 255).all()
+
+
+def test_pow_of_two_is_exact(renderer, oracle):
+    """kern_sdf_ao.hip replaces 1 / pow(2, k), k = 1..5, by the exact power of two: the math spec's pow gives exactly 2^k"""
+    import torch
+    k = np.arange(1, 6, dtype=np.float32)
+    two = np.full(5, 2.0, np.float32)
+    assert oracle.math("pow", two, k).tolist() == [2.0, 4.0, 8.0, 16.0, 32.0]
+    got = renderer.math("pow", torch.from_numpy(two).cuda(), torch.from_numpy(k).cuda()).cpu().numpy()
+    assert got.tolist() == [2.0, 4.0, 8.0, 16.0, 32.0]
