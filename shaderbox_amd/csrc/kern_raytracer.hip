@@ -46,7 +46,8 @@ __device__ __forceinline__ void hit_sphere(v3 ro, v3 rd, const RtSphere& s, Hit&
     hit.t = t0;
     hit.mat = s.mat;
     hit.o = impact;
-    hit.n = (impact - s.o) / s.r;
+    const v3 dn = impact - s.o;
+    hit.n = V3(div_by(dn.x, s.rr), div_by(dn.y, s.rr), div_by(dn.z, s.rr));     // (impact - origin) / radius, exact (sbx_math.h)
 }
 __device__ __forceinline__ Hit trace(const FrameRaytracer& F, v3 ro, v3 rd, int mat_to_ignore) {   // :70-86
     Hit hit;
@@ -62,6 +63,7 @@ __device__ __forceinline__ Hit trace(const FrameRaytracer& F, v3 ro, v3 rd, int 
 __device__ __forceinline__ RtMaterial material_of(const FrameRaytracer& F, int id) {
     RtMaterial m;
     m.base_color = V3(0, 0, 0); m.roughness = 0.f; m.ior = 0.f; m.reflectivity = 0.f;
+    m.r0 = 1.f;                                                  // ior 0: ((1 - 0) / (1 + 0))^2
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         if (i == id) m = F.mats[i];
@@ -77,7 +79,8 @@ __device__ __forceinline__ v3 cook_torrance(v3 V, v3 L, const Hit& hit, const Rt
     const float rough_a = 1.f / (rough_sq * NdotH * NdotH * NdotH * NdotH);
     const float rough_exp = (NdotH * NdotH - 1.f) / (rough_sq * NdotH * NdotH);
     const float rough_term = rough_a * exp_(rough_exp);
-    const float fresnel_term = fresnel_factor(1.f, mat.ior, VdotH);
+    const float Fc = 1.f - VdotH;                                 // fresnel_factor(1, ior, VdotH) with R0 from the frame
+    const float fresnel_term = mat.r0 + (1.f - mat.r0) * (Fc * Fc * Fc * Fc * Fc);
     const float specular = (geo_term * rough_term * fresnel_term) / (3.14159265359f * NdotV * NdotL);
     return fmax_(0.f, NdotL) * (specular + mat.base_color);
 }

@@ -155,13 +155,17 @@ static FrameRaytracer build_raytracer(const sbx_uniforms& U) {
     const v3 eye = mul(rot_y, V3(0, cb, 2.333f * cb));
     F.cam = make_camera(U.u_res[0], U.u_res[1], tan_(radians_(30.f)), eye, V3(0, cb, 0));   // FOV :138
     // materials: zero-initialised slots (App. B5), mat_debug :20-25, cornell box cornell_box.h:47-55
-    for (int i = 0; i < 8; ++i) F.mats[i] = RtMaterial{V3(0, 0, 0), 0.f, 0.f, 0.f};
-    F.mats[0] = RtMaterial{V3(1.f, 1.f, 1.f), 0.f, 1.f, 0.f};
-    F.mats[1] = RtMaterial{V3(0.7913f, 0.7913f, 0.7913f), .5f, 1.f, 0.f};
-    F.mats[2] = RtMaterial{V3(0.6795f, 0.0612f, 0.0529f), .5f, 1.f, 0.f};
-    F.mats[3] = RtMaterial{V3(0.1878f, 0.1274f, 0.4287f), .5f, 1.f, 0.f};
-    F.mats[4] = RtMaterial{V3(0.95f, 0.64f, 0.54f), .1f, 1.f, 1.f};
-    F.mats[5] = RtMaterial{V3(1.f, 0.77f, 0.345f), .05f, 1.333f, 1.f};
+    for (int i = 0; i < 8; ++i) F.mats[i] = RtMaterial{V3(0, 0, 0), 0.f, 0.f, 0.f, 0.f};
+    F.mats[0] = RtMaterial{V3(1.f, 1.f, 1.f), 0.f, 1.f, 0.f, 0.f};
+    F.mats[1] = RtMaterial{V3(0.7913f, 0.7913f, 0.7913f), .5f, 1.f, 0.f, 0.f};
+    F.mats[2] = RtMaterial{V3(0.6795f, 0.0612f, 0.0529f), .5f, 1.f, 0.f, 0.f};
+    F.mats[3] = RtMaterial{V3(0.1878f, 0.1274f, 0.4287f), .5f, 1.f, 0.f, 0.f};
+    F.mats[4] = RtMaterial{V3(0.95f, 0.64f, 0.54f), .1f, 1.f, 1.f, 0.f};
+    F.mats[5] = RtMaterial{V3(1.f, 0.77f, 0.345f), .05f, 1.333f, 1.f, 0.f};
+    for (int i = 0; i < 8; ++i) {                                      // util_optics.h:10-11 with n1 = 1, per material
+        const float Rn = (1.f - F.mats[i].ior) / (1.f + F.mats[i].ior);
+        F.mats[i].r0 = Rn * Rn;
+    }
     // planes, in array-index order ground, behind, front, ceiling, left, right  cornell_box.h:57-69
     F.planes[0] = RtPlane{V3(0, -1, 0), 0.f, 1};
     F.planes[1] = RtPlane{V3(0, 0, -1), -cb, 1};
@@ -171,9 +175,9 @@ static FrameRaytracer build_raytracer(const sbx_uniforms& U) {
     F.planes[5] = RtPlane{V3(-1, 0, 0), -cb, 3};
     // spheres cornell_box.h:71-82 + animation app_raytracer.h:29-34
     const float s = sin_(U.u_time), c = cos_(U.u_time);
-    F.spheres[0] = RtSphere{V3(0, 2.5f * cb + 0.4f, 0), 1.5f, 0};
-    F.spheres[1] = RtSphere{V3(0.75f, 1, -0.75f) + V3(0, abs_(s), c + 1.f), 0.75f, 4};
-    F.spheres[2] = RtSphere{V3(-0.75f, 0.75f, 0.f), 0.75f, 5};
+    F.spheres[0] = RtSphere{V3(0, 2.5f * cb + 0.4f, 0), 1.5f, 0, recip64(1.5f)};
+    F.spheres[1] = RtSphere{V3(0.75f, 1, -0.75f) + V3(0, abs_(s), c + 1.f), 0.75f, 4, recip64(0.75f)};
+    F.spheres[2] = RtSphere{V3(-0.75f, 0.75f, 0.f), 0.75f, 5, recip64(0.75f)};
     F.light = V3(0, 2.f * cb - 0.2f, 1.5f);
     return F;
 }

@@ -96,8 +96,9 @@ struct FrameEgg {
 
 // ---- APP_RAYTRACER (src/app_raytracer.h, cornell_box.h) -------------------------------------
 struct RtPlane { v3 n; float d; int mat; };
-struct RtSphere { v3 o; float r; int mat; };
-struct RtMaterial { v3 base_color; float roughness, ior, reflectivity; };
+struct RtSphere { v3 o; float r; int mat; double rr; };   // rr = recip64(r): the normal's three divisions by r (intersect.h:32)
+struct RtMaterial { v3 base_color; float roughness, ior, reflectivity;
+                    float r0; };   // fresnel_factor(1, ior, .)'s R0 = ((1 - ior) / (1 + ior))^2, util_optics.h:10-11
 struct FrameRaytracer {
     Camera cam;
     RtPlane planes[6];
