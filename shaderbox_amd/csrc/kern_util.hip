@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restri
     case 7: r = hash1(x); break;
     case 8: r = x / y; break;                       // IEEE division
     case 9: r = div_by(x, recip64(y)); break;       // the same through the binary64 reciprocal (sbx_math.h)
+    case 11: r = pow_h_(x, y); break;               // the former series pow (comparison with the table form)
     case 10: r = exp_h13_(x); break;                // the former 13-term exp (equivalence test against the table form)
     default: r = 0.f;
     }
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restri
 }
 
 int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t n, hipStream_t s) {
-    if (fn < 0 || fn > 10) return -1;
+    if (fn < 0 || fn > 11) return -1;
     hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, a, b, out, n);
     return 0;
 }

@@ -222,7 +222,10 @@ SBX_HD float exp_(float x) {
     const double y = p * kExp2Tab[ki & 31];
     return (float)u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
 }
-SBX_HD float pow_(float x, float y) {
+// The former pow (atanh-series log2 with a binary64 division, 13-term 2^t), kept as the test hook "pow_h": the table
+// form below agrees with it except on a ~1e-8 fraction of inputs that sit on a binary32 rounding boundary to within
+// the ~1e-16 accuracy of either binary64 value (tests/test_gpu_parity.py::test_pow_table_vs_series).
+SBX_HD float pow_h_(float x, float y) {
     if (y == 0.0f) return 1.0f;
     if (x != x || y != y) return u2f(0x7fc00000u);
     if (x < 0.0f) return u2f(0x7fc00000u);
@@ -232,6 +235,127 @@ SBX_HD float pow_(float x, float y) {
     if (t < -160.0) t = -160.0;
     if (t > 136.0) t = 136.0;
     return (float)d_exp2(t);
+}
+// pow (oracle/sbx_math_ref.h m_pow): 2^(y log2 x) through two table forms, 23 binary64 operations against 45
+// (a quarter of APP_RAYTRACER's and 4 % of APP_CLOUDS' time is linear_to_srgb's three pow).
+//   log2 x: x = 2^k z, z in [0.6875, 1.375), 128 intervals of z with centre c_i (the two next to 1.0 use c = 1, which
+//           keeps the relative accuracy near x = 1): k + logc_i + log2(1 + r), r = z * invc_i - 1 (one fma), |r| < 2^-7,
+//           log2(1 + r) = r (A0 + ... + A7 r^7);
+//   2^t   : t = k/32 + r exactly, 2^(k>>5) * 2^((k&31)/32) * exp(r ln2) with the degree-6 Taylor polynomial and the
+//           table of exp_.
+// Constants: tools/gen_math_coeffs.py --log2-table / --exp-table.
+#define SBX_LOG2_TAB_VALUES \
+    {0x1.734f0c541fe8dp+0, -0x1.12aceeefcd824p-1}, {0x1.713786d9c7c09p+0, -0x1.0e809617b46b5p-1}, \
+    {0x1.6f26016f26017p+0, -0x1.0a5a3dc175219p-1}, {0x1.6d1a62681c861p+0, -0x1.0639d4c219d60p-1}, \
+    {0x1.6b1490aa31a3dp+0, -0x1.021f4a37ecbfbp-1}, {0x1.691473a88d0c0p+0, -0x1.fc151b11b3641p-2}, \
+    {0x1.6719f3601671ap+0, -0x1.f3f71cc1b629cp-2}, {0x1.6524f853b4aa3p+0, -0x1.ebe47960e3c08p-2}, \
+    {0x1.63356b88ac0dep+0, -0x1.e3dd1156507dep-2}, {0x1.614b36831ae94p+0, -0x1.dbe0c58c3cff3p-2}, \
+    {0x1.5f66434292dfcp+0, -0x1.d3ef776d43ff4p-2}, {0x1.5d867c3ece2a5p+0, -0x1.cc0908e19b7bcp-2}, \
+    {0x1.5babcc647fa91p+0, -0x1.c42d5c4c688b2p-2}, {0x1.59d61f123ccaap+0, -0x1.bc5c5489254cbp-2}, \
+    {0x1.5805601580560p+0, -0x1.b495d4e9185f7p-2}, {0x1.56397ba7c52e2p+0, -0x1.acd9c130dd540p-2}, \
+    {0x1.54725e6bb82fep+0, -0x1.a527fd95fd8ffp-2}, {0x1.52aff56a8054bp+0, -0x1.9d806ebc9921dp-2}, \
+    {0x1.50f22e111c4c5p+0, -0x1.95e2f9b51f04cp-2}, {0x1.4f38f62dd4c9bp+0, -0x1.8e4f83fa145f0p-2}, \
+    {0x1.4d843bedc2c4cp+0, -0x1.86c5f36dea3dep-2}, {0x1.4bd3edda68fe1p+0, -0x1.7f462e58e1689p-2}, \
+    {0x1.4a27fad76014ap+0, -0x1.77d01b66fbd36p-2}, {0x1.4880522014880p+0, -0x1.7063a1a5fb4f1p-2}, \
+    {0x1.46dce34596066p+0, -0x1.6900a8836d0d4p-2}, {0x1.453d9e2c776cap+0, -0x1.61a717cac1983p-2}, \
+    {0x1.43a2730abee4dp+0, -0x1.5a56d7a370dedp-2}, {0x1.420b5265e5951p+0, -0x1.530fd08f29fa6p-2}, \
+    {0x1.40782d10e6566p+0, -0x1.4bd1eb680e548p-2}, {0x1.3ee8f42a5af07p+0, -0x1.449d115ef7d88p-2}, \
+    {0x1.3d5d991aa75c6p+0, -0x1.3d712bf9c9df0p-2}, {0x1.3bd60d9232955p+0, -0x1.364e2511cc823p-2}, \
+    {0x1.3a524387ac822p+0, -0x1.2f33e6d2120f0p-2}, {0x1.38d22d366088ep+0, -0x1.28225bb5e64a5p-2}, \
+    {0x1.3755bd1c945eep+0, -0x1.21196e87473d2p-2}, {0x1.35dce5f9f2af8p+0, -0x1.1a190a5d674a0p-2}, \
+    {0x1.34679ace01346p+0, -0x1.13211a9b38422p-2}, {0x1.32f5ced6a1dfap+0, -0x1.0c318aedff3c0p-2}, \
+    {0x1.3187758e9ebb6p+0, -0x1.054a474bf0eb7p-2}, {0x1.301c82ac40260p+0, -0x1.fcd677e5ac81bp-3}, \
+    {0x1.2eb4ea1fed14bp+0, -0x1.ef28aacd72230p-3}, {0x1.2d50a012d50a0p+0, -0x1.e18b00e13123cp-3}, \
+    {0x1.2bef98e5a3711p+0, -0x1.d3fd543a4ad5dp-3}, {0x1.2a91c92f3c105p+0, -0x1.c67f7f770a67bp-3}, \
+    {0x1.293725bb804a5p+0, -0x1.b9115db83a3dfp-3}, {0x1.27dfa38a1ce4dp+0, -0x1.abb2ca9ec746ep-3}, \
+    {0x1.268b37cd60127p+0, -0x1.9e63a24971f4ap-3}, {0x1.2539d7e9177b2p+0, -0x1.9123c1528c6cdp-3}, \
+    {0x1.23eb79717605bp+0, -0x1.83f304cdc5aa4p-3}, {0x1.22a0122a0122ap+0, -0x1.76d14a4601225p-3}, \
+    {0x1.21579804855e6p+0, -0x1.69be6fbb3aa6fp-3}, {0x1.2012012012012p+0, -0x1.5cba53a0762edp-3}, \
+    {0x1.1ecf43c7fb84cp+0, -0x1.4fc4d4d9bb311p-3}, {0x1.1d8f5672e4abdp+0, -0x1.42ddd2ba1b4aep-3}, \
+    {0x1.1c522fc1ce059p+0, -0x1.36052d01c3dd8p-3}, {0x1.1b17c67f2bae3p+0, -0x1.293ac3dc1a66cp-3}, \
+    {0x1.19e0119e0119ep+0, -0x1.1c7e77dde33dbp-3}, {0x1.18ab083902bdbp+0, -0x1.0fd02a03727edp-3}, \
+    {0x1.1778a191bd684p+0, -0x1.032fbbaee6d64p-3}, {0x1.1648d50fc3201p+0, -0x1.ed3a1d4cdbeb9p-4}, \
+    {0x1.151b9a3fdd5c9p+0, -0x1.d4300a2524d46p-4}, {0x1.13f0e8d344724p+0, -0x1.bb4102f925391p-4}, \
+    {0x1.12c8b89edc0acp+0, -0x1.a26ccd9981858p-4}, {0x1.11a3019a74826p+0, -0x1.89b33091d6fdep-4}, \
+    {0x1.107fbbe011080p+0, -0x1.7113f3259e07fp-4}, {0x1.0f5edfab325a2p+0, -0x1.588edd4d1ceb2p-4}, \
+    {0x1.0e40655826011p+0, -0x1.4023b7b26aca0p-4}, {0x1.0d24456359e3ap+0, -0x1.27d24bae824dfp-4}, \
+    {0x1.0c0a7868b4171p+0, -0x1.0f9a634663ae7p-4}, {0x1.0af2f722eecb5p+0, -0x1.eef792508b68ap-5}, \
+    {0x1.09ddba6af8360p+0, -0x1.beec9151aac2bp-5}, {0x1.08cabb37565e2p+0, -0x1.8f135b8107911p-5}, \
+    {0x1.07b9f29b8eae2p+0, -0x1.5f6b8a11c3c73p-5}, {0x1.06ab59c7912fbp+0, -0x1.2ff4b77413db9p-5}, \
+    {0x1.059eea0727586p+0, -0x1.00ae7f502c1b2p-5}, {0x1.04949cc1664c5p+0, -0x1.a330fd028f734p-6}, \
+    {0x1.038c6b78247fcp+0, -0x1.4564a62192839p-6}, {0x1.02864fc7729e9p+0, -0x1.cfee70c5ce606p-7}, \
+    {0x1.0182436517a37p+0, -0x1.15cfe8eaec7f5p-7}, {0x1.0000000000000p+0, 0x0.0p+0}, \
+    {0x1.0000000000000p+0, 0x0.0p+0}, {0x1.fa11caa01fa12p-1, 0x1.1363117a97b03p-6}, \
+    {0x1.f6310aca0dbb5p-1, 0x1.c9363ba850f9cp-6}, {0x1.f25f644230ab5p-1, 0x1.3ed3094685a27p-5}, \
+    {0x1.ee9c7f8458e02p-1, 0x1.985bfc3495193p-5}, {0x1.eae807aba01ebp-1, 0x1.f13898332539dp-5}, \
+    {0x1.e741aa59750e4p-1, 0x1.24b5b7e135a41p-4}, {0x1.e3a9179dc1a73p-1, 0x1.507b836033bbap-4}, \
+    {0x1.e01e01e01e01ep-1, 0x1.7beee96b8a281p-4}, {0x1.dca01dca01dcap-1, 0x1.a7111df348494p-4}, \
+    {0x1.d92f2231e7f8ap-1, 0x1.d1e34e35b82d7p-4}, {0x1.d5cac807572b2p-1, 0x1.fc66a0f0b00a5p-4}, \
+    {0x1.d272ca3fc5b1ap-1, 0x1.134e1b4890631p-3}, {0x1.cf26e5c44bfc6p-1, 0x1.284294b07a640p-3}, \
+    {0x1.cbe6d9601cbe7p-1, 0x1.3d1146d9a8a63p-3}, {0x1.c8b265afb8a42p-1, 0x1.51bab907a5c8ap-3}, \
+    {0x1.c5894d10d4986p-1, 0x1.663f6fac91315p-3}, {0x1.c26b5392ea01cp-1, 0x1.7a9fec7d05de0p-3}, \
+    {0x1.bf583ee868d8bp-1, 0x1.8edcae8352b6bp-3}, {0x1.bc4fd65883e7bp-1, 0x1.a2f632320b86cp-3}, \
+    {0x1.b951e2b18ff23p-1, 0x1.b6ecf175f95ecp-3}, {0x1.b65e2e3beee05p-1, 0x1.cac163c770dcap-3}, \
+    {0x1.b37484ad806cep-1, 0x1.de73fe3b1480ep-3}, {0x1.b094b31d922a4p-1, 0x1.f205339208f27p-3}, \
+    {0x1.adbe87f94905ep-1, 0x1.02baba24d0664p-2}, {0x1.aaf1d2f87ebfdp-1, 0x1.0c62975542a8dp-2}, \
+    {0x1.a82e65130e159p-1, 0x1.15fa676bb08fep-2}, {0x1.a574107688a4ap-1, 0x1.1f825f6d88e13p-2}, \
+    {0x1.a2c2a87c51ca0p-1, 0x1.28fab35b32684p-2}, {0x1.a01a01a01a01ap-1, 0x1.32639636b2836p-2}, \
+    {0x1.9d79f176b682dp-1, 0x1.3bbd3a0a1dcfbp-2}, {0x1.9ae24ea5510dap-1, 0x1.4507cfedd4fc5p-2}, \
+    {0x1.9852f0d8ec0ffp-1, 0x1.4e43880e8fb6bp-2}, {0x1.95cbb0be377aep-1, 0x1.577091b3378c9p-2}, \
+    {0x1.934c67f9b2ce6p-1, 0x1.608f1b42948aep-2}, {0x1.90d4f120190d5p-1, 0x1.699f5248cd4b8p-2}, \
+    {0x1.8e6527af1373fp-1, 0x1.72a1637cbc183p-2}, {0x1.8bfce8062ff3ap-1, 0x1.7b957ac51aac4p-2}, \
+    {0x1.899c0f601899cp-1, 0x1.847bc33d8618ep-2}, {0x1.87427bcc092b9p-1, 0x1.8d54673b5c371p-2}, \
+    {0x1.84f00c2780614p-1, 0x1.961f90527409bp-2}, {0x1.82a4a0182a4a0p-1, 0x1.9edd6759b25e0p-2}, \
+    {0x1.8060180601806p-1, 0x1.a78e146f7bef4p-2}, {0x1.7e225515a4f1dp-1, 0x1.b031befe06435p-2}, \
+    {0x1.7beb3922e017cp-1, 0x1.b8c88dbf88679p-2}, {0x1.79baa6bb6398bp-1, 0x1.c152a6c24cae7p-2}, \
+    {0x1.77908119ac60dp-1, 0x1.c9d02f6ca47b5p-2}, {0x1.756cac201756dp-1, 0x1.d2414c80bf27cp-2},
+#if defined(__HIP_DEVICE_COMPILE__)
+__constant__ const double kLog2Tab[128][2] = {SBX_LOG2_TAB_VALUES};
+#else
+constexpr double kLog2Tab[128][2] = {SBX_LOG2_TAB_VALUES};
+#endif
+SBX_HD double d_log2_tab(double x) {
+    const uint64_t ix = d2u(x);
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const int i = (int)((tmp >> 45) & 127);
+    const int k = (int)((int64_t)tmp >> 52);
+    const double z = u2d(ix - (tmp & 0xfff0000000000000ull));
+    const double r = __builtin_fma(z, kLog2Tab[i][0], -1.0);
+    double p = -0x1.71547652b82fep-3;                          // A7 = -1/(8 ln2)
+    p = __builtin_fma(p, r, 0x1.a61762a7aded9p-3);
+    p = __builtin_fma(p, r, -0x1.ec709dc3a03fdp-3);
+    p = __builtin_fma(p, r, 0x1.2776c50ef9bfep-2);
+    p = __builtin_fma(p, r, -0x1.71547652b82fep-2);
+    p = __builtin_fma(p, r, 0x1.ec709dc3a03fdp-2);
+    p = __builtin_fma(p, r, -0x1.71547652b82fep-1);
+    p = __builtin_fma(p, r, 0x1.71547652b82fep+0);             // A0 = 1/ln2
+    return __builtin_fma(r, p, (double)k + kLog2Tab[i][1]);
+}
+SBX_HD double d_exp2_tab(double t) {
+    double kd = __builtin_fma(t, 32.0, D_MAGIC);
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - D_MAGIC;
+    const double u = __builtin_fma(kd, -0.03125, t) * D_LN2;
+    double p = 0x1.6c16c16c16c17p-10;
+    p = __builtin_fma(p, u, 0x1.1111111111111p-7);
+    p = __builtin_fma(p, u, 0x1.5555555555555p-5);
+    p = __builtin_fma(p, u, 0x1.5555555555555p-3);
+    p = __builtin_fma(p, u, 0.5);
+    p = __builtin_fma(p, u, 1.0);
+    p = __builtin_fma(p, u, 1.0);
+    const double y = p * kExp2Tab[ki & 31];
+    return u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
+}
+SBX_HD float pow_(float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    if (x != x || y != y) return u2f(0x7fc00000u);
+    if (x < 0.0f) return u2f(0x7fc00000u);
+    if (x == 0.0f) return (y > 0.0f) ? 0.0f : u2f(0x7f800000u);
+    if (x == u2f(0x7f800000u)) return (y > 0.0f) ? x : 0.0f;
+    double t = (double)y * d_log2_tab((double)x);
+    if (t < -160.0) t = -160.0;
+    if (t > 136.0) t = 136.0;
+    return (float)d_exp2_tab(t);
 }
 SBX_HD double d_atan_pos(double z) {
     bool inv = z > 1.0;

@@ -453,3 +453,29 @@ def test_pow_of_two_is_exact(renderer, oracle):
     assert oracle.math("pow", two, k).tolist() == [2.0, 4.0, 8.0, 16.0, 32.0]
     got = renderer.math("pow", torch.from_numpy(two).cuda(), torch.from_numpy(k).cuda()).cpu().numpy()
     assert got.tolist() == [2.0, 4.0, 8.0, 16.0, 32.0]
+
+
+def test_pow_table_vs_series(renderer, oracle):
+    """pow (table forms of log2 and 2^t: the spec, oracle m_pow) against the former atanh-series / 13-term form: both
+    are binary64-internal and accurate to ~1e-16, so they can only differ where the exact value sits that close to a
+    binary32 rounding boundary: a tiny fraction of inputs, by one ulp.  Device pow == oracle pow bit for bit."""
+    import torch
+    rng = np.random.default_rng(17)
+    n = 1 << 24
+    tot = diff = 0
+    for y in (1 / 2.2, 1.5, 10.0, 30.0, 50.0, 1500.0):
+        x = torch.from_numpy(np.concatenate([rng.uniform(0, 1.5, n // 2), rng.uniform(0.98, 1.02, n // 4),
+                                             np.abs(rng.standard_normal(n // 4)) * 4]).astype(np.float32)).cuda()
+        yy = torch.full_like(x, float(np.float32(y)))
+        a = renderer.math("pow", x, yy)
+        b = renderer.math("pow_h", x, yy)
+        d = (a.view(torch.int32) - b.view(torch.int32)).abs()
+        d = torch.where(torch.isnan(a) & torch.isnan(b), torch.zeros_like(d), d)
+        assert int(d.max()) <= 1, y
+        tot += x.numel(); diff += int((d != 0).sum())
+        xs = x[:200000].cpu().numpy()
+        want = oracle.math("pow", xs, np.full_like(xs, np.float32(y)))
+        got = a[:200000].cpu().numpy()
+        assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all(), y
+    print("pow table vs series: %d of %d inputs differ (by one ulp)" % (diff, tot))
+    assert diff <= tot * 1e-6

@@ -76,3 +76,30 @@ def test_exp_is_correctly_rounded_against_mpmath(oracle):
     want = np.array([rn32(mp.exp(mp.mpf(float(v)))) for v in x], np.float32)
     assert (got.view(np.uint32) == want.view(np.uint32)).all(), (x[got != want][:5], got[got != want][:5], want[got != want][:5])
     assert got[-1].view(np.uint32) == 0x000f6dce
+
+
+def test_pow_is_correctly_rounded_against_mpmath(oracle):
+    """m_pow (table forms of log2 and 2^t) against x**y in 200-bit arithmetic rounded once to binary32, for the
+    exponents the apps use (1/2.2 of linear_to_srgb, 1.5 of the phase functions, 10/30/50/1500 of the sun lobes)."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    rng = np.random.default_rng(5)
+
+    def rn32(v):
+        if v == 0:
+            return np.float32(0)
+        if v >= mp.mpf(2) ** 128:
+            return np.float32(np.inf)
+        e = max(int(mp.floor(mp.log(v, 2))), -126)
+        q = v / mp.mpf(2) ** (e - 23)
+        n = int(mp.floor(q)); f = q - n
+        if f > 0.5 or (f == 0.5 and n & 1):
+            n += 1
+        return np.float32(float(mp.mpf(n) * mp.mpf(2) ** (e - 23)))
+    for y in (1 / 2.2, 1.5, 10.0, 30.0, 50.0, 1500.0):
+        yy = np.float32(y)
+        x = np.concatenate([rng.uniform(0, 1.2, 700), rng.uniform(0.99, 1.01, 300), np.abs(rng.standard_normal(300)) * 5]).astype(np.float32)
+        x = x[x > 0]
+        got = oracle.math("pow", x, np.full_like(x, yy))
+        want = np.array([rn32(mp.mpf(float(v)) ** mp.mpf(float(yy))) for v in x], np.float32)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), (y, x[got != want][:3])

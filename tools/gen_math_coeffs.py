@@ -140,3 +140,36 @@ def exp_table():
 
 if __name__ == "__main__" and "--exp-table" in __import__("sys").argv:
     exp_table()
+
+
+def log2_table():
+    """Constants of the table form of log2 used by pow (sbx_math.h d_log2, oracle d_log2).
+    x = 2^k z with z in [0.6875, 1.375): tmp = bits(x) - OFF (OFF = bits(0.6875)), i = (tmp >> 45) & 127,
+    k = tmp >> 52 (arithmetic), z = bits(x) - (tmp & 0xfff0000000000000).  Interval i of z has centre c_i; the two
+    intervals next to 1.0 (i = 79, 80) take c = 1 so that log2 keeps its relative accuracy near 1.
+    invc_i = RN64(1 / c_i), logc_i = RN64(-log2(invc_i)) computed from the ROUNDED invc_i, so that
+    log2(z) = logc_i + log2(z * invc_i) holds up to the rounding of logc_i alone.  |z * invc_i - 1| < 2^-7."""
+    import struct
+    OFF = 0x3fe6000000000000
+
+    def dbl(bits):
+        return struct.unpack("<d", struct.pack("<Q", bits))[0]
+    rows = []
+    rmax = mp.mpf(0)
+    for i in range(128):
+        lo, hi = dbl(OFF + (i << 45)), dbl(OFF + ((i + 1) << 45))
+        c = mp.mpf(1) if i in (79, 80) else (mp.mpf(lo) + mp.mpf(hi)) / 2
+        invc = float(1 / c)
+        logc = float(-mp.log(mp.mpf(invc), 2))
+        rows.append((invc, logc))
+        for z in (lo, hi):
+            rmax = max(rmax, abs(mp.mpf(z) * mp.mpf(invc) - 1))
+    print("// {invc, logc}, i = 0..127; max |z*invc - 1| = %s" % mp.nstr(rmax, 6))
+    for i in range(0, 128, 2):
+        print("    " + ", ".join("{%s, %s}" % (float.hex(a), float.hex(b)) for a, b in rows[i:i + 2]) + ",")
+    print("// log2(1 + r) = r * (A0 + A1 r + ... + A7 r^7), A_j = (-1)^j / ((j + 1) ln 2):")
+    print("    " + ", ".join(float.hex(float((-1) ** j / ((j + 1) * mp.log(2)))) for j in range(8)))
+
+
+if __name__ == "__main__" and "--log2-table" in __import__("sys").argv:
+    log2_table()
