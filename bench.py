@@ -46,7 +46,7 @@ OPS_PER_PIXEL = {"clouds": 60248.0, "egg": 15276.0, "raytracer": 564.0, "atmosph
                  "planet": 21253.0, "sdf_ao": 7255.0}       # (no survey count for vinyl: roofline is omitted there)
 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (WRITE_SIZE + 2 x FETCH_SIZE,
 # KB -> bytes, per MI355X_MICROARCH.md), for the default workload only; see DESIGN.md §6
-MEASURED_TRAFFIC_BYTES = {("clouds", 3840, 2160): int(129600 * 1024 + 2 * 183.29 * 1024)}   # profiles/r01_clouds_final_*
+MEASURED_TRAFFIC_BYTES = {("clouds", 3840, 2160): int(129600 * 1024 + 2 * 187.415 * 1024)}   # profiles/r01_clouds_final_*
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0
 
