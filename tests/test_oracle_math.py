@@ -103,3 +103,34 @@ def test_pow_is_correctly_rounded_against_mpmath(oracle):
         got = oracle.math("pow", x, np.full_like(x, yy))
         want = np.array([rn32(mp.mpf(float(v)) ** mp.mpf(float(yy))) for v in x], np.float32)
         assert (got.view(np.uint32) == want.view(np.uint32)).all(), (y, x[got != want][:3])
+
+
+def test_math_tables_match_their_generator():
+    """The 2^(j/32) and log2 {invc, logc} tables in oracle/sbx_math_ref.h and shaderbox_amd/csrc/sbx_math.h are the
+    ones tools/gen_math_coeffs.py derives with mpmath (two independent statements of the spec, one provenance)."""
+    mp = pytest.importorskip("mpmath")
+    import os
+    import re
+    import struct
+    mp.mp.prec = 200
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp_tab = [float(mp.mpf(2) ** (mp.mpf(j) / 32)) for j in range(32)]
+    OFF = 0x3fe6000000000000
+
+    def dbl(bits):
+        return struct.unpack("<d", struct.pack("<Q", bits))[0]
+    log_tab = []
+    for i in range(128):
+        lo, hi = dbl(OFF + (i << 45)), dbl(OFF + ((i + 1) << 45))
+        c = mp.mpf(1) if i in (79, 80) else (mp.mpf(lo) + mp.mpf(hi)) / 2
+        invc = float(1 / c)
+        log_tab += [invc, float(-mp.log(mp.mpf(invc), 2))]
+    hexf = r"-?0x1\.[0-9a-f]+p[+-]\d+"
+    for path in ("oracle/sbx_math_ref.h", "shaderbox_amd/csrc/sbx_math.h"):
+        txt = open(os.path.join(root, path)).read()
+        e = txt[txt.index("0x1.0000000000000p+0, 0x1.059b0d3158574p+0"):]
+        got = [float.fromhex(v) for v in re.findall(hexf, e)[:32]]
+        assert got == exp_tab, path
+        pairs = txt[txt.index("{0x1.734f0c541fe8dp+0"):]
+        got = [float.fromhex(v) for v in re.findall(hexf, pairs)[:256]]
+        assert got == log_tab, path
