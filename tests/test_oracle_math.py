@@ -125,7 +125,7 @@ def test_math_tables_match_their_generator():
         c = mp.mpf(1) if i in (79, 80) else (mp.mpf(lo) + mp.mpf(hi)) / 2
         invc = float(1 / c)
         log_tab += [invc, float(-mp.log(mp.mpf(invc), 2))]
-    hexf = r"-?0x1\.[0-9a-f]+p[+-]\d+"
+    hexf = r"-?0x[01]\.[0-9a-f]+p[+-]\d+"
     for path in ("oracle/sbx_math_ref.h", "shaderbox_amd/csrc/sbx_math.h"):
         txt = open(os.path.join(root, path)).read()
         e = txt[txt.index("0x1.0000000000000p+0, 0x1.059b0d3158574p+0"):]
