@@ -10,6 +10,8 @@ HBM (nothing crosses PCIe inside the timed region).
 Frames are independent, so consecutive frames are pipelined over two HIP streams (double-buffered
 framebuffers, --streams): the drain of one frame's kernel (its last, longest waves) overlaps the start of
 the next frame.  The timed region still runs from the first launch to the completion of all K frames.
+One-time initialisation (code-object load, APP_CLOUDS' y table, first submission on each stream, first touch of the
+framebuffers, RCCL peer set-up) happens once before the W warm-up steps and is not a step.
 
 N = 1 : the frame is one kernel launch.
 N > 1 : one process per GPU (torch.distributed / RCCL).  The SAME frame is sharded as cyclic 8-row
@@ -123,6 +125,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # One-time initialisation, outside warm-up and timing (context creation is excluded): the first launch
+    # of a kernel loads the code object and builds APP_CLOUDS' y table; the first RCCL transfer sets up the peer links.
+    for st in streams:                                  # a HIP stream's hardware queue is created on its first submission
+        with torch.cuda.stream(st):
+            R.render(app, 64, 36, t)
+    if not use_dist:
+        for f in frames:
+            f.zero_()                                   # first touch of the framebuffers (page mapping) is not rendering
+    else:
+        for p in plans:
+            for buf in (p.slab, p.gathered, p.frame):
+                if buf is not None:
+                    buf.zero_()
+    if dist is not None:
+        tiny = torch.zeros(4, device=dev)
+        dist.gather(tiny, [torch.zeros(4, device=dev) for _ in range(world)] if rank == 0 else None, dst=0)
+    sync()
     for i in range(args.warmup):
         step(i)
     sync()
