@@ -2,6 +2,12 @@
  *
  * TEST INFRASTRUCTURE ONLY (see oracle/README.md).
  *
+ * PINNING: the reference has no tests, golden vectors or fixtures, and its own C++ program cannot be built
+ * in this image (VML + SDL harness are external and absent), so this restatement is pinned against the known
+ * answers of SURVEY.md Appendix C (tests/test_oracle_kat.py) — values the survey obtained by compiling the
+ * reference headers verbatim over glibc.  Against the author's actual binary: PARITY UNPINNED.  APP_VINYL and
+ * app_clouds_best.h have no Appendix C values at all (review + libm comparison only).
+ *
  * One struct per APP_* project define (/root/reference/README.md:11-22).  An app object
  * is constructed afresh for every pixel, which is how this oracle implements the GLSL
  * per-invocation meaning of the reference's `_mutable` globals (src/def.h:18; SURVEY.md

@@ -3,6 +3,12 @@
  * TEST INFRASTRUCTURE ONLY (see oracle/README.md): loaded by tests/, by
  * __graft_entry__.smoke() and by bench.py's cpu_baseline leg, never by the product.
  *
+ * PINNING: the reference has no tests, golden vectors or fixtures, and its own C++ program cannot be built
+ * in this image (VML + SDL harness are external and absent), so this restatement is pinned against the known
+ * answers of SURVEY.md Appendix C (tests/test_oracle_kat.py) — values the survey obtained by compiling the
+ * reference headers verbatim over glibc.  Against the author's actual binary: PARITY UNPINNED.  APP_VINYL and
+ * app_clouds_best.h have no Appendix C values at all (review + libm comparison only).
+ *
  * The host loop here plays the role of the reference's external per-pixel harness
  * (vml/test/SDL_app/SDL_app.cpp, named at /root/reference/src/Makefile:21, absent from
  * the tree): for every pixel it constructs a fresh app (GLSL per-invocation semantics)
