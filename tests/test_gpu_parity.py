@@ -479,3 +479,32 @@ def test_pow_table_vs_series(renderer, oracle):
         assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all(), y
     print("pow table vs series: %d of %d inputs differ (by one ulp)" % (diff, tot))
     assert diff <= tot * 1e-6
+
+
+def test_two_contexts_in_two_threads(renderer, oracle):
+    """One caller per context is the rule; two contexts used from two threads on two streams at once must not disturb
+    each other (the reference's C++ globals are thread_local for the same reason, src/def.h:7-8)."""
+    import threading
+    import shaderbox_amd
+    import torch
+    from oracle.oracle import APP_IDS
+    want = {app: oracle.render(APP_IDS[app], 160, 90, 0.37) for app in ("clouds", "planet")}
+    errs = []
+
+    def work(app):
+        try:
+            r = shaderbox_amd.Renderer(0)
+            s = torch.cuda.Stream()
+            for _ in range(20):
+                with torch.cuda.stream(s):
+                    f = r.render(app, 160, 90, 0.37)
+                s.synchronize()
+                g = f.cpu().numpy()
+                if compare(g, want[app]) != (0.0, 0):
+                    errs.append(app)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(a,)) for a in ("clouds", "planet")]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
