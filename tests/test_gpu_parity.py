@@ -508,3 +508,23 @@ def test_two_contexts_in_two_threads(renderer, oracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+def test_render_is_graph_capturable(renderer):
+    """sbx_render_rows only enqueues work on the given stream, so a host may capture frames into a HIP graph
+    (here through torch.cuda.graph) and replay them: same pixels."""
+    import torch
+    for app, w, h in (("egg", 128, 128), ("clouds", 160, 90)):
+        out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+        ref = renderer.render(app, w, h, 0.37).clone()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            renderer.render(app, w, h, 0.37, out=out)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(4):
+                renderer.render(app, w, h, 0.37, out=out)
+        out.zero_(); torch.cuda.synchronize()
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), app
