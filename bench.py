@@ -65,6 +65,11 @@ def main():
     ap.add_argument("--block-rows", type=int, default=8)
     ap.add_argument("--gather-groups", type=int, default=1,
                     help="N>1: issue the gather in this many pipelined pieces (1 = one plain gather)")
+    ap.add_argument("--root-rounds", default="auto",
+                    help="N>1: root relief 'm0/m' — row-blocks go out in cycles of m rounds and rank 0 (the gather's root, which "
+                         "also lands N-1 slabs and assembles the frame) sits out the rounds >= m0; '1/1' = plain cyclic split; "
+                         "'auto' (default) measures the root's per-frame landing+assembly cost against its render time on rank 0 "
+                         "and picks m0/8 so that all ranks finish together (shaderbox_amd/shard.py relief_rounds)")
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight: consecutive frames alternate over this many HIP streams, each with its own "
                          "framebuffers, so the drain of one frame's kernel overlaps the next frame (1 = strictly serial)")
@@ -113,7 +118,9 @@ def main():
                 R.render(app, W, H, t, out=frames[i % ns])
     else:
         from shaderbox_amd.distributed import FramePlan
-        plans = [FramePlan(R, dist, W, H, br, groups=args.gather_groups) for _ in range(ns)]
+        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank)
+        plans = [FramePlan(R, dist, W, H, br, groups=args.gather_groups, root_rounds=relief[0], rounds=relief[1])
+                 for _ in range(ns)]
         slab = plans[0].slab
 
         def step(i=0):
@@ -157,7 +164,7 @@ def main():
         if not use_dist:
             R.render(app, W, H, t, out=frame)
         else:
-            R.render_rank(app, W, H, t, br, rank, world, out=slab)
+            R.render_rank(app, W, H, t, br, rank, world, out=slab, root_rounds=relief[0], rounds=relief[1])
         kernel_ms.append(R.last_kernel_ms())
     sync()
     if dist is not None:
@@ -175,7 +182,7 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = pixels / (ms_per_step * 1e-3) / 1e6
         ops = OPS_PER_PIXEL.get(app)
-        launch_pixels = pixels if world == 1 else shard.rank_rows(H, br, 0, world) * W
+        launch_pixels = pixels if not use_dist else shard.rank_rows(H, br, 0, world, relief[0], relief[1]) * W
         roofline = None
         if ops is not None:
             achieved = ops * launch_pixels / (kmean * 1e-3) / 1e12
@@ -197,8 +204,8 @@ def main():
                                       % (app.upper(), W, H, t),
                           "frames_in_flight": ns,
                           "parallelism": "1 GPU, one launch per frame" if world == 1 else
-                                         "cyclic %d-row blocks over %d GPUs + 1 RCCL gather (in %d pipelined pieces) + assemble"
-                                         % (br, world, args.gather_groups)},
+                                         "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + 1 RCCL gather "
+                                         "(in %d pipelined pieces) + assemble" % (br, world, relief[0], relief[1], args.gather_groups)},
                "roofline": roofline, "roofline_hbm": roofline_hbm if ops is not None else None}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(app, W, H, t, args.cpu_row_stride)
@@ -206,6 +213,51 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank):
+    """(root_rounds, rounds) of the split, identical on every rank.  'auto': rank 0 measures, with two launches in flight
+    as in the timed loop, what its plain 1/N strip costs per frame (t_s) and what only the root has to do per frame — landing
+    world-1 slabs in its HBM (a device copy stands in for RCCL's receive kernels) and the assembly kernel (e); the ranks
+    adopt shard.best_relief(H, br, world, e / (world * t_s)), the split whose modelled slowest rank is fastest."""
+    from shaderbox_amd import shard
+    if world <= 1:
+        return (1, 1)
+    if spec != "auto":
+        m0, m = (int(v) for v in spec.split("/"))
+        return (m0, m)
+    pick = torch.zeros(2, dtype=torch.int64, device=dev)
+    if rank == 0:
+        rmax = shard.rank_rows_max(H, br, world)
+        frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        slabs = [torch.empty((rmax, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        src = torch.zeros((world - 1, rmax, W, 4), dtype=torch.float32, device=dev)
+        gathered = torch.zeros((world, rmax, W, 4), dtype=torch.float32, device=dev)
+        st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+        def strips(k):
+            for i in range(k):
+                with torch.cuda.stream(st[i % 2]):
+                    R.render_rank(app, W, H, t, br, 0, world, out=slabs[i % 2])
+            torch.cuda.synchronize(dev)
+        strips(4)
+        t0 = time.perf_counter()
+        strips(16)
+        t_s = (time.perf_counter() - t0) * 1e3 / 16
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(3):
+            if i == 1:
+                a.record()
+            gathered[1:].copy_(src)
+            R.assemble(gathered, W, H, br, world, out=frame)
+        b.record()
+        torch.cuda.synchronize(dev)
+        e = a.elapsed_time(b) / 2.0
+        m0, m = shard.best_relief(H, br, world, e / (world * t_s))
+        pick[0], pick[1] = m0, m
+        del frame, slabs, src, gathered
+    dist.broadcast(pick, src=0)
+    return (int(pick[0].item()), int(pick[1].item()))
 
 
 def cpu_baseline(app, W, H, t, stride):

@@ -136,6 +136,19 @@ int sbx_rank_rows_max(int height, int block_rows, int nranks);
 int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks,
                  const float* gathered, float* frame, void* stream);
 
+/* The same split with ROOT RELIEF.  Rank 0, the gather's root, also receives nranks - 1 slabs and assembles the frame;
+ * so that it does not become the slowest rank it can be dealt fewer row-blocks: blocks go out in cycles of `rounds`
+ * rounds, a round gives one block to every rank, and rank 0 is left out of the rounds >= root_rounds
+ * (0 <= root_rounds <= rounds; root_rounds = rounds = 1 is the plain cyclic split of the calls above).
+ * sbx_render_split renders slab rows [r0, r1) of `rank` (r1 is clipped to the rank's row count), sbx_split_rows_max
+ * is the slab height every rank allocates, sbx_assemble_split the root-side scatter. */
+int sbx_split_rank_rows(int height, int block_rows, int rank, int nranks, int root_rounds, int rounds);
+int sbx_split_rows_max(int height, int block_rows, int nranks, int root_rounds, int rounds);
+int sbx_render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                     int nranks, int root_rounds, int rounds, int r0, int r1, float* rgba, void* stream);
+int sbx_assemble_split(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, int root_rounds, int rounds,
+                       const float* gathered, float* frame, void* stream);
+
 /* The write into hlsltoy's DXGI_FORMAT_R8G8B8A8_UNORM back buffer (util/hlsltoy/src/hlsltoy.cpp:79,192): float RGBA
  * rows -> 8-bit RGBA by the Direct3D float -> UNORM rule (NaN -> 0, clamp to [0, 1], * 255 + .5, truncate).
  * `rgba` and `out` are device pointers (width * rows pixels each); flip_y != 0 writes the top row first

@@ -94,6 +94,10 @@ def load_library(path=None):
     lib.sbx_rank_rows.argtypes = [ci, ci, ci, ci]
     lib.sbx_rank_rows_max.argtypes = [ci, ci, ci]
     lib.sbx_assemble.argtypes = [vp, ci, ci, ci, ci, fp, fp, vp]
+    lib.sbx_split_rank_rows.argtypes = [ci, ci, ci, ci, ci, ci]
+    lib.sbx_split_rows_max.argtypes = [ci, ci, ci, ci, ci]
+    lib.sbx_render_split.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, ci, ci, fp, vp]
+    lib.sbx_assemble_split.argtypes = [vp, ci, ci, ci, ci, ci, ci, fp, fp, vp]
     lib.sbx_set_timing.argtypes = [vp, ci]
     lib.sbx_set_variant.argtypes = [vp, ci]
     lib.sbx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -191,12 +195,15 @@ class Renderer:
                                              ctypes.c_void_p(buf.data_ptr()), self._stream()))
         return buf
 
-    def render_rank(self, app, width, height, time, block_rows, rank, nranks, mouse=(0.0, 0.0), aux=None, out=None):
-        """Render the cyclic row-blocks of `rank`; `out` has shard.rank_rows_max() rows (tail rows unused)."""
+    def render_rank(self, app, width, height, time, block_rows, rank, nranks, mouse=(0.0, 0.0), aux=None, out=None,
+                    root_rounds=1, rounds=1):
+        """Render the cyclic row-blocks of `rank` (optionally with root relief, shard.py); `out` has
+        shard.rank_rows_max() rows (tail rows unused)."""
         u = self.uniforms(width, height, time, mouse)
-        buf = self._buffer(shard.rank_rows_max(int(height), block_rows, nranks), int(width), out)
-        self._check(self.lib.sbx_render_rank(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
-                                             rank, nranks, ctypes.c_void_p(buf.data_ptr()), self._stream()))
+        buf = self._buffer(shard.rank_rows_max(int(height), block_rows, nranks, root_rounds, rounds), int(width), out)
+        self._check(self.lib.sbx_render_split(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
+                                              rank, nranks, root_rounds, rounds, 0, 0x7fffffff,
+                                              ctypes.c_void_p(buf.data_ptr()), self._stream()))
         return buf
 
     def pack_unorm8(self, frame, flip_y=True):
@@ -221,28 +228,28 @@ class Renderer:
         return tuple(out)
 
     def render_rank_rows(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0),
-                         aux=None):
+                         aux=None, root_rounds=1, rounds=1):
         """Render slab rows [r0, r1) of `rank` into slab[r0:r1] (pipelined multi-GPU frames)."""
         u = self.uniforms(width, height, time, mouse)
         if r1 <= r0:
             return slab
         view = slab[r0:r1]
-        self._check(self.lib.sbx_render_rank_rows(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
-                                                  rank, nranks, int(r0), int(r1), ctypes.c_void_p(view.data_ptr()),
-                                                  self._stream()))
+        self._check(self.lib.sbx_render_split(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
+                                              rank, nranks, root_rounds, rounds, int(r0), int(r1),
+                                              ctypes.c_void_p(view.data_ptr()), self._stream()))
         return slab
 
-    def assemble(self, gathered, width, height, block_rows, nranks, out=None):
+    def assemble(self, gathered, width, height, block_rows, nranks, out=None, root_rounds=1, rounds=1):
         """Root side: scatter the rank-major gathered slabs to their global rows -> [H, W, 4]."""
         frame = self._buffer(int(height), int(width), out)
-        need = int(nranks) * shard.rank_rows_max(int(height), int(block_rows), int(nranks)) * int(width) * 4
+        need = int(nranks) * shard.rank_rows_max(int(height), int(block_rows), int(nranks), root_rounds, rounds) * int(width) * 4
         if not (gathered.is_cuda and gathered.dtype == self.torch.float32 and gathered.is_contiguous()
                 and gathered.numel() >= need):
             raise ValueError("gathered must be a contiguous float32 device tensor of >= nranks * rows_max * W * 4 = %d floats"
                              % need)
-        self._check(self.lib.sbx_assemble(self.ctx, int(width), int(height), block_rows, nranks,
-                                          ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
-                                          self._stream()))
+        self._check(self.lib.sbx_assemble_split(self.ctx, int(width), int(height), block_rows, nranks, root_rounds, rounds,
+                                                ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
+                                                self._stream()))
         return frame
 
     def set_variant(self, variant):

@@ -9,23 +9,32 @@ namespace sbx {
 // densely in increasing y (sbx_render_rank).  One thread moves one float4 pixel; consecutive
 // threads move consecutive pixels of a row, so both the read and the write are coalesced 16-B
 // accesses.  Each XCD streams whole rows; there is no reuse to tile for.
-__global__ void __launch_bounds__(256) k_assemble(int width, int height, int block_rows, int nranks, int rows_max,
-                                                   const float4* __restrict__ gathered, float4* __restrict__ frame) {
+// The split is RowMap's (sbx_frame.h): cycles of `rounds` rounds, rank 0 left out of the rounds >= root_rounds.
+__global__ void __launch_bounds__(256) k_assemble(int width, int height, int block_rows, int nranks, int root_rounds,
+                                                   int rounds, int rows_max, const float4* __restrict__ gathered,
+                                                   float4* __restrict__ frame) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)width * height;
     if (i >= total) return;
     const int y = (int)(i / width), x = (int)(i - (size_t)y * width);
     const int blk = y / block_rows, in_blk = y - blk * block_rows;
-    const int rank = blk % nranks, local_blk = blk / nranks;
+    const int V = split_cycle_blocks(nranks, root_rounds, rounds);
+    const int cycle = blk / V, v = blk - cycle * V;
+    int rank, round;
+    if (v < root_rounds * nranks) { round = v / nranks; rank = v - round * nranks; }
+    else { const int w = v - root_rounds * nranks; const int q = w / (nranks - 1); round = root_rounds + q; rank = 1 + (w - q * (nranks - 1)); }
+    const int cnt = rank == 0 ? root_rounds : rounds;
+    const int local_blk = cycle * cnt + round;
     const size_t src = ((size_t)rank * rows_max + (size_t)local_blk * block_rows + in_blk) * width + x;
     frame[i] = gathered[src];
 }
 
-void launch_assemble(int width, int height, int block_rows, int nranks, int rows_max,
+void launch_assemble(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
                      const float* gathered, float* frame, hipStream_t s) {
     const size_t total = (size_t)width * height;
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, width, height, block_rows,
-                       nranks, rows_max, reinterpret_cast<const float4*>(gathered), reinterpret_cast<float4*>(frame));
+                       nranks, root_rounds, rounds, rows_max, reinterpret_cast<const float4*>(gathered),
+                       reinterpret_cast<float4*>(frame));
 }
 
 // float RGBA -> R8G8B8A8_UNORM, the back-buffer write of hlsltoy (util/hlsltoy/src/hlsltoy.cpp:79,192), by the

@@ -410,7 +410,7 @@ int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* 
     int rc = check_common(ctx, uni, rgba, W, H);
     if (rc != SBX_OK) return rc;
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(ctx, SBX_ERR_ARG, "bad row range");
-    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0, 0};
+    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0, 0, 1, 1};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
 }
 
@@ -453,60 +453,82 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
     return SBX_OK;
 }
 
-int sbx_rank_rows(int height, int block_rows, int rank, int nranks) {
-    if (height <= 0 || block_rows <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return SBX_ERR_ARG;
+static bool split_ok(int height, int block_rows, int nranks, int root_rounds, int rounds) {
+    return height > 0 && block_rows > 0 && nranks > 0 && rounds >= 1 && root_rounds >= 0 && root_rounds <= rounds &&
+           (nranks > 1 || root_rounds == rounds);          // a lone rank cannot be relieved
+}
+int sbx_split_rank_rows(int height, int block_rows, int rank, int nranks, int root_rounds, int rounds) {
+    if (!split_ok(height, block_rows, nranks, root_rounds, rounds) || rank < 0 || rank >= nranks) return SBX_ERR_ARG;
     const int nblocks = (height + block_rows - 1) / block_rows;
+    const int V = split_cycle_blocks(nranks, root_rounds, rounds);
+    const int cnt = rank == 0 ? root_rounds : rounds;
     int rows = 0;
-    for (int b = rank; b < nblocks; b += nranks) {
-        const int y = b * block_rows;
-        rows += (y + block_rows <= height) ? block_rows : (height - y);
-    }
+    for (int cycle = 0; cycle * V < nblocks; ++cycle)
+        for (int round = 0; round < cnt; ++round) {
+            const int v = round < root_rounds ? round * nranks + rank
+                                              : root_rounds * nranks + (round - root_rounds) * (nranks - 1) + (rank - 1);
+            const int b = cycle * V + v;
+            if (b >= nblocks) continue;
+            const int y = b * block_rows;
+            rows += (y + block_rows <= height) ? block_rows : (height - y);
+        }
     return rows;
 }
+int sbx_split_rows_max(int height, int block_rows, int nranks, int root_rounds, int rounds) {
+    if (!split_ok(height, block_rows, nranks, root_rounds, rounds)) return SBX_ERR_ARG;
+    int mx = 0;                                             // the fullest slab (equal-count gather: every slab is this tall)
+    for (int r = 0; r < nranks; ++r) {
+        const int rows = sbx_split_rank_rows(height, block_rows, r, nranks, root_rounds, rounds);
+        if (rows > mx) mx = rows;
+    }
+    return ((mx + block_rows - 1) / block_rows) * block_rows;
+}
+int sbx_rank_rows(int height, int block_rows, int rank, int nranks) {
+    return sbx_split_rank_rows(height, block_rows, rank, nranks, 1, 1);
+}
 int sbx_rank_rows_max(int height, int block_rows, int nranks) {
-    if (height <= 0 || block_rows <= 0 || nranks <= 0) return SBX_ERR_ARG;
-    const int nblocks = (height + block_rows - 1) / block_rows;
-    return ((nblocks + nranks - 1) / nranks) * block_rows;
+    return sbx_split_rows_max(height, block_rows, nranks, 1, 1);
 }
 
-int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
-                    int nranks, float* rgba, void* stream) {
-    int W, H;
-    int rc = check_common(ctx, uni, rgba, W, H);
-    if (rc != SBX_OK) return rc;
-    const int rows = sbx_rank_rows(H, block_rows, rank, nranks);
-    if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
-    RowMap M{W, H, 0, block_rows, nranks, rank, rows, 0};
-    return render_mapped(ctx, app, uni, aux, M, rgba, stream);
-}
-
-int sbx_render_rank_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
-                         int nranks, int r0, int r1, float* rgba, void* stream) {
+int sbx_render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                     int nranks, int root_rounds, int rounds, int r0, int r1, float* rgba, void* stream) {
     int W, H;
     if (ctx && uni && r0 == r1 && r0 >= 0) return SBX_OK;
     int rc = check_common(ctx, uni, rgba, W, H);
     if (rc != SBX_OK) return rc;
-    const int rows = sbx_rank_rows(H, block_rows, rank, nranks);
+    const int rows = sbx_split_rank_rows(H, block_rows, rank, nranks, root_rounds, rounds);
     if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
     if (r0 < 0 || r1 < r0) return fail(ctx, SBX_ERR_ARG, "bad slab row range");
-    if (r1 > rows) r1 = rows;                 // the slab is padded to rank_rows_max; the tail has no pixels
+    if (r1 > rows) r1 = rows;                 // the slab is padded to the split's rows_max; the tail has no pixels
     if (r0 >= r1) return SBX_OK;
-    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0};
+    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
 }
+int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                    int nranks, float* rgba, void* stream) {
+    return sbx_render_split(ctx, app, uni, aux, block_rows, rank, nranks, 1, 1, 0, 0x7fffffff, rgba, stream);
+}
+int sbx_render_rank_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                         int nranks, int r0, int r1, float* rgba, void* stream) {
+    return sbx_render_split(ctx, app, uni, aux, block_rows, rank, nranks, 1, 1, r0, r1, rgba, stream);
+}
 
-int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, const float* gathered,
-                 float* frame, void* stream) {
+int sbx_assemble_split(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, int root_rounds, int rounds,
+                       const float* gathered, float* frame, void* stream) {
     if (!ctx) return SBX_ERR_ARG;
-    if (!gathered || !frame || width <= 0 || height <= 0 || block_rows <= 0 || nranks <= 0)
+    if (!gathered || !frame || width <= 0 || !split_ok(height, block_rows, nranks, root_rounds, rounds))
         return fail(ctx, SBX_ERR_ARG, "bad assemble arguments");
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
-    launch_assemble(width, height, block_rows, nranks, sbx_rank_rows_max(height, block_rows, nranks), gathered, frame,
-                    (hipStream_t)stream);
+    launch_assemble(width, height, block_rows, nranks, root_rounds, rounds,
+                    sbx_split_rows_max(height, block_rows, nranks, root_rounds, rounds), gathered, frame, (hipStream_t)stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "assemble launch", e);
     return SBX_OK;
+}
+int sbx_assemble(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, const float* gathered,
+                 float* frame, void* stream) {
+    return sbx_assemble_split(ctx, width, height, block_rows, nranks, 1, 1, gathered, frame, stream);
 }
 
 int sbx_pack_unorm8(sbx_ctx* ctx, int width, int rows, const float* rgba, unsigned char* out, int flip_y, void* stream) {

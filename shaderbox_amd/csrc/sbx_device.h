@@ -55,7 +55,7 @@ void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t
 void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, hipStream_t s);
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant);
-void launch_assemble(int width, int height, int block_rows, int nranks, int rows_max,
+void launch_assemble(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
                      const float* gathered, float* frame, hipStream_t s);
 void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);

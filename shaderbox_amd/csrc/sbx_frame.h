@@ -15,16 +15,29 @@ namespace sbx {
 // local row r of a launch -> global row y of the frame.
 //   contiguous strip:  block_rows = nrows, nranks = 1, rank = 0      -> y = y0 + r
 //   cyclic row-blocks: rank owns blocks rank, rank+nranks, ...        
+//   cyclic with root relief: the blocks are dealt in cycles of `rounds` rounds; a round deals one block to every
+//     rank, except that rank 0 (the gather's root, which also receives and assembles the frame) is left out of the
+//     rounds >= root_rounds.  root_rounds = rounds = 1 is the plain cyclic split.
 struct RowMap {
     int width, height;
     int y0, block_rows, nranks, rank;
     int nrows;   // local rows in this launch
     int r0;      // first local row of this launch within the rank's slab (sub-range launches)
+    int root_rounds, rounds;
 };
+// blocks in one cycle, and the position of (round, rank) in it
+SBX_HD int split_cycle_blocks(int nranks, int root_rounds, int rounds) {
+    return root_rounds * nranks + (rounds - root_rounds) * (nranks - 1);
+}
 SBX_HD int row_to_y(const RowMap& m, int r) {
     const int rr = r + m.r0;
-    const int blk = rr / m.block_rows;
-    return m.y0 + (blk * m.nranks + m.rank) * m.block_rows + (rr - blk * m.block_rows);
+    const int blk = rr / m.block_rows;                       // local block index in the rank's slab
+    const int cnt = (m.rank == 0) ? m.root_rounds : m.rounds;    // blocks this rank gets per cycle
+    const int cycle = blk / cnt, round = blk - cycle * cnt;
+    const int v = (round < m.root_rounds) ? round * m.nranks + m.rank
+                                          : m.root_rounds * m.nranks + (round - m.root_rounds) * (m.nranks - 1) + (m.rank - 1);
+    const int gblk = cycle * split_cycle_blocks(m.nranks, m.root_rounds, m.rounds) + v;
+    return m.y0 + gblk * m.block_rows + (rr - blk * m.block_rows);
 }
 
 // Camera part of mainImage (src/main.h:33-48) + get_primary_ray (src/util.h:5-20)

@@ -21,12 +21,14 @@ from . import shard
 class FramePlan:
     """Buffers and schedule of one rank for repeated frames of a fixed size."""
 
-    def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS, groups=1):
+    def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS, groups=1, root_rounds=1,
+                 rounds=1):
         self.r, self.dist = renderer, dist
         self.width, self.height, self.block_rows = int(width), int(height), int(block_rows)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
-        self.rows_max = shard.rank_rows_max(self.height, self.block_rows, self.world)
+        self.root_rounds, self.rounds = int(root_rounds), int(rounds)      # root relief (shard.py); 1, 1 = plain cyclic
+        self.rows_max = shard.rank_rows_max(self.height, self.block_rows, self.world, self.root_rounds, self.rounds)
         nblocks = self.rows_max // self.block_rows
         groups = max(1, min(int(groups), nblocks))
         # slab row ranges of the groups: whole blocks, as even as possible
@@ -47,7 +49,8 @@ class FramePlan:
         last = len(self.ranges) - 1
         for g, (a, b) in enumerate(self.ranges):
             self.r.render_rank_rows(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
-                                    a, b, self.slab, mouse=mouse, aux=aux)
+                                    a, b, self.slab, mouse=mouse, aux=aux, root_rounds=self.root_rounds,
+                                    rounds=self.rounds)
             # the gather of the path (one logical gather, issued per group so that it overlaps the next render)
             w = self.dist.gather(self.slab[a:b], self.glists[g], dst=0, async_op=(g != last))
             if w is not None:
@@ -56,5 +59,5 @@ class FramePlan:
             w.wait()          # stream-level wait on GPUs: the slab/gathered buffers are safe to reuse/read after it
         if self.rank == 0:
             return self.r.assemble(self.gathered, self.width, self.height, self.block_rows, self.world,
-                                   out=self.frame)
+                                   out=self.frame, root_rounds=self.root_rounds, rounds=self.rounds)
         return None

@@ -22,28 +22,28 @@ class OracleRenderer:
         return torch.zeros(tuple(shape), dtype=torch.float32)
 
     def render_rank_rows(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0),
-                         aux=None):
+                         aux=None, root_rounds=1, rounds=1):
         from oracle.oracle import APP_IDS
         from shaderbox_amd import shard
-        rows = shard.rank_row_indices(height, block_rows, rank, nranks)[r0:r1]
+        rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)[r0:r1]
         if rows:
             img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
             slab[r0:r0 + len(rows)] = torch.from_numpy(img)
         return slab
 
-    def assemble(self, gathered, width, height, block_rows, nranks, out=None):
+    def assemble(self, gathered, width, height, block_rows, nranks, out=None, root_rounds=1, rounds=1):
         from shaderbox_amd import shard          # mirror of k_assemble (kern_util.hip)
-        for y, (r, local) in enumerate(shard.slab_source(height, block_rows, nranks)):
+        for y, (r, local) in enumerate(shard.slab_source(height, block_rows, nranks, root_rounds, rounds)):
             out[y] = gathered[r, local]
         return out
 
 
-def _worker(rank, world, port, app, w, h, t, br, groups, result_path):
+def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1, 1)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from shaderbox_amd.distributed import FramePlan
-    plan = FramePlan(OracleRenderer(), dist, w, h, br, groups=groups)
+    plan = FramePlan(OracleRenderer(), dist, w, h, br, groups=groups, root_rounds=relief[0], rounds=relief[1])
     frame = None
     for _ in range(2):                       # buffers are reused across frames
         frame = plan.render(app, t)
@@ -72,4 +72,17 @@ def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, app,
     got = np.load(path)
     ref = oracle.render(APP_IDS[app], w, h, 0.37)
     assert got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,app,w,h,br,groups,relief", [(2, "egg", 64, 45, 4, 1, (1, 3)), (3, "clouds", 96, 54, 2, 2, (2, 5)),
+                                                             (3, "raytracer", 64, 50, 5, 1, (0, 2))])
+def test_gather_with_root_relief(tmp_path, oracle, world, app, w, h, br, groups, relief):
+    """the split that deals the gather's root fewer row-blocks (shard.py) assembles the same frame, incl. a root that
+    renders nothing at all"""
+    from oracle.oracle import APP_IDS
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, groups, path, relief), nprocs=world, join=True)
+    got = np.load(path)
+    ref = oracle.render(APP_IDS[app], w, h, 0.37)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -528,3 +528,27 @@ def test_render_is_graph_capturable(renderer):
         out.zero_(); torch.cuda.synchronize()
         g.replay(); torch.cuda.synchronize()
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), app
+
+
+def test_root_relief_split_invariance(renderer):
+    """The split that deals the gather's root fewer row-blocks (sbx_render_split / sbx_assemble_split): N ranks
+    emulated on one GPU, assembled, equal the frame rendered in one launch — also at the BASELINE frame size."""
+    import torch
+    from shaderbox_amd import shard
+    cases = [("clouds", 200, 117, 8, 8, 7, 8), ("clouds", 200, 117, 3, 2, 1, 3), ("egg", 203, 95, 4, 4, 0, 2),
+             ("planet", 160, 90, 8, 8, 2, 5), ("clouds", 3840, 2160, 8, 8, 7, 8)]
+    for app, w, h, nranks, br, m0, m in cases:
+        full = renderer.render(app, w, h, .37)
+        rmax = shard.rank_rows_max(h, br, nranks, m0, m)
+        slabs = torch.zeros((nranks, rmax, w, 4), dtype=torch.float32, device=full.device)
+        for r in range(nranks):
+            renderer.render_rank(app, w, h, .37, br, r, nranks, out=slabs[r], root_rounds=m0, rounds=m)
+        frame = renderer.assemble(slabs, w, h, br, nranks, root_rounds=m0, rounds=m)
+        assert torch.equal(frame.view(torch.int32), full.view(torch.int32)), (app, w, nranks, br, m0, m)
+        if w <= 256:                 # slab produced in pieces
+            slabs2 = torch.zeros_like(slabs)
+            for r in range(nranks):
+                for a, b in [(0, br), (br, 3 * br), (3 * br, rmax)]:
+                    renderer.render_rank_rows(app, w, h, .37, br, r, nranks, a, min(b, rmax), slabs2[r], root_rounds=m0, rounds=m)
+            assert torch.equal(slabs2.view(torch.int32), slabs.view(torch.int32))
+        del full, slabs, frame

@@ -110,3 +110,24 @@ def test_app_ids():
     assert shaderbox_amd.app_id("egg") == 3 and shaderbox_amd.app_id("APP_SDF_AO") == 6
     with pytest.raises(ValueError):
         shaderbox_amd.app_id("APP_NOPE")
+
+
+def test_split_with_root_relief_is_a_partition_and_matches_c(lib):
+    """shard.py (Python mirror) and sbx_split_* (C) agree; every row has exactly one owner and slab position"""
+    lib.sbx_split_rank_rows.argtypes = [ctypes.c_int] * 6
+    lib.sbx_split_rows_max.argtypes = [ctypes.c_int] * 5
+    for H, br, N, m0, m in [(2160, 8, 8, 7, 8), (2160, 8, 8, 0, 3), (187, 8, 3, 1, 2), (54, 8, 2, 1, 1), (90, 4, 4, 2, 5),
+                            (4320, 8, 8, 7, 8), (1, 8, 8, 1, 1), (2160, 2, 8, 13, 16)]:
+        src = shard.slab_source(H, br, N, m0, m)
+        seen = set()
+        for r in range(N):
+            idx = shard.rank_row_indices(H, br, r, N, m0, m)
+            assert len(idx) == shard.rank_rows(H, br, r, N, m0, m) == lib.sbx_split_rank_rows(H, br, r, N, m0, m)
+            assert len(idx) <= shard.rank_rows_max(H, br, N, m0, m)
+            for lr, y in enumerate(idx):
+                assert src[y] == (r, lr)
+                seen.add(y)
+        assert seen == set(range(H))
+        assert shard.rank_rows_max(H, br, N, m0, m) == lib.sbx_split_rows_max(H, br, N, m0, m)
+    assert lib.sbx_split_rank_rows(100, 8, 0, 4, 3, 2) < 0 and lib.sbx_split_rank_rows(100, 8, 0, 1, 0, 1) < 0
+    assert shard.relief_rounds(8, 0.022) == (7, 8) and shard.relief_rounds(1, 0.5) == (1, 1) and shard.relief_rounds(8, 0.5) == (0, 8)

@@ -53,3 +53,76 @@ for n in (1, 2, 4, 8):
     if n == 1:
         base = worst
     print("  2 streams, N=%d: slowest rank %.3f ms/frame -> compute-only speed-up %.2fx" % (n, worst, base / worst))
+
+# the ROOT's frame at N = 8, emulated on one GPU: its own strip + a 7-slab device copy standing in for the data RCCL's
+# receive kernels write into its HBM + the assembly kernel, two frames in flight as in bench.py — for the plain cyclic
+# split and for the split with root relief that bench.py's calibration picks (shard.relief_rounds)
+n = 8
+streams = [torch.cuda.Stream() for _ in range(2)]
+
+
+def frames_per_ms(fn):
+    for i in range(6):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 40
+    for i in range(K):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / K
+
+
+def emulate(m0, m):
+    rows_max = shard.rank_rows_max(H, 8, n, m0, m)
+    bufs = [dict(slab=torch.empty((rows_max, W, 4), dtype=torch.float32, device="cuda"),
+                 peers=torch.rand((n - 1, rows_max, W, 4), dtype=torch.float32, device="cuda"),
+                 gathered=torch.empty((n, rows_max, W, 4), dtype=torch.float32, device="cuda"),
+                 frame=torch.empty((H, W, 4), dtype=torch.float32, device="cuda")) for _ in range(2)]
+
+    def root_frame(i):
+        b = bufs[i % 2]
+        with torch.cuda.stream(streams[i % 2]):
+            R.render_rank(app, W, H, 0.37, 8, 0, n, out=b["slab"], root_rounds=m0, rounds=m)
+            b["gathered"][0].copy_(b["slab"])
+            b["gathered"][1:].copy_(b["peers"])
+            R.assemble(b["gathered"], W, H, 8, n, out=b["frame"], root_rounds=m0, rounds=m)
+
+    def peer_frame(r):
+        def f(i):
+            with torch.cuda.stream(streams[i % 2]):
+                R.render_rank(app, W, H, 0.37, 8, r, n, out=bufs[i % 2]["slab"], root_rounds=m0, rounds=m)
+        return f
+    root_ms = frames_per_ms(root_frame)
+    peer_ms = max(frames_per_ms(peer_frame(r)) for r in range(1, n))
+    worst = max(root_ms, peer_ms)
+    print("  2 streams, N=8, root sits out rounds >= %d of %d: root (strip + landing + assembly) %.3f ms/frame, slowest peer "
+          "%.3f ms/frame -> %.2fx of the N=1 frame rate" % (m0, m, root_ms, peer_ms, base / worst))
+
+
+emulate(1, 1)
+# calibration as in bench.py choose_relief(): pipelined cost of the plain 1/8 strip (t_s) and the root-only work (e)
+rmax = shard.rank_rows_max(H, 8, n)
+src = torch.zeros((n - 1, rmax, W, 4), dtype=torch.float32, device="cuda")
+g = torch.zeros((n, rmax, W, 4), dtype=torch.float32, device="cuda")
+sl = [torch.empty((rmax, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+
+
+def strip(i):
+    with torch.cuda.stream(streams[i % 2]):
+        R.render_rank(app, W, H, 0.37, 8, 0, n, out=sl[i % 2])
+
+
+t_s = frames_per_ms(strip)
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for i in range(3):
+    if i == 1:
+        a.record()
+    g[1:].copy_(src)
+    R.assemble(g, W, H, 8, n, out=frame)
+b.record(); torch.cuda.synchronize()
+e = a.elapsed_time(b) / 2.0
+m0, m = shard.best_relief(H, 8, n, e / (n * t_s))
+print("  calibration: plain strip %.3f ms/frame, root-only work %.3f ms per frame -> relief %d/%d" % (t_s, e, m0, m))
+del src, g, sl
+emulate(m0, m)
