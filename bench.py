@@ -80,6 +80,9 @@ def main():
                     help="cpu_baseline renders every k-th row of the frame (0 = pick from the core count: ~10 s of wall time)")
     args = ap.parse_args()
 
+    # HIP maps streams onto a few hardware queues (4 by default); two streams that share a queue do not overlap at all,
+    # and this process uses up to four (default, two frame streams, RCCL's): ask for more queues before HIP starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import shaderbox_amd
     from shaderbox_amd import shard
@@ -118,7 +121,7 @@ def main():
                 R.render(app, W, H, t, out=frames[i % ns])
     else:
         from shaderbox_amd.distributed import FramePlan
-        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank)
+        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams)
         plans = [FramePlan(R, dist, W, H, br, groups=args.gather_groups, root_rounds=relief[0], rounds=relief[1])
                  for _ in range(ns)]
         slab = plans[0].slab
@@ -215,7 +218,7 @@ def main():
         dist.destroy_process_group()
 
 
-def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank):
+def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, streams):
     """(root_rounds, rounds) of the split, identical on every rank.  'auto': rank 0 measures, with two launches in flight
     as in the timed loop, what its plain 1/N strip costs per frame (t_s) and what only the root has to do per frame — landing
     world-1 slabs in its HBM (a device copy stands in for RCCL's receive kernels) and the assembly kernel (e); the ranks
@@ -233,11 +236,11 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank):
         slabs = [torch.empty((rmax, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         src = torch.zeros((world - 1, rmax, W, 4), dtype=torch.float32, device=dev)
         gathered = torch.zeros((world, rmax, W, 4), dtype=torch.float32, device=dev)
-        st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        st = streams                                    # the loop's own streams (no extra hardware queues)
 
         def strips(k):
             for i in range(k):
-                with torch.cuda.stream(st[i % 2]):
+                with torch.cuda.stream(st[i % len(st)]):
                     R.render_rank(app, W, H, t, br, 0, world, out=slabs[i % 2])
             torch.cuda.synchronize(dev)
         strips(4)

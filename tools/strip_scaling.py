@@ -34,9 +34,12 @@ for br in (8, 16):
 
 # throughput with frames pipelined over 2 streams (what bench.py does): ms per frame of one rank's share
 import time
+R.set_timing(False)          # per-launch event pairs are not part of the pipelined loop
+streams = [torch.cuda.Stream() for _ in range(2)]   # created once: HIP maps streams onto a few hardware queues, and two
+                                                     # streams that land on the same queue do not overlap at all
 for n in (1, 2, 4, 8):
+    torch.cuda.empty_cache()
     slabs = [torch.empty((shard.rank_rows_max(H, 8, n), W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-    streams = [torch.cuda.Stream() for _ in range(2)]
     worst = 0.0
     for r in range(n):
         for i in range(6):
@@ -58,7 +61,6 @@ for n in (1, 2, 4, 8):
 # receive kernels write into its HBM + the assembly kernel, two frames in flight as in bench.py — for the plain cyclic
 # split and for the split with root relief that bench.py's calibration picks (shard.relief_rounds)
 n = 8
-streams = [torch.cuda.Stream() for _ in range(2)]
 
 
 def frames_per_ms(fn):
