@@ -131,3 +131,10 @@ def test_split_with_root_relief_is_a_partition_and_matches_c(lib):
         assert shard.rank_rows_max(H, br, N, m0, m) == lib.sbx_split_rows_max(H, br, N, m0, m)
     assert lib.sbx_split_rank_rows(100, 8, 0, 4, 3, 2) < 0 and lib.sbx_split_rank_rows(100, 8, 0, 1, 0, 1) < 0
     assert shard.relief_rounds(8, 0.022) == (7, 8) and shard.relief_rounds(1, 0.5) == (1, 1) and shard.relief_rounds(8, 0.5) == (0, 8)
+    # the search over actual row counts: no root-only cost -> plain split; the measured APP_CLOUDS 4K ratio -> 3/4; a root
+    # whose extra work exceeds a whole share renders nothing
+    assert shard.best_relief(2160, 8, 8, 0.0) == (1, 1) and shard.best_relief(2160, 8, 1, 0.3) == (1, 1)
+    assert shard.best_relief(2160, 8, 8, 0.0252) == (3, 4) and shard.best_relief(2160, 8, 8, 0.5)[0] == 0
+    m0, m = shard.best_relief(2160, 8, 4, 0.0252)
+    rows = [shard.rank_rows(2160, 8, r, 4, m0, m) for r in range(4)]
+    assert rows[0] < min(rows[1:]) and sum(rows) == 2160
