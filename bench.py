@@ -28,8 +28,10 @@ Extra objects on the JSON line:
   roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel
                  of HBM traffic), so bound = "valu": achieved = algorithmic scalar fp ops per launch
                  (SURVEY.md §8d per-pixel count x pixels) / mean launch duration measured with HIP events on
-                 the launch stream; peak = 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md).  `hbm` gives the
-                 framebuffer store rate for completeness.
+                 the launch stream; peak = 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md); the same figure against the
+                 39.3 T lane-ops/s scalar-issue ceiling of SURVEY.md §8d is `frac_of_scalar_issue_ceiling` (above 1: the
+                 count is of the REFERENCE algorithm's operations, most of which the kernel no longer executes).
+                 `roofline_hbm` gives the framebuffer store rate for completeness.
   cpu_baseline : the CPU oracle (kind "port") timed on this host's cores on a bounded sample of the same
                  frame (every 8th row), rank 0, N = 1 only.
 """
@@ -50,6 +52,7 @@ OPS_PER_PIXEL = {"clouds": 60248.0, "egg": 15276.0, "raytracer": 564.0, "atmosph
 # KB -> bytes, per MI355X_MICROARCH.md), for the default workload only; see DESIGN.md §6
 MEASURED_TRAFFIC_BYTES = {("clouds", 3840, 2160): int(129600 * 1024 + 2 * 187.415 * 1024)}   # profiles/r01_clouds_final_*
 PEAK_FP32_VECTOR_TFLOPS = 157.3
+SCALAR_ISSUE_TLANEOPS = 39.3        # 256 CU x 64 lanes x 2.4 GHz: one non-packed, non-FMA lane-op per lane per cycle (SURVEY.md §8d ii)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -192,6 +195,7 @@ def main():
             roofline = {"bound": "valu", "kernel": "k_" + app, "achieved": round(achieved, 4),
                         "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5),
+                        "frac_of_scalar_issue_ceiling": round(achieved / SCALAR_ISSUE_TLANEOPS, 4),
                         "ops_per_pixel": ops, "pixels_per_launch": launch_pixels,
                         "kernel_ms": round(kmean, 4),
                         "traffic": MEASURED_TRAFFIC_BYTES.get((app, W, H)) if world == 1 else None}
