@@ -47,7 +47,10 @@ typedef enum sbx_app {
     SBX_APP_SDF_AO = 6,
     /* not an APP_* define of the reference: the stand-alone shader src/app_clouds_best.h (own mainImage :669-696),
        numbered after the reference's apps */
-    SBX_APP_CLOUDS_BEST = 7
+    SBX_APP_CLOUDS_BEST = 7,
+    /* APP_CLOUDS compiled with USE_NOISE_TEX (src/app_clouds.h:9,51-56,69-81): density from two 3-D noise textures
+       (sbx_set_noise_volumes) instead of the procedural fBm; same aux block as APP_CLOUDS */
+    SBX_APP_CLOUDS_TEX = 8
 } sbx_app;
 
 typedef enum sbx_status {
@@ -183,6 +186,21 @@ int sbx_noise_eval(sbx_ctx* ctx, const char* fn, const float* xyz, const float* 
 /* The size^3 RGBA32F noise volume util/ddsvolgen bakes (ddsvolgen.cpp:101-117): R =
  * fbm_worley_tile((xyz + .5)/size, 2, 1, .5), G = B = A = 0, x fastest.  `rgba`: size^3 * 4 floats. */
 int sbx_worley_volume(sbx_ctx* ctx, int size, float* rgba, void* stream);
+
+/* Bind the two 3-D noise textures of APP_CLOUDS' USE_NOISE_TEX build: u_tex_noise (t1, the cloud shape) and
+ * u_tex_noise_2 (t2, the Worley detail), src/app_clouds.h:52-55 — what hlsltoy loads from the .dds files named on its
+ * command line and binds with a MIN_MAG_MIP_LINEAR / WRAP sampler (util/hlsltoy/src/hlsltoy.cpp:227-249, 437).
+ * Each is a size^3 RGBA32F volume in device memory, x fastest (the layout util/ddsvolgen writes, ddsvolgen.cpp:101-117;
+ * sbx_worley_volume produces one).  The shader reads only .r: the call copies that channel into the context (R32F,
+ * a quarter of the footprint), asynchronously on `stream`; the caller's buffers are not referenced afterwards.
+ * SampleLevel is evaluated by the sbx texture-filter spec: texel centres at (i + .5) / size, WRAP,
+ * trilinear blend with binary32 weights in x, y, z order.  Renders of SBX_APP_CLOUDS_TEX must be ordered after this
+ * call (same stream, or an event). */
+int sbx_set_noise_volumes(sbx_ctx* ctx, int shape_size, const float* shape_rgba, int detail_size,
+                          const float* detail_rgba, void* stream);
+/* SampleLevel(linear, wrap, lod 0).r of a size^3 RGBA32F device volume at n points (xyz interleaved, device):
+ * the texture-filter spec on its own, for parity tests. */
+int sbx_tex3d_eval(sbx_ctx* ctx, int size, const float* rgba, const float* xyz, float* out, size_t n, void* stream);
 
 const char* sbx_last_error(sbx_ctx* ctx);
 const char* sbx_version(void);

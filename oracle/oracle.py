@@ -11,9 +11,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST = range(8)
+APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST, APP_CLOUDS_TEX = range(9)
 APP_IDS = {"planet": APP_PLANET, "clouds": APP_CLOUDS, "egg": APP_EGG, "raytracer": APP_RAYTRACER,
-           "atmosphere": APP_ATMOSPHERE, "sdf_ao": APP_SDF_AO, "vinyl": APP_VINYL, "clouds_best": APP_CLOUDS_BEST}
+           "atmosphere": APP_ATMOSPHERE, "sdf_ao": APP_SDF_AO, "vinyl": APP_VINYL, "clouds_best": APP_CLOUDS_BEST,
+           "clouds_tex": APP_CLOUDS_TEX}
 
 
 def build(variant=""):
@@ -37,6 +38,9 @@ class Oracle:
         self.lib.sbxo_kat.argtypes = [ctypes.c_char_p, fp, fp]
         self.lib.sbxo_noise.argtypes = [ctypes.c_char_p, fp, fp, fp, ctypes.c_long]
         self.lib.sbxo_worley_volume.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
+        self.lib.sbxo_set_noise_volumes.argtypes = [ctypes.c_int, fp, ctypes.c_int, fp]
+        self.lib.sbxo_tex3d.argtypes = [ctypes.c_int, fp, fp, fp, ctypes.c_long]
+        self._volumes = None
 
     @staticmethod
     def _uni(width, height, time, mouse):
@@ -97,6 +101,23 @@ class Oracle:
         out = np.zeros_like(xyz)
         if self.lib.sbxo_noise(fn.encode(), self._fp(xyz), self._fp(par), self._fp(out), len(xyz)) != 0:
             raise ValueError("oracle: unknown noise function %r" % fn)
+        return out
+
+    def set_noise_volumes(self, shape_rgba, detail_rgba):
+        """Bind the two RGBA32F [size, size, size, 4] volumes of APP_CLOUDS' USE_NOISE_TEX build (t1 = shape, t2 = detail)."""
+        a = np.ascontiguousarray(shape_rgba, dtype=np.float32)
+        b = np.ascontiguousarray(detail_rgba, dtype=np.float32)
+        assert a.ndim == 4 and a.shape[3] == 4 and a.shape[0] == a.shape[1] == a.shape[2]
+        assert b.ndim == 4 and b.shape[3] == 4 and b.shape[0] == b.shape[1] == b.shape[2]
+        self._volumes = (a, b)                      # the oracle keeps the pointers
+        self.lib.sbxo_set_noise_volumes(a.shape[0], self._fp(a), b.shape[0], self._fp(b))
+
+    def tex3d(self, rgba, xyz):
+        """SampleLevel(linear, wrap, 0).r of the volume at points xyz[n, 3] -> float32 [n]"""
+        v = np.ascontiguousarray(rgba, dtype=np.float32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(len(xyz), dtype=np.float32)
+        self.lib.sbxo_tex3d(v.shape[0], self._fp(v), self._fp(xyz), self._fp(out), len(xyz))
         return out
 
     def worley_volume(self, size, z0=0, z1=None):

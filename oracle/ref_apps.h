@@ -178,9 +178,47 @@ struct AppEgg {
 /* =================================================================================== */
 /* APP_CLOUDS — src/app_clouds.h (SKY_SPHERE and USE_NOISE_TEX undefined, :8-9)         */
 /* =================================================================================== */
+/* The two 3-D noise textures of the USE_NOISE_TEX build (app_clouds.h:51-56: u_tex_noise = t1, u_tex_noise_2 = t2),
+ * as util/ddsvolgen bakes them (ddsvolgen.cpp:101-117: RGBA32F, size^3, x fastest) and hlsltoy binds them with a
+ * MIN_MAG_MIP_LINEAR / WRAP sampler (util/hlsltoy/src/hlsltoy.cpp:227-249, 437). */
+struct noise_tex_t { const float* rgba = nullptr; int size = 0; };
+
+/* SampleLevel(u_sampler0, pos, 0).r as the sbx spec fixes it (the reference leaves the filter to the GPU):
+ * texel centres at (i + .5) / size, WRAP addressing, trilinear blend in the mix(x), mix(y), mix(z) order with full
+ * binary32 weights.  PARITY UNPINNED against real D3D11 texture hardware (which quantises the weights to 8 bits). */
+static inline void tex_axis(float c, int size, int& i0, int& i1, float& f) {
+    const float fsize = (float)size;
+    const float u = c * fsize - .5f;
+    const float fl = m_floor(u);
+    f = u - fl;
+    float m = m_mod(fl, fsize);
+    if (m < 0.f) m += fsize;
+    if (m >= fsize) m -= fsize;
+    const int i = (m >= 0.f && m < fsize) ? (int)m : 0;
+    i0 = i;
+    i1 = (i + 1 == size) ? 0 : i + 1;
+}
+static inline float tex3d_sample_r(const noise_tex_t& T, vec3 p) {
+    int x0, x1, y0, y1, z0, z1;
+    float fx, fy, fz;
+    tex_axis(p.x, T.size, x0, x1, fx);
+    tex_axis(p.y, T.size, y0, y1, fy);
+    tex_axis(p.z, T.size, z0, z1, fz);
+    auto at = [&](int x, int y, int z) { return T.rgba[(((size_t)z * T.size + y) * T.size + x) * 4]; };
+    return m_mix(m_mix(m_mix(at(x0, y0, z0), at(x1, y0, z0), fx), m_mix(at(x0, y1, z0), at(x1, y1, z0), fx), fy),
+                 m_mix(m_mix(at(x0, y0, z1), at(x1, y0, z1), fx), m_mix(at(x0, y1, z1), at(x1, y1, z1), fx), fy), fz);
+}
+/* util.h:127-138 */
+static inline float remap(float original_value, float original_min, float original_max, float new_min, float new_max) {
+    return new_min + (((original_value - original_min) / (original_max - original_min)) * (new_max - new_min));
+}
+
 struct AppClouds {
     uniforms_t U;
     clouds_aux_t A;
+    /* USE_NOISE_TEX build (app_clouds.h:9): both set -> density_func samples the volumes instead of the fBm */
+    noise_tex_t tex_noise, tex_noise_2;
+    bool use_noise_tex() const { return tex_noise.rgba != nullptr && tex_noise_2.rgba != nullptr; }
     static constexpr float hg_g = .2f;                         /* app_clouds.h:5 */
     static constexpr float cld_noise_factor = .001f;           /* app_clouds.h:20 */
 
@@ -204,9 +242,17 @@ struct AppClouds {
         return fbm_generic<4>(pos, lacunarity, init_gain, gain, [](vec3 p) { return noise_iq(p); });
     }
     /* app_clouds.h:62-86 */
-    float density_func(vec3 pos_in, float /*height*/) const {
+    float density_func(vec3 pos_in, float height) const {
         vec3 pos = pos_in * cld_noise_factor;
-        float shape = fbm(pos * 2.03f, 2.64f, .5f, .5f);
+        float shape;
+        if (use_noise_tex()) {                                  /* #ifdef USE_NOISE_TEX :69-70, :74-81 */
+            shape = tex3d_sample_r(tex_noise, pos);
+            float w = tex3d_sample_r(tex_noise_2, pos);
+            float ww = m_mix(w, 1.f - w, height);
+            shape = remap(shape, ww * .7f, 1.f, 0.f, 1.f);
+        } else {
+            shape = fbm(pos * 2.03f, 2.64f, .5f, .5f);          /* :72 */
+        }
         const float cov = 1.f - A.cld_coverage;
         return shape * m_smoothstep(cov, cov + .0135f, shape);
     }

@@ -26,7 +26,11 @@ using namespace sbxref;
 
 /* app ids: same order as the README table (/root/reference/README.md:15-22) + SDF_AO */
 enum { APP_PLANET = 0, APP_CLOUDS = 1, APP_VINYL = 2, APP_EGG = 3, APP_RAYTRACER = 4, APP_ATMOSPHERE = 5, APP_SDF_AO = 6,
-       APP_CLOUDS_BEST = 7 /* src/app_clouds_best.h: not an APP_* define of the reference, numbered after them */ };
+       APP_CLOUDS_BEST = 7 /* src/app_clouds_best.h: not an APP_* define of the reference, numbered after them */,
+       APP_CLOUDS_TEX = 8  /* APP_CLOUDS compiled with USE_NOISE_TEX (src/app_clouds.h:9,51-56,69-81) */ };
+
+/* the two bound 3-D textures of the USE_NOISE_TEX build (t1, t2): set by sbxo_set_noise_volumes, owned by the caller */
+static noise_tex_t g_tex_noise, g_tex_noise_2;
 
 /* aux blocks arrive as the 16-byte-register images of src/uniform_buffer.h:39-60 */
 static clouds_aux_t parse_clouds_aux(const void* aux) {
@@ -62,6 +66,10 @@ static bool pixel(int app, const uniforms_t& U, const void* aux, float fx, float
     switch (app) {
     case APP_EGG: { AppEgg a; a.U = U; c = main_image(a, fc); break; }
     case APP_CLOUDS: { AppClouds a; a.U = U; a.A = parse_clouds_aux(aux); c = main_image(a, fc); break; }
+    case APP_CLOUDS_TEX: {
+        if (!g_tex_noise.rgba || !g_tex_noise_2.rgba) return false;
+        AppClouds a; a.U = U; a.A = parse_clouds_aux(aux); a.tex_noise = g_tex_noise; a.tex_noise_2 = g_tex_noise_2;
+        c = main_image(a, fc); break; }
     case APP_RAYTRACER: { AppRaytracer a; a.U = U; c = main_image(a, fc); break; }
     case APP_ATMOSPHERE: { AppAtmosphere a; a.U = U; c = main_image(a, fc); break; }
     case APP_SDF_AO: { AppSdfAo a; a.U = U; a.A = parse_sdf_ao_aux(aux); c = main_image(a, fc); break; }
@@ -75,6 +83,20 @@ static bool pixel(int app, const uniforms_t& U, const void* aux, float fx, float
 }
 
 extern "C" {
+
+/* Bind the RGBA32F size^3 volumes (x fastest, as util/ddsvolgen writes them) to t1 / t2 for APP_CLOUDS_TEX.
+ * The pointers are kept, not copied. */
+int sbxo_set_noise_volumes(int size1, const float* rgba1, int size2, const float* rgba2) {
+    g_tex_noise.rgba = rgba1; g_tex_noise.size = size1;
+    g_tex_noise_2.rgba = rgba2; g_tex_noise_2.size = size2;
+    return 0;
+}
+/* SampleLevel(linear, wrap, 0).r of a volume at n points (xyz interleaved): the texture-filter spec on its own */
+int sbxo_tex3d(int size, const float* rgba, const float* xyz, float* out, long n) {
+    noise_tex_t T; T.rgba = rgba; T.size = size;
+    for (long i = 0; i < n; ++i) out[i] = tex3d_sample_r(T, vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+    return 0;
+}
 
 /* mainImage for one pixel. uniforms = {u_res.x, u_res.y, u_mouse.x, u_mouse.y, u_time} */
 int sbxo_main_image(int app, const float* uniforms, const void* aux, float fx, float fy, float* rgba) {

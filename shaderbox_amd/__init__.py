@@ -17,10 +17,11 @@ from . import shard  # noqa: F401  (pure-python row-block arithmetic, no GPU nee
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsbx.so")
 
-APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST = range(8)
+APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST, APP_CLOUDS_TEX = range(9)
 APPS = {"APP_PLANET": APP_PLANET, "APP_CLOUDS": APP_CLOUDS, "APP_VINYL": APP_VINYL, "APP_EGG": APP_EGG,
         "APP_RAYTRACER": APP_RAYTRACER, "APP_ATMOSPHERE": APP_ATMOSPHERE, "APP_SDF_AO": APP_SDF_AO,
-        "APP_CLOUDS_BEST": APP_CLOUDS_BEST}    # src/app_clouds_best.h (stand-alone shader, not an APP_* define)
+        "APP_CLOUDS_BEST": APP_CLOUDS_BEST,    # src/app_clouds_best.h (stand-alone shader, not an APP_* define)
+        "APP_CLOUDS_TEX": APP_CLOUDS_TEX}      # APP_CLOUDS + USE_NOISE_TEX (src/app_clouds.h:9)
 
 SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -104,6 +105,8 @@ def load_library(path=None):
     lib.sbx_math_eval.argtypes = [vp, ctypes.c_char_p, fp, fp, fp, ctypes.c_size_t, vp]
     lib.sbx_noise_eval.argtypes = [vp, ctypes.c_char_p, fp, fp, fp, ctypes.c_size_t, vp]
     lib.sbx_worley_volume.argtypes = [vp, ci, fp, vp]
+    lib.sbx_set_noise_volumes.argtypes = [vp, ci, fp, ci, fp, vp]
+    lib.sbx_tex3d_eval.argtypes = [vp, ci, fp, fp, fp, ctypes.c_size_t, vp]
     lib.sbx_last_error.argtypes = [vp]
     lib.sbx_last_error.restype = ctypes.c_char_p
     lib.sbx_version.restype = ctypes.c_char_p
@@ -278,6 +281,27 @@ class Renderer:
         """The ddsvolgen noise volume: float32 [size, size, size, 4] (z, y, x, rgba)."""
         out = self.torch.empty((size, size, size, 4), dtype=self.torch.float32, device=self.tdev)
         self._check(self.lib.sbx_worley_volume(self.ctx, int(size), ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def set_noise_volumes(self, shape_rgba, detail_rgba):
+        """Bind the two 3-D noise textures of APP_CLOUDS' USE_NOISE_TEX build (t1 = shape, t2 = Worley detail): float32
+        device tensors [size, size, size, 4] as worley_volume() / ddsvolgen produce them.  The library keeps its own copy
+        of the .r channel; render with app 'clouds_tex' afterwards (same stream)."""
+        for v in (shape_rgba, detail_rgba):
+            assert v.is_cuda and v.dtype == self.torch.float32 and v.is_contiguous() and v.dim() == 4 and v.shape[3] == 4
+            assert v.shape[0] == v.shape[1] == v.shape[2]
+        self._check(self.lib.sbx_set_noise_volumes(self.ctx, int(shape_rgba.shape[0]), ctypes.c_void_p(shape_rgba.data_ptr()),
+                                                   int(detail_rgba.shape[0]), ctypes.c_void_p(detail_rgba.data_ptr()),
+                                                   self._stream()))
+
+    def tex3d(self, rgba, xyz):
+        """SampleLevel(linear, wrap, 0).r of an RGBA32F device volume at points xyz[n, 3] (the texture-filter spec)."""
+        assert rgba.is_cuda and rgba.dtype == self.torch.float32 and rgba.is_contiguous() and rgba.shape[3] == 4
+        xyz = xyz.to(self.tdev, self.torch.float32).contiguous().view(-1, 3)
+        out = self.torch.empty((xyz.shape[0],), dtype=self.torch.float32, device=self.tdev)
+        self._check(self.lib.sbx_tex3d_eval(self.ctx, int(rgba.shape[0]), ctypes.c_void_p(rgba.data_ptr()),
+                                            ctypes.c_void_p(xyz.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                            xyz.shape[0], self._stream()))
         return out
 
     def math(self, fn, a, b=None):

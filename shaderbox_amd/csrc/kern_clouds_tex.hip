@@ -1,0 +1,164 @@
+// shaderbox_amd/csrc/kern_clouds_tex.hip — APP_CLOUDS compiled with USE_NOISE_TEX.
+//
+// Follows /root/reference/src/app_clouds.h with USE_NOISE_TEX defined (:9): density_func :62-86 takes its
+// shape from u_tex_noise (t1) and erodes it with u_tex_noise_2 (t2) through remap() (src/util.h:127-138):
+//     shape = u_tex_noise.SampleLevel(u_sampler0, pos, 0).r                          :69-70
+//     w     = u_tex_noise_2.SampleLevel(u_sampler0, pos, 0).r                        :75-78
+//     ww    = mix(w, 1 - w, height) ;  shape = remap(shape, ww * .7, 1, 0, 1)        :79-80
+// with `height` = i / steps of the march that samples (:108, :183) — the one place the reference uses it.
+// The volumes are the RGBA32F size^3 textures util/ddsvolgen bakes (ddsvolgen.cpp:101-117) and hlsltoy binds
+// with a MIN_MAG_MIP_LINEAR / WRAP sampler (util/hlsltoy/src/hlsltoy.cpp:227-249, 437).
+//
+// The reference leaves the texture filter to the GPU; the sbx spec fixes it ("SampleLevel"):
+//   per axis  u = c * size - .5 ;  i = floor(u) ;  f = u - i ;  i0 = wrap(i), i1 = wrap(i0 + 1)
+//   texel    = mix(mix(mix(t000, t100, fx), mix(t010, t110, fx), fy),
+//                  mix(mix(t001, t101, fx), mix(t011, t111, fx), fy), fz)   with mix(a, b, t) = a (1 - t) + b t
+//   wrap(i)  = i - size * floor(i / size), evaluated in binary32 and folded once into [0, size); NaN -> 0
+// i.e. texel centres at (i + .5) / size, full binary32 weights (a D3D11 sampler quantises them to 8 bits:
+// against real texture hardware parity is unpinned, against the oracle it is bit-exact).
+//
+// MI355X shape of the problem: this is the one kernel of the library that READS memory — 16 texel fetches per
+// density sample, ~157 samples per pixel.  The library keeps its own R32F copy of the .r channel the shader
+// uses (8.4 MB per 128^3 volume instead of 33.5 MB: both volumes sit in the 256 MB Infinity Cache and mostly
+// in the 4 MB L2 of each XCD), neighbouring pixels of a wave tile sample neighbouring texels, and the straight
+// per-lane kernel below needs few registers, so 8 waves per SIMD hide the L2 latency.  HBM traffic stays the
+// framebuffer (16 B/pixel) plus one pass over the volumes; roofline and FETCH_SIZE in DESIGN.md §4.8.
+#include "sbx_device.h"
+
+namespace sbx {
+
+struct NoiseTex { const float* r; int size; float fsize; };
+
+__device__ __forceinline__ void tex_axis(float c, const NoiseTex& T, int& i0, int& i1, float& f) {
+    const float u = c * T.fsize - .5f;
+    const float fl = floor_(u);
+    f = u - fl;
+    float m = fl - T.fsize * floor_(fl / T.fsize);             // GLSL mod(fl, size): exact for |fl| < 2^24 and size 2^k
+    if (m < 0.f) m += T.fsize;                                 // a rounded quotient can land one period off
+    if (m >= T.fsize) m -= T.fsize;
+    const int i = (m >= 0.f && m < T.fsize) ? (int)m : 0;      // NaN / infinite coordinates sample texel 0
+    i0 = i;
+    i1 = (i + 1 == T.size) ? 0 : i + 1;
+}
+
+__device__ __forceinline__ float tex3d_r(const NoiseTex& T, v3 p) {     // SampleLevel(linear, wrap, lod 0).r
+    int x0, x1, y0, y1, z0, z1;
+    float fx, fy, fz;
+    tex_axis(p.x, T, x0, x1, fx);
+    tex_axis(p.y, T, y0, y1, fy);
+    tex_axis(p.z, T, z0, z1, fz);
+    const size_t s1 = (size_t)T.size, s2 = s1 * s1;
+    const float* r0 = T.r + z0 * s2;
+    const float* r1 = T.r + z1 * s2;
+    const float t000 = r0[y0 * s1 + x0], t100 = r0[y0 * s1 + x1];
+    const float t010 = r0[y1 * s1 + x0], t110 = r0[y1 * s1 + x1];
+    const float t001 = r1[y0 * s1 + x0], t101 = r1[y0 * s1 + x1];
+    const float t011 = r1[y1 * s1 + x0], t111 = r1[y1 * s1 + x1];
+    const float a = mix_(t000, t100, fx), b = mix_(t010, t110, fx);
+    const float c = mix_(t001, t101, fx), d = mix_(t011, t111, fx);
+    return mix_(mix_(a, b, fy), mix_(c, d, fy), fz);
+}
+
+__device__ __forceinline__ float remap_(float v, float omin, float omax, float nmin, float nmax) {   // util.h:127-138
+    return nmin + (((v - omin) / (omax - omin)) * (nmax - nmin));
+}
+
+__device__ __forceinline__ float tex_density(const FrameClouds& F, const NoiseTex& T1, const NoiseTex& T2, v3 pos_in, float height) {
+    const v3 pos = pos_in * .001f;                             // cld_noise_factor :20,66
+    float shape = tex3d_r(T1, pos);                            // :69-70
+    const float w = tex3d_r(T2, pos);                          // :75-78
+    const float ww = mix_(w, 1.f - w, height);                 // :79
+    shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);            // :80
+    return shape * smoothstep_(F.cov, F.cov_hi, shape);        // :83-84
+}
+
+__device__ __forceinline__ float hg_phase_tex(float mu, float g) {   // volumetric.h:27-33, note (4 + PI)
+    return (1.f - g * g) / ((4.f + 3.14159265359f) * pow_(1.f + g * g - 2.f * g * mu, 1.5f));
+}
+
+__global__ void __launch_bounds__(WG_THREADS) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out,
+                                                            NoiseTex T1, NoiseTex T2) {
+    const Pixel px = pixel_of_thread<8>(M);
+    if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 dir = primary_dir(F.cam, pc);
+
+    float sun_amount = fmax_(dot(dir, F.sun_dir), 0.f);        // render_sky_color :36-46
+    v3 sky = mix3(V3(.0f, .1f, .4f), V3(.3f, .6f, .8f), 1.0f - dir.y);
+    sky = sky + F.sun_color * fmin_(pow_(sun_amount, 1500.0f) * 5.0f, 1.0f);
+    sky = sky + F.sun_color * fmin_(pow_(sun_amount, 10.0f) * .6f, 1.0f);
+    sky = abs3(sky);
+
+    const float cutoff = dot(dir, V3(0, 1, 0));
+    v3 col = sky;
+    if (!(cutoff < 0.05f)) {                                   // :212
+        const v3 projection = dir / dir.y;                     // render_clouds :153-202
+        v3 origin = F.cam.eye + projection * 150.f;
+        origin = origin + F.wind_off;
+        const float phase = hg_phase_tex(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
+        const v3 lstep = F.sun_dir * F.dt;
+        float transmittance = 1.f, radiance = 0.f, alpha = 0.f, t = 0.f;
+        for (int i = 0; i < F.steps; ++i) {
+            const float height = (float)i / (float)F.steps;    // :183
+            const v3 pos = origin + t * projection;
+            t += F.dt;
+            const float density = tex_density(F, T1, T2, pos, height);
+            if (!(density < .005f)) {                          // integrate_volume :132
+                const float T_i = exp_(-density * F.sigma * F.dt);
+                transmittance *= T_i;
+                v3 lp = pos + lstep;                           // illuminate_volume :91-123
+                float ltrans = 1.f;
+                for (int j = 0; j < F.lsteps; ++j) {
+                    const float lh = (float)j / (float)F.lsteps;                    // :108
+                    const float d = tex_density(F, T1, T2, lp, lh);
+                    ltrans *= exp_(-d * F.sigma * F.dt);
+                    lp = lp + lstep;
+                }
+                radiance += (density * F.sigma) * (ltrans * F.sun_power * phase) * transmittance * F.dt;
+                alpha += (1.f - T_i) * (1.f - alpha);
+            }
+            if (alpha > .999f) break;
+        }
+        const float a = alpha * smoothstep_(.0f, .2f, cutoff);
+        col = abs3(mix3(sky, V3s(radiance), a));               // :215-217
+    }
+    store_rgba(out, px.idx, to_srgb(col));
+}
+
+// .r of an RGBA32F volume -> the library's R32F copy (one float4 read, one float written per voxel)
+__global__ void __launch_bounds__(256) k_extract_r(const float4* __restrict__ rgba, float* __restrict__ r, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) r[i] = rgba[i].x;
+}
+
+void launch_extract_r(const float* rgba, float* r, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_extract_r, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(rgba), r, n);
+}
+
+// the filter on its own, straight from an RGBA32F volume (parity tests of the spec): same operations as tex3d_r
+__global__ void __launch_bounds__(256) k_tex3d_eval(int size, const float* __restrict__ rgba, const float* __restrict__ xyz,
+                                                    float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const NoiseTex T{nullptr, size, (float)size};
+    int x0, x1, y0, y1, z0, z1;
+    float fx, fy, fz;
+    tex_axis(xyz[3 * i], T, x0, x1, fx);
+    tex_axis(xyz[3 * i + 1], T, y0, y1, fy);
+    tex_axis(xyz[3 * i + 2], T, z0, z1, fz);
+    auto at = [&](int x, int y, int z) { return rgba[(((size_t)z * size + y) * size + x) * 4]; };
+    const float a = mix_(at(x0, y0, z0), at(x1, y0, z0), fx), b = mix_(at(x0, y1, z0), at(x1, y1, z0), fx);
+    const float c = mix_(at(x0, y0, z1), at(x1, y0, z1), fx), d = mix_(at(x0, y1, z1), at(x1, y1, z1), fx);
+    out[i] = mix_(mix_(a, b, fy), mix_(c, d, fy), fz);
+}
+void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_tex3d_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, size, rgba, xyz, out, n);
+}
+
+void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, const float* shape_r, int shape_size,
+                       const float* detail_r, int detail_size) {
+    const NoiseTex T1{shape_r, shape_size, (float)shape_size}, T2{detail_r, detail_size, (float)detail_size};
+    hipLaunchKernelGGL(k_clouds_tex, grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2);
+}
+
+}  // namespace sbx

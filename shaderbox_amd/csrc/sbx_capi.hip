@@ -15,23 +15,40 @@
 
 using namespace sbx;
 
+struct YtabSlot {
+    // launches that read this table and may still be running: one event per stream, re-recorded after every consumer
+    std::vector<std::pair<hipStream_t, hipEvent_t>> users;
+};
+struct TimingPair { hipEvent_t ev0{}, ev1{}; bool complete = false; };
+
 struct sbx_ctx {
     int device = 0;
     bool timing = false;
     int variant = 0;
-    char* ytab = nullptr;      // CLOUDS_YTAB_RING tables of CLOUDS_YTAB_BYTES, device memory
-    unsigned ytab_next = 0;
-    // the table depends only on (eye.y + wind.y, dt, steps): it is rebuilt, into the next ring slot, only when that
-    // key or the stream changes (default wind has no y component, so an animation reuses one table)
+    // APP_CLOUDS y tables: CLOUDS_YTAB_RING slots for eager launches + CLOUDS_YTAB_CAPTURE slots that only launches
+    // recorded into a stream capture use (a captured graph bakes the slot pointer in, so eager rebuilds must never
+    // touch it, and the build is always part of the graph).
+    char* ytab = nullptr;
+    unsigned ytab_next = 0, ytab_cap_next = 0;
+    // The eager table depends only on (eye.y, wind.y * t, dt, steps): it is rebuilt, into the next ring slot, only when
+    // that key changes (default wind has no y component, so an animation reuses one table).  The state below is
+    // committed only when a build has actually been ENQUEUED on a stream that is executing (not capturing).
     bool ytab_valid = false;
     float ytab_key[3] = {0, 0, 0};
     int ytab_steps = 0;
+    int ytab_slot = 0;
     hipStream_t ytab_stream = nullptr;
-    void* ytab_cur = nullptr;
     hipEvent_t ytab_ready{};
     bool have_ytab_event = false;
-    bool have_events = false;
-    hipEvent_t ev0{}, ev1{};
+    YtabSlot slots[CLOUDS_YTAB_RING];
+    std::vector<hipEvent_t> event_pool;
+    // per-stream timing events (sbx_set_timing): a pair brackets the last launch on its stream
+    std::vector<std::pair<hipStream_t, TimingPair>> timers;
+    int last_timer = -1;
+    // APP_CLOUDS_TEX: the library's R32F copies of the two bound noise volumes (sbx_set_noise_volumes)
+    float* noise_tex = nullptr;      // shape (t1)
+    float* noise_tex2 = nullptr;     // detail (t2)
+    int noise_tex_size = 0, noise_tex2_size = 0;
     // sbx_main_image: the frame of the last (app, uniforms, aux) seen, on the device and on the host
     float* mi_dev = nullptr;
     size_t mi_floats = 0;
@@ -315,7 +332,7 @@ int sbx_create(int device, sbx_ctx** out) {
     sbx_ctx* ctx = new sbx_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
-        hipMalloc((void**)&ctx->ytab, (size_t)CLOUDS_YTAB_RING * CLOUDS_YTAB_BYTES) != hipSuccess) {
+        hipMalloc((void**)&ctx->ytab, (size_t)(CLOUDS_YTAB_RING + CLOUDS_YTAB_CAPTURE) * CLOUDS_YTAB_BYTES) != hipSuccess) {
         delete ctx;
         return SBX_ERR_HIP;
     }
@@ -325,11 +342,81 @@ int sbx_create(int device, sbx_ctx** out) {
 
 void sbx_destroy(sbx_ctx* ctx) {
     if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
     if (ctx->ytab) (void)hipFree(ctx->ytab);
     if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
+    if (ctx->noise_tex) (void)hipFree(ctx->noise_tex);
+    if (ctx->noise_tex2) (void)hipFree(ctx->noise_tex2);
     if (ctx->have_ytab_event) (void)hipEventDestroy(ctx->ytab_ready);
-    if (ctx->have_events) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
+    for (auto& sl : ctx->slots) for (auto& u : sl.users) (void)hipEventDestroy(u.second);
+    for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto& t : ctx->timers) { (void)hipEventDestroy(t.second.ev0); (void)hipEventDestroy(t.second.ev1); }
     delete ctx;
+}
+
+static bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+// APP_CLOUDS launch with the y-table bookkeeping.  Three cases:
+//  (1) no table (per-lane variant, or a step count the table does not cover): nothing cached, nothing touched;
+//  (2) the stream is being captured: the build goes into the capture, into a slot of the capture ring, together with
+//      the render kernel; cache key, events and the eager ring are left alone (nothing has executed yet);
+//  (3) eager: rebuild into the next ring slot only when the key changed — after waiting for every launch that may
+//      still be reading that slot — and record, per stream, an event behind each consumer of the current slot.
+static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, float* rgba, hipStream_t s, bool capturing) {
+    const bool uses_table = ctx->variant == 0 && F.steps > 0 && F.steps <= CLOUDS_YTAB_ROWS;
+    if (!uses_table) {
+        launch_clouds(F, M, rgba, s, ctx->variant, nullptr, 0, false);
+        return SBX_OK;
+    }
+    if (capturing) {
+        char* tab = ctx->ytab + (size_t)(CLOUDS_YTAB_RING + (ctx->ytab_cap_next++ % CLOUDS_YTAB_CAPTURE)) * CLOUDS_YTAB_BYTES;
+        launch_clouds(F, M, rgba, s, 0, tab, CLOUDS_YTAB_ROWS, true);
+        return SBX_OK;
+    }
+    const float key[3] = {F.cam.eye.y, F.wind_off.y, F.dt};
+    const bool rebuild = !ctx->ytab_valid || F.steps != ctx->ytab_steps || std::memcmp(key, ctx->ytab_key, sizeof(key)) != 0;
+    if (!ctx->have_ytab_event) {
+        if (hipEventCreateWithFlags(&ctx->ytab_ready, hipEventDisableTiming) != hipSuccess)
+            return fail(ctx, SBX_ERR_HIP, "hipEventCreate");
+        ctx->have_ytab_event = true;
+    }
+    int slot = ctx->ytab_slot;
+    if (rebuild) {
+        slot = (int)(ctx->ytab_next++ % CLOUDS_YTAB_RING);
+        YtabSlot& sl = ctx->slots[slot];
+        for (auto& u : sl.users) {                                 // earlier readers of the slot we are about to overwrite
+            if (u.first != s) (void)hipStreamWaitEvent(s, u.second, 0);
+            ctx->event_pool.push_back(u.second);
+        }
+        sl.users.clear();
+    } else if (s != ctx->ytab_stream) {
+        (void)hipStreamWaitEvent(s, ctx->ytab_ready, 0);           // table was built on another stream
+    }
+    char* tab = ctx->ytab + (size_t)slot * CLOUDS_YTAB_BYTES;
+    launch_clouds(F, M, rgba, s, 0, tab, CLOUDS_YTAB_ROWS, rebuild);
+    if (rebuild) {
+        (void)hipEventRecord(ctx->ytab_ready, s);                  // the build is enqueued: now the cache state is true
+        std::memcpy(ctx->ytab_key, key, sizeof(key));
+        ctx->ytab_steps = F.steps;
+        ctx->ytab_slot = slot;
+        ctx->ytab_stream = s;
+        ctx->ytab_valid = true;
+    }
+    YtabSlot& sl = ctx->slots[slot];
+    hipEvent_t ev{};
+    bool found = false;
+    for (auto& u : sl.users) if (u.first == s) { ev = u.second; found = true; break; }
+    if (!found) {
+        if (!ctx->event_pool.empty()) { ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipEventCreate");
+        sl.users.emplace_back(s, ev);
+    }
+    (void)hipEventRecord(ev, s);
+    return SBX_OK;
 }
 
 static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, const RowMap& M,
@@ -338,41 +425,35 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     if (M.nrows == 0) return SBX_OK;
-    if (ctx->timing) {
-        if (!ctx->have_events) {
-            if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess)
+    // argument checks come before anything is enqueued or recorded
+    if (app < SBX_APP_PLANET || app > SBX_APP_CLOUDS_TEX) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
+    sbx_aux_clouds AC;
+    if (app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX) {
+        if (aux) AC = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&AC);
+        if (AC.cld_march_steps < 0 || AC.illum_march_steps < 0) return fail(ctx, SBX_ERR_ARG, "negative march steps");
+    }
+    if (app == SBX_APP_CLOUDS_TEX && !ctx->noise_tex) return fail(ctx, SBX_ERR_ARG, "APP_CLOUDS with USE_NOISE_TEX needs sbx_set_noise_volume first");
+    const bool capturing = stream_is_capturing(s);
+    TimingPair* tp = nullptr;
+    if (ctx->timing && !capturing) {                               // events recorded into a capture would time nothing
+        int idx = -1;
+        for (size_t i = 0; i < ctx->timers.size(); ++i) if (ctx->timers[i].first == s) idx = (int)i;
+        if (idx < 0) {
+            TimingPair p;
+            if ((e = hipEventCreate(&p.ev0)) != hipSuccess || (e = hipEventCreate(&p.ev1)) != hipSuccess)
                 return fail(ctx, SBX_ERR_HIP, "hipEventCreate", e);
-            ctx->have_events = true;
+            ctx->timers.emplace_back(s, p);
+            idx = (int)ctx->timers.size() - 1;
         }
-        (void)hipEventRecord(ctx->ev0, s);
+        tp = &ctx->timers[idx].second;
+        tp->complete = false;
+        ctx->last_timer = idx;
+        (void)hipEventRecord(tp->ev0, s);
     }
+    int rc = SBX_OK;
     switch (app) {
-    case SBX_APP_CLOUDS: {
-        sbx_aux_clouds A;
-        if (aux) A = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&A);
-        if (A.cld_march_steps < 0 || A.illum_march_steps < 0) return fail(ctx, SBX_ERR_ARG, "negative march steps");
-        const FrameClouds F = build_clouds(*uni, A);
-        const float key[3] = {F.cam.eye.y, F.wind_off.y, F.dt};
-        bool rebuild = !ctx->ytab_valid || F.steps != ctx->ytab_steps ||
-                       std::memcmp(key, ctx->ytab_key, sizeof(key)) != 0;
-        if (!ctx->have_ytab_event) {
-            if (hipEventCreateWithFlags(&ctx->ytab_ready, hipEventDisableTiming) != hipSuccess)
-                return fail(ctx, SBX_ERR_HIP, "hipEventCreate");
-            ctx->have_ytab_event = true;
-        }
-        if (rebuild) {
-            ctx->ytab_cur = ctx->ytab + (size_t)(ctx->ytab_next++ % CLOUDS_YTAB_RING) * CLOUDS_YTAB_BYTES;
-            std::memcpy(ctx->ytab_key, key, sizeof(key));
-            ctx->ytab_steps = F.steps;
-            ctx->ytab_valid = true;
-            ctx->ytab_stream = s;
-        } else if (s != ctx->ytab_stream) {
-            (void)hipStreamWaitEvent(s, ctx->ytab_ready, 0);      // table was built on another stream
-        }
-        launch_clouds(F, M, rgba, s, ctx->variant, ctx->ytab_cur, CLOUDS_YTAB_ROWS, rebuild);
-        if (rebuild) (void)hipEventRecord(ctx->ytab_ready, s);
-        break;
-    }
+    case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
+    case SBX_APP_CLOUDS_TEX: launch_clouds_tex(build_clouds(*uni, AC), M, rgba, s, ctx->noise_tex, ctx->noise_tex_size, ctx->noise_tex2, ctx->noise_tex2_size); break;
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, ctx->variant); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
@@ -385,9 +466,10 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s, ctx->variant); break;
     case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s, ctx->variant); break;
     case SBX_APP_CLOUDS_BEST: launch_clouds_best(build_clouds_best(*uni), M, rgba, s); break;
-    default: return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
+    default: break;
     }
-    if (ctx->timing) (void)hipEventRecord(ctx->ev1, s);
+    if (tp) { (void)hipEventRecord(tp->ev1, s); tp->complete = true; }
+    if (rc != SBX_OK) return rc;
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "kernel launch", e);
     return SBX_OK;
@@ -418,7 +500,7 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
                    float fragColor[4]) {
     if (!ctx) return SBX_ERR_ARG;
     if (!uni || !fragCoord || !fragColor) return fail(ctx, SBX_ERR_ARG, "NULL argument");
-    const int aux_bytes = !aux ? 0 : (app == SBX_APP_CLOUDS ? (int)sizeof(sbx_aux_clouds)
+    const int aux_bytes = !aux ? 0 : ((app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX) ? (int)sizeof(sbx_aux_clouds)
                                       : (app == SBX_APP_SDF_AO ? (int)sizeof(sbx_aux_sdf_ao) : 0));
     const bool hit = ctx->mi_valid && ctx->mi_app == app && std::memcmp(&ctx->mi_uni, uni, sizeof(*uni)) == 0 &&
                      ctx->mi_aux_bytes == aux_bytes && (aux_bytes == 0 || std::memcmp(ctx->mi_aux, aux, aux_bytes) == 0);
@@ -556,10 +638,11 @@ int sbx_set_timing(sbx_ctx* ctx, int enabled) {
 }
 int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms) {
     if (!ctx || !ms) return SBX_ERR_ARG;
-    if (!ctx->have_events) return fail(ctx, SBX_ERR_ARG, "no timed launch yet");
-    hipError_t e = hipEventSynchronize(ctx->ev1);
+    if (ctx->last_timer < 0 || !ctx->timers[ctx->last_timer].second.complete) return fail(ctx, SBX_ERR_ARG, "no timed launch yet");
+    TimingPair& p = ctx->timers[ctx->last_timer].second;          // the pair of the stream of the last timed launch
+    hipError_t e = hipEventSynchronize(p.ev1);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipEventSynchronize", e);
-    e = hipEventElapsedTime(ms, ctx->ev0, ctx->ev1);
+    e = hipEventElapsedTime(ms, p.ev0, p.ev1);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipEventElapsedTime", e);
     return SBX_OK;
 }
@@ -608,6 +691,47 @@ int sbx_worley_volume(sbx_ctx* ctx, int size, float* rgba, void* stream) {
     launch_worley_volume(size, rgba, (hipStream_t)stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "worley_volume launch", e);
+    return SBX_OK;
+}
+
+int sbx_set_noise_volumes(sbx_ctx* ctx, int shape_size, const float* shape_rgba, int detail_size, const float* detail_rgba,
+                          void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!shape_rgba || !detail_rgba || shape_size <= 0 || detail_size <= 0 || shape_size > 1024 || detail_size > 1024)
+        return fail(ctx, SBX_ERR_ARG, "bad noise volume arguments");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    const size_t n1 = (size_t)shape_size * shape_size * shape_size, n2 = (size_t)detail_size * detail_size * detail_size;
+    // (re)allocation frees buffers an in-flight render may read: hipFree synchronises the device first
+    if (shape_size != ctx->noise_tex_size || !ctx->noise_tex) {
+        if (ctx->noise_tex) (void)hipFree(ctx->noise_tex);
+        ctx->noise_tex = nullptr; ctx->noise_tex_size = 0;
+        if ((e = hipMalloc((void**)&ctx->noise_tex, n1 * sizeof(float))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
+        ctx->noise_tex_size = shape_size;
+    }
+    if (detail_size != ctx->noise_tex2_size || !ctx->noise_tex2) {
+        if (ctx->noise_tex2) (void)hipFree(ctx->noise_tex2);
+        ctx->noise_tex2 = nullptr; ctx->noise_tex2_size = 0;
+        if ((e = hipMalloc((void**)&ctx->noise_tex2, n2 * sizeof(float))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
+        ctx->noise_tex2_size = detail_size;
+    }
+    ctx->mi_valid = false;                                         // a cached sbx_main_image frame may have used the old volumes
+    launch_extract_r(shape_rgba, ctx->noise_tex, n1, (hipStream_t)stream);
+    launch_extract_r(detail_rgba, ctx->noise_tex2, n2, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "noise volume copy launch", e);
+    return SBX_OK;
+}
+
+int sbx_tex3d_eval(sbx_ctx* ctx, int size, const float* rgba, const float* xyz, float* out, size_t n, void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!rgba || !xyz || !out || size <= 0 || size > 1024) return fail(ctx, SBX_ERR_ARG, "bad tex3d arguments");
+    if (n == 0) return SBX_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    launch_tex3d_eval(size, rgba, xyz, out, n, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "tex3d_eval launch", e);
     return SBX_OK;
 }
 

@@ -47,7 +47,13 @@ void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_
                    bool build_table);
 constexpr int CLOUDS_YTAB_ROWS = 1024;      // march steps covered by the per-frame y table
 constexpr int CLOUDS_YTAB_BYTES = CLOUDS_YTAB_ROWS * 48;
-constexpr int CLOUDS_YTAB_RING = 8;         // tables in flight (one per launch, round robin)
+constexpr int CLOUDS_YTAB_RING = 8;         // eager tables: one per REBUILD (key change), round robin; reuse of a slot waits
+                                            // for the launches that may still read it (sbx_capi.hip render_clouds)
+constexpr int CLOUDS_YTAB_CAPTURE = 8;      // tables used only by launches recorded into a stream capture
+void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, const float* shape_r, int shape_size,
+                       const float* detail_r, int detail_size);
+void launch_extract_r(const float* rgba, float* r, size_t n, hipStream_t s);
+void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out, size_t n, hipStream_t s);
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s);
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s);

@@ -1,0 +1,219 @@
+"""GPU tests added in round 2: context-state hazards of APP_CLOUDS' y table, the USE_NOISE_TEX build of
+APP_CLOUDS, per-stream timing, and wider full-size oracle coverage."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(gpu, ref):
+    both_nan = np.isnan(gpu) & np.isnan(ref)
+    d = np.where(both_nan, 0.0, np.abs(gpu.astype(np.float64) - ref.astype(np.float64)))
+    d = np.nan_to_num(d, nan=np.inf)
+    bits = (gpu.view(np.uint32) != ref.view(np.uint32)) & ~both_nan
+    return float(d.max()), int(bits.any(axis=-1).sum())
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    import shaderbox_amd
+    return shaderbox_amd.Renderer(0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# y-table state of a context
+# ---------------------------------------------------------------------------------------------------------
+def test_perlane_variant_first_then_default(oracle):
+    """A fresh context that renders APP_CLOUDS with the per-lane kernel first (which builds no y table) and the default
+    kernel afterwards with the same key must build the table then (round 1 marked it valid without building it)."""
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS
+    r = shaderbox_amd.Renderer(0)
+    ref = oracle.render(APP_CLOUDS, 160, 90, .37)
+    r.set_variant(1)
+    a = r.render("clouds", 160, 90, .37).cpu().numpy()
+    r.set_variant(0)
+    b = r.render("clouds", 160, 90, .37).cpu().numpy()
+    assert compare(a, ref) == (0.0, 0)
+    assert compare(b, ref) == (0.0, 0)
+    r.close()
+
+
+def test_first_clouds_frame_inside_a_capture(oracle):
+    """The FIRST APP_CLOUDS render of a fresh context happens inside a stream capture: nothing has executed, so the
+    context must not believe its table exists.  Eager renders afterwards (same key, then nine other keys to cycle the eager
+    ring) and replays of the graph all give the oracle's pixels."""
+    import torch
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS
+    r = shaderbox_amd.Renderer(0)
+    r.set_timing(True)                       # timing events must stay out of the capture
+    w, h = 160, 90
+    ref = oracle.render(APP_CLOUDS, w, h, .37)
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        torch.zeros(1, device="cuda")        # the stream exists before the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        r.render("clouds", w, h, .37, out=out)
+    eager = r.render("clouds", w, h, .37).cpu().numpy()           # same key, eager, BEFORE any replay
+    assert compare(eager, ref) == (0.0, 0)
+    g.replay(); torch.cuda.synchronize()
+    assert compare(out.cpu().numpy(), ref) == (0.0, 0)
+    aux = shaderbox_amd.clouds_defaults()
+    for k in range(9):                                            # nine other keys: the eager ring wraps
+        aux.cld_thick = 100.0 + 3.0 * k
+        r.render("clouds", 64, 36, .37, aux=aux)
+    out.zero_(); torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
+    assert compare(out.cpu().numpy(), ref) == (0.0, 0)
+    assert r.last_kernel_ms() > 0.0                               # timing pairs come from eager launches only
+    r.close()
+
+
+def test_table_ring_reuse_across_streams(oracle):
+    """Key changes on every frame (animated cld_thick) over two streams, more rebuilds than ring slots, large frames in
+    flight: a rebuild into a reused slot must wait for the launches still reading it.  Every frame equals the per-lane
+    kernel's (which uses no table)."""
+    import torch
+    import shaderbox_amd
+    r = shaderbox_amd.Renderer(0)
+    w, h = 1280, 720
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    aux = shaderbox_amd.clouds_defaults()
+    n = 20
+    frames = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(n)]
+    for i in range(n):
+        aux.cld_thick = 90.0 + 2.5 * i
+        with torch.cuda.stream(streams[i % 2]):
+            r.render("clouds", w, h, .37, aux=aux, out=frames[i])
+    torch.cuda.synchronize()
+    r.set_variant(1)
+    for i in range(0, n, 3):
+        aux.cld_thick = 90.0 + 2.5 * i
+        ref = r.render("clouds", w, h, .37, aux=aux)
+        assert torch.equal(ref.view(torch.int32), frames[i].view(torch.int32)), i
+    r.close()
+
+
+def test_timing_is_per_stream(renderer):
+    """sbx_last_kernel_ms pairs the events of ONE launch even with launches in flight on two streams; an argument error
+    records nothing."""
+    import torch
+    import shaderbox_amd
+    r = shaderbox_amd.Renderer(0)
+    r.set_timing(True)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+    b = torch.empty((36, 64, 4), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            r.render("clouds", 1920, 1080, .37, out=a)
+        with torch.cuda.stream(s2):
+            r.render("clouds", 64, 36, .37, out=b)
+    small = r.last_kernel_ms()               # the last timed launch was the small one
+    with torch.cuda.stream(s1):
+        r.render("clouds", 1920, 1080, .37, out=a)
+    big = r.last_kernel_ms()
+    assert 0.0 < small < big
+    aux = shaderbox_amd.clouds_defaults()
+    aux.cld_march_steps = -1
+    with pytest.raises(shaderbox_amd.SbxError):
+        r.render("clouds", 64, 36, .37, aux=aux)
+    assert abs(r.last_kernel_ms() - big) < 1e-6                   # the failed call left the last pair alone
+    r.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# USE_NOISE_TEX build of APP_CLOUDS
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def volumes(renderer):
+    """two different baked volumes (ddsvolgen's tiled-Worley fBm at two sizes), device + host copies"""
+    v1 = renderer.worley_volume(32)
+    v2 = renderer.worley_volume(16)
+    return v1, v2, v1.cpu().numpy(), v2.cpu().numpy()
+
+
+def test_texture_filter_matches_oracle(renderer, oracle, volumes):
+    import torch
+    v1, v2, h1, h2 = volumes
+    rng = np.random.default_rng(7)
+    pts = np.concatenate([rng.uniform(-3, 3, (20000, 3)), rng.uniform(-1e4, 1e4, (2000, 3)),
+                          np.array([[0, 0, 0], [1, 1, 1], [.5 / 32, .5 / 32, .5 / 32], [1 - .5 / 32, .25, .75], [-1e-7, 0, 0],
+                                    [np.nan, 0, 0], [np.inf, .1, .2], [1e30, -1e30, 3e38]])]).astype(np.float32)
+    for dev, host in ((v1, h1), (v2, h2)):
+        gpu = renderer.tex3d(dev, torch.from_numpy(pts)).cpu().numpy()
+        ref = oracle.tex3d(host, pts)
+        both_nan = np.isnan(gpu) & np.isnan(ref)                  # non-finite coordinates: NaN on both sides (sign is not data)
+        assert np.array_equal(gpu.view(np.uint32)[~both_nan], ref.view(np.uint32)[~both_nan])
+        assert both_nan.sum() <= 3
+    # texel centres reproduce the texels
+    c = (np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(32), indexing="ij"), -1).reshape(-1, 3)[:, ::-1] + .5) / 32
+    got = renderer.tex3d(v1, torch.from_numpy(c.astype(np.float32))).cpu().numpy().reshape(32, 32, 32)
+    assert np.array_equal(got, h1[..., 0])
+
+
+@pytest.mark.parametrize("w,h,t", [(192, 108, 0.0), (256, 144, .37), (160, 160, 2.5)])
+def test_clouds_tex_matches_oracle(renderer, oracle, volumes, w, h, t):
+    from oracle.oracle import APP_CLOUDS_TEX
+    v1, v2, h1, h2 = volumes
+    renderer.set_noise_volumes(v1, v2)
+    oracle.set_noise_volumes(h1, h2)
+    ref = oracle.render(APP_CLOUDS_TEX, w, h, t)
+    gpu = renderer.render("clouds_tex", w, h, t).cpu().numpy()
+    maxd, nbits = compare(gpu, ref)
+    assert maxd <= 1e-4 and nbits == 0
+    assert np.isfinite(gpu).all() and gpu[h - 1].std() > 0        # clouds, not a flat sky
+
+
+def test_clouds_tex_aux_and_errors(renderer, oracle, volumes):
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS_TEX
+    v1, v2, h1, h2 = volumes
+    fresh = shaderbox_amd.Renderer(0)
+    with pytest.raises(shaderbox_amd.SbxError):                   # no volumes bound
+        fresh.render("clouds_tex", 64, 36, .37)
+    fresh.close()
+    renderer.set_noise_volumes(v2, v1)                            # swapped roles, other sizes
+    oracle.set_noise_volumes(h2, h1)
+    aux = shaderbox_amd.clouds_defaults()
+    aux.cld_march_steps, aux.illum_march_steps, aux.cld_coverage, aux.cld_thick = 37, 4, .7, 90.0
+    aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = .3, .5, -.8
+    aux.wind_dir[0], aux.wind_dir[1] = .1, .05
+    ref = oracle.render(APP_CLOUDS_TEX, 160, 90, 1.25, mouse=(1.5, 0.0), aux=aux)
+    gpu = renderer.render("clouds_tex", 160, 90, 1.25, mouse=(1.5, 0.0), aux=aux).cpu().numpy()
+    assert compare(gpu, ref) == (0.0, 0)
+
+
+def test_clouds_tex_full_size_rows(renderer, oracle):
+    """3840x2160 with two 128^3 volumes (the size ddsvolgen bakes): evenly spread full rows against the oracle."""
+    from oracle.oracle import APP_CLOUDS_TEX
+    v = renderer.worley_volume(128)
+    v2 = renderer.worley_volume(64)
+    renderer.set_noise_volumes(v, v2)
+    oracle.set_noise_volumes(v.cpu().numpy(), v2.cpu().numpy())
+    W, H = 3840, 2160
+    gpu = renderer.render("clouds_tex", W, H, .37)
+    rows = list(range(540, H, 100)) + [H - 1]
+    ref = oracle.render_rows(APP_CLOUDS_TEX, W, H, .37, rows)
+    got = gpu[rows].cpu().numpy()
+    assert compare(got, ref) == (0.0, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# wider full-size oracle coverage for the apps that have no second kernel variant
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("app,w,h,nrows", [("raytracer", 3840, 2160, 64), ("atmosphere", 7680, 4320, 64),
+                                           ("clouds_best", 3840, 2160, 64)])
+def test_full_size_many_rows_match_oracle(renderer, oracle, app, w, h, nrows):
+    from oracle.oracle import APP_IDS
+    rows = [int(round(i * (h - 1) / (nrows - 1))) for i in range(nrows)]
+    gpu = renderer.render(app, w, h, .37)
+    got = gpu[rows].cpu().numpy()
+    ref = oracle.render_rows(APP_IDS[app], w, h, .37, rows)
+    maxd, nbits = compare(got, ref)
+    print("%s %dx%d: %d rows, max|diff| %.3g, differing pixels %d" % (app, w, h, nrows, maxd, nbits))
+    assert maxd <= 1e-4 and nbits == 0
