@@ -14,31 +14,49 @@ One-time initialisation (code-object load, APP_CLOUDS' y table, first submission
 framebuffers, RCCL peer set-up) happens once before the W warm-up steps and is not a step.
 
 N = 1 : the frame is one kernel launch.
-N > 1 : one process per GPU (torch.distributed / RCCL).  The SAME frame is sharded as cyclic 8-row
-        blocks (shaderbox_amd/shard.py), every rank renders its blocks, ONE gather over xGMI brings the
-        slabs to rank 0, and one small kernel scatters them to their rows.  Total work is fixed ->
-        "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
+N > 1 : one process per GPU (torch.distributed / RCCL).  `python bench.py --gpus N` launched as a plain command starts
+        its own N ranks (re-executes itself under torch.distributed.run on 127.0.0.1); launched by torch.distributed.run
+        it uses the ranks it is given.  The SAME frame is sharded as cyclic 8-row blocks (shaderbox_amd/shard.py), every
+        rank renders its blocks, ONE gather over xGMI brings the slabs to rank 0, and one small kernel scatters them to
+        their rows.  Total work is fixed -> "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
 
-Extra objects on the JSON line:
-                 kernel_ms is the duration of an un-overlapped launch (measured after the timed region, one launch at a
-                 time); the committed rocprofv3 summary (profiles/r01_clouds_final_rocprof_summary.txt) is of this
-                 command with --streams 1 — with two frames in flight the per-kernel durations rocprof reports are
-                 stretched by the overlap.
+Extra objects on the JSON line (N = 1 unless noted):
+  roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel of HBM traffic),
+                 so bound = "valu":
+                   achieved / frac      algorithmic scalar fp ops per launch (SURVEY.md §8d per-pixel count x pixels)
+                                        / mean UN-OVERLAPPED launch duration (HIP events on the launch stream, measured
+                                        after the timed region one launch at a time) against the 157.3 TFLOP/s fp32
+                                        vector peak.  This is a USEFUL-WORK ratio: the count is of the REFERENCE
+                                        algorithm's operations, most of which the kernel no longer executes.
+                   valu_issue_frac      the HARDWARE view: VALU wave-instructions the kernel actually issued
+                                        (SQ_INSTS_VALU) x 2 cycles (wave64 on a SIMD-32) / (1024 SIMDs x the shader
+                                        cycles the launch was active = GRBM_GUI_ACTIVE / 8 XCDs, same pass).
+                   valu_busy_pct        rocprofv3's VALUBusy halved (its gfx94x formula assumes 4-cycle issue).
+                   traffic              HBM bytes per launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction of
+                                        MI355X_MICROARCH.md), separate PMC passes.
+                 The three PMC-derived fields are measured in this run (`--pmc auto`: rocprofv3 is started on a short
+                 serial run of this script, one counter group per pass; `pmc_source` says so) or, when rocprofv3 is not
+                 usable, taken from the committed summary under profiles/ (named in `pmc_source`), or null.
   roofline_hbm : the same kernel against HBM (16 B/pixel written once): far from the bound by design.
-  roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel
-                 of HBM traffic), so bound = "valu": achieved = algorithmic scalar fp ops per launch
-                 (SURVEY.md §8d per-pixel count x pixels) / mean launch duration measured with HIP events on
-                 the launch stream; peak = 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md); the same figure against the
-                 39.3 T lane-ops/s scalar-issue ceiling of SURVEY.md §8d is `frac_of_scalar_issue_ceiling` (above 1: the
-                 count is of the REFERENCE algorithm's operations, most of which the kernel no longer executes).
-                 `roofline_hbm` gives the framebuffer store rate for completeness.
-  cpu_baseline : the CPU oracle (kind "port") timed on this host's cores on a bounded sample of the same
-                 frame (every 8th row), rank 0, N = 1 only.
+  serial       : Mpixels/s of one un-overlapped launch (SURVEY.md §8d defines the metric per launch; `value` has
+                 `frames_in_flight` launches overlapping).
+  parity       : rows of the timed GPU frame against the CPU oracle's rows of the same frame (the ones cpu_baseline
+                 renders): max |diff| and pixels with any differing bit.  > 1e-4 -> non-zero exit status.
+                 N > 1: the assembled frame against a one-launch render of the same frame on rank 0 (bit-identical).
+  cpu_baseline : the CPU oracle (kind "port") timed on this host's cores on a bounded sample of the same frame (every
+                 k-th row, dealt to the threads in 64-pixel tiles), strict build (g++ -O2 -ffp-contract=off).
+  cpu_baseline_speed : the same sample with the optimisation level of the reference's own C++ build
+                 (-O3 -march=native -funroll-loops, /root/reference/src/Makefile:12-13), compiled on this host at run time.
+  other_configs: the other BASELINE.json GPU configs, timed the same way (pipelined frames + un-overlapped kernel time).
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -47,13 +65,55 @@ sys.path.insert(0, ROOT)
 # algorithmic scalar fp ops per pixel at the canonical frame (every
 # transcendental counted as ONE op), measured at the listed resolution
 OPS_PER_PIXEL = {"clouds": 60248.0, "egg": 15276.0, "raytracer": 564.0, "atmosphere": 2493.0,
-                 "planet": 21253.0, "sdf_ao": 7255.0}       # (no survey count for vinyl: roofline is omitted there)
-# HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (WRITE_SIZE + 2 x FETCH_SIZE,
-# KB -> bytes, per MI355X_MICROARCH.md), for the default workload only; see DESIGN.md §6
-MEASURED_TRAFFIC_BYTES = {("clouds", 3840, 2160): int(129600 * 1024 + 2 * 187.415 * 1024)}   # profiles/r01_clouds_final_*
+                 "planet": 21253.0, "sdf_ao": 7255.0}       # (no survey count for vinyl / clouds_best / clouds_tex)
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 SCALAR_ISSUE_TLANEOPS = 39.3        # 256 CU x 64 lanes x 2.4 GHz: one non-packed, non-FMA lane-op per lane per cycle (SURVEY.md §8d ii)
 PEAK_HBM_GBPS = 8000.0
+N_SIMD = 1024                       # 256 CU x 4
+VALU_ISSUE_CYCLES = 2.0             # wave64 VALU instruction on a SIMD-32 (MI355X_MICROARCH.md)
+NOMINAL_CLOCK_HZ = 2.4e9
+# the other BASELINE.json configs that fit one GPU: (app, W, H) — C2, C3, C5 (both apps)
+OTHER_CONFIGS = [("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320)]
+KERNEL_OF = {"clouds": "k_clouds", "egg": "k_egg", "raytracer": "k_raytracer", "atmosphere": "k_atmosphere",
+             "planet": "k_planet", "sdf_ao": "k_sdf_ao", "vinyl": "k_vinyl", "clouds_best": "k_clouds_best",
+             "clouds_tex": "k_clouds_tex"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` as a plain command: start N ranks of this script under torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env["SBX_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args):
+    """--launch-check: ranks only rendezvous (gloo, no GPU) and rank 0 prints one JSON line; tests the launcher."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
+                          "self_launched": os.environ.get("SBX_BENCH_SELF_LAUNCHED") == "1"}))
+    dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -72,7 +132,7 @@ def main():
                     help="N>1: root relief 'm0/m' — row-blocks go out in cycles of m rounds and rank 0 (the gather's root, which "
                          "also lands N-1 slabs and assembles the frame) sits out the rounds >= m0; '1/1' = plain cyclic split; "
                          "'auto' (default) measures the root's per-frame landing+assembly cost against its render time on rank 0 "
-                         "and picks m0/8 so that all ranks finish together (shaderbox_amd/shard.py relief_rounds)")
+                         "and picks the split whose modelled slowest rank is fastest (shaderbox_amd/shard.py best_relief)")
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight: consecutive frames alternate over this many HIP streams, each with its own "
                          "framebuffers, so the drain of one frame's kernel overlaps the next frame (1 = strictly serial)")
@@ -81,7 +141,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=0,
                     help="cpu_baseline renders every k-th row of the frame (0 = pick from the core count: ~10 s of wall time)")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "live", "profiles", "off"],
+                    help="where roofline.traffic / valu_issue_frac / valu_busy_pct come from: 'live' = rocprofv3 passes of a short "
+                         "serial run of this script, 'profiles' = the committed summary, 'auto' = live, else profiles, else null")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (the driver's command shape at N = 1, 2, 4, 8)
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if args.launch_check:
+        sys.exit(launch_check(args))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit("bench.py --gpus %d runs under WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     # HIP maps streams onto a few hardware queues (4 by default); two streams that share a queue do not overlap at all,
     # and this process uses up to four (default, two frame streams, RCCL's): ask for more queues before HIP starts.
@@ -90,13 +166,6 @@ def main():
     import shaderbox_amd
     from shaderbox_amd import shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
     dist = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -115,9 +184,9 @@ def main():
 
     ns = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(ns)] if ns > 1 else [torch.cuda.current_stream(dev)]
+    relief = (1, 1)
     if not use_dist:
         frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
-        frame = frames[0]
 
         def step(i=0):
             with torch.cuda.stream(streams[i % ns]):
@@ -158,17 +227,17 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    kernel_ms = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     sync()
     elapsed = time.perf_counter() - t0
-    # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region so that
-    # the event queries do not perturb it)
-    for _ in range(min(args.steps, 5)):
+    # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region, one launch at a time,
+    # so that the event queries do not perturb it and the launches do not overlap)
+    kernel_ms = []
+    for _ in range(min(max(args.steps, 3), 10)):
         if not use_dist:
-            R.render(app, W, H, t, out=frame)
+            R.render(app, W, H, t, out=frames[0])
         else:
             R.render_rank(app, W, H, t, br, rank, world, out=slab, root_rounds=relief[0], rounds=relief[1])
         kernel_ms.append(R.last_kernel_ms())
@@ -183,26 +252,33 @@ def main():
     else:
         kmean = sum(kernel_ms) / len(kernel_ms)
 
+    status = 0
     if rank == 0:
         pixels = W * H
         ms_per_step = elapsed * 1e3 / args.steps
         value = pixels / (ms_per_step * 1e-3) / 1e6
         ops = OPS_PER_PIXEL.get(app)
         launch_pixels = pixels if not use_dist else shard.rank_rows(H, br, 0, world, relief[0], relief[1]) * W
-        roofline = None
+        roofline = roofline_hbm = None
         if ops is not None:
             achieved = ops * launch_pixels / (kmean * 1e-3) / 1e12
-            roofline = {"bound": "valu", "kernel": "k_" + app, "achieved": round(achieved, 4),
+            roofline = {"bound": "valu", "kernel": KERNEL_OF.get(app, "k_" + app), "achieved": round(achieved, 4),
                         "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5),
+                        "frac_is": "useful-work ratio: reference-algorithm ops / kernel time / fp32 vector peak (the kernel executes "
+                                   "far fewer operations than the reference algorithm); hardware utilisation is valu_issue_frac",
                         "frac_of_scalar_issue_ceiling": round(achieved / SCALAR_ISSUE_TLANEOPS, 4),
                         "ops_per_pixel": ops, "pixels_per_launch": launch_pixels,
-                        "kernel_ms": round(kmean, 4),
-                        "traffic": MEASURED_TRAFFIC_BYTES.get((app, W, H)) if world == 1 else None}
+                        "kernel_ms": round(kmean, 4), "kernel_ms_min": round(min(kernel_ms), 4),
+                        "traffic": None, "valu_issue_frac": None, "valu_busy_pct": None, "pmc_source": None}
             hbm = 16.0 * launch_pixels / (kmean * 1e-3) / 1e9
-            roofline_hbm = {"bound": "hbm", "kernel": "k_" + app, "achieved": round(hbm, 2), "peak": PEAK_HBM_GBPS,
-                            "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBPS, 5), "bytes_per_pixel": 16,
-                            "traffic": MEASURED_TRAFFIC_BYTES.get((app, W, H)) if world == 1 else None}
+            roofline_hbm = {"bound": "hbm", "kernel": KERNEL_OF.get(app, "k_" + app), "achieved": round(hbm, 2),
+                            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBPS, 5),
+                            "bytes_per_pixel": 16, "traffic": None}
+            if world == 1 and not use_dist and args.pmc != "off":
+                pmc = pmc_counters(args, app, W, H, t)
+                if pmc:
+                    fill_pmc(roofline, roofline_hbm, pmc, kmean)
         out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(value, 3),
                "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
@@ -213,13 +289,201 @@ def main():
                           "parallelism": "1 GPU, one launch per frame" if world == 1 else
                                          "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + 1 RCCL gather "
                                          "(in %d pipelined pieces) + assemble" % (br, world, relief[0], relief[1], args.gather_groups)},
-               "roofline": roofline, "roofline_hbm": roofline_hbm if ops is not None else None}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(app, W, H, t, args.cpu_row_stride)
+               "serial": {"value": round(launch_pixels / (kmean * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
+                          "what": "one un-overlapped launch (HIP events), %d pixels" % launch_pixels},
+               "roofline": roofline, "roofline_hbm": roofline_hbm}
+        if use_dist:
+            # the assembled frame of the multi-GPU path against a one-launch render of the same frame: same bits
+            whole = R.render(app, W, H, t)
+            a, b = plans[(args.steps - 1) % ns].frame.view(torch.int32), whole.view(torch.int32)
+            bad = int((a != b).any(dim=-1).sum().item())
+            out["parity"] = {"against": "one-launch render of the same frame on rank 0", "rows": H,
+                             "mismatching_pixels": bad}
+            if bad:
+                status = 3
+        elif not args.no_cpu_baseline:
+            base, rows, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
+            out["cpu_baseline"] = base
+            # parity of the TIMED frame: the oracle rows just rendered against the same rows of the GPU frame
+            gpu = frames[(args.steps - 1) % ns][rows].cpu().numpy()
+            out["parity"] = parity(gpu, ref, len(rows))
+            if not (out["parity"]["max_abs_diff"] <= 1e-4):
+                status = 3
+            speed = cpu_baseline_speed(app, W, H, t, rows)
+            if speed is not None:
+                out["cpu_baseline_speed"] = speed
+        if world == 1 and not use_dist and not args.no_other_configs and app == "clouds":
+            out["other_configs"] = other_configs(R, torch, dev, streams, t)
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(status)
+
+
+def parity(gpu, ref, nrows):
+    import numpy as np
+    both_nan = np.isnan(gpu) & np.isnan(ref)
+    d = np.where(both_nan, 0.0, np.abs(gpu.astype(np.float64) - ref.astype(np.float64)))
+    d = np.nan_to_num(d, nan=np.inf)
+    bits = (gpu.view(np.uint32) != ref.view(np.uint32)) & ~both_nan
+    return {"against": "CPU oracle (oracle/), same frame", "rows": nrows, "pixels": int(gpu.shape[0] * gpu.shape[1]),
+            "max_abs_diff": float(d.max()), "mismatching_pixels": int(bits.any(axis=-1).sum()), "tolerance": 1e-4}
+
+
+def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2):
+    """pipelined frames (as the headline) + un-overlapped kernel time of one config"""
+    ns = len(streams)
+    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
+
+    def step(i):
+        with torch.cuda.stream(streams[i % ns]):
+            R.render(app, W, H, t, out=frames[i % ns])
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    k = []
+    for _ in range(5):
+        R.render(app, W, H, t, out=frames[0])
+        k.append(R.last_kernel_ms())
+    torch.cuda.synchronize(dev)
+    del frames
+    kmean = sum(k) / len(k)
+    ops = OPS_PER_PIXEL.get(app)
+    achieved = ops * W * H / (kmean * 1e-3) / 1e12 if ops else None
+    return {"workload": "APP_%s %dx%d u_time=%g" % (app.upper(), W, H, t), "value": round(W * H / (ms * 1e-3) / 1e6, 2),
+            "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "steps": steps, "frames_in_flight": ns,
+            "kernel": KERNEL_OF.get(app), "kernel_ms": round(kmean, 4),
+            "serial_value": round(W * H / (kmean * 1e-3) / 1e6, 2),
+            "roofline": None if achieved is None else
+            {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "ops_per_pixel": ops},
+            "hbm_store_gbps": round(16.0 * W * H / (kmean * 1e-3) / 1e9, 1)}
+
+
+def other_configs(R, torch, dev, streams, t):
+    return [time_config(R, torch, dev, streams, a, w, h, t) for a, w, h in OTHER_CONFIGS]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# PMC-derived roofline fields
+# ---------------------------------------------------------------------------------------------------------
+PMC_PASSES = [("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"]),
+              ("busy", ["VALUBusy", "VALUUtilization"]),
+              ("wr", ["WRITE_SIZE"]),
+              ("rd", ["FETCH_SIZE"])]
+
+
+def run_pmc_pass(counters, app, W, H, t, outdir, timeout=240):
+    """one rocprofv3 counter pass (kernel-trace + pmc only) over a short serial run of this script; returns
+    {counter: mean over the dispatches of the app's render kernel}"""
+    import csv
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    cmd = [exe, "--kernel-trace", "-f", "csv", "--pmc"] + counters + ["-d", outdir, "-o", "pmc", "--", sys.executable,
+           os.path.abspath(__file__), "--app", app, "--width", str(W), "--height", str(H), "--time", repr(t), "--steps", "4",
+           "--warmup", "1", "--streams", "1", "--no-cpu-baseline", "--pmc", "off", "--no-other-configs"]
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    except (subprocess.TimeoutExpired, OSError):
+        return None
+    if r.returncode != 0:
+        return None
+    kname = KERNEL_OF.get(app, "k_" + app)
+
+    def mine(kn):
+        return ("sbx::" + kname + "<") in kn or ("sbx::" + kname + "(") in kn
+    rows = []
+    for base, _, files in os.walk(outdir):
+        for f in files:
+            if f.endswith("counter_collection.csv"):
+                rows += [row for row in csv.DictReader(open(os.path.join(base, f))) if mine(row.get("Kernel_Name", ""))]
+    # only the full-frame launches count (the run also renders one 64x36 frame per stream while initialising)
+    grid = max([float(row.get("Grid_Size", 0) or 0) for row in rows], default=0.0)
+    acc = {}
+    for row in rows:
+        if float(row.get("Grid_Size", 0) or 0) == grid:
+            acc.setdefault(row.get("Counter_Name", "?"), []).append(float(row.get("Counter_Value", "nan")))
+    res = {c: sum(v) / len(v) for c, v in acc.items()}
+    dur = []
+    for base, _, files in os.walk(outdir):
+        for f in files:
+            if f.endswith("kernel_trace.csv"):
+                for row in csv.DictReader(open(os.path.join(base, f))):
+                    if mine(row.get("Kernel_Name", "")):
+                        try:
+                            dur.append((float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-6)
+                        except (KeyError, ValueError):
+                            pass
+    dur = [d for d in dur if d >= .5 * max(dur)] if dur else []
+    if dur and "GRBM_GUI_ACTIVE" in res:
+        res["kernel_ms_profiled"] = sum(dur) / len(dur)
+    return res or None
+
+
+def pmc_counters(args, app, W, H, t):
+    """{counter: per-launch mean} + 'source'.  live: rocprofv3 passes now; profiles: profiles/r02_pmc_<app>_<W>x<H>.json"""
+    committed = os.path.join(ROOT, "profiles", "r02_pmc_%s_%dx%d.json" % (app, W, H))
+    if args.pmc in ("auto", "live"):
+        tmp = tempfile.mkdtemp(prefix="sbx_pmc_")
+        got = {}
+        try:
+            for name, counters in PMC_PASSES:
+                res = run_pmc_pass(counters, app, W, H, t, os.path.join(tmp, name))
+                if res is None:
+                    got = None
+                    break
+                got.update(res)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        if got:
+            got["source"] = "live: rocprofv3 --kernel-trace --pmc passes of `bench.py --steps 4 --warmup 1 --streams 1` in this run"
+            return got
+        if args.pmc == "live":
+            return None
+    if os.path.exists(committed):
+        got = json.load(open(committed))
+        got["source"] = "committed: profiles/" + os.path.basename(committed)
+        return got
+    return None
+
+
+def fill_pmc(roofline, roofline_hbm, pmc, kmean_ms):
+    roofline["pmc_source"] = pmc.get("source")
+    if "WRITE_SIZE" in pmc and "FETCH_SIZE" in pmc:      # KB; gfx950: FETCH_SIZE counts half of a wide streaming read
+        traffic = int(pmc["WRITE_SIZE"] * 1024 + 2 * pmc["FETCH_SIZE"] * 1024)
+        roofline["traffic"] = roofline_hbm["traffic"] = traffic
+        roofline["traffic_over_algorithmic"] = round(traffic / (16.0 * roofline["pixels_per_launch"]), 4)
+    if "SQ_INSTS_VALU" in pmc:
+        insts = pmc["SQ_INSTS_VALU"]
+        roofline["valu_insts_per_launch"] = insts
+        if "GRBM_GUI_ACTIVE" in pmc:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = shader cycles the profiled launch was active, whatever the clock
+            active = pmc["GRBM_GUI_ACTIVE"] / 8.0
+            roofline["valu_issue_frac"] = round(insts * VALU_ISSUE_CYCLES / (N_SIMD * active), 4)
+            roofline["valu_issue_frac_what"] = ("SQ_INSTS_VALU x %g issue cycles / (%d SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): share of "
+                                                "the VALU issue slots of the launch's active cycles that carried an instruction"
+                                                % (VALU_ISSUE_CYCLES, N_SIMD))
+            if pmc.get("kernel_ms_profiled"):
+                roofline["shader_clock_ghz_profiled"] = round(active / (pmc["kernel_ms_profiled"] * 1e-3) / 1e9, 3)
+                roofline["kernel_ms_profiled"] = round(pmc["kernel_ms_profiled"], 4)
+        roofline["valu_issue_frac_at_2p4ghz"] = round(insts * VALU_ISSUE_CYCLES / (N_SIMD * kmean_ms * 1e-3 * NOMINAL_CLOCK_HZ), 4)
+    if "VALUBusy" in pmc:
+        roofline["valu_busy_pct"] = round(pmc["VALUBusy"] / 2.0, 2)      # gfx94x formula assumes 4-cycle issue; gfx950 issues in 2
+        roofline["valu_busy_pct_raw_rocprof"] = round(pmc["VALUBusy"], 2)
+    if "VALUUtilization" in pmc:
+        roofline["valu_lane_utilization_pct"] = round(pmc["VALUUtilization"], 2)
 
 
 def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, streams):
@@ -267,21 +531,43 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
     return (int(pick[0].item()), int(pick[1].item()))
 
 
+def cpu_rows(H, stride, cores):
+    if stride <= 0:
+        stride = 8 if cores <= 16 else (4 if cores <= 64 else 2)
+    return stride, list(range(stride // 2, H, stride))
+
+
 def cpu_baseline(app, W, H, t, stride):
-    """The CPU oracle ('port' of the reference path, oracle/) on this host's cores, bounded sample."""
+    """The CPU oracle ('port' of the reference path, oracle/) on this host's cores, bounded sample.  Returns the
+    baseline object, the row indices and the rendered rows (the parity check reuses them)."""
     from oracle.oracle import APP_IDS, Oracle
     o = Oracle()
     cores = os.cpu_count() or 1
-    if stride <= 0:
-        stride = 8 if cores <= 16 else (4 if cores <= 64 else 2)
-    rows = list(range(stride // 2, H, stride))
-    o.render_rows(APP_IDS[app], W, H, t, rows[:cores], threads=cores)   # warm the threads/caches
+    stride, rows = cpu_rows(H, stride, cores)
+    o.render_rows(APP_IDS[app], W, H, t, rows[:max(1, cores // 60)], threads=cores)   # warm the threads/caches
+    t0 = time.perf_counter()
+    ref = o.render_rows(APP_IDS[app], W, H, t, rows, threads=cores)
+    dt = time.perf_counter() - t0
+    return ({"value": round(len(rows) * W / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+             "sample": "%d of %d rows (every %dth row) of the same %dx%d frame in 64-pixel tiles, %.1f s, g++ -O2 -ffp-contract=off"
+                       % (len(rows), H, stride, W, H, dt)}, rows, ref)
+
+
+def cpu_baseline_speed(app, W, H, t, rows):
+    """The same sample with the reference build's optimisation level (-O3 -march=native -funroll-loops), compiled HERE."""
+    from oracle.oracle import APP_IDS, Oracle
+    try:
+        o = Oracle(variant="_speed", subdir="_speed", rebuild=True)
+    except Exception:
+        return None
+    cores = os.cpu_count() or 1
+    o.render_rows(APP_IDS[app], W, H, t, rows[:max(1, cores // 60)], threads=cores)
     t0 = time.perf_counter()
     o.render_rows(APP_IDS[app], W, H, t, rows, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": round(len(rows) * W / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "%d of %d rows (every %dth row) of the same %dx%d frame, %.1f s, g++ -O2 -ffp-contract=off"
-                      % (len(rows), H, stride, W, H, dt)}
+            "sample": "the same %d rows, %.1f s, g++ -O3 -march=native -funroll-loops (timing only: contraction allowed, "
+                      "pixels not compared)" % (len(rows), dt)}
 
 
 if __name__ == "__main__":

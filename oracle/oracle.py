@@ -17,18 +17,18 @@ APP_IDS = {"planet": APP_PLANET, "clouds": APP_CLOUDS, "egg": APP_EGG, "raytrace
            "clouds_tex": APP_CLOUDS_TEX}
 
 
-def build(variant=""):
+def build(variant="", subdir=""):
     """(Re)build the oracle library with oracle/Makefile; returns its path."""
-    name = "libsbx_oracle%s.so" % variant
+    name = os.path.join(subdir, "libsbx_oracle%s.so" % variant)
     subprocess.run(["make", "-s", "-C", _HERE, name], check=True)
     return os.path.join(_HERE, name)
 
 
 class Oracle:
-    def __init__(self, variant="", rebuild=False):
-        path = os.path.join(_HERE, "libsbx_oracle%s.so" % variant)
+    def __init__(self, variant="", rebuild=False, subdir=""):
+        path = os.path.join(_HERE, subdir, "libsbx_oracle%s.so" % variant)
         if rebuild or not os.path.exists(path):
-            path = build(variant)
+            path = build(variant, subdir)
         self.lib = ctypes.CDLL(path)
         fp = ctypes.POINTER(ctypes.c_float)
         self.lib.sbxo_main_image.argtypes = [ctypes.c_int, fp, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, fp]

@@ -105,7 +105,8 @@ int sbxo_main_image(int app, const float* uniforms, const void* aux, float fx, f
 }
 
 /* Render the listed rows (global row indices, 0 = bottom) of a W x H frame into
- * out[nrows][W][4]; rows are dealt to `nthreads` std::threads through an atomic counter. */
+ * out[nrows][W][4]; the work is dealt to `nthreads` std::threads through an atomic counter in tiles of 64 pixels of
+ * one row (dealing whole rows leaves most of a many-core host idle behind the last few expensive rows). */
 int sbxo_render_rows(int app, const float* uniforms, const void* aux, const int* rows, int nrows,
                      float* out, int nthreads) {
     uniforms_t U; U.u_res = vec2(uniforms[0], uniforms[1]); U.u_mouse = vec2(uniforms[2], uniforms[3]); U.u_time = uniforms[4];
@@ -113,14 +114,19 @@ int sbxo_render_rows(int app, const float* uniforms, const void* aux, const int*
     float probe[4];
     if (!pixel(app, U, aux, .5f, .5f, probe)) return -1;
     if (nthreads < 1) nthreads = 1;
-    std::atomic<int> next(0);
+    const int TILE = 64;
+    const int tiles_x = (W + TILE - 1) / TILE;
+    const long ntiles = (long)nrows * tiles_x;
+    std::atomic<long> next(0);
     auto work = [&]() {
         for (;;) {
-            int r = next.fetch_add(1);
-            if (r >= nrows) break;
+            const long i = next.fetch_add(1);
+            if (i >= ntiles) break;
+            const int r = (int)(i / tiles_x), x0 = (int)(i % tiles_x) * TILE;
+            const int x1 = x0 + TILE < W ? x0 + TILE : W;
             const int y = rows[r];
             float* dst = out + (size_t)r * W * 4;
-            for (int x = 0; x < W; ++x) pixel(app, U, aux, (float)x + .5f, (float)y + .5f, dst + 4 * x);
+            for (int x = x0; x < x1; ++x) pixel(app, U, aux, (float)x + .5f, (float)y + .5f, dst + 4 * x);
         }
     };
     std::vector<std::thread> th;

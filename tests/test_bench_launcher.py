@@ -1,0 +1,64 @@
+"""bench.py's launcher and JSON contract.
+
+CPU: `python bench.py --gpus N` started as a plain command (no torch.distributed.run around it, the shape the driver
+uses at N = 1) must start its own N ranks; --launch-check makes the ranks rendezvous over gloo without touching a GPU.
+GPU: the JSON line of a short run carries the contract keys, the parity record and the N > 1 code path (--force-dist)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_plain_command_starts_its_own_ranks(n):
+    r, line = run_bench("--gpus", str(n), "--launch-check", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line == {"launch_check": True, "n_gpus": n, "rank_sum": float(sum(range(n))), "self_launched": True}
+
+
+def test_under_torchrun_uses_the_given_ranks():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["self_launched"] is False
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_and_parity():
+    r, line = run_bench("--steps", "3", "--warmup", "1", "--width", "640", "--height", "360", "--pmc", "off", "--cpu-row-stride", "8")
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_speed", "parity", "serial", "other_configs"):
+        assert k in line, k
+    assert line["parity"]["mismatching_pixels"] == 0 and line["parity"]["max_abs_diff"] == 0.0 and line["parity"]["rows"] == 45
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["value"] > 0
+    assert line["roofline"]["bound"] == "valu" and 0 < line["roofline"]["frac"]
+    assert [c["kernel"] for c in line["other_configs"]] == ["k_egg", "k_raytracer", "k_atmosphere", "k_planet"]
+    assert all(c["value"] > 0 and c["kernel_ms"] > 0 for c in line["other_configs"])
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_code_path_on_one_gpu():
+    """--force-dist runs render_rank + RCCL gather + assemble with one rank; the record carries the frame comparison"""
+    r, line = run_bench("--force-dist", "--steps", "3", "--warmup", "1", "--width", "640", "--height", "360")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 1 and line["parity"]["mismatching_pixels"] == 0 and line["parity"]["rows"] == 360
