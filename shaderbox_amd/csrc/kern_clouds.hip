@@ -7,7 +7,26 @@
 #include "sbx_device.h"
 #include "sbx_noise.h"
 #include "sbx_hashcache.h"
+#include <cmath>
 #include <cstdlib>
+
+#ifndef CL_SPEC_READS
+#define CL_SPEC_READS 0
+#endif
+#ifndef CL_NO_REG
+#define CL_NO_REG 0       // 1: never use the REG kernels (A/B timing)
+#endif
+#ifndef CL_EXP_LDS
+#define CL_EXP_LDS 1       // exp_ reads its table from LDS (0: from __constant__ memory through the vector L1)
+#endif
+#if CL_EXP_LDS
+#define CL_EXP(x) exp_tab_((x), etab)
+#else
+#define CL_EXP(x) exp_(x)
+#endif
+#ifndef CL_MIN_WAVES
+#define CL_MIN_WAVES 4     // waves per SIMD the register allocation is held to (__launch_bounds__)
+#endif
 
 namespace sbx {
 
@@ -222,13 +241,26 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
         miss_mask |= wave_mask(ne[k]);
         qx = qx * 2.64f; qz = qz * 2.64f;
     }
+#if CL_SPEC_READS
+    // The hashes are read together with the tags, before the hit test: ONE LDS round trip per stage instead of two
+    // (tags -> test -> hashes).  On a miss (18 % of the calls) the reads were wasted bandwidth, of which there is plenty.
+    float4 lo[4], hi[4];
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        lo[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
+        hi[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
+        asm volatile("" : "+v"(lo[k].x), "+v"(lo[k].y), "+v"(lo[k].z), "+v"(lo[k].w), "+v"(hi[k].x), "+v"(hi[k].y), "+v"(hi[k].z), "+v"(hi[k].w));
+    }
+#endif
     if (!wave_any_mask(miss_mask & active_mask)) {
+#if !CL_SPEC_READS
         float4 lo[4], hi[4];
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
             lo[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
             hi[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
         }
+#endif
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
             float ab, cd;
@@ -284,10 +316,21 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 // blend are the SAME binary32 values for all light samples of the step.  They are computed once; per
 // sample only the z terms, the cell lookup and the final z-mix remain.  Every value is produced by the
 // same operations on the same inputs as in the general path, hence identical bits.
-template <bool YTAB>
+// REG ("regular frame", decided on the host per launch: launch_clouds): the coverage edge and its reciprocal are finite and
+// |sigma * dt| <= 80.  Then (a) exp_'s binary32 range guard is the identity for every argument the march can produce
+// (-d * sigma * dt with d in [0, 1) or NaN) and is left out, (b) the smoothstep clamp is one v_med3_f32
+// (sbx_math.h x_smoothstep_rd_med3), and (c) "did the sample leave its lattice cell" is decided without a floor:
+// az = qz - curz is the fract the reference computes iff floor(qz) == curz, and
+//     0 <= RN(qz - curz) < 1   ==>   curz <= qz < curz + 1   ==>   floor(qz) == curz
+// (a float difference is never rounded to zero or across zero; a difference >= 1 is never rounded below 1), so ONE
+// unsigned compare of az's bits against those of 1.0f replaces v_floor + v_cmp (both half-rate instructions on gfx950,
+// profiles/r02_ubench_issue.txt).  The test is conservative (a fract that rounds up to 1.0 is treated as a move);
+// a move recomputes floor / fract / lookups exactly as the general form does.
+template <bool YTAB, bool REG>
 __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                WaveCache& S, int lane, const YRow& row, const float (&mfx)[4],
-                                               const float (&mnxy)[4]) {
+                                               const float (&mnxy)[4], const double (&etab)[32], float vsigma, float vdt,
+                                               float vcov) {
     float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4], curz[4];
     if (YTAB) {
         // lp.x = pos.x + 0 and lp.y = pos.y + 0: the x terms are the main sample's own (same operations on
@@ -322,22 +365,35 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
     for (int j = 0; j < F.lsteps; ++j) {
         // z terms of the sample.  The cell of octave k is the one of the previous sample iff floor(z) is (nxy is
         // fixed), and then ab/cd still hold its x/y blends whatever happened to the cache since: no lookup at all.
-        float fz[4], pzv[4];
+        float az[4], pzv[4];
         unsigned long long moved_mask = 0;
         float qz = (lp.z * .001f) * 2.03f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float pz = floor_(qz);
-            const float az = qz - pz;
-            fz[k] = az * az * (3.0f - 2.0f * az);
-            pzv[k] = pz;
-            moved_mask |= wave_mask(pz != curz[k]);       // first sample: curz is NaN, always true
+            if (REG) {
+                az[k] = qz - curz[k];                         // first sample: curz is NaN -> az NaN -> "moved"
+                moved_mask |= wave_mask(f2u(az[k]) >= 0x3f800000u);       // not (+0 <= az < 1)
+            } else {
+                const float pz = floor_(qz);
+                az[k] = qz - pz;
+                pzv[k] = pz;
+                moved_mask |= wave_mask(pz != curz[k]);       // first sample: curz is NaN, always true
+            }
             qz = qz * 2.64f;
         }
         if (wave_any_mask(moved_mask & lit_mask)) {
 #ifdef SBX_CL_STATS
             if (lane == 0) S.stat[3] += 1.f;
 #endif
+            if (REG) {                                        // the general form's floor / fract, for every lane and octave
+                float q2 = (lp.z * .001f) * 2.03f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pzv[k] = floor_(q2);
+                    az[k] = q2 - pzv[k];
+                    q2 = q2 * 2.64f;
+                }
+            }
             // some lit lane entered another cell in some octave: look all four up again (one uniform branch
             // per sample costs less than one per octave) and redo the x/y blends
             unsigned nbits[4];
@@ -377,12 +433,20 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
         float t = 0.f, H = .5f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gz = 1.0f - fz[k];
-            t += (ab[k] * gz + cd[k] * fz[k]) * H;
+            const float fz = az[k] * az[k] * (3.0f - 2.0f * az[k]);
+            const float gz = 1.0f - fz;
+            const float term = (ab[k] * gz + cd[k] * fz) * H;
+            // fbm's t = 0; t += ...: a blend of hashes in [0, 1) with weights in [0, 1] is >= +0 (or NaN), and 0 + x == x then
+            t = (REG && k == 0) ? term : t + term;
             H *= .5f;
         }
-        const float d = t * smoothstep_rd(F.cov, F.cov_rd, t);
-        ltrans *= exp_(-d * F.sigma * F.dt);
+        if (REG) {
+            const float d = x_smoothstep_rd_med3(vcov, F.cov_rd, t);
+            ltrans *= exp_tab_<false>(-d * vsigma * vdt, etab);
+        } else {
+            const float d = t * smoothstep_rd(F.cov, F.cov_rd, t);
+            ltrans *= CL_EXP(-d * F.sigma * F.dt);
+        }
         lp = lp + lstep;
     }
     return ltrans;
@@ -403,15 +467,21 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
 #ifndef CL_TX
 #define CL_TX 1
 #endif
+#ifndef CL_TOP_FIRST
+#define CL_TOP_FIRST false  // measured: top rows first is SLOWER (4.16 vs 4.01 ms): the heaviest tiles are the ones just above the horizon
+#endif
 #ifndef CL_TW
 #define CL_TW 32          // wave tile CL_TW x 64/CL_TW pixels (profiles/r01_tile_shapes.txt)
 #endif
-template <bool YTAB>
-__global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out,
+template <bool YTAB, bool REG>
+__global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out,
                                                           const YRow* __restrict__ ytab) {
     __shared__ WaveCache cache[CL_TX];
+    __shared__ double etab[32];                  // exp_'s 2^(j/32) table: per-lane reads come from LDS, not from the vector L1
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
+    if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    if (CL_TX > 1) __syncthreads();
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
 #ifdef SBX_CL_STATS
     if (lane < 4) S.stat[lane] = 0.f;
@@ -427,7 +497,7 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
         // Only what the march needs stays live across it (origin, projection, phase): the view direction
         // and the sky colour are recomputed in the epilogue from the pixel coordinates — same operations,
         // same bits — which keeps the register budget of the march at 4 waves per SIMD without spills.
-        const Pixel px = pixel_of_thread<CL_TW, CL_TX>(M);
+        const Pixel px = pixel_of_thread<CL_TW, CL_TX, CL_TOP_FIRST>(M);
         const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
         const v3 dir = primary_dir(F.cam, pc);
         const float cutoff = dot(dir, V3(0, 1, 0));
@@ -438,6 +508,10 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
             const v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
             const float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
             const v3 lstep = F.sun_dir * F.dt;
+            // frame constants the light march multiplies / subtracts with, held in VGPRs: an fp32 VALU instruction with an
+            // SGPR source issues at half rate on gfx950 (profiles/r02_ubench_issue.txt)
+            float vsigma = F.sigma, vdt = F.dt, vcov = F.cov;
+            asm volatile("" : "+v"(vsigma), "+v"(vdt), "+v"(vcov));
             float t = 0.f;
             unsigned long long alive_mask = wave_mask(alive);
             for (int i = 0; i < F.steps; ++i) {
@@ -458,15 +532,15 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
 #ifdef SBX_CL_STATS
                     st_lit += 1.f; st_litl += (float)__builtin_popcountll(lit_mask);
 #endif
-                    const float T_i = exp_(-density * F.sigma * F.dt);
+                    const float T_i = REG ? exp_tab_<false>(-density * vsigma * vdt, etab) : CL_EXP(-density * F.sigma * F.dt);
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
                     if (lstep.x == 0.f && lstep.y == 0.f) {        // uniform (kernel argument): z-only light step
-                        ltrans = light_march_z<YTAB>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy);
+                        ltrans = light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, etab, vsigma, vdt, vcov);
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
                             const float d = coop_density(F, lp, lit, S, lane);
-                            ltrans *= exp_(-d * F.sigma * F.dt);
+                            ltrans *= REG ? exp_tab_<false>(-d * vsigma * vdt, etab) : CL_EXP(-d * F.sigma * F.dt);
                             lp = lp + lstep;
                         }
                     }
@@ -482,7 +556,7 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
             }
         }
     }
-    const Pixel px = pixel_of_thread<CL_TW, CL_TX>(M);
+    const Pixel px = pixel_of_thread<CL_TW, CL_TX, CL_TOP_FIRST>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 dir = primary_dir(F.cam, pc);
@@ -501,16 +575,37 @@ __global__ void __launch_bounds__(64 * CL_TX, 4) k_clouds(FrameClouds F, RowMap 
     store_rgba(out, px.idx, to_srgb(col));
 }
 
+// "regular frame" (see light_march_z): every quantity the REG shortcuts rely on is checked here, on the host, per launch
+static bool clouds_regular(const FrameClouds& F) {
+#if CL_NO_REG
+    return false;
+#endif
+    const double sd = std::fabs((double)F.sigma) * std::fabs((double)F.dt);
+    return std::isfinite(F.cov) && std::isfinite(F.cov_rd) && F.cov_rd > 0.0 && std::isfinite(F.sigma) && std::isfinite(F.dt) &&
+           sd <= 80.0;
+}
+
 void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows,
                    bool build_table) {
+    const bool reg = clouds_regular(F);
+    const dim3 grid = grid_for<CL_TW, CL_TX>(M), block(64 * CL_TX);
+#ifdef SBX_CL_OCC_SWEEP
+    // experiment only (tools/ab_time.py): extra dynamic LDS per workgroup lowers the waves resident per SIMD
+    const char* pad_env = std::getenv("SBX_DEBUG_LDS_PAD");
+    const unsigned pad = pad_env ? (unsigned)std::atoi(pad_env) : 0u;
+#else
+    const unsigned pad = 0;
+#endif
     if (variant == 1) {
         hipLaunchKernelGGL(k_clouds_perlane, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out);
     } else if (ytab && F.steps <= ytab_rows && F.steps > 0) {
         YRow* tab = reinterpret_cast<YRow*>(ytab);
         if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
-        hipLaunchKernelGGL(k_clouds<true>, (grid_for<CL_TW, CL_TX>(M)), dim3(64 * CL_TX), 0, s, F, M, out, (const YRow*)tab);
+        if (reg) hipLaunchKernelGGL((k_clouds<true, true>), grid, block, pad, s, F, M, out, (const YRow*)tab);
+        else hipLaunchKernelGGL((k_clouds<true, false>), grid, block, 0, s, F, M, out, (const YRow*)tab);
     } else {
-        hipLaunchKernelGGL(k_clouds<false>, (grid_for<CL_TW, CL_TX>(M)), dim3(64 * CL_TX), 0, s, F, M, out, (const YRow*)nullptr);
+        if (reg) hipLaunchKernelGGL((k_clouds<false, true>), grid, block, 0, s, F, M, out, (const YRow*)nullptr);
+        else hipLaunchKernelGGL((k_clouds<false, false>), grid, block, 0, s, F, M, out, (const YRow*)nullptr);
     }
 }
 

@@ -21,13 +21,17 @@ constexpr int WG_TILES_X = SBX_WG_WAVES, WG_THREADS = 64 * SBX_WG_WAVES;
 
 struct Pixel { int x, y; size_t idx; bool valid; };
 
-template <int TW = 8, int TX = WG_TILES_X>
+// TOP_FIRST: workgroups are dispatched in increasing blockIdx (x fastest, then y); with TOP_FIRST the first ones take
+// the TOP rows of the launch.  For APP_CLOUDS the bottom rows never march (src/app_clouds.h:212), so the launch then ends
+// on its cheapest waves and the end-of-launch drain is not a few 100-step marches on a mostly empty chip.
+template <int TW = 8, int TX = WG_TILES_X, bool TOP_FIRST = false>
 __device__ __forceinline__ Pixel pixel_of_thread(const RowMap& M) {
     constexpr int TH = 64 / TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Pixel p;
     p.x = blockIdx.x * (TW * TX) + wave * TW + (lane % TW);
-    const int r = blockIdx.y * TH + (lane / TW);
+    const int by = TOP_FIRST ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int r = by * TH + (lane / TW);
     p.valid = (p.x < M.width) && (r < M.nrows);
     p.y = row_to_y(M, r);
     p.idx = (size_t)r * M.width + p.x;

@@ -37,7 +37,10 @@ __device__ __forceinline__ bool wave_any(bool x) {
     return any != 0;
 }
 
-constexpr int HC_SLOTS = 64;
+#ifndef SBX_HC_SLOTS
+#define SBX_HC_SLOTS 64
+#endif
+constexpr int HC_SLOTS = SBX_HC_SLOTS;
 struct alignas(16) WaveCache {
     float h[4][HC_SLOTS][8];          // corner order: +0,+1,+157,+158,+113,+114,+270,+271
     unsigned tag[4][HC_SLOTS];        // bits of n; 0x7fc00001 (a NaN) = empty
@@ -85,7 +88,10 @@ __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, i
 // the latch with the caller's pre-loop read and turned the loop into a per-lane (divergent) one — the
 // hash pass then ran with its worker lanes masked off and the loop never finished.
 struct H8 { float4 lo, hi; };
-__device__ __forceinline__ H8 hc_slow(WaveCache& S, int k, unsigned nbits, int slot, bool active, int lane) {
+#ifndef SBX_HC_SLOW_INLINE
+#define SBX_HC_SLOW_INLINE __forceinline__
+#endif
+__device__ SBX_HC_SLOW_INLINE H8 hc_slow(WaveCache& S, int k, unsigned nbits, int slot, bool active, int lane) {
     H8 r;
     r.lo = make_float4(0.f, 0.f, 0.f, 0.f);
     r.hi = r.lo;

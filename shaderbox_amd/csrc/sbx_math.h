@@ -62,6 +62,18 @@ SBX_HD float smoothstep_rd(float e0, double rd, float x) {
     float t = clamp_(div_by(x - e0, rd), 0.0f, 1.0f);
     return (t * t) * (3.0f - 2.0f * t);
 }
+#if defined(__HIPCC__)
+// x * smoothstep(e0, e1, x) with the clamp done by ONE v_med3_f32 (half the issue cost of two compare/select pairs).
+// v_med3_f32(t, 0, 1) differs from clamp_(t, 0, 1) in two cases only, and neither survives the operations around it:
+//   t = -0 : clamp_ gives -0, med3 may give +0 — the next operation is t * t = +0 either way;
+//   t NaN  : clamp_ gives NaN, med3 gives 0 — with e0 and rd finite t is NaN only if x is, and the result x * (...)
+//            is NaN either way.
+// Callers must have checked that e0 and rd are finite (kern_clouds.hip: the REG kernels).
+__device__ __forceinline__ float x_smoothstep_rd_med3(float e0, double rd, float x) {
+    const float t = __builtin_amdgcn_fmed3f(div_by(x - e0, rd), 0.0f, 1.0f);
+    return x * ((t * t) * (3.0f - 2.0f * t));
+}
+#endif
 SBX_HD float sqrt_(float x) { return __builtin_sqrtf(x); }
 
 // ---- binary64 cores ------------------------------------------------------------------------
@@ -205,8 +217,13 @@ __constant__ const double kExp2Tab[32] = {SBX_EXP2_TAB_VALUES};
 #else
 constexpr double kExp2Tab[32] = {SBX_EXP2_TAB_VALUES};
 #endif
-SBX_HD float exp_(float x) {
-    const double xd = (double)clamp_(x, -104.0f, 89.0f);
+// exp with the 2^(j/32) table read through `tab` (the __constant__ table, or a copy a kernel keeps in LDS: the per-lane
+// table read is a dependent memory access in every call, ~4x shorter from LDS than from the vector L1)
+// CLAMP = false leaves the binary32 range guard out: only for callers that have shown |x| <= 89 (or x NaN, which the
+// guard passes through unchanged anyway) for every argument they can produce — then the guard is the identity.
+template <bool CLAMP = true, class Tab>
+SBX_HD float exp_tab_(float x, const Tab& tab) {
+    const double xd = (double)(CLAMP ? clamp_(x, -104.0f, 89.0f) : x);
     double kd = __builtin_fma(xd, 0x1.71547652b82fep+5, D_MAGIC);          // 32/ln2
     const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
     kd = kd - D_MAGIC;
@@ -219,9 +236,10 @@ SBX_HD float exp_(float x) {
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    const double y = p * kExp2Tab[ki & 31];
+    const double y = p * tab[ki & 31];
     return (float)u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
 }
+SBX_HD float exp_(float x) { return exp_tab_(x, kExp2Tab); }
 // The former pow (atanh-series log2 with a binary64 division, 13-term 2^t), kept as the test hook "pow_h": the table
 // form below agrees with it except on a ~1e-8 fraction of inputs that sit on a binary32 rounding boundary to within
 // the ~1e-16 accuracy of either binary64 value (tests/test_gpu_parity.py::test_pow_table_vs_series).
