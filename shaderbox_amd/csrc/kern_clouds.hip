@@ -4,6 +4,11 @@
 // render :204-218, render_sky_color :36-46, render_clouds :153-202, integrate_volume :125-148,
 // illuminate_volume :91-123, density_func :62-86 over fbm = 4 octaves of noise_iq (:59),
 // henyey_greenstein_phase_func src/volumetric.h:27-33 with hg_g = .2 (:5).
+// 32-slot hash tables (4.9 KB per wave with the exp table): with the parked march state (2.3 KB) a wave needs 7.2 KB of LDS,
+// so 5 waves per SIMD (20 per CU) fit in the 160 KB; 64 slots time the same at equal occupancy (profiles/r02_clouds_ab.txt)
+#ifndef SBX_HC_SLOTS
+#define SBX_HC_SLOTS 32
+#endif
 #include "sbx_device.h"
 #include "sbx_noise.h"
 #include "sbx_hashcache.h"
@@ -13,6 +18,10 @@
 #ifndef CL_SPEC_READS
 #define CL_SPEC_READS 0
 #endif
+#ifndef CL_PARK
+#define CL_PARK 1          // park the march state in LDS during a lit step's light march
+#endif
+#define CL_PARK_N 9
 #ifndef CL_NO_REG
 #define CL_NO_REG 0       // 1: never use the REG kernels (A/B timing)
 #endif
@@ -25,7 +34,7 @@
 #define CL_EXP(x) exp_(x)
 #endif
 #ifndef CL_MIN_WAVES
-#define CL_MIN_WAVES 4     // waves per SIMD the register allocation is held to (__launch_bounds__)
+#define CL_MIN_WAVES 5     // waves per SIMD the register allocation is held to (__launch_bounds__): 96 VGPRs
 #endif
 
 namespace sbx {
@@ -473,10 +482,17 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
 #ifndef CL_TW
 #define CL_TW 32          // wave tile CL_TW x 64/CL_TW pixels (profiles/r01_tile_shapes.txt)
 #endif
-template <bool YTAB, bool REG>
+// ZL: the light step has no x and no y component (decided on the host), so the light march is light_march_z; the general
+// march is then not even compiled into the kernel (it was the register-pressure peak of the hot loop).
+template <bool YTAB, bool REG, bool ZL>
 __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out,
                                                           const YRow* __restrict__ ytab) {
     __shared__ WaveCache cache[CL_TX];
+#if CL_PARK
+    // the march state a lit step does not need while its light march runs, parked in LDS for that time (a manual spill to
+    // the fast memory: what the register allocator would otherwise send to scratch when the kernel is held to 96 VGPRs)
+    __shared__ float park[CL_TX][CL_PARK_N][64];
+#endif
     __shared__ double etab[32];                  // exp_'s 2^(j/32) table: per-lane reads come from LDS, not from the vector L1
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
@@ -504,9 +520,9 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
         marches = px.valid && !(cutoff < 0.05f);                  // :212
         bool alive = marches;
         if (wave_any(alive)) {                                    // wave-uniform
-            const v3 projection = dir / dir.y;                    // render_clouds :153-202
-            const v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
-            const float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
+            v3 projection = dir / dir.y;                          // render_clouds :153-202
+            v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
+            float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
             const v3 lstep = F.sun_dir * F.dt;
             // frame constants the light march multiplies / subtracts with, held in VGPRs: an fp32 VALU instruction with an
             // SGPR source issues at half rate on gfx950 (profiles/r02_ubench_issue.txt)
@@ -535,8 +551,21 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                     const float T_i = REG ? exp_tab_<false>(-density * vsigma * vdt, etab) : CL_EXP(-density * F.sigma * F.dt);
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
-                    if (lstep.x == 0.f && lstep.y == 0.f) {        // uniform (kernel argument): z-only light step
+                    if (ZL) {                                      // lstep.x == 0 && lstep.y == 0 (launch_clouds): z-only light step
+#if CL_PARK
+                        float* pk = &park[threadIdx.x >> 6][0][lane];
+                        pk[0 * 64] = origin.x; pk[1 * 64] = origin.z; pk[2 * 64] = projection.x; pk[3 * 64] = projection.z;
+                        pk[4 * 64] = t; pk[5 * 64] = transmittance; pk[6 * 64] = radiance; pk[7 * 64] = alpha; pk[8 * 64] = phase;
+                        asm volatile("" ::: "memory");
+                        asm volatile("" : "=v"(origin.x), "=v"(origin.z), "=v"(projection.x), "=v"(projection.z), "=v"(t),
+                                          "=v"(transmittance), "=v"(radiance), "=v"(alpha), "=v"(phase));     // dead from here
+#endif
                         ltrans = light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, etab, vsigma, vdt, vcov);
+#if CL_PARK
+                        asm volatile("" ::: "memory");
+                        origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
+                        t = pk[4 * 64]; transmittance = pk[5 * 64]; radiance = pk[6 * 64]; alpha = pk[7 * 64]; phase = pk[8 * 64];
+#endif
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
                             const float d = coop_density(F, lp, lit, S, lane);
@@ -596,16 +625,24 @@ void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_
 #else
     const unsigned pad = 0;
 #endif
+    const v3 lstep = F.sun_dir * F.dt;                          // the kernel's own expression
+    const bool zl = lstep.x == 0.f && lstep.y == 0.f;
     if (variant == 1) {
         hipLaunchKernelGGL(k_clouds_perlane, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out);
     } else if (ytab && F.steps <= ytab_rows && F.steps > 0) {
         YRow* tab = reinterpret_cast<YRow*>(ytab);
         if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
-        if (reg) hipLaunchKernelGGL((k_clouds<true, true>), grid, block, pad, s, F, M, out, (const YRow*)tab);
-        else hipLaunchKernelGGL((k_clouds<true, false>), grid, block, 0, s, F, M, out, (const YRow*)tab);
+        const YRow* ct = tab;
+        if (reg && zl) hipLaunchKernelGGL((k_clouds<true, true, true>), grid, block, pad, s, F, M, out, ct);
+        else if (reg) hipLaunchKernelGGL((k_clouds<true, true, false>), grid, block, 0, s, F, M, out, ct);
+        else if (zl) hipLaunchKernelGGL((k_clouds<true, false, true>), grid, block, 0, s, F, M, out, ct);
+        else hipLaunchKernelGGL((k_clouds<true, false, false>), grid, block, 0, s, F, M, out, ct);
     } else {
-        if (reg) hipLaunchKernelGGL((k_clouds<false, true>), grid, block, 0, s, F, M, out, (const YRow*)nullptr);
-        else hipLaunchKernelGGL((k_clouds<false, false>), grid, block, 0, s, F, M, out, (const YRow*)nullptr);
+        const YRow* ct = nullptr;
+        if (reg && zl) hipLaunchKernelGGL((k_clouds<false, true, true>), grid, block, 0, s, F, M, out, ct);
+        else if (reg) hipLaunchKernelGGL((k_clouds<false, true, false>), grid, block, 0, s, F, M, out, ct);
+        else if (zl) hipLaunchKernelGGL((k_clouds<false, false, true>), grid, block, 0, s, F, M, out, ct);
+        else hipLaunchKernelGGL((k_clouds<false, false, false>), grid, block, 0, s, F, M, out, ct);
     }
 }
 

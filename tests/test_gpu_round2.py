@@ -108,16 +108,22 @@ def test_timing_is_per_stream(renderer):
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     a = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
     b = torch.empty((36, 64, 4), dtype=torch.float32, device="cuda")
+    r.render("clouds", 1920, 1080, .37, out=a)
+    big_alone = r.last_kernel_ms()
+    r.render("clouds", 64, 36, .37, out=b)
+    small_alone = r.last_kernel_ms()
+    assert 0.0 < small_alone < big_alone / 5
     for _ in range(3):
         with torch.cuda.stream(s1):
             r.render("clouds", 1920, 1080, .37, out=a)
         with torch.cuda.stream(s2):
             r.render("clouds", 64, 36, .37, out=b)
-    small = r.last_kernel_ms()               # the last timed launch was the small one
+    small = r.last_kernel_ms()               # the pair of the LAST timed launch: the small frame on s2, which may have had to
+    assert 0.0 < small < 2.5 * big_alone     # wait for the big one's waves, but is never a pair straddling two launches
     with torch.cuda.stream(s1):
         r.render("clouds", 1920, 1080, .37, out=a)
     big = r.last_kernel_ms()
-    assert 0.0 < small < big
+    assert 0.5 * big_alone < big < 3 * big_alone
     aux = shaderbox_amd.clouds_defaults()
     aux.cld_march_steps = -1
     with pytest.raises(shaderbox_amd.SbxError):
