@@ -151,6 +151,11 @@ int sbx_render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void*
                      int nranks, int root_rounds, int rounds, int r0, int r1, float* rgba, void* stream);
 int sbx_assemble_split(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, int root_rounds, int rounds,
                        const float* gathered, float* frame, void* stream);
+/* The rows of `rank` written IN PLACE: `frame` is a full-size frame (height * width pixels) and every row of the rank
+ * lands at its global position; the other ranks' rows are not touched.  What the owner of the frame uses for its own share
+ * (no slab, no assembly pass). */
+int sbx_render_split_in_place(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                              int nranks, int root_rounds, int rounds, float* frame, void* stream);
 
 /* The write into hlsltoy's DXGI_FORMAT_R8G8B8A8_UNORM back buffer (util/hlsltoy/src/hlsltoy.cpp:79,192): float RGBA
  * rows -> 8-bit RGBA by the Direct3D float -> UNORM rule (NaN -> 0, clamp to [0, 1], * 255 + .5, truncate).
@@ -201,6 +206,30 @@ int sbx_set_noise_volumes(sbx_ctx* ctx, int shape_size, const float* shape_rgba,
 /* SampleLevel(linear, wrap, lod 0).r of a size^3 RGBA32F device volume at n points (xyz interleaved, device):
  * the texture-filter spec on its own, for parity tests. */
 int sbx_tex3d_eval(sbx_ctx* ctx, int size, const float* rgba, const float* xyz, float* out, size_t n, void* stream);
+
+/* ---- Multi-GPU frames inside the library (SURVEY.md §8b "Ownership", §8e "Collective") -----------------------------
+ * One process drives `nranks` ranks; devices[i] is the HIP device of rank i, rank 0 owns the frame.  With all devices
+ * distinct the library creates its communicator with ncclCommInitAll (rccl.h:236; librccl is dlopen'ed here, not linked)
+ * and every peer's row-blocks travel by grouped ncclSend / ncclRecv (rccl.h:700,722) straight into their rows of the
+ * root's frame — no staging slab, no assembly pass; rank 0 renders its own blocks in place.  Devices may repeat (several
+ * ranks on one GPU — how the N-rank schedule runs on fewer GPUs than ranks): those transfers are device copies.
+ * The split is the cyclic row-block split of sbx_render_split (default 8-row blocks, no root relief). */
+typedef struct sbx_multi sbx_multi;
+int sbx_multi_create(int nranks, const int* devices, sbx_multi** out);
+void sbx_multi_destroy(sbx_multi* m);
+int sbx_multi_ranks(const sbx_multi* m);
+int sbx_multi_uses_rccl(const sbx_multi* m);             /* 1: RCCL send/recv, 0: device / peer copies */
+int sbx_multi_set_split(sbx_multi* m, int block_rows, int root_rounds, int rounds);
+int sbx_multi_set_variant(sbx_multi* m, int variant);
+/* The two noise volumes of SBX_APP_CLOUDS_TEX (device memory on rank 0's device), handed to every rank; synchronous. */
+int sbx_multi_set_noise_volumes(sbx_multi* m, int shape_size, const float* shape_rgba, int detail_size,
+                                const float* detail_rgba);
+/* One frame over all ranks into `frame` (height * width RGBA32F pixels in rank 0's device memory).  Asynchronous: the
+ * work starts after what is already enqueued on `stream` (a stream of rank 0's device; NULL = its default stream) and
+ * `stream` continues when the whole frame is in place.  Up to two frames may be in flight (alternate two streams and two
+ * frames); the pixels are bit-identical to a one-GPU render. */
+int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void* aux, float* frame, void* stream);
+const char* sbx_multi_last_error(sbx_multi* m);
 
 const char* sbx_last_error(sbx_ctx* ctx);
 const char* sbx_version(void);

@@ -105,6 +105,18 @@ def load_library(path=None):
     lib.sbx_math_eval.argtypes = [vp, ctypes.c_char_p, fp, fp, fp, ctypes.c_size_t, vp]
     lib.sbx_noise_eval.argtypes = [vp, ctypes.c_char_p, fp, fp, fp, ctypes.c_size_t, vp]
     lib.sbx_worley_volume.argtypes = [vp, ci, fp, vp]
+    lib.sbx_render_split_in_place.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, fp, vp]
+    lib.sbx_multi_create.argtypes = [ci, ctypes.POINTER(ci), ctypes.POINTER(vp)]
+    lib.sbx_multi_destroy.argtypes = [vp]
+    lib.sbx_multi_destroy.restype = None
+    lib.sbx_multi_ranks.argtypes = [vp]
+    lib.sbx_multi_uses_rccl.argtypes = [vp]
+    lib.sbx_multi_set_split.argtypes = [vp, ci, ci, ci]
+    lib.sbx_multi_set_variant.argtypes = [vp, ci]
+    lib.sbx_multi_set_noise_volumes.argtypes = [vp, ci, fp, ci, fp]
+    lib.sbx_multi_render.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, fp, vp]
+    lib.sbx_multi_last_error.argtypes = [vp]
+    lib.sbx_multi_last_error.restype = ctypes.c_char_p
     lib.sbx_set_noise_volumes.argtypes = [vp, ci, fp, ci, fp, vp]
     lib.sbx_tex3d_eval.argtypes = [vp, ci, fp, fp, fp, ctypes.c_size_t, vp]
     lib.sbx_last_error.argtypes = [vp]
@@ -314,4 +326,65 @@ class Renderer:
         out = self.torch.empty_like(a)
         self._check(self.lib.sbx_math_eval(self.ctx, fn.encode(), ctypes.c_void_p(a.data_ptr()), bp,
                                            ctypes.c_void_p(out.data_ptr()), a.numel(), self._stream()))
+        return out
+
+
+class MultiRenderer:
+    """One sbx_multi: a single process driving `devices` (rank i on devices[i]; rank 0 owns the frame).  With distinct
+    devices the row-blocks travel over RCCL inside the library; repeated devices run the same schedule with device copies
+    (N ranks on one GPU).  Frames are float32 torch tensors [H, W, 4] on devices[0]."""
+
+    def __init__(self, devices):
+        import torch
+        if not torch.cuda.is_available():
+            raise SbxError(SBX_ERR_NO_DEVICE, "no GPU visible; shaderbox_amd has no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = ctypes.c_void_p()
+        rc = self.lib.sbx_multi_create(len(self.devices), arr, ctypes.byref(h))
+        if rc != SBX_OK:
+            raise SbxError(rc, "sbx_multi_create failed")
+        self.m = h
+        self.tdev = torch.device("cuda", self.devices[0])
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.lib.sbx_multi_destroy(self.m)
+            self.m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != SBX_OK:
+            raise SbxError(rc, (self.lib.sbx_multi_last_error(self.m) or b"").decode())
+
+    @property
+    def uses_rccl(self):
+        return self.lib.sbx_multi_uses_rccl(self.m) == 1
+
+    def set_split(self, block_rows=8, root_rounds=1, rounds=1):
+        self._check(self.lib.sbx_multi_set_split(self.m, int(block_rows), int(root_rounds), int(rounds)))
+
+    def set_variant(self, variant):
+        self._check(self.lib.sbx_multi_set_variant(self.m, int(variant)))
+
+    def set_noise_volumes(self, shape_rgba, detail_rgba):
+        self._check(self.lib.sbx_multi_set_noise_volumes(self.m, int(shape_rgba.shape[0]), ctypes.c_void_p(shape_rgba.data_ptr()),
+                                                         int(detail_rgba.shape[0]), ctypes.c_void_p(detail_rgba.data_ptr())))
+
+    def render(self, app, width, height, time, mouse=(0.0, 0.0), aux=None, out=None):
+        """The whole frame over all ranks; asynchronous on the current stream of devices[0]."""
+        u = Renderer.uniforms(width, height, time, mouse)
+        if out is None:
+            out = self.torch.empty((int(height), int(width), 4), dtype=self.torch.float32, device=self.tdev)
+        assert out.is_cuda and out.dtype == self.torch.float32 and out.is_contiguous() and out.numel() >= int(height) * int(width) * 4
+        stream = ctypes.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
+        self._check(self.lib.sbx_multi_render(self.m, app_id(app), ctypes.byref(u), Renderer._auxp(aux),
+                                              ctypes.c_void_p(out.data_ptr()), stream))
         return out

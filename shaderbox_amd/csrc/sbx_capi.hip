@@ -492,7 +492,7 @@ int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* 
     int rc = check_common(ctx, uni, rgba, W, H);
     if (rc != SBX_OK) return rc;
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(ctx, SBX_ERR_ARG, "bad row range");
-    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0, 0, 1, 1};
+    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0, 0, 1, 1, 0};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
 }
 
@@ -583,8 +583,19 @@ int sbx_render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void*
     if (r0 < 0 || r1 < r0) return fail(ctx, SBX_ERR_ARG, "bad slab row range");
     if (r1 > rows) r1 = rows;                 // the slab is padded to the split's rows_max; the tail has no pixels
     if (r0 >= r1) return SBX_OK;
-    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds};
+    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
+}
+int sbx_render_split_in_place(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                              int nranks, int root_rounds, int rounds, float* frame, void* stream) {
+    int W, H;
+    int rc = check_common(ctx, uni, frame, W, H);
+    if (rc != SBX_OK) return rc;
+    const int rows = sbx_split_rank_rows(H, block_rows, rank, nranks, root_rounds, rounds);
+    if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
+    if (rows == 0) return SBX_OK;
+    RowMap M{W, H, 0, block_rows, nranks, rank, rows, 0, root_rounds, rounds, 1};
+    return render_mapped(ctx, app, uni, aux, M, frame, stream);
 }
 int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
                     int nranks, float* rgba, void* stream) {

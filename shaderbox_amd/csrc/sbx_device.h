@@ -34,7 +34,7 @@ __device__ __forceinline__ Pixel pixel_of_thread(const RowMap& M) {
     const int r = by * TH + (lane / TW);
     p.valid = (p.x < M.width) && (r < M.nrows);
     p.y = row_to_y(M, r);
-    p.idx = (size_t)r * M.width + p.x;
+    p.idx = (size_t)(M.in_place ? p.y : r) * M.width + p.x;
     return p;
 }
 template <int TW = 8, int TX = WG_TILES_X>

@@ -24,6 +24,7 @@ struct RowMap {
     int nrows;   // local rows in this launch
     int r0;      // first local row of this launch within the rank's slab (sub-range launches)
     int root_rounds, rounds;
+    int in_place;   // 0: rows are written densely (slab row r); 1: at their global row y of a full-size frame
 };
 // blocks in one cycle, and the position of (round, rank) in it
 SBX_HD int split_cycle_blocks(int nranks, int root_rounds, int rounds) {

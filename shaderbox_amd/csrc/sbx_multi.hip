@@ -1,0 +1,326 @@
+// shaderbox_amd/csrc/sbx_multi.hip — multi-GPU frames inside the library (include/sbx.h, "sbx_multi_*").
+//
+// SURVEY.md §8b "Ownership" / §8e "Collective": the library owns the communicator; one PROCESS drives all the GPUs of the
+// node (single-process ncclCommInitAll, /opt/rocm/include/rccl/rccl.h:236), so a plain C or C++ host — the role of the
+// reference's frame-granular hosts, util/hlsltoy/src/hlsltoy.cpp:494-516 — can shard a frame without MPI, torchrun or a
+// second process.  The frame shards as the same cyclic row-blocks as the per-process path (sbx_split_*):
+//
+//   rank 0 (the owner of the frame) renders its blocks IN PLACE into the caller's frame (sbx_render_split_in_place);
+//   rank i > 0 renders its blocks densely into a slab on its own GPU, then sends every block to the row it belongs to:
+//       grouped ncclSend / ncclRecv (rccl.h:700,722), one pair per row-block, received straight into the final rows —
+//       no staging slab on the root and no assembly kernel.  xGMI is point-to-point: the N-1 peers use N-1 distinct links.
+//
+// Two frames may be in flight (double-buffered slabs and two stream sets per rank, alternating per call) so that the
+// drain of one frame's kernels overlaps the next frame, exactly as bench.py pipelines the per-process path.
+//
+// Ranks may share a device (devices[] with repeats).  That is how the N-rank schedule is exercised on fewer GPUs than
+// ranks (tests on a 1-GPU box): transfers then are device-to-device copies on the sending rank's stream, and RCCL is not
+// loaded.  RCCL itself is dlopen'ed on first use, so a single-GPU host of libsbx never needs it.
+#include "../../include/sbx.h"
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// the slice of the RCCL API this file uses (types as in rccl.h)
+typedef void* nccl_comm_t;
+typedef int nccl_result_t;
+constexpr int kNcclFloat = 7;            // ncclFloat32 (rccl.h ncclDataType_t)
+struct RcclApi {
+    void* handle = nullptr;
+    nccl_result_t (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+    nccl_result_t (*CommDestroy)(nccl_comm_t) = nullptr;
+    nccl_result_t (*GroupStart)() = nullptr;
+    nccl_result_t (*GroupEnd)() = nullptr;
+    nccl_result_t (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    nccl_result_t (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(nccl_result_t) = nullptr;
+    bool load(std::string& err) {
+        if (handle) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(handle, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+    }
+};
+RcclApi g_rccl;
+
+constexpr int kInFlight = 2;
+
+struct Rank {
+    int device = 0;
+    sbx_ctx* ctx = nullptr;
+    hipStream_t render[kInFlight] = {nullptr, nullptr};   // this rank's launches (and its sends / copies)
+    hipStream_t recv[kInFlight] = {nullptr, nullptr};     // rank 0 only: RCCL receives, beside its own rendering
+    hipEvent_t done[kInFlight] = {};                      // the rank's part of the frame is where it belongs
+    hipEvent_t recv_done[kInFlight] = {};
+    float* slab[kInFlight] = {nullptr, nullptr};
+    size_t slab_floats = 0;
+    nccl_comm_t comm = nullptr;
+};
+
+}  // namespace
+
+struct sbx_multi {
+    std::vector<Rank> ranks;
+    bool use_rccl = false;
+    int block_rows = 8, root_rounds = 1, rounds = 1;
+    unsigned calls = 0;
+    hipEvent_t start[kInFlight] = {};
+    std::string err;
+};
+
+static int mfail(sbx_multi* m, int code, const std::string& what, hipError_t e = hipSuccess) {
+    if (m) {
+        m->err = what;
+        if (e != hipSuccess) { m->err += ": "; m->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+extern "C" {
+
+void sbx_multi_destroy(sbx_multi* m) {
+    if (!m) return;
+    for (Rank& r : m->ranks) {
+        (void)hipSetDevice(r.device);
+        (void)hipDeviceSynchronize();
+        if (r.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r.comm);
+        for (int k = 0; k < kInFlight; ++k) {
+            if (r.slab[k]) (void)hipFree(r.slab[k]);
+            if (r.render[k]) (void)hipStreamDestroy(r.render[k]);
+            if (r.recv[k]) (void)hipStreamDestroy(r.recv[k]);
+            if (r.done[k]) (void)hipEventDestroy(r.done[k]);
+            if (r.recv_done[k]) (void)hipEventDestroy(r.recv_done[k]);
+        }
+        if (r.ctx) sbx_destroy(r.ctx);
+    }
+    if (!m->ranks.empty()) {
+        (void)hipSetDevice(m->ranks[0].device);
+        for (int k = 0; k < kInFlight; ++k) if (m->start[k]) (void)hipEventDestroy(m->start[k]);
+    }
+    delete m;
+}
+
+int sbx_multi_create(int nranks, const int* devices, sbx_multi** out) {
+    if (!out) return SBX_ERR_ARG;
+    *out = nullptr;
+    if (nranks < 1 || nranks > 64 || !devices) return SBX_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SBX_ERR_NO_DEVICE;
+    bool distinct = true;
+    for (int i = 0; i < nranks; ++i) {
+        if (devices[i] < 0 || devices[i] >= ndev) return SBX_ERR_ARG;
+        for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) distinct = false;
+    }
+    sbx_multi* m = new sbx_multi();
+    m->ranks.resize(nranks);
+    for (int i = 0; i < nranks; ++i) {
+        Rank& r = m->ranks[i];
+        r.device = devices[i];
+        int rc = sbx_create(r.device, &r.ctx);
+        if (rc != SBX_OK) { sbx_multi_destroy(m); return rc; }
+        hipError_t e = hipSetDevice(r.device);
+        for (int k = 0; k < kInFlight && e == hipSuccess; ++k) {
+            if ((e = hipStreamCreateWithFlags(&r.render[k], hipStreamNonBlocking)) != hipSuccess) break;
+            if ((e = hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming)) != hipSuccess) break;
+            if (i == 0) {
+                if ((e = hipStreamCreateWithFlags(&r.recv[k], hipStreamNonBlocking)) != hipSuccess) break;
+                if ((e = hipEventCreateWithFlags(&r.recv_done[k], hipEventDisableTiming)) != hipSuccess) break;
+                if ((e = hipEventCreateWithFlags(&m->start[k], hipEventDisableTiming)) != hipSuccess) break;
+            }
+        }
+        if (e != hipSuccess) { sbx_multi_destroy(m); return SBX_ERR_HIP; }
+    }
+    // peers write into the root's frame (copy mode) / RCCL sets its own peer mappings up: enable peer access where possible
+    for (int i = 1; i < nranks; ++i) {
+        if (m->ranks[i].device == m->ranks[0].device) continue;
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, m->ranks[i].device, m->ranks[0].device);
+        if (can) {
+            (void)hipSetDevice(m->ranks[i].device);
+            hipError_t e = hipDeviceEnablePeerAccess(m->ranks[0].device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+    }
+    const char* no_rccl = getenv("SBX_MULTI_NO_RCCL");      // diagnostic: peer copies instead of RCCL
+    if (distinct && nranks > 1 && !(no_rccl && no_rccl[0] == '1')) {
+        std::string err;
+        if (!g_rccl.load(err)) { sbx_multi_destroy(m); return SBX_ERR_UNSUPPORTED; }
+        std::vector<nccl_comm_t> comms(nranks, nullptr);
+        const nccl_result_t rc = g_rccl.CommInitAll(comms.data(), nranks, devices);
+        if (rc != 0) { sbx_multi_destroy(m); return SBX_ERR_HIP; }
+        for (int i = 0; i < nranks; ++i) m->ranks[i].comm = comms[i];
+        m->use_rccl = true;
+    }
+    *out = m;
+    return SBX_OK;
+}
+
+int sbx_multi_ranks(const sbx_multi* m) { return m ? (int)m->ranks.size() : SBX_ERR_ARG; }
+int sbx_multi_uses_rccl(const sbx_multi* m) { return m ? (m->use_rccl ? 1 : 0) : SBX_ERR_ARG; }
+const char* sbx_multi_last_error(sbx_multi* m) { return m ? m->err.c_str() : "no multi-GPU context"; }
+
+int sbx_multi_set_split(sbx_multi* m, int block_rows, int root_rounds, int rounds) {
+    if (!m) return SBX_ERR_ARG;
+    const int n = (int)m->ranks.size();
+    if (block_rows <= 0 || rounds < 1 || root_rounds < 0 || root_rounds > rounds || (n == 1 && root_rounds != rounds))
+        return mfail(m, SBX_ERR_ARG, "bad split");
+    m->block_rows = block_rows; m->root_rounds = root_rounds; m->rounds = rounds;
+    return SBX_OK;
+}
+
+int sbx_multi_set_variant(sbx_multi* m, int variant) {
+    if (!m) return SBX_ERR_ARG;
+    for (Rank& r : m->ranks) {
+        const int rc = sbx_set_variant(r.ctx, variant);
+        if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(r.ctx));
+    }
+    return SBX_OK;
+}
+
+int sbx_multi_set_noise_volumes(sbx_multi* m, int shape_size, const float* shape_rgba, int detail_size, const float* detail_rgba) {
+    if (!m) return SBX_ERR_ARG;
+    if (!shape_rgba || !detail_rgba || shape_size <= 0 || detail_size <= 0) return mfail(m, SBX_ERR_ARG, "bad noise volume arguments");
+    Rank& root = m->ranks[0];
+    const size_t b1 = (size_t)shape_size * shape_size * shape_size * 16, b2 = (size_t)detail_size * detail_size * detail_size * 16;
+    for (Rank& r : m->ranks) {
+        hipError_t e = hipSetDevice(r.device);
+        if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+        int rc;
+        if (r.device == root.device) {
+            rc = sbx_set_noise_volumes(r.ctx, shape_size, shape_rgba, detail_size, detail_rgba, nullptr);
+            (void)hipDeviceSynchronize();
+        } else {                               // the volumes live on rank 0's device: stage a copy on this rank's device
+            float *t1 = nullptr, *t2 = nullptr;
+            if ((e = hipMalloc((void**)&t1, b1)) != hipSuccess || (e = hipMalloc((void**)&t2, b2)) != hipSuccess) {
+                if (t1) (void)hipFree(t1);
+                return mfail(m, SBX_ERR_HIP, "hipMalloc", e);
+            }
+            e = hipMemcpyPeer(t1, r.device, shape_rgba, root.device, b1);
+            if (e == hipSuccess) e = hipMemcpyPeer(t2, r.device, detail_rgba, root.device, b2);
+            rc = e == hipSuccess ? sbx_set_noise_volumes(r.ctx, shape_size, t1, detail_size, t2, nullptr) : SBX_ERR_HIP;
+            (void)hipDeviceSynchronize();
+            (void)hipFree(t1); (void)hipFree(t2);
+            if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipMemcpyPeer", e);
+        }
+        if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(r.ctx));
+    }
+    return SBX_OK;
+}
+
+// global block index of local block `lb` of `rank` (the arithmetic of sbx_frame.h row_to_y / shard.py)
+static int global_block(int lb, int rank, int nranks, int root_rounds, int rounds) {
+    const int cnt = rank == 0 ? root_rounds : rounds;
+    const int cycle = lb / cnt, round = lb - cycle * cnt;
+    const int v = round < root_rounds ? round * nranks + rank
+                                      : root_rounds * nranks + (round - root_rounds) * (nranks - 1) + (rank - 1);
+    return cycle * (root_rounds * nranks + (rounds - root_rounds) * (nranks - 1)) + v;
+}
+
+int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void* aux, float* frame, void* stream) {
+    if (!m) return SBX_ERR_ARG;
+    if (!uni || !frame) return mfail(m, SBX_ERR_ARG, "NULL uniforms or frame");
+    const int W = (int)uni->u_res[0], H = (int)uni->u_res[1];
+    if (W <= 0 || H <= 0 || (float)W != uni->u_res[0] || (float)H != uni->u_res[1]) return mfail(m, SBX_ERR_ARG, "bad u_res");
+    const int n = (int)m->ranks.size();
+    const int br = m->block_rows, m0 = m->root_rounds, mr = m->rounds;
+    const int k = (int)(m->calls++ % kInFlight);
+    hipStream_t user = (hipStream_t)stream;
+    Rank& root = m->ranks[0];
+    hipError_t e = hipSetDevice(root.device);
+    if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+    // everything this frame does starts after what the caller has already enqueued on `stream` (e.g. the last reader of `frame`)
+    if ((e = hipEventRecord(m->start[k], user)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
+    const size_t row_floats = (size_t)W * 4;
+    // ---- every rank renders its share -------------------------------------------------------------------
+    for (int i = 0; i < n; ++i) {
+        Rank& r = m->ranks[i];
+        if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+        if ((e = hipStreamWaitEvent(r.render[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+        int rc;
+        if (i == 0) {
+            rc = sbx_render_split_in_place(r.ctx, app, uni, aux, br, 0, n, m0, mr, frame, r.render[k]);
+        } else {
+            const int rows = sbx_split_rank_rows(H, br, i, n, m0, mr);
+            if (rows < 0) return mfail(m, SBX_ERR_ARG, "bad split");
+            const size_t need = (size_t)(rows > 0 ? rows : 1) * row_floats;
+            if (need > r.slab_floats) {
+                for (int q = 0; q < kInFlight; ++q) {
+                    if (r.slab[q]) (void)hipFree(r.slab[q]);          // hipFree waits for the device: nothing reads the old slab
+                    r.slab[q] = nullptr;
+                    if ((e = hipMalloc((void**)&r.slab[q], need * sizeof(float))) != hipSuccess) { r.slab_floats = 0; return mfail(m, SBX_ERR_HIP, "hipMalloc slab", e); }
+                }
+                r.slab_floats = need;
+            }
+            rc = sbx_render_split(r.ctx, app, uni, aux, br, i, n, m0, mr, 0, 0x7fffffff, r.slab[k], r.render[k]);
+        }
+        if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(r.ctx));
+    }
+    // ---- the one exchange step: every peer's row-blocks to their rows of the root's frame -------------------
+    if (n > 1) {
+        if (m->use_rccl) {
+            if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+            if ((e = hipStreamWaitEvent(root.recv[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+            nccl_result_t nr = g_rccl.GroupStart();
+            for (int i = 1; i < n && nr == 0; ++i) {
+                Rank& r = m->ranks[i];
+                const int rows = sbx_split_rank_rows(H, br, i, n, m0, mr);
+                for (int lr = 0, lb = 0; lr < rows && nr == 0; lr += br, ++lb) {
+                    const int y = global_block(lb, i, n, m0, mr) * br;
+                    const int cnt = (y + br <= H) ? br : (H - y);
+                    const size_t floats = (size_t)cnt * row_floats;
+                    nr = g_rccl.Send(r.slab[k] + (size_t)lr * row_floats, floats, kNcclFloat, 0, r.comm, r.render[k]);
+                    if (nr == 0) nr = g_rccl.Recv(frame + (size_t)y * row_floats, floats, kNcclFloat, i, root.comm, root.recv[k]);
+                }
+            }
+            const nccl_result_t ne = g_rccl.GroupEnd();
+            if (nr != 0 || ne != 0) return mfail(m, SBX_ERR_HIP, std::string("RCCL send/recv: ") + g_rccl.GetErrorString(nr != 0 ? nr : ne));
+            if ((e = hipEventRecord(root.recv_done[k], root.recv[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
+        } else {
+            for (int i = 1; i < n; ++i) {
+                Rank& r = m->ranks[i];
+                if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+                const int rows = sbx_split_rank_rows(H, br, i, n, m0, mr);
+                for (int lr = 0, lb = 0; lr < rows; lr += br, ++lb) {
+                    const int y = global_block(lb, i, n, m0, mr) * br;
+                    const int cnt = (y + br <= H) ? br : (H - y);
+                    const size_t bytes = (size_t)cnt * row_floats * sizeof(float);
+                    if (r.device == root.device)
+                        e = hipMemcpyAsync(frame + (size_t)y * row_floats, r.slab[k] + (size_t)lr * row_floats, bytes, hipMemcpyDeviceToDevice, r.render[k]);
+                    else
+                        e = hipMemcpyPeerAsync(frame + (size_t)y * row_floats, root.device, r.slab[k] + (size_t)lr * row_floats, r.device, bytes, r.render[k]);
+                    if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "row-block copy", e);
+                }
+            }
+        }
+    }
+    // ---- the caller's stream continues when every part of the frame is in place ---------------------------------
+    for (int i = 0; i < n; ++i) {
+        Rank& r = m->ranks[i];
+        if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+        if ((e = hipEventRecord(r.done[k], r.render[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
+    }
+    if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+    for (int i = 0; i < n; ++i)
+        if ((e = hipStreamWaitEvent(user, m->ranks[i].done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+    if (n > 1 && m->use_rccl)
+        if ((e = hipStreamWaitEvent(user, root.recv_done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+    return SBX_OK;
+}
+
+}  // extern "C"

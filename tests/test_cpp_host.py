@@ -87,3 +87,64 @@ def test_ddsvolgen_writes_the_volume(built, oracle, tmp_path):
     vox = np.frombuffer(raw, dtype=np.float32, offset=148).reshape(32, 32, 32, 4)
     ref = oracle.worley_volume(32, 0, 3)
     assert np.array_equal(vox[:3].view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cli_animation_with_aux_flags_matches_oracle(built, oracle, tmp_path):
+    """§8f-1: the run-time aux surface and the per-frame loop of the interactive host (util/hlsltoy/src/hlsltoy.cpp:
+    466-491, 502-516) on the command line: a 3-frame sequence with non-default APP_CLOUDS aux values, every frame
+    written, every frame equal to the oracle at u_time = time + f * dt."""
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS, APP_SDF_AO
+    w, h, t0, dt = 160, 90, 0.25, 0.5
+    subprocess.run([os.path.join(built, "sbx_render"), "--app", "clouds", "--res", "%dx%d" % (w, h), "--time", str(t0), "--dt", str(dt),
+                    "--frames", "3", "--coverage", "0.6", "--thick", "100", "--steps", "60", "--light-steps", "4", "--sun", "0.2,0.5,-0.8",
+                    "--wind", "0.1,0.02,0.2", "--sigma", "0.2", "--sun-power", "6", "--sun-color", "1,0.8,0.6", "--mouse", "1.5,0",
+                    "--f32", str(tmp_path / "seq.f32"), "--ppm", str(tmp_path / "seq_%02d.ppm")], check=True)
+    aux = shaderbox_amd.AuxClouds()
+    shaderbox_amd.load_library().sbx_aux_clouds_defaults(aux)
+    aux.cld_coverage, aux.cld_thick, aux.cld_march_steps, aux.illum_march_steps, aux.sigma_scattering, aux.sun_power = .6, 100., 60, 4, .2, 6.
+    aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = .2, .5, -.8
+    aux.wind_dir[0], aux.wind_dir[1], aux.wind_dir[2] = .1, .02, .2
+    aux.sun_color[0], aux.sun_color[1], aux.sun_color[2] = 1., .8, .6
+    frames = []
+    for f in range(3):
+        got = np.fromfile(str(tmp_path / ("seq_%04d.f32" % f)), dtype=np.float32).reshape(h, w, 4)
+        ref = oracle.render(APP_CLOUDS, w, h, np.float32(t0) + np.float32(f) * np.float32(dt), mouse=(1.5, 0.0), aux=aux)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f
+        assert os.path.getsize(str(tmp_path / ("seq_%02d.ppm" % f))) == len("P6\n%d %d\n255\n" % (w, h)) + w * h * 3
+        frames.append(got)
+    assert not np.array_equal(frames[0], frames[2])              # the wind moves the clouds
+    # APP_SDF_AO's block
+    subprocess.run([os.path.join(built, "sbx_render"), "--app", "sdf_ao", "--res", "96x54", "--time", "0.5", "--fog-density", "0.25",
+                    "--fog-falloff", "0.3", "--f32", str(tmp_path / "ao.f32")], check=True)
+    a2 = shaderbox_amd.AuxSdfAo()
+    a2.fog_density, a2.fog_falloff = .25, .3
+    got = np.fromfile(str(tmp_path / "ao.f32"), dtype=np.float32).reshape(54, 96, 4)
+    assert np.array_equal(got.view(np.uint32), oracle.render(APP_SDF_AO, 96, 54, .5, aux=a2).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cli_multi_gpu_and_noise_textures(built, oracle, tmp_path):
+    """--gpus N shards the frame inside the library (on a 1-GPU box the ranks share the device); clouds_tex reads the
+    .dds volumes sbx_ddsvolgen writes (the files hlsltoy takes as argv[2], argv[3])."""
+    from oracle.oracle import APP_CLOUDS_TEX, APP_IDS
+    w, h = 200, 117
+    for app in ("clouds", "egg"):
+        subprocess.run([os.path.join(built, "sbx_render"), "--app", app, "--res", "%dx%d" % (w, h), "--gpus", "3",
+                        "--f32", str(tmp_path / "m.f32")], check=True)
+        got = np.fromfile(str(tmp_path / "m.f32"), dtype=np.float32).reshape(h, w, 4)
+        assert np.array_equal(got.view(np.uint32), oracle.render(APP_IDS[app], w, h, .37).view(np.uint32)), app
+    vols = []
+    for size, name in ((16, "shape.dds"), (8, "detail.dds")):
+        subprocess.run([os.path.join(built, "sbx_ddsvolgen"), "--size", str(size), "--out", str(tmp_path / name)], check=True)
+        raw = np.fromfile(str(tmp_path / name), dtype=np.uint8)
+        vols.append(raw[4 + 124 + 20:].view(np.float32).reshape(size, size, size, 4).copy())
+    oracle.set_noise_volumes(vols[0], vols[1])
+    for extra in ([], ["--gpus", "2"]):
+        subprocess.run([os.path.join(built, "sbx_render"), "--app", "clouds_tex", "--res", "160x90", "--noise-tex",
+                        "%s,%s" % (tmp_path / "shape.dds", tmp_path / "detail.dds"), "--f32", str(tmp_path / "t.f32")] + extra, check=True)
+        got = np.fromfile(str(tmp_path / "t.f32"), dtype=np.float32).reshape(90, 160, 4)
+        assert np.array_equal(got.view(np.uint32), oracle.render(APP_CLOUDS_TEX, 160, 90, .37).view(np.uint32))
+    r = subprocess.run([os.path.join(built, "sbx_render"), "--app", "clouds_tex", "--res", "32x18"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--noise-tex" in r.stderr
