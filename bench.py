@@ -145,10 +145,16 @@ def main():
                     help="where roofline.traffic / valu_issue_frac / valu_busy_pct come from: 'live' = rocprofv3 passes of a short "
                          "serial run of this script, 'profiles' = the committed summary, 'auto' = live, else profiles, else null")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--engine", default="dist", choices=["dist", "lib"],
+                    help="N>1: 'dist' = one process per GPU (torch.distributed / RCCL gather, the contract's launch shape); 'lib' = ONE "
+                         "process drives the N GPUs through the library's own multi-GPU path (sbx_multi_*: RCCL send/recv per "
+                         "row-block straight into the final rows, no assembly pass); with fewer GPUs than N the ranks share devices")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.engine == "lib" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(bench_lib(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (the driver's command shape at N = 1, 2, 4, 8)
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -320,6 +326,62 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(status)
+
+
+def bench_lib(args):
+    """--engine lib: one process, N ranks inside the library (sbx_multi_*)."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import shaderbox_amd
+    ndev = torch.cuda.device_count()
+    n = args.gpus
+    devices = list(range(n)) if ndev >= n else [i % max(ndev, 1) for i in range(n)]
+    M = shaderbox_amd.MultiRenderer(devices)
+    m0, m = (1, 1) if args.root_rounds == "auto" else tuple(int(v) for v in args.root_rounds.split("/"))
+    M.set_split(args.block_rows, m0, m)
+    W, H, app, t = args.width, args.height, args.app, args.time
+    dev = torch.device("cuda", devices[0])
+    torch.cuda.set_device(dev)
+    ns = max(1, min(2, args.streams))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
+
+    def step(i):
+        with torch.cuda.stream(streams[i % ns]):
+            M.render(app, W, H, t, out=frames[i % ns])
+
+    def sync():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+    for i in range(2):
+        step(i)                       # one-time initialisation: code objects, y tables, peer links, slabs
+    sync()
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    R = shaderbox_amd.Renderer(devices[0])
+    whole = R.render(app, W, H, t)
+    a, b = frames[(args.steps - 1) % ns].view(torch.int32), whole.view(torch.int32)
+    bad = int((a != b).any(dim=-1).sum().item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(W * H / (ms_per_step * 1e-3) / 1e6, 3),
+           "unit": "Mpixels/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)" % (app.upper(), W, H, t),
+                      "frames_in_flight": ns, "engine": "lib (one process, sbx_multi_*)",
+                      "parallelism": "cyclic %d-row blocks over %d ranks on devices %s, %s, root renders in place"
+                                     % (args.block_rows, n, devices, "RCCL send/recv per row-block into the final rows" if M.uses_rccl
+                                        else "device copies per row-block (ranks share devices: emulation, not a scaling number)")},
+           "parity": {"against": "one-launch render of the same frame", "rows": H, "mismatching_pixels": bad}}
+    print(json.dumps(out))
+    M.close()
+    return 3 if bad else 0
 
 
 def parity(gpu, ref, nrows):

@@ -7,6 +7,10 @@
 // host from (0,1,0), i.e. it restarts from its initialiser for every pixel (GLSL semantics).
 // Magnitudes are ~6.4e6 in binary32, so the evaluation order below is part of the result.
 #include "sbx_device.h"
+#include <cmath>
+#ifndef ATM_NO_FIN
+#define ATM_NO_FIN 0
+#endif
 
 namespace sbx {
 
@@ -19,28 +23,41 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
     const float radius2 = ATM_ATMOS_R * ATM_ATMOS_R;
     const float tca = dot(rc, rd);
     const float d2 = dot(rc, rc) - tca * tca;
-    const float thc = sqrt_(radius2 - d2);
+    const float thc = sqrt_n_(radius2 - d2);   // both ~4e13: the difference is a multiple of 4e6, zero or negative
     t1 = tca + thc;
     return d2 < radius2;
 }
 
-__device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM) {   // :50-76
+// exp_ of this kernel reads the 2^(j/32) table from LDS.  For the density terms exp(-height / H) — 288 of the 336 exp of an
+// in-dome pixel — the binary32 range guard is left out when the uniforms are finite (FIN, decided on the host): a sample lies
+// inside the atmosphere shell, so -height / H is in [-50.1, 0.001], far inside the guard's [-104, 89], and a NaN passes
+// through the guard unchanged.  exp(-tau) keeps its guard: grazing sun rays reach optical depths beyond 104 (measured: a ring
+// of 9 % of the pixels turns NaN / inf without it).
+#define ATM_EXP_H(x) exp_tab_<!FIN>((x), etab)
+#define ATM_EXP(x) exp_tab_<true>((x), etab)
+
+template <bool FIN>
+__device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, const double (&etab)[32]) {   // :50-76
     float t1;
     isect_atmosphere(ro, rd, t1);
     float march_pos = 0.f;
     const float march_step = t1 / 8.f;
     for (int i = 0; i < 8; ++i) {
         const v3 s = ro + rd * (march_pos + 0.5f * march_step);
-        const float height = length(s) - ATM_EARTH_R;
+        const float height = sqrt_n_(dot(s, s)) - ATM_EARTH_R;   // length(s), |s| ~ 6.4e6
         if (height < 0.f) return false;
-        odR += exp_(div_by(-height, ATM_HR_RD)) * march_step;
-        odM += exp_(div_by(-height, ATM_HM_RD)) * march_step;
+        odR += ATM_EXP_H(div_by(-height, ATM_HR_RD)) * march_step;
+        odM += ATM_EXP_H(div_by(-height, ATM_HM_RD)) * march_step;
         march_pos += march_step;
     }
     return true;
 }
 
+template <bool FIN>
 __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
+    __shared__ double etab[32];
+    if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    __syncthreads();
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
@@ -65,15 +82,15 @@ __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, Ro
         v3 sumR = V3(0, 0, 0), sumM = V3(0, 0, 0);
         for (int i = 0; i < 16; ++i) {
             const v3 s = ro + rd * (march_pos + 0.5f * march_step);
-            const float height = length(s) - ATM_EARTH_R;
-            const float hr = exp_(div_by(-height, ATM_HR_RD)) * march_step;
-            const float hm = exp_(div_by(-height, ATM_HM_RD)) * march_step;
+            const float height = sqrt_n_(dot(s, s)) - ATM_EARTH_R;   // length(s)
+            const float hr = ATM_EXP_H(div_by(-height, ATM_HR_RD)) * march_step;
+            const float hm = ATM_EXP_H(div_by(-height, ATM_HM_RD)) * march_step;
             odR += hr;
             odM += hm;
             float lR = 0.f, lM = 0.f;
-            if (sun_light(s, F.sun_dir, lR, lM)) {
+            if (sun_light<FIN>(s, F.sun_dir, lR, lM, etab)) {
                 const v3 tau = betaR * (odR + lR) + betaM * 1.1f * (odM + lM);
-                const v3 att = V3(exp_(-tau.x), exp_(-tau.y), exp_(-tau.z));
+                const v3 att = V3(ATM_EXP(-tau.x), ATM_EXP(-tau.y), ATM_EXP(-tau.z));
                 sumR = sumR + hr * att;
                 sumM = sumM + hm * att;
             }
@@ -85,7 +102,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, Ro
 }
 
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_atmosphere, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    // FIN: camera and sun direction are finite numbers (they are for every finite u_res / u_time)
+    const float chk[] = {F.cam.res_x, F.cam.res_y, F.cam.aspect_x, F.cam.fov, F.sun_dir.x, F.sun_dir.y, F.sun_dir.z,
+                         F.cam.fwd.x, F.cam.fwd.y, F.cam.fwd.z, F.cam.up.x, F.cam.up.y, F.cam.up.z, F.cam.right.x, F.cam.right.y, F.cam.right.z};
+    bool fin = std::isfinite(F.cam.rres_x) && std::isfinite(F.cam.rres_y);
+    for (float v : chk) fin = fin && std::isfinite(v);
+#if ATM_NO_FIN
+    fin = false;
+#endif
+    if (fin) hipLaunchKernelGGL(k_atmosphere<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_atmosphere<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

@@ -154,8 +154,11 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
     return abs3(sky);
 }
 
+#ifndef PL_MIN_WAVES
+#define PL_MIN_WAVES 4
+#endif
 template <bool SKIP>
-__global__ void __launch_bounds__(WG_THREADS, 4) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
+__global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
     __shared__ WaveCache cache[WG_THREADS / 64];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];

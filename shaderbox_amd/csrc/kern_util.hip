@@ -81,13 +81,15 @@ __global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restri
     case 9: r = div_by(x, recip64(y)); break;       // the same through the binary64 reciprocal (sbx_math.h)
     case 11: r = pow_h_(x, y); break;               // the former series pow (comparison with the table form)
     case 10: r = exp_h13_(x); break;                // the former 13-term exp (equivalence test against the table form)
+    case 12: r = sqrt_n_(x); break;                 // v_sqrt_f32 + fix-up (exact outside (0, 2^-96))
+    case 13: r = sqrt_ieee_(x); break;              // the compiler's IEEE expansion
     default: r = 0.f;
     }
     out[i] = r;
 }
 
 int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t n, hipStream_t s) {
-    if (fn < 0 || fn > 11) return -1;
+    if (fn < 0 || fn > 13) return -1;
     hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, a, b, out, n);
     return 0;
 }

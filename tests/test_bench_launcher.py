@@ -62,3 +62,11 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
     r, line = run_bench("--force-dist", "--steps", "3", "--warmup", "1", "--width", "640", "--height", "360")
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 1 and line["parity"]["mismatching_pixels"] == 0 and line["parity"]["rows"] == 360
+
+
+@pytest.mark.gpu
+def test_bench_library_engine_on_one_gpu():
+    """--engine lib: one process, the N-rank schedule of sbx_multi_* (ranks share the device on a 1-GPU box)"""
+    r, line = run_bench("--gpus", "4", "--engine", "lib", "--steps", "4", "--warmup", "1", "--width", "640", "--height", "360")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 4 and line["parity"]["mismatching_pixels"] == 0 and "sbx_multi" in line["config"]["engine"]

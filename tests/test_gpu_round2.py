@@ -277,3 +277,20 @@ def test_library_multi_gpu_errors_and_noise_volumes(renderer, oracle, volumes):
     ref = oracle.render(APP_CLOUDS_TEX, 160, 90, .37)
     assert compare(got.cpu().numpy(), ref) == (0.0, 0)
     m.close()
+
+
+def test_sqrt_n_is_ieee_sqrt(renderer):
+    """sqrt_n_ (v_sqrt_f32 + two-sided fix-up, sbx_math.h; used by APP_ATMOSPHERE) against the compiler's IEEE expansion on ALL
+    2^32 binary32 inputs: identical everywhere except for non-zero arguments of magnitude below 2^-96, which its callers exclude
+    (NaN results compare equal)."""
+    import torch
+    chunk = 1 << 26
+    for start in range(0, 1 << 32, chunk):
+        bits = torch.arange(start, start + chunk, dtype=torch.int64, device="cuda").to(torch.int32)   # wraps to the bit pattern
+        x = bits.view(torch.float32)
+        a = renderer.math("sqrt_n", x)
+        b = renderer.math("sqrt_ieee", x)
+        same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+        excluded = (x.abs() > 0) & (x.abs() < 2.0 ** -96)       # v_sqrt_f32 flushes denormals: -tiny gives -0, not NaN
+        bad = ~same & ~excluded
+        assert not bool(bad.any()), "first mismatch at bits 0x%08x" % int(bits[bad][0].item() & 0xffffffff)
