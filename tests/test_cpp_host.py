@@ -66,8 +66,17 @@ def test_bench_cpu_baseline_leg(oracle):
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    cb = bench.cpu_baseline("egg", 64, 36, 0.37, 4)
+    cb, rows, ref = bench.cpu_baseline("egg", 64, 36, 0.37, 4)
     assert cb["kind"] == "port" and cb["unit"] == "Mpixels/s" and cb["cores"] >= 1 and cb["value"] > 0
+    assert rows == list(range(2, 36, 4)) and ref.shape == (len(rows), 64, 4)
+    # the parity record: identical rows -> 0 / 0; one flipped bit -> one mismatching pixel
+    assert bench.parity(ref.copy(), ref, len(rows))["mismatching_pixels"] == 0
+    bad = ref.copy()
+    bad[1, 2, 0] = np.nextafter(bad[1, 2, 0], np.float32(2))
+    rec = bench.parity(bad, ref, len(rows))
+    assert rec["mismatching_pixels"] == 1 and 0 < rec["max_abs_diff"] < 1e-6
+    sp = bench.cpu_baseline_speed("egg", 64, 36, 0.37, rows)
+    assert sp is None or (sp["value"] > 0 and "march=native" in sp["sample"])
     assert set(bench.OPS_PER_PIXEL) == {"clouds", "egg", "raytracer", "atmosphere", "planet", "sdf_ao"}
 
 
