@@ -21,7 +21,13 @@
 #ifndef CL_PARK
 #define CL_PARK 1          // park the march state in LDS during a lit step's light march
 #endif
-#define CL_PARK_N 9
+#define CL_PARK_N 10
+#ifndef CL_LIPSKIP
+#define CL_LIPSKIP 1       // skip main samples proved clear by the Lipschitz bound (coop_density_row)
+#endif
+#ifndef CL_EPILOGUE_RELOAD
+#define CL_EPILOGUE_RELOAD 1
+#endif
 #ifndef CL_NO_REG
 #define CL_NO_REG 0       // 1: never use the REG kernels (A/B timing)
 #endif
@@ -302,16 +308,42 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
 // bound is below cov for EVERY alive lane of the wave the sample cannot be lit and the remaining octaves are not
 // evaluated (54 % / 73 % of the main samples of the 4K frame; the skipped octaves are the ones that miss most).
 // A skipped sample returns 0, which integrate_volume treats exactly like the true value.
+//
+// Skipping clear air (LIP, REG kernels only).  When the first stage already fails — s + .1876 < cov with s = .5 N(q0) + .25 N(q1)
+// the sum of octaves 0-1 — the NEXT samples of the march are often clear as well, and that can be PROVED without evaluating
+// them.  The value noise N is a trilinear blend, with smoothstep weights S(a) = a^2 (3 - 2a), |S'| <= 1.5, of lattice hashes
+// in [0, 1], hence 1.5-Lipschitz in every coordinate and continuous across cells.  One march step moves the sample by
+// dt * (proj.x, 1, proj.z), i.e. by dt * .00203 * (|proj.x| + 1 + |proj.z|) =: D in the L1 norm of q0 and by 2.64 D in q1, so
+//     |s(i + j) - s(i)| <= j * 1.5 * (.5 + .25 * 2.64) * D = j * 1.74 D   (+ a few 1e-6 of binary32 rounding).
+// With gap = (cov - .1876 - 1e-3) - s(i) and c = 1.01 * 1.74 D (rounded up, per lane, fixed for the march), the next
+// floor(gap / c) samples of that lane satisfy the stage-1 test; the minimum over the alive lanes (taken as the largest of
+// 1, 2, 4, 8, 16 that every alive lane allows) is the number of main samples the wave skips entirely: each would have
+// returned density 0, which integrate_volume ignores (src/app_clouds.h:132), so only `t += dt` remains of them.  The 1e-3
+// and the 1 % dominate every rounding on the way (positions ~3e3 +- 1e-4, t <= 125 +- 4e-4, noise +- 2e-6).
+template <bool LIP>
 __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
                                                   unsigned long long active_mask, WaveCache& S, int lane,
-                                                  float (&fx)[4], float (&nxy)[4]) {
+                                                  float (&fx)[4], float (&nxy)[4], float lip_inv, int& skip) {
     float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
     const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
     const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
     const float rpy[4] = {row.py157.x, row.py157.y, row.py157.z, row.py157.w};
     float t = 0.f, H = .5f;
     row_octaves<0, 2>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
-    if (!wave_any_mask(active_mask & wave_mask(!(t + .1876f < F.cov)))) return 0.f;      // NaN compares false: goes on
+    if (!wave_any_mask(active_mask & wave_mask(!(t + .1876f < F.cov)))) {                // NaN compares false: goes on
+        if (LIP) {
+            const float r = ((F.cov - .1886f) - t) * lip_inv;                            // samples this lane can prove clear
+            if (!wave_any_mask(active_mask & wave_mask(!(r >= 1.f)))) {
+                skip = 1;
+                if (!wave_any_mask(active_mask & wave_mask(!(r >= 4.f)))) {
+                    skip = 4;
+                    if (!wave_any_mask(active_mask & wave_mask(!(r >= 16.f)))) skip = 16;
+                    else if (!wave_any_mask(active_mask & wave_mask(!(r >= 8.f)))) skip = 8;
+                } else if (!wave_any_mask(active_mask & wave_mask(!(r >= 2.f)))) skip = 2;
+            }
+        }
+        return 0.f;
+    }
     row_octaves<2, 3>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
     if (!wave_any_mask(active_mask & wave_mask(!(t + .06255f < F.cov)))) return 0.f;
     row_octaves<3, 4>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
@@ -484,8 +516,14 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
 #endif
 // ZL: the light step has no x and no y component (decided on the host), so the light march is light_march_z; the general
 // march is then not even compiled into the kernel (it was the register-pressure peak of the hot loop).
+// The epilogue reads the camera / sky constants AGAIN from the kernarg segment (a fresh pointer the compiler cannot connect
+// with the loads of the prologue) instead of keeping ~40 SGPRs live across the march: the march was at the 102-SGPR limit,
+// with SGPRs spilled to VGPR lanes.  ClArgs mirrors the kernel's argument list: the kernarg segment lays the arguments out in
+// order at their natural alignment, exactly like this struct.  (Passing ONE struct argument instead made every use in the
+// march a scalar load: 3.5 -> 4.0 ms.)
+struct ClArgs { FrameClouds F; RowMap M; float* out; const YRow* ytab; };
 template <bool YTAB, bool REG, bool ZL>
-__global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out,
+__global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out_arg,
                                                           const YRow* __restrict__ ytab) {
     __shared__ WaveCache cache[CL_TX];
 #if CL_PARK
@@ -507,7 +545,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
     float transmittance = 1.f, radiance = 0.f, alpha = 0.f;
     bool marches;
 #ifdef SBX_CL_STATS
-    float st_steps = 0.f, st_lit = 0.f, st_alive = 0.f, st_litl = 0.f;
+    float st_steps = 0.f, st_lit = 0.f, st_alive = 0.f, st_litl = 0.f, st_skipped = 0.f;
 #endif
     {
         // Only what the march needs stays live across it (origin, projection, phase): the view direction
@@ -526,6 +564,10 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
             const v3 lstep = F.sun_dir * F.dt;
             // frame constants the light march multiplies / subtracts with, held in VGPRs: an fp32 VALU instruction with an
             // SGPR source issues at half rate on gfx950 (profiles/r02_ubench_issue.txt)
+            constexpr bool LIP = YTAB && REG && (CL_LIPSKIP != 0);
+            // 1 / c of coop_density_row's skip bound; c = 1.01 * 1.74 * D, D = dt * .001 * 2.03 * (|proj.x| + 1 + |proj.z|)
+            float lip_inv = 1.0f / ((1.01f * 1.74f) * ((F.dt * (.001f * 2.03f)) * ((abs_(projection.x) + 1.0f) + abs_(projection.z))));
+            int skip = 0;
             float vsigma = F.sigma, vdt = F.dt, vcov = F.cov;
             asm volatile("" : "+v"(vsigma), "+v"(vdt), "+v"(vcov));
             float t = 0.f;
@@ -535,13 +577,21 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
 #ifdef SBX_CL_STATS
                 st_steps += 1.f; st_alive += (float)__builtin_popcountll(alive_mask);
 #endif
+                if (LIP && skip > 0) {                            // proved clear for every alive lane (coop_density_row): density 0
+                    --skip;
+                    t += F.dt;
+#ifdef SBX_CL_STATS
+                    st_skipped += 1.f;
+#endif
+                    continue;
+                }
                 const v3 pos = origin + t * projection;
                 t += F.dt;
                 YRow row;
                 if (YTAB) row = ytab[i];                          // uniform index: scalar loads (reading row i + 1 ahead
                                                                   // over the back edge costs 12 more live SGPRs: +6 % time)
                 float mfx[4] = {0.f, 0.f, 0.f, 0.f}, mnxy[4] = {0.f, 0.f, 0.f, 0.f};
-                const float density = YTAB ? coop_density_row(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy)
+                const float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, lip_inv, skip)
                                            : coop_density(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
@@ -557,15 +607,18 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                         float* pk = &park[threadIdx.x >> 6][0][lane];
                         pk[0 * 64] = origin.x; pk[1 * 64] = origin.z; pk[2 * 64] = projection.x; pk[3 * 64] = projection.z;
                         pk[4 * 64] = t; pk[5 * 64] = transmittance; pk[6 * 64] = radiance; pk[7 * 64] = alpha; pk[8 * 64] = phase;
+                        if (LIP) pk[9 * 64] = lip_inv;
                         asm volatile("" ::: "memory");
                         asm volatile("" : "=v"(origin.x), "=v"(origin.z), "=v"(projection.x), "=v"(projection.z), "=v"(t),
                                           "=v"(transmittance), "=v"(radiance), "=v"(alpha), "=v"(phase));     // dead from here
+                        if (LIP) asm volatile("" : "=v"(lip_inv));
 #endif
                         ltrans = light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, etab, vsigma, vdt, vcov);
 #if CL_PARK
                         asm volatile("" ::: "memory");
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
                         t = pk[4 * 64]; transmittance = pk[5 * 64]; radiance = pk[6 * 64]; alpha = pk[7 * 64]; phase = pk[8 * 64];
+                        if (LIP) lip_inv = pk[9 * 64];
 #endif
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
@@ -586,11 +639,24 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
             }
         }
     }
-    const Pixel px = pixel_of_thread<CL_TW, CL_TX, CL_TOP_FIRST>(M);
+#if CL_EPILOGUE_RELOAD
+    typedef const __attribute__((address_space(4))) ClArgs* KArgPtr;
+    KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));                                   // a pointer of unknown origin: its loads are new loads
+    const ClArgs* kg = (const ClArgs*)ka;                          // (the address space is still known: scalar loads)
+    const FrameClouds& FE = kg->F;
+    const RowMap& ME = kg->M;
+    float* const out = kg->out;
+#else
+    const FrameClouds& FE = F;
+    const RowMap& ME = M;
+    float* const out = out_arg;
+#endif
+    const Pixel px = pixel_of_thread<CL_TW, CL_TX, CL_TOP_FIRST>(ME);
     if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
-    const v3 dir = primary_dir(F.cam, pc);
-    const v3 sky = clouds_sky(F, dir);
+    const v2 pc = point_cam(FE.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v3 dir = primary_dir(FE.cam, pc);
+    const v3 sky = clouds_sky(FE, dir);
     v3 col = sky;
     if (marches) {
         const float a = alpha * smoothstep_(.0f, .2f, dot(dir, V3(0, 1, 0)));
@@ -599,7 +665,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
 #ifdef SBX_CL_STATS
     __builtin_amdgcn_wave_barrier();
     if (lane == 1) { st_steps = S.stat[0]; st_lit = S.stat[1]; st_alive = S.stat[2]; st_litl = S.stat[3]; }
-    reinterpret_cast<float4*>(out)[px.idx] = make_float4(st_steps, st_lit, st_alive, st_litl);
+    reinterpret_cast<float4*>(out)[px.idx] = make_float4(st_steps, st_lit, (lane == 2) ? st_skipped : st_alive, st_litl);
     return;
 #endif
     store_rgba(out, px.idx, to_srgb(col));
