@@ -21,7 +21,7 @@
 #ifndef CL_PARK
 #define CL_PARK 1          // park the march state in LDS during a lit step's light march
 #endif
-#define CL_PARK_N 10
+#define CL_PARK_N 12
 #ifndef CL_LIPSKIP
 #define CL_LIPSKIP 1       // skip main samples proved clear by the Lipschitz bound (coop_density_row)
 #endif
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                 if (YTAB) row = ytab[i];                          // uniform index: scalar loads (reading row i + 1 ahead
                                                                   // over the back edge costs 12 more live SGPRs: +6 % time)
                 float mfx[4] = {0.f, 0.f, 0.f, 0.f}, mnxy[4] = {0.f, 0.f, 0.f, 0.f};
-                const float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, lip_inv, skip)
+                float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, lip_inv, skip)
                                            : coop_density(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
 #ifdef SBX_CL_STATS
                     st_lit += 1.f; st_litl += (float)__builtin_popcountll(lit_mask);
 #endif
-                    const float T_i = REG ? exp_tab_<false>(-density * vsigma * vdt, etab) : CL_EXP(-density * F.sigma * F.dt);
+                    float T_i = REG ? exp_tab_<false>(-density * vsigma * vdt, etab) : CL_EXP(-density * F.sigma * F.dt);
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
                     if (ZL) {                                      // lstep.x == 0 && lstep.y == 0 (launch_clouds): z-only light step
@@ -608,10 +608,12 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                         pk[0 * 64] = origin.x; pk[1 * 64] = origin.z; pk[2 * 64] = projection.x; pk[3 * 64] = projection.z;
                         pk[4 * 64] = t; pk[5 * 64] = transmittance; pk[6 * 64] = radiance; pk[7 * 64] = alpha; pk[8 * 64] = phase;
                         if (LIP) pk[9 * 64] = lip_inv;
+                        pk[10 * 64] = density; pk[11 * 64] = T_i;
                         asm volatile("" ::: "memory");
                         asm volatile("" : "=v"(origin.x), "=v"(origin.z), "=v"(projection.x), "=v"(projection.z), "=v"(t),
                                           "=v"(transmittance), "=v"(radiance), "=v"(alpha), "=v"(phase));     // dead from here
                         if (LIP) asm volatile("" : "=v"(lip_inv));
+                        asm volatile("" : "=v"(density), "=v"(T_i));
 #endif
                         ltrans = light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, etab, vsigma, vdt, vcov);
 #if CL_PARK
@@ -619,6 +621,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
                         t = pk[4 * 64]; transmittance = pk[5 * 64]; radiance = pk[6 * 64]; alpha = pk[7 * 64]; phase = pk[8 * 64];
                         if (LIP) lip_inv = pk[9 * 64];
+                        density = pk[10 * 64]; T_i = pk[11 * 64];
 #endif
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {

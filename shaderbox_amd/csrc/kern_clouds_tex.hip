@@ -27,13 +27,14 @@
 
 namespace sbx {
 
-struct NoiseTex { const float* r; int size; float fsize; };
+struct NoiseTex { const float* r; int size; float fsize; double rsize; };   // rsize = recip64(fsize): fl / size as an exact multiply (sbx_math.h div_by)
 
 __device__ __forceinline__ void tex_axis(float c, const NoiseTex& T, int& i0, int& i1, float& f) {
     const float u = c * T.fsize - .5f;
     const float fl = floor_(u);
     f = u - fl;
-    float m = fl - T.fsize * floor_(fl / T.fsize);             // GLSL mod(fl, size): exact for |fl| < 2^24 and size 2^k
+    float m = fl - T.fsize * floor_(div_by(fl, T.rsize));      // GLSL mod(fl, size) = fl - size * floor(fl / size); the quotient
+                                                               // through the binary64 reciprocal is the IEEE quotient, bit for bit
     if (m < 0.f) m += T.fsize;                                 // a rounded quotient can land one period off
     if (m >= T.fsize) m -= T.fsize;
     const int i = (m >= 0.f && m < T.fsize) ? (int)m : 0;      // NaN / infinite coordinates sample texel 0
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(256) k_tex3d_eval(int size, const float* __res
                                                     float* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const NoiseTex T{nullptr, size, (float)size};
+    const NoiseTex T{nullptr, size, (float)size, recip64((float)size)};
     int x0, x1, y0, y1, z0, z1;
     float fx, fy, fz;
     tex_axis(xyz[3 * i], T, x0, x1, fx);
@@ -157,7 +158,8 @@ void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out
 
 void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, const float* shape_r, int shape_size,
                        const float* detail_r, int detail_size) {
-    const NoiseTex T1{shape_r, shape_size, (float)shape_size}, T2{detail_r, detail_size, (float)detail_size};
+    const NoiseTex T1{shape_r, shape_size, (float)shape_size, recip64((float)shape_size)};
+    const NoiseTex T2{detail_r, detail_size, (float)detail_size, recip64((float)detail_size)};
     hipLaunchKernelGGL(k_clouds_tex, grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2);
 }
 
