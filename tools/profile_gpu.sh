@@ -21,7 +21,7 @@ pmc() {
   echo "# rocprofv3 --kernel-trace --pmc $* -- python bench.py $ARGS" >> $OUT/summary.txt
   rocprofv3 --kernel-trace -f csv --pmc $* -d $OUT/pmc_$name -o pmc -- python bench.py $ARGS > $OUT/pmc_$name.log 2>&1
   f=$(find $OUT/pmc_$name -name '*counter_collection.csv' | head -1)
-  if [ -n "$f" ]; then python tools/pmc_summary.py "$f" >> $OUT/summary.txt; else echo "(no counter file; see pmc_$name.log)" >> $OUT/summary.txt; tail -5 $OUT/pmc_$name.log >> $OUT/summary.txt; fi
+  if [ -n "$f" ]; then python tools/pmc_summary.py "$f" --largest-grid >> $OUT/summary.txt; else echo "(no counter file; see pmc_$name.log)" >> $OUT/summary.txt; tail -5 $OUT/pmc_$name.log >> $OUT/summary.txt; fi
 }
 pmc valu SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE
 pmc busy SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE
