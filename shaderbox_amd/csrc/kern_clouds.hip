@@ -542,7 +542,14 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
 #endif
     __builtin_amdgcn_wave_barrier();
 
+#if CL_PARK
+    // The integrator state of the pixel (transmittance, radiance, alpha) and its phase value change only in LIT steps (a fifth
+    // of the main steps): they live in LDS slots 5-8 of the wave's park area for the whole march, not in registers.
+    float* const pk = &park[threadIdx.x >> 6][0][lane];
+    pk[5 * 64] = 1.f; pk[6 * 64] = 0.f; pk[7 * 64] = 0.f;
+#else
     float transmittance = 1.f, radiance = 0.f, alpha = 0.f;
+#endif
     bool marches;
 #ifdef SBX_CL_STATS
     float st_steps = 0.f, st_lit = 0.f, st_alive = 0.f, st_litl = 0.f, st_skipped = 0.f;
@@ -560,7 +567,11 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
         if (wave_any(alive)) {                                    // wave-uniform
             v3 projection = dir / dir.y;                          // render_clouds :153-202
             v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
+#if CL_PARK
+            pk[8 * 64] = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
+#else
             float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
+#endif
             const v3 lstep = F.sun_dir * F.dt;
             // frame constants the light march multiplies / subtracts with, held in VGPRs: an fp32 VALU instruction with an
             // SGPR source issues at half rate on gfx950 (profiles/r02_ubench_issue.txt)
@@ -604,22 +615,19 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                     float ltrans = 1.f;
                     if (ZL) {                                      // lstep.x == 0 && lstep.y == 0 (launch_clouds): z-only light step
 #if CL_PARK
-                        float* pk = &park[threadIdx.x >> 6][0][lane];
+                        // what the march does not need while a light march runs: parked for that time (slots 0-4, 9-11)
                         pk[0 * 64] = origin.x; pk[1 * 64] = origin.z; pk[2 * 64] = projection.x; pk[3 * 64] = projection.z;
-                        pk[4 * 64] = t; pk[5 * 64] = transmittance; pk[6 * 64] = radiance; pk[7 * 64] = alpha; pk[8 * 64] = phase;
+                        pk[4 * 64] = t;
                         if (LIP) pk[9 * 64] = lip_inv;
                         pk[10 * 64] = density; pk[11 * 64] = T_i;
-                        asm volatile("" ::: "memory");
-                        asm volatile("" : "=v"(origin.x), "=v"(origin.z), "=v"(projection.x), "=v"(projection.z), "=v"(t),
-                                          "=v"(transmittance), "=v"(radiance), "=v"(alpha), "=v"(phase));     // dead from here
-                        if (LIP) asm volatile("" : "=v"(lip_inv));
-                        asm volatile("" : "=v"(density), "=v"(T_i));
+                        asm volatile("" ::: "memory");     // the reloads below cannot be forwarded from these stores: the values
+                                                           // are dead across the light march
 #endif
                         ltrans = light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, etab, vsigma, vdt, vcov);
 #if CL_PARK
                         asm volatile("" ::: "memory");
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
-                        t = pk[4 * 64]; transmittance = pk[5 * 64]; radiance = pk[6 * 64]; alpha = pk[7 * 64]; phase = pk[8 * 64];
+                        t = pk[4 * 64];
                         if (LIP) lip_inv = pk[9 * 64];
                         density = pk[10 * 64]; T_i = pk[11 * 64];
 #endif
@@ -630,6 +638,22 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                             lp = lp + lstep;
                         }
                     }
+#if CL_PARK
+                    const float illum = ltrans * F.sun_power * pk[8 * 64];
+                    bool full = false;
+                    if (lit) {
+                        const float transmittance = pk[5 * 64] * T_i;
+                        pk[5 * 64] = transmittance;
+                        pk[6 * 64] = pk[6 * 64] + (density * F.sigma) * illum * transmittance * F.dt;
+                        float alpha = pk[7 * 64];
+                        alpha += (1.f - T_i) * (1.f - alpha);
+                        pk[7 * 64] = alpha;
+                        full = alpha > .999f;                     // :197 — alpha changes in lit steps only, so the exit test lives here
+                    }
+                    if (full) alive = false;
+                    alive_mask &= ~wave_mask(full);
+                }
+#else
                     const float illum = ltrans * F.sun_power * phase;
                     if (lit) {
                         transmittance *= T_i;
@@ -639,6 +663,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                 }
                 if (alpha > .999f) alive = false;                 // :197
                 alive_mask &= ~wave_mask(alpha > .999f);
+#endif
             }
         }
     }
@@ -662,6 +687,9 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
     const v3 sky = clouds_sky(FE, dir);
     v3 col = sky;
     if (marches) {
+#if CL_PARK
+        const float radiance = pk[6 * 64], alpha = pk[7 * 64];
+#endif
         const float a = alpha * smoothstep_(.0f, .2f, dot(dir, V3(0, 1, 0)));
         col = abs3(mix3(sky, V3s(radiance), a));               // :215-217
     }
