@@ -323,16 +323,20 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
 template <bool LIP>
 __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
                                                   unsigned long long active_mask, WaveCache& S, int lane,
-                                                  float (&fx)[4], float (&nxy)[4], float lip_inv, int& skip) {
+                                                  float (&fx)[4], float (&nxy)[4], const float* lip_slot, int& skip) {
     float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
     const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
     const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
     const float rpy[4] = {row.py157.x, row.py157.y, row.py157.z, row.py157.w};
     float t = 0.f, H = .5f;
+    float lip_inv = 0.f;
+    if (LIP) lip_inv = *lip_slot;                        // 1 / c of this lane, kept in LDS (read early, used after the first stage)
     row_octaves<0, 2>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
     if (!wave_any_mask(active_mask & wave_mask(!(t + .1876f < F.cov)))) {                // NaN compares false: goes on
         if (LIP) {
-            const float r = ((F.cov - .1886f) - t) * lip_inv;                            // samples this lane can prove clear
+            float c = F.cov;
+            asm volatile("" : "+v"(c));                  // (keeps cov - .1886 from being hoisted into a register held for the whole march)
+            const float r = ((c - .1886f) - t) * lip_inv;                                // samples this lane can prove clear
             if (!wave_any_mask(active_mask & wave_mask(!(r >= 1.f)))) {
                 skip = 1;
                 if (!wave_any_mask(active_mask & wave_mask(!(r >= 4.f)))) {
@@ -577,7 +581,13 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
             // SGPR source issues at half rate on gfx950 (profiles/r02_ubench_issue.txt)
             constexpr bool LIP = YTAB && REG && (CL_LIPSKIP != 0);
             // 1 / c of coop_density_row's skip bound; c = 1.01 * 1.74 * D, D = dt * .001 * 2.03 * (|proj.x| + 1 + |proj.z|)
-            float lip_inv = 1.0f / ((1.01f * 1.74f) * ((F.dt * (.001f * 2.03f)) * ((abs_(projection.x) + 1.0f) + abs_(projection.z))));
+            const float lip_inv = 1.0f / ((1.01f * 1.74f) * ((F.dt * (.001f * 2.03f)) * ((abs_(projection.x) + 1.0f) + abs_(projection.z))));
+#if CL_PARK
+            if (LIP) pk[9 * 64] = lip_inv;                // lives in LDS: it is needed only where a first stage fails
+            const float* lip_slot = &pk[9 * 64];
+#else
+            const float* lip_slot = &lip_inv;
+#endif
             int skip = 0;
             float vsigma = F.sigma, vdt = F.dt, vcov = F.cov;
             asm volatile("" : "+v"(vsigma), "+v"(vdt), "+v"(vcov));
@@ -602,7 +612,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                 if (YTAB) row = ytab[i];                          // uniform index: scalar loads (reading row i + 1 ahead
                                                                   // over the back edge costs 12 more live SGPRs: +6 % time)
                 float mfx[4] = {0.f, 0.f, 0.f, 0.f}, mnxy[4] = {0.f, 0.f, 0.f, 0.f};
-                float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, lip_inv, skip)
+                float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, lip_slot, skip)
                                            : coop_density(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
@@ -618,7 +628,6 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                         // what the march does not need while a light march runs: parked for that time (slots 0-4, 9-11)
                         pk[0 * 64] = origin.x; pk[1 * 64] = origin.z; pk[2 * 64] = projection.x; pk[3 * 64] = projection.z;
                         pk[4 * 64] = t;
-                        if (LIP) pk[9 * 64] = lip_inv;
                         pk[10 * 64] = density; pk[11 * 64] = T_i;
                         asm volatile("" ::: "memory");     // the reloads below cannot be forwarded from these stores: the values
                                                            // are dead across the light march
@@ -628,7 +637,6 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                         asm volatile("" ::: "memory");
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
                         t = pk[4 * 64];
-                        if (LIP) lip_inv = pk[9 * 64];
                         density = pk[10 * 64]; T_i = pk[11 * 64];
 #endif
                     } else {
@@ -680,7 +688,15 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
     const RowMap& ME = M;
     float* const out = out_arg;
 #endif
+#if CL_EPILOGUE_RELOAD
+    // the thread's coordinates as values of unknown origin too: otherwise the pixel arithmetic of the prologue is kept
+    // alive (spilled to scratch: 20 B per lane written and read back through HBM) for the whole march
+    int tid = (int)threadIdx.x, bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    asm volatile("" : "+v"(tid), "+s"(bx), "+s"(by));
+    const Pixel px = pixel_of<CL_TW, CL_TX, CL_TOP_FIRST>(ME, tid, bx, by, (int)gridDim.y);
+#else
     const Pixel px = pixel_of_thread<CL_TW, CL_TX, CL_TOP_FIRST>(ME);
+#endif
     if (!px.valid) return;
     const v2 pc = point_cam(FE.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 dir = primary_dir(FE.cam, pc);

@@ -25,17 +25,21 @@ struct Pixel { int x, y; size_t idx; bool valid; };
 // the TOP rows of the launch.  For APP_CLOUDS the bottom rows never march (src/app_clouds.h:212), so the launch then ends
 // on its cheapest waves and the end-of-launch drain is not a few 100-step marches on a mostly empty chip.
 template <int TW = 8, int TX = WG_TILES_X, bool TOP_FIRST = false>
-__device__ __forceinline__ Pixel pixel_of_thread(const RowMap& M) {
+__device__ __forceinline__ Pixel pixel_of(const RowMap& M, int tid, int bx, int by_in, int grid_y) {
     constexpr int TH = 64 / TW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     Pixel p;
-    p.x = blockIdx.x * (TW * TX) + wave * TW + (lane % TW);
-    const int by = TOP_FIRST ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    p.x = bx * (TW * TX) + wave * TW + (lane % TW);
+    const int by = TOP_FIRST ? (grid_y - 1 - by_in) : by_in;
     const int r = by * TH + (lane / TW);
     p.valid = (p.x < M.width) && (r < M.nrows);
     p.y = row_to_y(M, r);
     p.idx = (size_t)(M.in_place ? p.y : r) * M.width + p.x;
     return p;
+}
+template <int TW = 8, int TX = WG_TILES_X, bool TOP_FIRST = false>
+__device__ __forceinline__ Pixel pixel_of_thread(const RowMap& M) {
+    return pixel_of<TW, TX, TOP_FIRST>(M, (int)threadIdx.x, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 template <int TW = 8, int TX = WG_TILES_X>
 inline dim3 grid_for(const RowMap& M) {
