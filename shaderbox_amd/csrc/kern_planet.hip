@@ -7,6 +7,9 @@
 // matrices, transpose(rot) and the light vector are frame constants (FramePlanet).
 // NaN policy: smoothstep(1-.3s, 1-.2s, N) with s = 0 is 0/0 for N == 1 (:270-273); NaN is data and
 // flows to the framebuffer exactly as IEEE arithmetic dictates.
+#ifndef SBX_HC_SLOTS
+#define SBX_HC_SLOTS 32         // 4.7 KB of LDS per wave: 5 waves per SIMD fit (64 slots: 9.3 KB, 4 waves)
+#endif
 #include "sbx_device.h"
 #include "sbx_noise.h"
 #include "sbx_hashcache.h"
@@ -51,19 +54,23 @@ __device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_
 
 // fBm over the cached noise: octaves START..OCT-1 are fetched in cooperative batches of <= 4 (register budget) and
 // added to (t, H, q) in octave order exactly as fbm.h:6 (t += basis * H; p *= lacunarity; H *= gain)
+#ifndef PL_BATCH
+#define PL_BATCH 2          // octaves fetched per cooperative batch: 4 at a time (round 1) peaked at 32 hash registers and spilled
+#endif
 template <int OCT, int MODE, int START>
 __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacunarity, float& H, float gain, float& t, bool on, int lane) {
+    constexpr int B = PL_BATCH;
 #pragma unroll
-    for (int base = START; base < OCT; base += 4) {
-        if (base + 4 <= OCT) {
-            v3 p[4]; int tab[4]; float nz[4];
+    for (int base = START; base < OCT; base += B) {
+        if (base + B <= OCT) {
+            v3 p[B]; int tab[B]; float nz[B];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
-            coop_noise_n<4>(S, p, tab, on, lane, nz);
+            for (int i = 0; i < B; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
+            coop_noise_n<B>(S, p, tab, on, lane, nz);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
+            for (int i = 0; i < B; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         } else {
-            constexpr int R = (OCT - START) % 4;
+            constexpr int R = (OCT - START) % B;
             v3 p[R > 0 ? R : 1]; int tab[R > 0 ? R : 1]; float nz[R > 0 ? R : 1];
 #pragma unroll
             for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
@@ -154,8 +161,12 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
     return abs3(sky);
 }
 
+// Occupancy (7680x4320, tools/ab_time.py): 4 waves/SIMD with batches of 4 octaves: 128 VGPRs, 34 spills, 8.02 ms (round 1);
+// batches of 2: 126 VGPRs, NO spills, 8.00 ms; held to 3 waves: 9.65 ms; 5 waves (96 VGPRs, 32-slot tables so that LDS allows
+// them): 30 spills, some inside the cloud march, and still 7.3 ms — the fifth wave pays more than the spills cost (parking the
+// terrain results in LDS across the cloud march removed a third of them and changed nothing).
 #ifndef PL_MIN_WAVES
-#define PL_MIN_WAVES 4
+#define PL_MIN_WAVES 5
 #endif
 template <bool SKIP>
 __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
