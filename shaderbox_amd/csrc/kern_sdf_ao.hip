@@ -7,6 +7,10 @@
 #include "sbx_device.h"
 #include "sbx_sdf.h"
 
+#ifndef AO_MIN_WAVES
+#define AO_MIN_WAVES 4
+#endif
+
 namespace sbx {
 
 __device__ __forceinline__ D2 ao_sdf_pipe(const FrameSdfAo& F, v3 pos) {                          // :54-113
@@ -79,7 +83,7 @@ __device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos) {             
 }
 
 template <bool CULL>
-__global__ void __launch_bounds__(WG_THREADS) k_sdf_ao(FrameSdfAo F, RowMap M, float* __restrict__ out) {
+__global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);

@@ -9,6 +9,10 @@
 #include "sbx_sdf.h"
 #include "sbx_noise.h"
 
+#ifndef VI_MIN_WAVES
+#define VI_MIN_WAVES 5     // 3840x2160: 3 waves (134 VGPRs) 4.03 ms, 4 waves 3.85, 5 waves (96 VGPRs, spills outside the march) 3.71
+#endif
+
 namespace sbx {
 
 __device__ __forceinline__ float vinyl_logo(const FrameVinyl& F, v3 pos, float thick) {       // :68-85
@@ -139,7 +143,7 @@ __device__ __forceinline__ v3 vinyl_base_color(int mat) {                       
 }
 
 template <bool CULL>
-__global__ void __launch_bounds__(WG_THREADS) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
+__global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
