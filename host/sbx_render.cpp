@@ -27,8 +27,8 @@
 #include "../include/sbx.h"
 
 static int app_from_name(const std::string& s) {
-    const char* names[] = {"planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best", "clouds_tex"};
-    const int n = 9;
+    const char* names[] = {"planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best", "clouds_tex", "clouds_ue4"};
+    const int n = 10;
     std::string low;
     for (char c : s) low += (char)tolower(c);
     for (int i = 0; i < n; ++i)

@@ -50,7 +50,12 @@ typedef enum sbx_app {
     SBX_APP_CLOUDS_BEST = 7,
     /* APP_CLOUDS compiled with USE_NOISE_TEX (src/app_clouds.h:9,51-56,69-81): density from two 3-D noise textures
        (sbx_set_noise_volumes) instead of the procedural fBm; same aux block as APP_CLOUDS */
-    SBX_APP_CLOUDS_TEX = 8
+    SBX_APP_CLOUDS_TEX = 8,
+    /* the UE4 cloud variant, ue4/volumetric_clouds/Shaders/app_clouds.usf (ue4_render_clouds :234-265): a library for an
+       Unreal material, not a mainImage shader.  Host mapping of this build: cam_dir = the primary-ray direction of
+       APP_CLOUDS' camera, time = u_time, parameters = the TWEAK defaults (:4-17) or an sbx_aux_clouds_ue4 block, result
+       through main.h's sRGB epilogue.  No reference-held answers: parity unpinned. */
+    SBX_APP_CLOUDS_UE4 = 9
 } sbx_app;
 
 typedef enum sbx_status {
@@ -92,6 +97,15 @@ typedef struct sbx_aux_sdf_ao {
     float fog_falloff;   /* c0.y default .5 */
     float _pad[2];
 } sbx_aux_sdf_ao;
+
+/* the material parameters of ue4_render_clouds (app_clouds.usf:234-243) for SBX_APP_CLOUDS_UE4; NULL = the TWEAK block's
+ * defaults (:4-7) with the SUN_DIR / WIND_DIR macros (:13-14, functions of u_time) */
+typedef struct sbx_aux_clouds_ue4 {
+    float coverage, thickness, absorbtion, fuzziness;   /* c0   defaults .50, 15, 1.030725, .035 */
+    float sun_dir[3];    float _pad1;                   /* c1   used when use_dirs != 0 */
+    float wind_dir[3];   int32_t use_dirs;              /* c2   use_dirs = 0: SUN_DIR / WIND_DIR of the shader */
+} sbx_aux_clouds_ue4;
+void sbx_aux_clouds_ue4_defaults(sbx_aux_clouds_ue4* aux);
 
 typedef struct sbx_ctx sbx_ctx;
 

@@ -1163,6 +1163,95 @@ struct AppVinyl {
 };
 
 /* =================================================================================== */
+/* The UE4 cloud variant — ue4/volumetric_clouds/Shaders/app_clouds.usf.             */
+/* An HLSL library for an Unreal material: its entry is ue4_render_clouds(cam_dir, time, coverage, ...)     */
+/* (:234-265), called per pixel by a material graph that is a binary asset.  THE BUILD'S HOST MAPPING       */
+/* (there is nothing in the tree to pin it): cam_dir = the primary-ray direction of APP_CLOUDS' mainImage   */
+/* camera (src/app_clouds.h:23-30, FOV 1), time = u_time, the parameters = the TWEAK block's defaults       */
+/* (:4-17) unless an aux block overrides them, and the result goes through main.h's sRGB epilogue like      */
+/* every other app.  No known answers exist: PARITY UNPINNED (review only).                                 */
+/* =================================================================================== */
+struct clouds_ue4_aux_t {                                       /* the material's scalar / vector parameters */
+    float coverage = .50f, thickness = 15.f, absorbtion = 1.030725f, fuzziness = 0.035f;   /* :4-7 */
+    vec3 sun_dir, wind_dir;
+    bool has_dirs = false;                                      /* false: SUN_DIR / WIND_DIR macros (:13-14) */
+};
+struct AppCloudsUe4 {
+    uniforms_t U;
+    clouds_ue4_aux_t A;
+    static constexpr int STEPS = 25;                            /* :16 */
+    float fov() const { return 1.f; }
+    void setup_scene() {}
+    void setup_camera(vec3& eye, vec3& look_at) const {          /* host mapping: APP_CLOUDS' camera */
+        eye = vec3(0, -.5f, 0);
+        float angle = U.u_mouse.x * .5f;
+        look_at = mul(rotate_around_y(angle), vec3(0, 0, -1));
+    }
+    /* :123-135 — unrolled 4-octave fBm with its own weights; FBM_FREQ 2.76434 (:9) */
+    static float fbm(vec3 pos, float lacunarity) {
+        vec3 p = pos;
+        float t = 0.51749673f * noise_iq(p); p = p * lacunarity;
+        t += 0.25584929f * noise_iq(p); p = p * lacunarity;
+        t += 0.12527603f * noise_iq(p); p = p * lacunarity;
+        t += 0.06255931f * noise_iq(p);
+        return t;
+    }
+    static float noise_func(vec3 x) { return fbm(x, 2.76434f); }  /* :142-149 */
+    /* :151-162 (returns sky WITHOUT abs, unlike app_clouds.h) */
+    static vec3 render_sky_color(vec3 eye_dir, vec3 sun_dir) {
+        const vec3 sun_color = vec3(1.f, .7f, .55f);
+        float sun_amount = m_max(dot(eye_dir, sun_dir), 0.f);
+        vec3 sky = vmix(vec3(.0f, .1f, .4f), vec3(.3f, .6f, .8f), 1.0f - eye_dir.y);
+        sky += sun_color * m_min(m_pow(sun_amount, 1500.0f) * 5.0f, 1.0f);
+        sky += sun_color * m_min(m_pow(sun_amount, 10.0f) * .6f, 1.0f);
+        return sky;
+    }
+    /* :164-179 */
+    static float density_func(vec3 pos, vec3 offset, float coverage, float fuziness) {
+        vec3 p = pos * .0212242f + offset;
+        float dens = noise_func(p);
+        dens *= m_smoothstep(coverage, coverage + fuziness, dens);
+        return m_clamp(dens, 0.f, 1.f);
+    }
+    /* :181-231, plane projection branch */
+    static vec4 render_clouds(const ray_t& eye, vec3 /*sun_dir*/, vec3 wind_dir, float coverage, float thickness,
+                              float absorbtion, float fuzziness) {
+        const int steps = STEPS;
+        float march_step = thickness / float(steps);
+        vec3 dir_step = eye.direction / eye.direction.y * march_step;
+        vec3 pos = eye.origin + eye.direction * 100.f;
+        float T = 1.f;
+        vec3 C = vec3(0, 0, 0);
+        float alpha = 0.f;
+        for (int i = 0; i < steps; i++) {
+            float h = float(i) / float(steps);
+            float dens = density_func(pos, wind_dir, coverage, fuzziness);
+            float T_i = m_exp(-absorbtion * dens * march_step);
+            T *= T_i;
+            C += T * (m_exp(h) / 1.75f) * dens * march_step;
+            alpha += (1.f - T_i) * (1.f - alpha);
+            pos += dir_step;
+        }
+        return vec4(C, alpha);
+    }
+    /* :234-265 */
+    static vec3 ue4_render_clouds(vec3 cam_dir, float /*time*/, float coverage, float thickness, float absorbtion,
+                                  float fuzziness, vec3 sun_dir, vec3 wind_dir) {
+        ray_t eye_ray;
+        eye_ray.origin = vec3(0, 0, 0);
+        eye_ray.direction = cam_dir;
+        vec3 sky = render_sky_color(eye_ray.direction, sun_dir);
+        vec4 cld = render_clouds(eye_ray, sun_dir, wind_dir, 1.f - coverage, thickness, absorbtion, fuzziness);
+        return vmix(sky, cld.rgb(), cld.w);
+    }
+    vec3 render(const ray_t& eye_ray, vec3 /*point_cam*/) const {
+        vec3 sun = A.has_dirs ? A.sun_dir : normalize(vec3(0, m_abs(m_sin(U.u_time * .3f)), -1));     /* SUN_DIR :14 */
+        vec3 wind = A.has_dirs ? A.wind_dir : vec3(0, 0, -U.u_time * .2f);                           /* WIND_DIR :13 */
+        return ue4_render_clouds(eye_ray.direction, U.u_time, A.coverage, A.thickness, A.absorbtion, A.fuzziness, sun, wind);
+    }
+};
+
+/* =================================================================================== */
 /* "clouds_best" — src/app_clouds_best.h, the stand-alone (flattened) cloud shader; SURVEY.md §8f row 4. */
 /* Not selected by an APP_* define in the reference: it is a complete shader with its own mainImage      */
 /* (:669-696, identical to src/main.h) and FOV 1 (:663).  C++ branch of its macros (:31-40).             */

@@ -27,7 +27,8 @@ using namespace sbxref;
 /* app ids: same order as the README table (/root/reference/README.md:15-22) + SDF_AO */
 enum { APP_PLANET = 0, APP_CLOUDS = 1, APP_VINYL = 2, APP_EGG = 3, APP_RAYTRACER = 4, APP_ATMOSPHERE = 5, APP_SDF_AO = 6,
        APP_CLOUDS_BEST = 7 /* src/app_clouds_best.h: not an APP_* define of the reference, numbered after them */,
-       APP_CLOUDS_TEX = 8  /* APP_CLOUDS compiled with USE_NOISE_TEX (src/app_clouds.h:9,51-56,69-81) */ };
+       APP_CLOUDS_TEX = 8  /* APP_CLOUDS compiled with USE_NOISE_TEX (src/app_clouds.h:9,51-56,69-81) */,
+       APP_CLOUDS_UE4 = 9  /* ue4/volumetric_clouds/Shaders/app_clouds.usf under the build's host mapping (ref_apps.h) */ };
 
 /* the two bound 3-D textures of the USE_NOISE_TEX build (t1, t2): set by sbxo_set_noise_volumes, owned by the caller */
 static noise_tex_t g_tex_noise, g_tex_noise_2;
@@ -76,6 +77,15 @@ static bool pixel(int app, const uniforms_t& U, const void* aux, float fx, float
     case APP_PLANET: { AppPlanet a; a.U = U; c = main_image(a, fc); break; }
     case APP_VINYL: { AppVinyl a; a.U = U; c = main_image(a, fc); break; }
     case APP_CLOUDS_BEST: { AppCloudsBest a; a.U = U; c = main_image(a, fc); break; }
+    case APP_CLOUDS_UE4: {
+        AppCloudsUe4 a; a.U = U;
+        if (aux) {                                  /* sbx_aux_clouds_ue4: coverage, thickness, absorbtion, fuzziness, sun_dir@c1, wind_dir@c2, use_dirs@c2.w */
+            const float* f = (const float*)aux;
+            a.A.coverage = f[0]; a.A.thickness = f[1]; a.A.absorbtion = f[2]; a.A.fuzziness = f[3];
+            a.A.sun_dir = vec3(f[4], f[5], f[6]); a.A.wind_dir = vec3(f[8], f[9], f[10]);
+            a.A.has_dirs = ((const int*)aux)[11] != 0;
+        }
+        c = main_image(a, fc); break; }
     default: return false;
     }
     out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;

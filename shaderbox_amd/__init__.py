@@ -17,11 +17,12 @@ from . import shard  # noqa: F401  (pure-python row-block arithmetic, no GPU nee
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsbx.so")
 
-APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST, APP_CLOUDS_TEX = range(9)
+APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST, APP_CLOUDS_TEX, APP_CLOUDS_UE4 = range(10)
 APPS = {"APP_PLANET": APP_PLANET, "APP_CLOUDS": APP_CLOUDS, "APP_VINYL": APP_VINYL, "APP_EGG": APP_EGG,
         "APP_RAYTRACER": APP_RAYTRACER, "APP_ATMOSPHERE": APP_ATMOSPHERE, "APP_SDF_AO": APP_SDF_AO,
         "APP_CLOUDS_BEST": APP_CLOUDS_BEST,    # src/app_clouds_best.h (stand-alone shader, not an APP_* define)
-        "APP_CLOUDS_TEX": APP_CLOUDS_TEX}      # APP_CLOUDS + USE_NOISE_TEX (src/app_clouds.h:9)
+        "APP_CLOUDS_TEX": APP_CLOUDS_TEX,      # APP_CLOUDS + USE_NOISE_TEX (src/app_clouds.h:9)
+        "APP_CLOUDS_UE4": APP_CLOUDS_UE4}      # ue4/volumetric_clouds/Shaders/app_clouds.usf (host mapping: include/sbx.h)
 
 SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
@@ -45,6 +46,12 @@ class AuxClouds(ctypes.Structure):          # sbx_aux_clouds (cbuffer b1, APP_CL
                 ("illum_march_steps", ctypes.c_int32), ("sigma_scattering", ctypes.c_float),
                 ("cld_coverage", ctypes.c_float), ("cld_thick", ctypes.c_float),
                 ("atm_radius", ctypes.c_float), ("atm_ground_y", ctypes.c_float)]
+
+
+class AuxCloudsUe4(ctypes.Structure):       # sbx_aux_clouds_ue4
+    _fields_ = [("coverage", ctypes.c_float), ("thickness", ctypes.c_float), ("absorbtion", ctypes.c_float),
+                ("fuzziness", ctypes.c_float), ("sun_dir", ctypes.c_float * 3), ("_pad1", ctypes.c_float),
+                ("wind_dir", ctypes.c_float * 3), ("use_dirs", ctypes.c_int32)]
 
 
 class AuxSdfAo(ctypes.Structure):           # sbx_aux_sdf_ao (cbuffer b1, APP_SDF_AO)
@@ -83,6 +90,8 @@ def load_library(path=None):
     lib.sbx_aux_clouds_defaults.restype = None
     lib.sbx_aux_sdf_ao_defaults.argtypes = [ctypes.POINTER(AuxSdfAo)]
     lib.sbx_aux_sdf_ao_defaults.restype = None
+    lib.sbx_aux_clouds_ue4_defaults.argtypes = [ctypes.POINTER(AuxCloudsUe4)]
+    lib.sbx_aux_clouds_ue4_defaults.restype = None
     lib.sbx_create.argtypes = [ci, ctypes.POINTER(vp)]
     lib.sbx_destroy.argtypes = [vp]
     lib.sbx_destroy.restype = None

@@ -295,8 +295,35 @@ static FrameCloudsBest build_clouds_best(const sbx_uniforms& U) {
     return F;
 }
 
+static FrameCloudsUe4 build_clouds_ue4(const sbx_uniforms& U, const sbx_aux_clouds_ue4& A) {
+    FrameCloudsUe4 F;
+    const v3 eye = V3(0, -.5f, 0);                                      // host mapping: src/app_clouds.h:23-30
+    const v3 look_at = mul(rotate_around_y(U.u_mouse[0] * .5f), V3(0, 0, -1));
+    F.cam = make_camera(U.u_res[0], U.u_res[1], 1.f, eye, look_at);
+    if (A.use_dirs) {
+        F.sun_dir = V3(A.sun_dir[0], A.sun_dir[1], A.sun_dir[2]);
+        F.wind_dir = V3(A.wind_dir[0], A.wind_dir[1], A.wind_dir[2]);
+    } else {
+        F.sun_dir = normalize(V3(0, abs_(sin_(U.u_time * .3f)), -1));    // SUN_DIR app_clouds.usf:14
+        F.wind_dir = V3(0, 0, -U.u_time * .2f);                          // WIND_DIR :13
+    }
+    F.march_step = A.thickness / float(UE4_STEPS);                      // :199
+    F.absorbtion = A.absorbtion;
+    F.cov = 1.f - A.coverage;                                           // :256
+    F.cov_rd = recip64((F.cov + A.fuzziness) - F.cov);                  // :175
+    for (int i = 0; i < UE4_STEPS; ++i) F.eh[i] = exp_(float(i) / float(UE4_STEPS)) / 1.75f;   // :213,221
+    return F;
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+
+void sbx_aux_clouds_ue4_defaults(sbx_aux_clouds_ue4* a) {              // app_clouds.usf:4-7
+    if (!a) return;
+    std::memset(a, 0, sizeof(*a));
+    a->coverage = .50f; a->thickness = 15.f; a->absorbtion = 1.030725f; a->fuzziness = 0.035f;
+    a->sun_dir[2] = -1.f; a->use_dirs = 0;
+}
 
 void sbx_aux_clouds_defaults(sbx_aux_clouds* a) {                      // uniform_buffer.h:39-55
     if (!a) return;
@@ -426,7 +453,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     if (M.nrows == 0) return SBX_OK;
     // argument checks come before anything is enqueued or recorded
-    if (app < SBX_APP_PLANET || app > SBX_APP_CLOUDS_TEX) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
+    if (app < SBX_APP_PLANET || app > SBX_APP_CLOUDS_UE4) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
     sbx_aux_clouds AC;
     if (app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX) {
         if (aux) AC = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&AC);
@@ -466,6 +493,12 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s, ctx->variant); break;
     case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s, ctx->variant); break;
     case SBX_APP_CLOUDS_BEST: launch_clouds_best(build_clouds_best(*uni), M, rgba, s); break;
+    case SBX_APP_CLOUDS_UE4: {
+        sbx_aux_clouds_ue4 A;
+        if (aux) A = *(const sbx_aux_clouds_ue4*)aux; else sbx_aux_clouds_ue4_defaults(&A);
+        launch_clouds_ue4(build_clouds_ue4(*uni, A), M, rgba, s);
+        break;
+    }
     default: break;
     }
     if (tp) { (void)hipEventRecord(tp->ev1, s); tp->complete = true; }
@@ -501,7 +534,8 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
     if (!ctx) return SBX_ERR_ARG;
     if (!uni || !fragCoord || !fragColor) return fail(ctx, SBX_ERR_ARG, "NULL argument");
     const int aux_bytes = !aux ? 0 : ((app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX) ? (int)sizeof(sbx_aux_clouds)
-                                      : (app == SBX_APP_SDF_AO ? (int)sizeof(sbx_aux_sdf_ao) : 0));
+                                      : (app == SBX_APP_SDF_AO ? (int)sizeof(sbx_aux_sdf_ao)
+                                      : (app == SBX_APP_CLOUDS_UE4 ? (int)sizeof(sbx_aux_clouds_ue4) : 0)));
     const bool hit = ctx->mi_valid && ctx->mi_app == app && std::memcmp(&ctx->mi_uni, uni, sizeof(*uni)) == 0 &&
                      ctx->mi_aux_bytes == aux_bytes && (aux_bytes == 0 || std::memcmp(ctx->mi_aux, aux, aux_bytes) == 0);
     if (!hit) {

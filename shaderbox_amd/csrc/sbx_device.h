@@ -68,6 +68,7 @@ void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hi
 void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, hipStream_t s);
+void launch_clouds_ue4(const FrameCloudsUe4& F, const RowMap& M, float* out, hipStream_t s);
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_assemble(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
                      const float* gathered, float* frame, hipStream_t s);

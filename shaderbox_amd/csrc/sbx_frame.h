@@ -159,6 +159,18 @@ struct FrameCloudsBest {
     CBRow row[CB_STEPS];
 };
 
+// ---- the UE4 cloud variant (ue4/volumetric_clouds/Shaders/app_clouds.usf) ----------------
+constexpr int UE4_STEPS = 25;                                  // STEPS :16
+struct FrameCloudsUe4 {
+    Camera cam;               // host mapping: APP_CLOUDS' camera (src/app_clouds.h:23-30), FOV 1
+    v3 sun_dir, wind_dir;     // SUN_DIR / WIND_DIR :13-14 or the aux block's
+    float march_step;         // thickness / float(steps)                                     :199
+    float absorbtion;
+    float cov;                // 1 - coverage                                                 :256
+    double cov_rd;            // recip64((cov + fuzziness) - cov)                             :175
+    float eh[UE4_STEPS];      // exp(h) / 1.75 with h = float(i) / float(steps)               :213,221
+};
+
 // ---- APP_VINYL (src/app_vinyl.h; C++ build) -------------------------------------------------
 struct Capsule { v3 a, ab; double rd; };   // sd_capsule(p, a, b, r): ab = b - a, rd = recip64(dot(ab, ab))
 struct FrameVinyl {

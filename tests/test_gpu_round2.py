@@ -294,3 +294,37 @@ def test_sqrt_n_is_ieee_sqrt(renderer):
         excluded = (x.abs() > 0) & (x.abs() < 2.0 ** -96)       # v_sqrt_f32 flushes denormals: -tiny gives -0, not NaN
         bad = ~same & ~excluded
         assert not bool(bad.any()), "first mismatch at bits 0x%08x" % int(bits[bad][0].item() & 0xffffffff)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the UE4 cloud variant (ue4/volumetric_clouds/Shaders/app_clouds.usf) under the build's host mapping
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,t", [(192, 108, 0.0), (256, 144, .37), (160, 160, 2.5), (33, 9, 7.0)])
+def test_clouds_ue4_matches_oracle(renderer, oracle, w, h, t):
+    from oracle.oracle import APP_CLOUDS_UE4
+    ref = oracle.render(APP_CLOUDS_UE4, w, h, t)
+    gpu = renderer.render("clouds_ue4", w, h, t).cpu().numpy()
+    maxd, nbits = compare(gpu, ref)
+    assert maxd <= 1e-4 and nbits == 0
+
+
+def test_clouds_ue4_material_parameters(renderer, oracle):
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS_UE4
+    aux = shaderbox_amd.AuxCloudsUe4()
+    renderer.lib.sbx_aux_clouds_ue4_defaults(aux)
+    assert (aux.coverage, aux.thickness, aux.fuzziness, aux.use_dirs) == (.5, 15.0, np.float32(.035), 0)
+    aux.coverage, aux.thickness, aux.absorbtion, aux.fuzziness = .62, 22.0, .8, .05
+    aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = .0, .6, -.8
+    aux.wind_dir[0], aux.wind_dir[1], aux.wind_dir[2] = .3, 0.0, -1.1
+    aux.use_dirs = 1
+    ref = oracle.render(APP_CLOUDS_UE4, 160, 90, 1.25, mouse=(1.5, 0.0), aux=aux)
+    gpu = renderer.render("clouds_ue4", 160, 90, 1.25, mouse=(1.5, 0.0), aux=aux).cpu().numpy()
+    assert compare(gpu, ref) == (0.0, 0)
+    base = renderer.render("clouds_ue4", 160, 90, 1.25, mouse=(1.5, 0.0)).cpu().numpy()
+    assert not np.array_equal(base, gpu)
+    # full size: rows of a 3840x2160 frame
+    W, H = 3840, 2160
+    rows = list(range(20, H, 180))
+    got = renderer.render("clouds_ue4", W, H, .37)[rows].cpu().numpy()
+    assert compare(got, oracle.render_rows(APP_CLOUDS_UE4, W, H, .37, rows)) == (0.0, 0)

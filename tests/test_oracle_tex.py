@@ -96,3 +96,24 @@ def test_clouds_tex_needs_volumes():
     o.lib.sbxo_set_noise_volumes(0, None, 0, None)
     with pytest.raises(ValueError):
         o.render(APP_CLOUDS_TEX, 8, 8, 0.0)
+
+
+def test_ue4_cloud_variant_restatement(oracle):
+    """ue4/volumetric_clouds/Shaders/app_clouds.usf under the build's host mapping (oracle/ref_apps.h AppCloudsUe4): no
+    reference-held answers exist (PARITY UNPINNED); what can be checked on the CPU are the shader's own identities."""
+    from oracle.oracle import APP_CLOUDS_UE4
+    import ctypes
+    f = oracle.render(APP_CLOUDS_UE4, 48, 27, .37)
+    assert np.isfinite(f).all() and (f[..., 3] == 1).all()
+    # coverage 0 -> cov = 1 > any fBm value (weights sum to .96): density 0 everywhere, C = 0, alpha = 0: the pixel is the sky
+    aux = np.zeros(12, dtype=np.float32)
+    aux[:4] = (0.0, 15.0, 1.030725, .035)
+    class Raw(ctypes.Structure):
+        _fields_ = [("b", ctypes.c_uint8 * 48)]
+    raw = Raw.from_buffer_copy(aux.tobytes())
+    sky_only = oracle.render(APP_CLOUDS_UE4, 48, 27, .37, aux=raw)
+    assert not np.array_equal(sky_only, f)
+    # thickness 0 -> march_step 0: T_i = exp(0) = 1, C += ... * 0, alpha += 0: the same sky
+    aux[:4] = (0.5, 0.0, 1.030725, .035)
+    raw = Raw.from_buffer_copy(aux.tobytes())
+    assert np.array_equal(oracle.render(APP_CLOUDS_UE4, 48, 27, .37, aux=raw), sky_only)
