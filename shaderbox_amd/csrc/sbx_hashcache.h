@@ -132,9 +132,14 @@ __device__ __forceinline__ void hc_init(WaveCache& S, int lane) {
 
 // N independent noise_iq evaluations at p[0..N-1], evaluation i using table tab[i]: all lattice terms and
 // tag reads first, one wave-uniform all-hit test, then reads + blends.  `active` = lanes whose result is used.
+// INVARIANT: the tab[i] are pairwise DISTINCT (N <= 4 tables).  All tags are sampled up front; if two evaluations shared a
+// table, the insert that serves evaluation i could evict a cell evaluation j > i had seen present, and j would then read
+// another cell's hashes without looking at the tag again.  The callers pass (base + i) & 3 with N <= 4, or {0, 1, 2, 3};
+// the static_assert below holds N to the number of tables, the distinctness is the callers' contract.
 template <int N>
 __device__ __forceinline__ void coop_noise_n(WaveCache& S, const v3 (&p)[N], const int (&tab)[N], bool active, int lane,
                                              float (&out)[N]) {
+    static_assert(N >= 1 && N <= 4, "one table per evaluation: at most four per batch");
     float fx[N], fy[N], fz[N];
     unsigned nbits[N];
     int slot[N];

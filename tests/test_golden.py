@@ -3,8 +3,13 @@ CPU suite: the oracle still reproduces them bit-for-bit; GPU suite: so do the HI
 import glob
 import os
 
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from make_golden import fixture_volumes  # noqa: E402
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
 
@@ -22,13 +27,15 @@ def _same(a, b):
 
 
 def test_golden_set_is_complete():
-    assert {c[1] for c in _cases()} == {"egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet", "vinyl", "clouds_best"}
+    assert {c[1] for c in _cases()} == {"egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet", "vinyl", "clouds_best",
+                                        "clouds_ue4", "clouds_tex"}
 
 
 @pytest.mark.parametrize("path,app,w,h", list(_cases()))
 def test_oracle_reproduces_golden(oracle, path, app, w, h):
     from oracle.oracle import APP_IDS
     z = np.load(path)
+    oracle.set_noise_volumes(*fixture_volumes())
     for key in z.files:
         assert _same(oracle.render(APP_IDS[app], w, h, float(key[1:])), z[key]), (app, key)
 
@@ -37,7 +44,10 @@ def test_oracle_reproduces_golden(oracle, path, app, w, h):
 @pytest.mark.parametrize("path,app,w,h", list(_cases()))
 def test_kernels_reproduce_golden(path, app, w, h):
     import shaderbox_amd
+    import torch
     r = shaderbox_amd.Renderer(0)
+    if app == "clouds_tex":
+        r.set_noise_volumes(*[torch.from_numpy(v).cuda() for v in fixture_volumes()])
     z = np.load(path)
     for key in z.files:
         got = r.render(app, w, h, float(key[1:])).cpu().numpy()
