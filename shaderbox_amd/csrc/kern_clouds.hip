@@ -28,6 +28,9 @@
 #ifndef CL_EPILOGUE_RELOAD
 #define CL_EPILOGUE_RELOAD 1
 #endif
+#ifndef CL_EXP_ASM
+#define CL_EXP_ASM 1
+#endif
 #ifndef CL_NO_REG
 #define CL_NO_REG 0       // 1: never use the REG kernels (A/B timing)
 #endif
@@ -44,6 +47,39 @@
 #endif
 
 namespace sbx {
+
+// exp_tab_<false> (sbx_math.h) for the REG kernels with the middle of the Horner chain written as three-address v_fma_f64:
+// the compiler turns `p = fma(p, r, c)` with c in a VGPR pair into v_mov_b64 (copy c) + v_fmac_f64 (two-address), one extra
+// half-rate instruction per coefficient and exp.  Same operations, same operands, same order: identical bits
+// (tests: every REG frame against the per-lane kernel and the oracle).
+#if CL_EXP_ASM
+__device__ __forceinline__ double cl_fma64(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float cl_exp(float x, const double (&tab)[32]) {
+    const double xd = (double)x;
+    double kd = __builtin_fma(xd, 0x1.71547652b82fep+5, D_MAGIC);          // 32/ln2
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - D_MAGIC;
+    double r = __builtin_fma(kd, -0x1.62e42fefa0000p-6, xd);               // ln2/32, high 38 bits
+    r = __builtin_fma(kd, -0x1.cf79abc9e3b3ap-45, r);                      // ln2/32 - high
+    double p, c6 = 0x1.6c16c16c16c17p-10, c5 = 0x1.1111111111111p-7;         // 1/6!, 1/5!
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(c6), "v"(r), "v"(c5));
+    double c4 = 0x1.5555555555555p-5, c3 = 0x1.5555555555555p-3;
+    p = cl_fma64(p, r, c4);
+    p = cl_fma64(p, r, c3);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double y = p * tab[ki & 31];
+    return (float)u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
+}
+#define CL_EXP_REG(x) cl_exp((x), etab)
+#else
+#define CL_EXP_REG(x) exp_tab_<false>((x), etab)
+#endif
 
 __device__ __forceinline__ float clouds_density(const FrameClouds& F, v3 pos_in) {
     v3 pos = pos_in * .001f;                                   // cld_noise_factor, :20,66
@@ -487,7 +523,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
         }
         if (REG) {
             const float d = x_smoothstep_rd_med3(vcov, F.cov_rd, t);
-            ltrans *= exp_tab_<false>(-d * vsigma * vdt, etab);
+            ltrans *= CL_EXP_REG(-d * vsigma * vdt);
         } else {
             const float d = t * smoothstep_rd(F.cov, F.cov_rd, t);
             ltrans *= CL_EXP(-d * F.sigma * F.dt);
@@ -620,7 +656,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
 #ifdef SBX_CL_STATS
                     st_lit += 1.f; st_litl += (float)__builtin_popcountll(lit_mask);
 #endif
-                    float T_i = REG ? exp_tab_<false>(-density * vsigma * vdt, etab) : CL_EXP(-density * F.sigma * F.dt);
+                    float T_i = REG ? CL_EXP_REG(-density * vsigma * vdt) : CL_EXP(-density * F.sigma * F.dt);
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
                     if (ZL) {                                      // lstep.x == 0 && lstep.y == 0 (launch_clouds): z-only light step
@@ -642,7 +678,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
                             const float d = coop_density(F, lp, lit, S, lane);
-                            ltrans *= REG ? exp_tab_<false>(-d * vsigma * vdt, etab) : CL_EXP(-d * F.sigma * F.dt);
+                            ltrans *= REG ? CL_EXP_REG(-d * vsigma * vdt) : CL_EXP(-d * F.sigma * F.dt);
                             lp = lp + lstep;
                         }
                     }
