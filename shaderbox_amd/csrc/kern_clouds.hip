@@ -15,9 +15,6 @@
 #include <cmath>
 #include <cstdlib>
 
-#ifndef CL_SPEC_READS
-#define CL_SPEC_READS 0
-#endif
 #ifndef CL_PARK
 #define CL_PARK 1          // park the march state in LDS during a lit step's light march
 #endif
@@ -30,6 +27,9 @@
 #endif
 #ifndef CL_EXP_ASM
 #define CL_EXP_ASM 1
+#endif
+#ifndef CL_SEED
+#define CL_SEED 1
 #endif
 #ifndef CL_NO_REG
 #define CL_NO_REG 0       // 1: never use the REG kernels (A/B timing)
@@ -272,7 +272,8 @@ __device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, floa
 template <int K0, int K1>
 __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (&rgy)[4], const float (&rpy)[4], float& qx, float& qz,
                                             float& t, float& H, bool active, unsigned long long active_mask, WaveCache& S,
-                                            int lane, float (&fx)[4], float (&nxy)[4]) {
+                                            int lane, float (&fx)[4], float (&nxy)[4], float (&mab)[4], float (&mcd)[4],
+                                            float (&mpz)[4]) {
     float fz[4];
     unsigned nbits[4];
     int slot[4];
@@ -285,6 +286,7 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
         fx[k] = ax * ax * (3.0f - 2.0f * ax);
         fz[k] = az * az * (3.0f - 2.0f * az);
         nxy[k] = px + rpy[k];
+        mpz[k] = pz;
         const float n = nxy[k] + 113.0f * pz;            // p.x + p.y*157 + 113*p.z, noise_iq.h:19
         nbits[k] = f2u(n);
         slot[k] = (int)n & (HC_SLOTS - 1);
@@ -292,31 +294,17 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
         miss_mask |= wave_mask(ne[k]);
         qx = qx * 2.64f; qz = qz * 2.64f;
     }
-#if CL_SPEC_READS
-    // The hashes are read together with the tags, before the hit test: ONE LDS round trip per stage instead of two
-    // (tags -> test -> hashes).  On a miss (18 % of the calls) the reads were wasted bandwidth, of which there is plenty.
-    float4 lo[4], hi[4];
-#pragma unroll
-    for (int k = K0; k < K1; ++k) {
-        lo[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
-        hi[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
-        asm volatile("" : "+v"(lo[k].x), "+v"(lo[k].y), "+v"(lo[k].z), "+v"(lo[k].w), "+v"(hi[k].x), "+v"(hi[k].y), "+v"(hi[k].z), "+v"(hi[k].w));
-    }
-#endif
     if (!wave_any_mask(miss_mask & active_mask)) {
-#if !CL_SPEC_READS
         float4 lo[4], hi[4];
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
             lo[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
             hi[k] = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
         }
-#endif
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
-            float ab, cd;
-            hc_blend_xy(lo[k], hi[k], fx[k], rfy[k], rgy[k], ab, cd);
-            t += (ab * (1.0f - fz[k]) + cd * fz[k]) * H;
+            hc_blend_xy(lo[k], hi[k], fx[k], rfy[k], rgy[k], mab[k], mcd[k]);
+            t += (mab[k] * (1.0f - fz[k]) + mcd[k] * fz[k]) * H;
             H *= .5f;
         }
     } else {
@@ -329,9 +317,8 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
                 h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
                 h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
             }
-            float ab, cd;
-            hc_blend_xy(h.lo, h.hi, fx[k], rfy[k], rgy[k], ab, cd);
-            t += (ab * (1.0f - fz[k]) + cd * fz[k]) * H;
+            hc_blend_xy(h.lo, h.hi, fx[k], rfy[k], rgy[k], mab[k], mcd[k]);
+            t += (mab[k] * (1.0f - fz[k]) + mcd[k] * fz[k]) * H;
             H *= .5f;
         }
     }
@@ -359,7 +346,8 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
 template <bool LIP>
 __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
                                                   unsigned long long active_mask, WaveCache& S, int lane,
-                                                  float (&fx)[4], float (&nxy)[4], const float* lip_slot, int& skip) {
+                                                  float (&fx)[4], float (&nxy)[4], float (&mab)[4], float (&mcd)[4],
+                                                  float (&mpz)[4], const float* lip_slot, int& skip) {
     float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
     const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
     const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
@@ -367,7 +355,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
     float t = 0.f, H = .5f;
     float lip_inv = 0.f;
     if (LIP) lip_inv = *lip_slot;                        // 1 / c of this lane, kept in LDS (read early, used after the first stage)
-    row_octaves<0, 2>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
+    row_octaves<0, 2>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
     if (!wave_any_mask(active_mask & wave_mask(!(t + .1876f < F.cov)))) {                // NaN compares false: goes on
         if (LIP) {
             float c = F.cov;
@@ -384,9 +372,9 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
         }
         return 0.f;
     }
-    row_octaves<2, 3>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
+    row_octaves<2, 3>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
     if (!wave_any_mask(active_mask & wave_mask(!(t + .06255f < F.cov)))) return 0.f;
-    row_octaves<3, 4>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy);
+    row_octaves<3, 4>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
     return t * smoothstep_rd(F.cov, F.cov_rd, t);        // :83-84
 }
 
@@ -410,7 +398,8 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 template <bool YTAB, bool REG>
 __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                WaveCache& S, int lane, const YRow& row, const float (&mfx)[4],
-                                               const float (&mnxy)[4], const double (&etab)[32], float vsigma, float vdt,
+                                               const float (&mnxy)[4], const float (&mab)[4], const float (&mcd)[4],
+                                               const float (&mpz)[4], const double (&etab)[32], float vsigma, float vdt,
                                                float vcov) {
     float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4], curz[4];
     if (YTAB) {
@@ -422,8 +411,12 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             fx[k] = mfx[k]; fy[k] = rfy[k]; gy[k] = rgy[k]; nxy[k] = mnxy[k];
-            curz[k] = u2f(0x7fc00001u);
-            ab[k] = cd[k] = 0.f;
+            // The march starts in the lattice cells of the MAIN sample of the step (same x, same y, z one light step away):
+            // its x/y blends ab, cd — hc_blend_xy of the same hashes with the same fx, fy — and its floor(z) are the current cell
+            // of every octave, so the first light sample needs a lookup only where it has left that cell, like every later one
+            // (a lit main sample has always evaluated all four octaves).
+            curz[k] = CL_SEED ? mpz[k] : u2f(0x7fc00001u);
+            ab[k] = mab[k]; cd[k] = mcd[k];
         }
     } else {
         float qx = (lp.x * .001f) * 2.03f, qy = (lp.y * .001f) * 2.03f;
@@ -648,7 +641,9 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                 if (YTAB) row = ytab[i];                          // uniform index: scalar loads (reading row i + 1 ahead
                                                                   // over the back edge costs 12 more live SGPRs: +6 % time)
                 float mfx[4] = {0.f, 0.f, 0.f, 0.f}, mnxy[4] = {0.f, 0.f, 0.f, 0.f};
-                float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, lip_slot, skip)
+                float mab[4] = {0.f, 0.f, 0.f, 0.f}, mcd[4] = {0.f, 0.f, 0.f, 0.f};
+                float mpz[4] = {u2f(0x7fc00001u), u2f(0x7fc00001u), u2f(0x7fc00001u), u2f(0x7fc00001u)};
+                float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, mab, mcd, mpz, lip_slot, skip)
                                            : coop_density(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
@@ -668,7 +663,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                         asm volatile("" ::: "memory");     // the reloads below cannot be forwarded from these stores: the values
                                                            // are dead across the light march
 #endif
-                        ltrans = light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, etab, vsigma, vdt, vcov);
+                        ltrans = light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
 #if CL_PARK
                         asm volatile("" ::: "memory");
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
