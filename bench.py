@@ -442,7 +442,7 @@ PMC_PASSES = [("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "GRB
               ("rd", ["FETCH_SIZE"])]
 
 
-def run_pmc_pass(counters, app, W, H, t, outdir, timeout=240):
+def run_pmc_pass(counters, app, W, H, t, outdir, timeout=100):
     """one rocprofv3 counter pass (kernel-trace + pmc only) over a short serial run of this script; returns
     {counter: mean over the dispatches of the app's render kernel}"""
     import csv
