@@ -25,6 +25,10 @@
 // framebuffer (16 B/pixel) plus one pass over the volumes; roofline and FETCH_SIZE in DESIGN.md §4.8.
 #include "sbx_device.h"
 
+#ifndef TEX_MIN_WAVES
+#define TEX_MIN_WAVES 5
+#endif
+
 namespace sbx {
 
 struct NoiseTex { const float* r; int size; float fsize; double rsize; };   // rsize = recip64(fsize): fl / size as an exact multiply (sbx_math.h div_by)
@@ -42,19 +46,43 @@ __device__ __forceinline__ void tex_axis(float c, const NoiseTex& T, int& i0, in
     i1 = (i + 1 == T.size) ? 0 : i + 1;
 }
 
+// wave-uniform "any lane" (the opaque form of sbx_hashcache.h: the branch must not be folded back into a per-lane one)
+__device__ __forceinline__ bool tex_wave_any(bool x) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(x);
+    unsigned any = (unsigned)m | (unsigned)(m >> 32);
+    asm volatile("" : "+s"(any));
+    return any != 0;
+}
+
+// POW2 (both volume sizes are powers of two, decided on the host): for |floor(u)| < 2^31 the spec's wrap
+// fl - size * floor(fl / size) — every operation exact for a power-of-two size — IS the two's-complement (int)fl & (size - 1),
+// so the float division, two floors, the fold-in selects and the range test of tex_axis collapse into cvt + and.  Coordinates
+// beyond that (|c| >= 2^30 / size, or NaN) send the whole wave through the general form.
+template <bool POW2>
 __device__ __forceinline__ float tex3d_r(const NoiseTex& T, v3 p) {     // SampleLevel(linear, wrap, lod 0).r
     int x0, x1, y0, y1, z0, z1;
     float fx, fy, fz;
-    tex_axis(p.x, T, x0, x1, fx);
-    tex_axis(p.y, T, y0, y1, fy);
-    tex_axis(p.z, T, z0, z1, fz);
-    const size_t s1 = (size_t)T.size, s2 = s1 * s1;
-    const float* r0 = T.r + z0 * s2;
-    const float* r1 = T.r + z1 * s2;
-    const float t000 = r0[y0 * s1 + x0], t100 = r0[y0 * s1 + x1];
-    const float t010 = r0[y1 * s1 + x0], t110 = r0[y1 * s1 + x1];
-    const float t001 = r1[y0 * s1 + x0], t101 = r1[y0 * s1 + x1];
-    const float t011 = r1[y1 * s1 + x0], t111 = r1[y1 * s1 + x1];
+    const float lim = 1073741824.0f / T.fsize;
+    if (POW2 && !tex_wave_any(!(abs_(p.x) < lim) || !(abs_(p.y) < lim) || !(abs_(p.z) < lim))) {
+        const int mask = T.size - 1;
+        const float ux = p.x * T.fsize - .5f, uy = p.y * T.fsize - .5f, uz = p.z * T.fsize - .5f;
+        const float lx = floor_(ux), ly = floor_(uy), lz = floor_(uz);
+        fx = ux - lx; fy = uy - ly; fz = uz - lz;
+        x0 = (int)lx & mask; y0 = (int)ly & mask; z0 = (int)lz & mask;
+        x1 = (x0 + 1) & mask; y1 = (y0 + 1) & mask; z1 = (z0 + 1) & mask;
+    } else {
+        tex_axis(p.x, T, x0, x1, fx);
+        tex_axis(p.y, T, y0, y1, fy);
+        tex_axis(p.z, T, z0, z1, fz);
+    }
+    // 32-bit texel indices from one base pointer (a volume has at most 2^30 texels)
+    const unsigned s1 = (unsigned)T.size;
+    const unsigned r0 = (unsigned)z0 * s1 * s1, r1 = (unsigned)z1 * s1 * s1;
+    const unsigned a0 = (unsigned)y0 * s1, a1 = (unsigned)y1 * s1;
+    const float t000 = T.r[r0 + a0 + (unsigned)x0], t100 = T.r[r0 + a0 + (unsigned)x1];
+    const float t010 = T.r[r0 + a1 + (unsigned)x0], t110 = T.r[r0 + a1 + (unsigned)x1];
+    const float t001 = T.r[r1 + a0 + (unsigned)x0], t101 = T.r[r1 + a0 + (unsigned)x1];
+    const float t011 = T.r[r1 + a1 + (unsigned)x0], t111 = T.r[r1 + a1 + (unsigned)x1];
     const float a = mix_(t000, t100, fx), b = mix_(t010, t110, fx);
     const float c = mix_(t001, t101, fx), d = mix_(t011, t111, fx);
     return mix_(mix_(a, b, fy), mix_(c, d, fy), fz);
@@ -64,20 +92,22 @@ __device__ __forceinline__ float remap_(float v, float omin, float omax, float n
     return nmin + (((v - omin) / (omax - omin)) * (nmax - nmin));
 }
 
+template <bool POW2>
 __device__ __forceinline__ float tex_density(const FrameClouds& F, const NoiseTex& T1, const NoiseTex& T2, v3 pos_in, float height) {
     const v3 pos = pos_in * .001f;                             // cld_noise_factor :20,66
-    float shape = tex3d_r(T1, pos);                            // :69-70
-    const float w = tex3d_r(T2, pos);                          // :75-78
+    float shape = tex3d_r<POW2>(T1, pos);                      // :69-70
+    const float w = tex3d_r<POW2>(T2, pos);                    // :75-78
     const float ww = mix_(w, 1.f - w, height);                 // :79
     shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);            // :80
-    return shape * smoothstep_(F.cov, F.cov_hi, shape);        // :83-84
+    return shape * smoothstep_rd(F.cov, F.cov_rd, shape);      // :83-84 (division by the frame constant through its exact reciprocal)
 }
 
 __device__ __forceinline__ float hg_phase_tex(float mu, float g) {   // volumetric.h:27-33, note (4 + PI)
     return (1.f - g * g) / ((4.f + 3.14159265359f) * pow_(1.f + g * g - 2.f * g * mu, 1.5f));
 }
 
-__global__ void __launch_bounds__(WG_THREADS) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out,
+template <bool POW2>
+__global__ void __launch_bounds__(WG_THREADS, TEX_MIN_WAVES) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out,
                                                             NoiseTex T1, NoiseTex T2) {
     const Pixel px = pixel_of_thread<8>(M);
     if (!px.valid) return;
@@ -103,7 +133,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_tex(FrameClouds F, RowMap
             const float height = (float)i / (float)F.steps;    // :183
             const v3 pos = origin + t * projection;
             t += F.dt;
-            const float density = tex_density(F, T1, T2, pos, height);
+            const float density = tex_density<POW2>(F, T1, T2, pos, height);
             if (!(density < .005f)) {                          // integrate_volume :132
                 const float T_i = exp_(-density * F.sigma * F.dt);
                 transmittance *= T_i;
@@ -111,7 +141,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_tex(FrameClouds F, RowMap
                 float ltrans = 1.f;
                 for (int j = 0; j < F.lsteps; ++j) {
                     const float lh = (float)j / (float)F.lsteps;                    // :108
-                    const float d = tex_density(F, T1, T2, lp, lh);
+                    const float d = tex_density<POW2>(F, T1, T2, lp, lh);
                     ltrans *= exp_(-d * F.sigma * F.dt);
                     lp = lp + lstep;
                 }
@@ -160,7 +190,9 @@ void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStr
                        const float* detail_r, int detail_size) {
     const NoiseTex T1{shape_r, shape_size, (float)shape_size, recip64((float)shape_size)};
     const NoiseTex T2{detail_r, detail_size, (float)detail_size, recip64((float)detail_size)};
-    hipLaunchKernelGGL(k_clouds_tex, grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2);
+    const bool pow2 = (shape_size & (shape_size - 1)) == 0 && (detail_size & (detail_size - 1)) == 0;
+    if (pow2) hipLaunchKernelGGL(k_clouds_tex<true>, grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2);
+    else hipLaunchKernelGGL(k_clouds_tex<false>, grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2);
 }
 
 }  // namespace sbx

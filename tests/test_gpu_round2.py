@@ -189,6 +189,20 @@ def test_clouds_tex_aux_and_errors(renderer, oracle, volumes):
     ref = oracle.render(APP_CLOUDS_TEX, 160, 90, 1.25, mouse=(1.5, 0.0), aux=aux)
     gpu = renderer.render("clouds_tex", 160, 90, 1.25, mouse=(1.5, 0.0), aux=aux).cpu().numpy()
     assert compare(gpu, ref) == (0.0, 0)
+    # coordinates beyond the power-of-two fast path's range (|c| >= 2^30 / size): the wave falls back to the general wrap
+    aux.wind_dir[0], aux.wind_dir[1] = 1e8, 0.0
+    ref = oracle.render(APP_CLOUDS_TEX, 96, 54, 1.0, aux=aux)
+    gpu = renderer.render("clouds_tex", 96, 54, 1.0, aux=aux).cpu().numpy()
+    assert compare(gpu, ref) == (0.0, 0)
+    # volumes whose size is not a power of two (any data is a volume): the general wrap for every sample
+    c1, c2 = v1[:24, :24, :24].contiguous(), v2[:12, :12, :12].contiguous()
+    renderer.set_noise_volumes(c1, c2)
+    oracle.set_noise_volumes(c1.cpu().numpy(), c2.cpu().numpy())
+    shaderbox_amd.load_library().sbx_aux_clouds_defaults(aux)
+    for t in (0.0, .37):
+        ref = oracle.render(APP_CLOUDS_TEX, 160, 90, t, aux=aux)
+        gpu = renderer.render("clouds_tex", 160, 90, t, aux=aux).cpu().numpy()
+        assert compare(gpu, ref) == (0.0, 0)
 
 
 def test_clouds_tex_full_size_rows(renderer, oracle):
