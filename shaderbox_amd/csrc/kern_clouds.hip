@@ -4,10 +4,11 @@
 // render :204-218, render_sky_color :36-46, render_clouds :153-202, integrate_volume :125-148,
 // illuminate_volume :91-123, density_func :62-86 over fbm = 4 octaves of noise_iq (:59),
 // henyey_greenstein_phase_func src/volumetric.h:27-33 with hg_g = .2 (:5).
-// 32-slot hash tables (4.9 KB per wave with the exp table): with the parked march state (2.3 KB) a wave needs 7.2 KB of LDS,
-// so 5 waves per SIMD (20 per CU) fit in the 160 KB; 64 slots time the same at equal occupancy (profiles/r02_clouds_ab.txt)
+// 16-slot hash tables: with the exp table (256 B) and the parked march state (3 KB) a wave needs 5.7 KB of LDS, so 6 waves
+// per SIMD (24 per CU) fit in the 160 KB.  64, 32 and 16 slots time the same at equal occupancy (profiles/r02_clouds_ab.txt):
+// a wave rarely holds more than a few cells per octave.
 #ifndef SBX_HC_SLOTS
-#define SBX_HC_SLOTS 32
+#define SBX_HC_SLOTS 16
 #endif
 #include "sbx_device.h"
 #include "sbx_noise.h"
@@ -43,7 +44,8 @@
 #define CL_EXP(x) exp_(x)
 #endif
 #ifndef CL_MIN_WAVES
-#define CL_MIN_WAVES 5     // waves per SIMD the register allocation is held to (__launch_bounds__): 96 VGPRs
+#define CL_MIN_WAVES 6     // waves per SIMD the register allocation is held to (__launch_bounds__): 80 VGPRs (78 used, no spills;
+                           // 7 waves = 72 VGPRs spill 6 and lose 4 %)
 #endif
 
 namespace sbx {
@@ -439,69 +441,50 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
     for (int j = 0; j < F.lsteps; ++j) {
         // z terms of the sample.  The cell of octave k is the one of the previous sample iff floor(z) is (nxy is
         // fixed), and then ab/cd still hold its x/y blends whatever happened to the cache since: no lookup at all.
-        float az[4], pzv[4];
-        unsigned long long moved_mask = 0;
+        float az[4], pzv[4], qzv[4];
+        unsigned long long moved_mask = 0, mk[4];
         float qz = (lp.z * .001f) * 2.03f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            qzv[k] = qz;
             if (REG) {
-                az[k] = qz - curz[k];                         // first sample: curz is NaN -> az NaN -> "moved"
-                moved_mask |= wave_mask(f2u(az[k]) >= 0x3f800000u);       // not (+0 <= az < 1)
+                az[k] = qz - curz[k];                         // general form's first sample: curz is NaN -> az NaN -> "moved"
+                mk[k] = wave_mask(f2u(az[k]) >= 0x3f800000u);              // not (+0 <= az < 1)
             } else {
                 const float pz = floor_(qz);
                 az[k] = qz - pz;
                 pzv[k] = pz;
-                moved_mask |= wave_mask(pz != curz[k]);       // first sample: curz is NaN, always true
+                mk[k] = wave_mask(pz != curz[k]);             // first sample: curz is NaN, always true
             }
+            moved_mask |= mk[k];
             qz = qz * 2.64f;
         }
         if (wave_any_mask(moved_mask & lit_mask)) {
 #ifdef SBX_CL_STATS
             if (lane == 0) S.stat[3] += 1.f;
 #endif
-            if (REG) {                                        // the general form's floor / fract, for every lane and octave
-                float q2 = (lp.z * .001f) * 2.03f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    pzv[k] = floor_(q2);
-                    az[k] = q2 - pzv[k];
-                    q2 = q2 * 2.64f;
-                }
-            }
-            // some lit lane entered another cell in some octave: look all four up again (one uniform branch
-            // per sample costs less than one per octave) and redo the x/y blends
-            unsigned nbits[4];
-            int slot[4];
-            bool ne[4];
-            unsigned long long miss_mask = 0;
+            // some lit lane has left its cell in some octave: look up again — and redo the x/y blends of — exactly the octaves
+            // in which that happened (mostly the finest one); the others keep their cell and their blends
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                if (!wave_any_mask(mk[k] & lit_mask)) continue;
+                if (REG) {                                    // the general form's floor / fract, for every lane
+                    pzv[k] = floor_(qzv[k]);
+                    az[k] = qzv[k] - pzv[k];
+                }
                 const float n = nxy[k] + 113.0f * pzv[k];
-                nbits[k] = f2u(n);
-                slot[k] = (int)n & (HC_SLOTS - 1);
-                ne[k] = (S.tag[k][slot[k]] != nbits[k]);
-                miss_mask |= wave_mask(ne[k]);
+                const unsigned nbits = f2u(n);
+                const int slot = (int)n & (HC_SLOTS - 1);
+                const bool ne = (S.tag[k][slot] != nbits);
                 curz[k] = pzv[k];
-            }
-            if (wave_any_mask(miss_mask & lit_mask)) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    H8 h;
-                    if (wave_any(lit && ne[k])) {
-                        h = hc_slow(S, k, nbits[k], slot[k], lit, lane);
-                    } else {
-                        h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
-                        h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
-                    }
-                    hc_blend_xy(h.lo, h.hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
+                H8 h;
+                if (wave_any(lit && ne)) {
+                    h = hc_slow(S, k, nbits, slot, lit, lane);
+                } else {
+                    h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot][0]);
+                    h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
-                    const float4 hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
-                    hc_blend_xy(lo, hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
-                }
+                hc_blend_xy(h.lo, h.hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
             }
         }
         float t = 0.f, H = .5f;
