@@ -31,25 +31,35 @@ EXTRA = {}
 HEADERS = ["sbx_math.h", "sbx_vec.h", "sbx_frame.h", "sbx_device.h", "sbx_noise.h", "sbx_hashcache.h", "sbx_sdf.h", "../../include/sbx.h"]
 
 
-def _newer(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _key(src):
+    """Content key of one translation unit: the source, every shared header, the flags and the compiler path.  Staleness is
+    decided by CONTENT, not by mtime: objects and the library travel to the GPU box outside git (an mtime rule can
+    ship a stale binary after a checkout or a copy)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, src)] + [os.path.join(CSRC, x) for x in HEADERS]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join([HIPCC] + FLAGS + EXTRA.get(src, [])).encode())
+    return h.hexdigest()
 
 
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    if force or _newer(obj, deps):
+    keyfile = obj + ".key"
+    key = _key(src)
+    old = open(keyfile).read().strip() if os.path.exists(keyfile) else ""
+    if force or not os.path.exists(obj) or old != key:
         cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         if r.stderr.strip():
             sys.stderr.write(r.stderr)
-        return obj, True
-    return obj, False
+        with open(keyfile, "w") as f:
+            f.write(key)
+        return obj, True, key
+    return obj, False, key
 
 
 def build(force=False, verbose=True):
@@ -57,12 +67,17 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         results = list(ex.map(lambda s: _compile(s, force), SOURCES))
-    objs = [o for o, _ in results]
-    if force or any(c for _, c in results) or not os.path.exists(LIB):
+    objs = [o for o, _, _ in results]
+    libkey = "\n".join(k for _, _, k in results)
+    libkeyfile = LIB + ".key"
+    old = open(libkeyfile).read() if os.path.exists(libkeyfile) else ""
+    if force or any(c for _, c, _ in results) or not os.path.exists(LIB) or old != libkey:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        with open(libkeyfile, "w") as f:
+            f.write(libkey)
         if verbose:
             print("built", LIB)
     elif verbose:
