@@ -244,6 +244,10 @@ int sbx_multi_set_noise_volumes(sbx_multi* m, int shape_size, const float* shape
  * frames); the pixels are bit-identical to a one-GPU render. */
 int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void* aux, float* frame, void* stream);
 const char* sbx_multi_last_error(sbx_multi* m);
+/* Self-test of the RCCL calls the multi-GPU path is made of, on ONE device: dlopen librccl, ncclCommInitAll({device}), one
+ * grouped ncclSend / ncclRecv pair from the rank to itself on two streams, compare.  0 = ok; *step (may be NULL) names the
+ * failing step: 1 load, 2 communicator, 3 buffers, 4 group call, 5 data. */
+int sbx_multi_rccl_selftest(int device, int* step);
 
 const char* sbx_last_error(sbx_ctx* ctx);
 const char* sbx_version(void);

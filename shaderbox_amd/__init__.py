@@ -124,6 +124,7 @@ def load_library(path=None):
     lib.sbx_multi_set_variant.argtypes = [vp, ci]
     lib.sbx_multi_set_noise_volumes.argtypes = [vp, ci, fp, ci, fp]
     lib.sbx_multi_render.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, fp, vp]
+    lib.sbx_multi_rccl_selftest.argtypes = [ci, ctypes.POINTER(ci)]
     lib.sbx_multi_last_error.argtypes = [vp]
     lib.sbx_multi_last_error.restype = ctypes.c_char_p
     lib.sbx_set_noise_volumes.argtypes = [vp, ci, fp, ci, fp, vp]

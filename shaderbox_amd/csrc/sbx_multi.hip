@@ -171,6 +171,53 @@ int sbx_multi_create(int nranks, const int* devices, sbx_multi** out) {
     return SBX_OK;
 }
 
+// Self-test of the RCCL slice this file uses, runnable on ONE GPU: load librccl, ncclCommInitAll over {device}, one grouped
+// ncclSend / ncclRecv pair from the rank to itself on two streams (the shape of sbx_multi_render's exchange), compare.
+// Returns SBX_OK, or a negative status with the failing step in *step (1 load, 2 init, 3 alloc, 4 group, 5 data).
+int sbx_multi_rccl_selftest(int device, int* step) {
+    int dummy = 0;
+    int& st = step ? *step : dummy;
+    std::string err;
+    st = 1;
+    if (!g_rccl.load(err)) return SBX_ERR_UNSUPPORTED;
+    st = 2;
+    if (hipSetDevice(device) != hipSuccess) return SBX_ERR_HIP;
+    nccl_comm_t comm = nullptr;
+    if (g_rccl.CommInitAll(&comm, 1, &device) != 0) return SBX_ERR_HIP;
+    st = 3;
+    const size_t n = 3840 * 8 * 4;                              // one 8-row block of a 4K frame
+    float *a = nullptr, *b = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    int rc = SBX_OK;
+    if (hipMalloc((void**)&a, n * 4) != hipSuccess || hipMalloc((void**)&b, n * 4) != hipSuccess ||
+        hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) rc = SBX_ERR_HIP;
+    std::vector<float> h(n), g(n, 0.f);
+    if (rc == SBX_OK) {
+        for (size_t i = 0; i < n; ++i) h[i] = (float)(i % 977) * .25f;
+        if (hipMemcpy(a, h.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemset(b, 0, n * 4) != hipSuccess) rc = SBX_ERR_HIP;
+    }
+    if (rc == SBX_OK) {
+        st = 4;
+        nccl_result_t nr = g_rccl.GroupStart();
+        if (nr == 0) nr = g_rccl.Send(a, n, kNcclFloat, 0, comm, s1);
+        if (nr == 0) nr = g_rccl.Recv(b, n, kNcclFloat, 0, comm, s2);
+        const nccl_result_t ne = g_rccl.GroupEnd();
+        if (nr != 0 || ne != 0) rc = SBX_ERR_HIP;
+        if (hipStreamSynchronize(s1) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess) rc = SBX_ERR_HIP;
+    }
+    if (rc == SBX_OK) {
+        st = 5;
+        if (hipMemcpy(g.data(), b, n * 4, hipMemcpyDeviceToHost) != hipSuccess || std::memcmp(g.data(), h.data(), n * 4) != 0) rc = SBX_ERR_HIP;
+    }
+    if (s1) (void)hipStreamDestroy(s1);
+    if (s2) (void)hipStreamDestroy(s2);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    (void)g_rccl.CommDestroy(comm);
+    if (rc == SBX_OK) st = 0;
+    return rc;
+}
+
 int sbx_multi_ranks(const sbx_multi* m) { return m ? (int)m->ranks.size() : SBX_ERR_ARG; }
 int sbx_multi_uses_rccl(const sbx_multi* m) { return m ? (m->use_rccl ? 1 : 0) : SBX_ERR_ARG; }
 const char* sbx_multi_last_error(sbx_multi* m) { return m ? m->err.c_str() : "no multi-GPU context"; }

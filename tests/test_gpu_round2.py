@@ -272,6 +272,15 @@ def test_library_multi_gpu_frame_equals_single_gpu(renderer, nranks):
     m.close()
 
 
+def test_rccl_slice_of_the_library_on_one_gpu(renderer):
+    """The RCCL calls sbx_multi_render is made of — dlopen, ncclCommInitAll, a grouped ncclSend / ncclRecv pair on two streams —
+    run from a rank to itself on the one GPU of the box (the N-device exchange itself needs N devices)."""
+    import ctypes
+    step = ctypes.c_int(-1)
+    rc = renderer.lib.sbx_multi_rccl_selftest(0, ctypes.byref(step))
+    assert (rc, step.value) == (0, 0)
+
+
 def test_library_multi_gpu_errors_and_noise_volumes(renderer, oracle, volumes):
     import torch
     import shaderbox_amd
