@@ -47,7 +47,8 @@ Extra objects on the JSON line (N = 1 unless noted):
                  k-th row, dealt to the threads in 64-pixel tiles), strict build (g++ -O2 -ffp-contract=off).
   cpu_baseline_speed : the same sample with the optimisation level of the reference's own C++ build
                  (-O3 -march=native -funroll-loops, /root/reference/src/Makefile:12-13), compiled on this host at run time.
-  other_configs: the other BASELINE.json GPU configs, timed the same way (pipelined frames + un-overlapped kernel time).
+  other_configs: the other BASELINE.json GPU configs, timed the same way (pipelined frames + un-overlapped kernel time), each
+                 with its own `parity` object: 16 evenly spread full rows of the rendered frame against the CPU oracle.
 """
 import argparse
 import json
@@ -319,7 +320,9 @@ def main():
             if speed is not None:
                 out["cpu_baseline_speed"] = speed
         if world == 1 and not use_dist and not args.no_other_configs and app == "clouds":
-            out["other_configs"] = other_configs(R, torch, dev, streams, t)
+            out["other_configs"] = other_configs(R, torch, dev, streams, t, check_rows=0 if args.no_cpu_baseline else 16)
+            if any(c["parity"] and not (c["parity"]["max_abs_diff"] <= 1e-4) for c in out["other_configs"]):
+                status = 3
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
@@ -394,7 +397,7 @@ def parity(gpu, ref, nrows):
             "max_abs_diff": float(d.max()), "mismatching_pixels": int(bits.any(axis=-1).sum()), "tolerance": 1e-4}
 
 
-def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2):
+def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_rows=0):
     """pipelined frames (as the headline) + un-overlapped kernel time of one config"""
     ns = len(streams)
     frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
@@ -415,6 +418,13 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2):
         R.render(app, W, H, t, out=frames[0])
         k.append(R.last_kernel_ms())
     torch.cuda.synchronize(dev)
+    par = None
+    if check_rows:
+        # parity of this config in the same record: evenly spread full rows of the last rendered frame against the CPU oracle
+        from oracle.oracle import APP_IDS, Oracle
+        rows = sorted(set(int(round(i * (H - 1) / (check_rows - 1))) for i in range(check_rows)))
+        ref = Oracle().render_rows(APP_IDS[app], W, H, t, rows)
+        par = parity(frames[0][rows].cpu().numpy(), ref, len(rows))
     del frames
     kmean = sum(k) / len(k)
     ops = OPS_PER_PIXEL.get(app)
@@ -426,11 +436,11 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2):
             "roofline": None if achieved is None else
             {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
              "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "ops_per_pixel": ops},
-            "hbm_store_gbps": round(16.0 * W * H / (kmean * 1e-3) / 1e9, 1)}
+            "hbm_store_gbps": round(16.0 * W * H / (kmean * 1e-3) / 1e9, 1), "parity": par}
 
 
-def other_configs(R, torch, dev, streams, t):
-    return [time_config(R, torch, dev, streams, a, w, h, t) for a, w, h in OTHER_CONFIGS]
+def other_configs(R, torch, dev, streams, t, check_rows=16):
+    return [time_config(R, torch, dev, streams, a, w, h, t, check_rows=check_rows) for a, w, h in OTHER_CONFIGS]
 
 
 # ---------------------------------------------------------------------------------------------------------

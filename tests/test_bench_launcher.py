@@ -54,6 +54,7 @@ def test_bench_line_contract_and_parity():
     assert line["roofline"]["bound"] == "valu" and 0 < line["roofline"]["frac"]
     assert [c["kernel"] for c in line["other_configs"]] == ["k_egg", "k_raytracer", "k_atmosphere", "k_planet"]
     assert all(c["value"] > 0 and c["kernel_ms"] > 0 for c in line["other_configs"])
+    assert all(c["parity"]["rows"] == 16 and c["parity"]["mismatching_pixels"] == 0 for c in line["other_configs"])
 
 
 @pytest.mark.gpu
