@@ -32,6 +32,7 @@ __device__ __forceinline__ Pixel pixel_of(const RowMap& M, int tid, int bx, int 
     p.x = bx * (TW * TX) + wave * TW + (lane % TW);
     // (dispatching the block rows from the middle of the launch outwards — heaviest tiles first for centred scenes — LOSES:
     // EGG 1080p 0.54 -> 0.77 ms, VINYL 4K 3.73 -> 4.07: heavy waves that run together share their SIMDs' issue slots)
+    // (so does visiting the rows with a stride: APP_CLOUDS 4K 2.86 ms in row order, 2.87 / 2.91 / 3.41 with strides 7 / 37 / 269)
     const int by = TOP_FIRST ? (grid_y - 1 - by_in) : by_in;
     const int r = by * TH + (lane / TW);
     p.valid = (p.x < M.width) && (r < M.nrows);
