@@ -7,8 +7,8 @@ Workload (BASELINE.json `metric`): APP_CLOUDS, 3840x2160, canonical frame u_time
 default aux uniforms.  One "step" = one whole frame rendered into an RGBA32F framebuffer resident in
 HBM (nothing crosses PCIe inside the timed region).
 
-Frames are independent, so consecutive frames are pipelined over two HIP streams (double-buffered
-framebuffers, --streams): the drain of one frame's kernel (its last, longest waves) overlaps the start of
+Frames are independent, so consecutive frames are pipelined over three HIP streams (one framebuffer per
+stream, --streams; 1 / 2 / 3 / 4 in flight: 2 849 / 3 088 / 3 145 / 3 122 Mpixels/s): the drain of one frame's kernel (its last, longest waves) overlaps the start of
 the next frame.  The timed region still runs from the first launch to the completion of all K frames.
 One-time initialisation (code-object load, APP_CLOUDS' y table, first submission on each stream, first touch of the
 framebuffers, RCCL peer set-up) happens once before the W warm-up steps and is not a step.
@@ -134,7 +134,7 @@ def main():
                          "also lands N-1 slabs and assembles the frame) sits out the rounds >= m0; '1/1' = plain cyclic split; "
                          "'auto' (default) measures the root's per-frame landing+assembly cost against its render time on rank 0 "
                          "and picks the split whose modelled slowest rank is fastest (shaderbox_amd/shard.py best_relief)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight: consecutive frames alternate over this many HIP streams, each with its own "
                          "framebuffers, so the drain of one frame's kernel overlaps the next frame (1 = strictly serial)")
     ap.add_argument("--force-dist", action="store_true",
