@@ -32,6 +32,9 @@
 #ifndef CL_SEED
 #define CL_SEED 1
 #endif
+#ifndef CL_ABLATE_LIGHT
+#define CL_ABLATE_LIGHT 0   // timing experiment only: no light march (wrong pixels)
+#endif
 #ifndef CL_NO_REG
 #define CL_NO_REG 0       // 1: never use the REG kernels (A/B timing)
 #endif
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
                         asm volatile("" ::: "memory");     // the reloads below cannot be forwarded from these stores: the values
                                                            // are dead across the light march
 #endif
-                        ltrans = light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
+                        ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
 #if CL_PARK
                         asm volatile("" ::: "memory");
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
