@@ -129,6 +129,12 @@ def main():
     ap.add_argument("--block-rows", type=int, default=8)
     ap.add_argument("--gather-groups", type=int, default=1,
                     help="N>1: issue the gather in this many pipelined pieces (1 = one plain gather)")
+    ap.add_argument("--exchange", choices=["direct", "gather"], default="direct",
+                    help="N>1 (engine dist): 'direct' = the root renders in place and receives the peers' slabs by ONE grouped "
+                         "send/recv (distributed.py); 'gather' = dist.gather of equal RGBA slabs + assembly of all of them (round 1)")
+    ap.add_argument("--channels", type=int, choices=[3, 4], default=3,
+                    help="N>1, exchange direct: floats per pixel that cross xGMI (3: alpha, the constant 1 of main.h:52, is written "
+                         "by the root's assembly)")
     ap.add_argument("--root-rounds", default="auto",
                     help="N>1: root relief 'm0/m' — row-blocks go out in cycles of m rounds and rank 0 (the gather's root, which "
                          "also lands N-1 slabs and assembles the frame) sits out the rounds >= m0; '1/1' = plain cyclic split; "
@@ -200,10 +206,11 @@ def main():
                 R.render(app, W, H, t, out=frames[i % ns])
     else:
         from shaderbox_amd.distributed import FramePlan
-        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams)
-        plans = [FramePlan(R, dist, W, H, br, groups=args.gather_groups, root_rounds=relief[0], rounds=relief[1])
-                 for _ in range(ns)]
-        slab = plans[0].slab
+        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, args.exchange,
+                               args.channels)
+        plans = [FramePlan(R, dist, W, H, br, groups=args.gather_groups, root_rounds=relief[0], rounds=relief[1],
+                           exchange=args.exchange, channels=args.channels) for _ in range(ns)]
+        slab = torch.empty((plans[0].rows_max, W, 4), dtype=torch.float32, device=dev)   # for the un-overlapped kernel timing
 
         def step(i=0):
             with torch.cuda.stream(streams[i % ns]):
@@ -224,7 +231,7 @@ def main():
             f.zero_()                                   # first touch of the framebuffers (page mapping) is not rendering
     else:
         for p in plans:
-            for buf in (p.slab, p.gathered, p.frame):
+            for buf in (p.slab, p.gathered, p.peers, p.frame):
                 if buf is not None:
                     buf.zero_()
     if dist is not None:
@@ -294,8 +301,11 @@ def main():
                                       % (app.upper(), W, H, t),
                           "frames_in_flight": ns,
                           "parallelism": "1 GPU, one launch per frame" if world == 1 else
-                                         "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + 1 RCCL gather "
-                                         "(in %d pipelined pieces) + assemble" % (br, world, relief[0], relief[1], args.gather_groups)},
+                                         "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + %s "
+                                         "(in %d pipelined pieces) + assemble" % (br, world, relief[0], relief[1], 
+                                         "1 RCCL gather of RGBA slabs" if args.exchange == "gather" else
+                                         "1 grouped RCCL send/recv of the peers' %d-channel slabs to the root (root in place)" % args.channels,
+                                         args.gather_groups)},
                "serial": {"value": round(launch_pixels / (kmean * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
                           "what": "one un-overlapped launch (HIP events), %d pixels" % launch_pixels},
                "roofline": roofline, "roofline_hbm": roofline_hbm}
@@ -558,11 +568,25 @@ def fill_pmc(roofline, roofline_hbm, pmc, kmean_ms):
         roofline["valu_lane_utilization_pct"] = round(pmc["VALUUtilization"], 2)
 
 
-def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, streams):
-    """(root_rounds, rounds) of the split, identical on every rank.  'auto': rank 0 measures, with two launches in flight
-    as in the timed loop, what its plain 1/N strip costs per frame (t_s) and what only the root has to do per frame — landing
-    world-1 slabs in its HBM (a device copy stands in for RCCL's receive kernels) and the assembly kernel (e); the ranks
-    adopt shard.best_relief(H, br, world, e / (world * t_s)), the split whose modelled slowest rank is fastest."""
+def relief_candidates(max_rounds=8):
+    """(root_rounds, rounds) from the plain split down to a root that renders half a share, coarsest cycle first"""
+    seen, out = set(), []
+    for m in range(1, max_rounds + 1):
+        for m0 in range(m, 0, -1):
+            f = m0 / m
+            if f >= .5 and f not in seen:
+                seen.add(f)
+                out.append((m0, m))
+    return sorted(out, key=lambda c: -c[0] / c[1])
+
+
+def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, exchange="direct", channels=3):
+    """(root_rounds, rounds) of the split, identical on every rank.  'auto': rank 0 MEASURES the candidates — for each split,
+    with the launches in flight on the timed loop's own streams, the root's frame (its strip + landing world-1 slabs in its HBM,
+    a device copy standing in for RCCL's receive kernels, + the assembly kernel) and a peer's frame (ranks 1 and world-1) — and
+    broadcasts the split whose slower side is fastest.  (Round 1 modelled it from two isolated measurements; HBM-bound copies
+    that run beside render waves take longer than alone, and a strip's time is not proportional to its rows, so the model
+    under-relieved the root.)"""
     from shaderbox_amd import shard
     if world <= 1:
         return (1, 1)
@@ -571,34 +595,53 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
         return (m0, m)
     pick = torch.zeros(2, dtype=torch.int64, device=dev)
     if rank == 0:
-        rmax = shard.rank_rows_max(H, br, world)
-        frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-        slabs = [torch.empty((rmax, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
-        src = torch.zeros((world - 1, rmax, W, 4), dtype=torch.float32, device=dev)
-        gathered = torch.zeros((world, rmax, W, 4), dtype=torch.float32, device=dev)
+        ch = channels if exchange == "direct" else 4
         st = streams                                    # the loop's own streams (no extra hardware queues)
+        nb = max(2, len(st))
+        frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(nb)]
 
-        def strips(k):
-            for i in range(k):
-                with torch.cuda.stream(st[i % len(st)]):
-                    R.render_rank(app, W, H, t, br, 0, world, out=slabs[i % 2])
+        def per_frame(fn, k=18):
+            for i in range(4):
+                fn(i)
             torch.cuda.synchronize(dev)
-        strips(4)
-        t0 = time.perf_counter()
-        strips(16)
-        t_s = (time.perf_counter() - t0) * 1e3 / 16
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for i in range(3):
-            if i == 1:
-                a.record()
-            gathered[1:].copy_(src)
-            R.assemble(gathered, W, H, br, world, out=frame)
-        b.record()
-        torch.cuda.synchronize(dev)
-        e = a.elapsed_time(b) / 2.0
-        m0, m = shard.best_relief(H, br, world, e / (world * t_s))
-        pick[0], pick[1] = m0, m
-        del frame, slabs, src, gathered
+            t0 = time.perf_counter()
+            for i in range(k):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) * 1e3 / k
+
+        best = None
+        for m0, m in relief_candidates():
+            rmax = shard.rank_rows_max(H, br, world, m0, m)
+            src = torch.zeros((world - 1, rmax, W, ch), dtype=torch.float32, device=dev)
+            land = [torch.zeros((world, rmax, W, ch), dtype=torch.float32, device=dev) for _ in range(nb)]
+            slabs = [torch.empty((rmax, W, ch), dtype=torch.float32, device=dev) for _ in range(nb)]
+
+            def root_frame(i):
+                with torch.cuda.stream(st[i % len(st)]):
+                    g, f = land[i % nb], frames[i % nb]
+                    if exchange == "direct":
+                        R.render_rank_in_place(app, W, H, t, br, 0, world, f, root_rounds=m0, rounds=m)
+                        g[1:].copy_(src)
+                        R.assemble_peers(g[1:], W, H, br, world, f, root_rounds=m0, rounds=m)
+                    else:
+                        R.render_rank_rows(app, W, H, t, br, 0, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
+                        g[0].copy_(slabs[i % nb])
+                        g[1:].copy_(src)
+                        R.assemble(g, W, H, br, world, out=f, root_rounds=m0, rounds=m)
+
+            def peer_frame(r):
+                def fn(i):
+                    with torch.cuda.stream(st[i % len(st)]):
+                        R.render_rank_rows(app, W, H, t, br, r, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
+                return fn
+            cost = max(per_frame(root_frame), max(per_frame(peer_frame(r)) for r in sorted({1, world - 1})))
+            if best is None or cost < best[0] * .995:        # a later (more relieved) split must win by a margin
+                best = (cost, (m0, m))
+            del src, land, slabs
+        pick[0], pick[1] = best[1]
+        del frames
+        torch.cuda.empty_cache()
     dist.broadcast(pick, src=0)
     return (int(pick[0].item()), int(pick[1].item()))
 

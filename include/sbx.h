@@ -170,6 +170,17 @@ int sbx_assemble_split(sbx_ctx* ctx, int width, int height, int block_rows, int 
  * (no slab, no assembly pass). */
 int sbx_render_split_in_place(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
                               int nranks, int root_rounds, int rounds, float* frame, void* stream);
+/* The direct exchange of a one-process-per-GPU host (the reference has no multi-device path; SURVEY.md 8e "Collective": the
+ * peers' row-blocks go to the root by point-to-point sends, the root's own rows never move).  The alpha of every pixel is the
+ * constant 1 that mainImage's caller writes (src/main.h:52), so a peer's slab crosses xGMI as 3 floats per pixel:
+ * sbx_render_split_rgb = sbx_render_split with a slab of rows x width x 3 floats (12 bytes per pixel, 25 % fewer bytes on
+ * the link and in the root's HBM).  sbx_assemble_peers scatters the slabs of ranks 1 .. nranks-1 (`peers`: rank-major,
+ * sbx_split_rows_max() rows each, `channels` = 3 or 4 floats per pixel) to their global rows of the RGBA `frame`, writing
+ * alpha = 1 for 3-channel slabs, and leaves the rows of rank 0 — rendered with sbx_render_split_in_place — untouched. */
+int sbx_render_split_rgb(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                         int nranks, int root_rounds, int rounds, int r0, int r1, float* rgb, void* stream);
+int sbx_assemble_peers(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, int root_rounds, int rounds,
+                       int channels, const float* peers, float* frame, void* stream);
 
 /* The write into hlsltoy's DXGI_FORMAT_R8G8B8A8_UNORM back buffer (util/hlsltoy/src/hlsltoy.cpp:79,192): float RGBA
  * rows -> 8-bit RGBA by the Direct3D float -> UNORM rule (NaN -> 0, clamp to [0, 1], * 255 + .5, truncate).

@@ -108,6 +108,8 @@ def load_library(path=None):
     lib.sbx_split_rows_max.argtypes = [ci, ci, ci, ci, ci]
     lib.sbx_render_split.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, ci, ci, fp, vp]
     lib.sbx_assemble_split.argtypes = [vp, ci, ci, ci, ci, ci, ci, fp, fp, vp]
+    lib.sbx_render_split_rgb.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, ci, ci, fp, vp]
+    lib.sbx_assemble_peers.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, fp, fp, vp]
     lib.sbx_set_timing.argtypes = [vp, ci]
     lib.sbx_set_variant.argtypes = [vp, ci]
     lib.sbx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -254,15 +256,46 @@ class Renderer:
 
     def render_rank_rows(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0),
                          aux=None, root_rounds=1, rounds=1):
-        """Render slab rows [r0, r1) of `rank` into slab[r0:r1] (pipelined multi-GPU frames)."""
+        """Render slab rows [r0, r1) of `rank` into slab[r0:r1] (pipelined multi-GPU frames).  A slab whose last dimension
+        is 3 is written without alpha (sbx_render_split_rgb: what crosses xGMI in the direct exchange)."""
         u = self.uniforms(width, height, time, mouse)
         if r1 <= r0:
             return slab
+        assert slab.is_cuda and slab.dtype == self.torch.float32 and slab.is_contiguous() and slab.shape[-1] in (3, 4)
+        assert slab.shape[1] == int(width) and slab.shape[0] >= r1
         view = slab[r0:r1]
-        self._check(self.lib.sbx_render_split(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
-                                              rank, nranks, root_rounds, rounds, int(r0), int(r1),
-                                              ctypes.c_void_p(view.data_ptr()), self._stream()))
+        fn = self.lib.sbx_render_split_rgb if slab.shape[-1] == 3 else self.lib.sbx_render_split
+        self._check(fn(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, rank, nranks, root_rounds, rounds,
+                       int(r0), int(r1), ctypes.c_void_p(view.data_ptr()), self._stream()))
         return slab
+
+    def render_rank_in_place(self, app, width, height, time, block_rows, rank, nranks, frame, mouse=(0.0, 0.0), aux=None,
+                             root_rounds=1, rounds=1):
+        """The rows of `rank` at their global positions of the full-size `frame` [H, W, 4]; other rows are not touched."""
+        u = self.uniforms(width, height, time, mouse)
+        assert frame.is_cuda and frame.dtype == self.torch.float32 and frame.is_contiguous()
+        assert tuple(frame.shape) == (int(height), int(width), 4)
+        self._check(self.lib.sbx_render_split_in_place(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
+                                                       rank, nranks, root_rounds, rounds, ctypes.c_void_p(frame.data_ptr()),
+                                                       self._stream()))
+        return frame
+
+    def assemble_peers(self, peers, width, height, block_rows, nranks, frame, root_rounds=1, rounds=1):
+        """Root side of the direct exchange: scatter the slabs of ranks 1 .. nranks-1 (`peers` [nranks-1, rows_max, W, 3|4])
+        to their rows of `frame` [H, W, 4] (alpha = 1 for 3-channel slabs); rank 0's rows are left as rendered in place."""
+        if int(nranks) == 1:
+            return frame
+        ch = int(peers.shape[-1])
+        need = (int(nranks) - 1) * shard.rank_rows_max(int(height), int(block_rows), int(nranks), root_rounds, rounds) * int(width) * ch
+        if not (peers.is_cuda and peers.dtype == self.torch.float32 and peers.is_contiguous() and ch in (3, 4)
+                and peers.numel() >= need):
+            raise ValueError("peers must be a contiguous float32 device tensor of >= (nranks-1) * rows_max * W * C = %d floats" % need)
+        assert frame.is_cuda and frame.dtype == self.torch.float32 and frame.is_contiguous()
+        assert tuple(frame.shape) == (int(height), int(width), 4)
+        self._check(self.lib.sbx_assemble_peers(self.ctx, int(width), int(height), block_rows, nranks, root_rounds, rounds, ch,
+                                                ctypes.c_void_p(peers.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
+                                                self._stream()))
+        return frame
 
     def assemble(self, gathered, width, height, block_rows, nranks, out=None, root_rounds=1, rounds=1):
         """Root side: scatter the rank-major gathered slabs to their global rows -> [H, W, 4]."""

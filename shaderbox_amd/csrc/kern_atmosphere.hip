@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, Ro
         }
         col = 20.0f * (sumR * phaseR * betaR + sumM * phaseM * betaM);   // sun_power :41
     }
-    store_rgba(out, px.idx, to_srgb(col));
+    store_rgba(M, out, px.idx, to_srgb(col));
 }
 
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s) {

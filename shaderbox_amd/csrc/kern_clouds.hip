@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, Ro
         const float a = alpha * smoothstep_(.0f, .2f, cutoff);
         col = abs3(mix3(sky, V3s(radiance), a));               // :215-217 (radiance is r=g=b)
     }
-    store_rgba(out, px.idx, to_srgb(col));
+    store_rgba(M, out, px.idx, to_srgb(col));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(64 * CL_TX, CL_MIN_WAVES) k_clouds(FrameClouds
     reinterpret_cast<float4*>(out)[px.idx] = make_float4(st_steps, st_lit, (lane == 2) ? st_skipped : st_alive, st_litl);
     return;
 #endif
-    store_rgba(out, px.idx, to_srgb(col));
+    store_rgba(ME, out, px.idx, to_srgb(col));
 }
 
 // "regular frame" (see light_march_z): every quantity the REG shortcuts rely on is checked here, on the host, per launch

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, R
         const float a = alpha * smoothstep_(.0f, .2f, cutoff);
         col = mix3(sky, V3s(C), a);                                        // :658
     }
-    store_rgba(out, px.idx, to_srgb(col));
+    store_rgba(M, out, px.idx, to_srgb(col));
 }
 
 void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, hipStream_t s) {

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(WG_THREADS, TEX_MIN_WAVES) k_clouds_tex(FrameC
         const float a = alpha * smoothstep_(.0f, .2f, cutoff);
         col = abs3(mix3(sky, V3s(radiance), a));               // :215-217
     }
-    store_rgba(out, px.idx, to_srgb(col));
+    store_rgba(M, out, px.idx, to_srgb(col));
 }
 
 // .r of an RGBA32F volume -> the library's R32F copy (one float4 read, one float written per voxel)

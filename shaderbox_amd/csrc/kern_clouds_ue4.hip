@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_ue4(FrameCloudsUe4 F, Row
     v3 sky = mix3(V3(.0f, .1f, .4f), V3(.3f, .6f, .8f), 1.0f - dir.y);
     sky = sky + V3(1.f, .7f, .55f) * fmin_(pow_(sun_amount, 1500.0f) * 5.0f, 1.0f);
     sky = sky + V3(1.f, .7f, .55f) * fmin_(pow_(sun_amount, 10.0f) * .6f, 1.0f);
-    store_rgba(out, px.idx, to_srgb(mix3(sky, V3s(C), alpha)));
+    store_rgba(M, out, px.idx, to_srgb(mix3(sky, V3s(C), alpha)));
 }
 
 void launch_clouds_ue4(const FrameCloudsUe4& F, const RowMap& M, float* out, hipStream_t s) {

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float*
     const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);
     const float depth_factor = 1.f - step_(1.f, depth);
     color = abs3(mix3(color, V3(.6f, .6f, .6f), bar_factor * depth_factor));
-    store_rgba(out, px.idx, to_srgb(color));
+    store_rgba(M, out, px.idx, to_srgb(color));
 }
 
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant) {

@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
     }
     if (!px.valid) return;
     if (!hit_atm) col = planet_background(rd);                   // :316-318
-    store_rgba(out, px.idx, to_srgb(col));
+    store_rgba(M, out, px.idx, to_srgb(col));
 }
 
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant) {

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowM
             break;
         }
     }
-    store_rgba(out, px.idx, to_srgb(color));
+    store_rgba(M, out, px.idx, to_srgb(color));
 }
 
 void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s) {

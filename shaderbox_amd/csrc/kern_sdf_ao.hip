@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
                            * (1.f - exp_(-t * rd.y * F.fog_falloff))
                            / (rd.y * F.fog_falloff);
     const v3 col = abs3(mix3(rgb, V3(1, 1, 1), fog_factor));
-    store_rgba(out, px.idx, to_srgb(col));
+    store_rgba(M, out, px.idx, to_srgb(col));
 }
 
 void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant) {

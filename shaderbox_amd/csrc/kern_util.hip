@@ -37,6 +37,46 @@ void launch_assemble(int width, int height, int block_rows, int nranks, int root
                        reinterpret_cast<float4*>(frame));
 }
 
+// The root of the direct exchange renders its own row-blocks IN PLACE (sbx_render_split_in_place), so only the peers' rows
+// move: `peers` = the slabs of ranks 1 .. nranks-1 (rank-major, rows_max rows each), C floats per pixel — 3 when the slabs
+// crossed xGMI without their alpha (RowMap.rgb), which is the constant 1 of main.h:52 and is written here.  Rows of rank 0
+// are left alone.  One thread per frame pixel; reads and writes of a wave are contiguous (64 x 12 or 16 B in, 64 x 16 B out).
+template <int C>
+__global__ void __launch_bounds__(256) k_assemble_peers(int width, int height, int block_rows, int nranks, int root_rounds,
+                                                         int rounds, int rows_max, const float* __restrict__ peers,
+                                                         float4* __restrict__ frame) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)width * height;
+    if (i >= total) return;
+    const int y = (int)(i / width), x = (int)(i - (size_t)y * width);
+    const int blk = y / block_rows, in_blk = y - blk * block_rows;
+    const int V = split_cycle_blocks(nranks, root_rounds, rounds);
+    const int cycle = blk / V, v = blk - cycle * V;
+    int rank, round;
+    if (v < root_rounds * nranks) { round = v / nranks; rank = v - round * nranks; }
+    else { const int w = v - root_rounds * nranks; const int q = w / (nranks - 1); round = root_rounds + q; rank = 1 + (w - q * (nranks - 1)); }
+    if (rank == 0) return;                                   // rendered where it belongs
+    const int local_blk = cycle * rounds + round;
+    const size_t src = ((size_t)(rank - 1) * rows_max + (size_t)local_blk * block_rows + in_blk) * width + x;
+    if (C == 4) {
+        frame[i] = reinterpret_cast<const float4*>(peers)[src];
+    } else {
+        const float* p = peers + src * 3;
+        frame[i] = make_float4(p[0], p[1], p[2], 1.0f);
+    }
+}
+void launch_assemble_peers(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
+                           int channels, const float* peers, float* frame, hipStream_t s) {
+    const size_t total = (size_t)width * height;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (channels == 3)
+        hipLaunchKernelGGL(k_assemble_peers<3>, grid, block, 0, s, width, height, block_rows, nranks, root_rounds, rounds, rows_max,
+                           peers, reinterpret_cast<float4*>(frame));
+    else
+        hipLaunchKernelGGL(k_assemble_peers<4>, grid, block, 0, s, width, height, block_rows, nranks, root_rounds, rounds, rows_max,
+                           peers, reinterpret_cast<float4*>(frame));
+}
+
 // float RGBA -> R8G8B8A8_UNORM, the back-buffer write of hlsltoy (util/hlsltoy/src/hlsltoy.cpp:79,192), by the
 // Direct3D float -> UNORM rule: NaN -> 0, clamp to [0, 1], scale by 255, add .5, truncate.  One pixel per thread:
 // a 16-byte load and a 4-byte store, both coalesced.  flip != 0 writes the top row first (D3D / PPM order).

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
         }
         t += d.d;
     }
-    store_rgba(out, px.idx, to_srgb(color));
+    store_rgba(M, out, px.idx, to_srgb(color));
 }
 
 void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant) {

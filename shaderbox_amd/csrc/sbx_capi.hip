@@ -606,8 +606,8 @@ int sbx_rank_rows_max(int height, int block_rows, int nranks) {
     return sbx_split_rows_max(height, block_rows, nranks, 1, 1);
 }
 
-int sbx_render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
-                     int nranks, int root_rounds, int rounds, int r0, int r1, float* rgba, void* stream) {
+static int render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank, int nranks,
+                        int root_rounds, int rounds, int r0, int r1, int rgb, float* rgba, void* stream) {
     int W, H;
     if (ctx && uni && r0 == r1 && r0 >= 0) return SBX_OK;
     int rc = check_common(ctx, uni, rgba, W, H);
@@ -617,8 +617,16 @@ int sbx_render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void*
     if (r0 < 0 || r1 < r0) return fail(ctx, SBX_ERR_ARG, "bad slab row range");
     if (r1 > rows) r1 = rows;                 // the slab is padded to the split's rows_max; the tail has no pixels
     if (r0 >= r1) return SBX_OK;
-    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0};
+    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0, rgb};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
+}
+int sbx_render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                     int nranks, int root_rounds, int rounds, int r0, int r1, float* rgba, void* stream) {
+    return render_split(ctx, app, uni, aux, block_rows, rank, nranks, root_rounds, rounds, r0, r1, 0, rgba, stream);
+}
+int sbx_render_split_rgb(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                         int nranks, int root_rounds, int rounds, int r0, int r1, float* rgb, void* stream) {
+    return render_split(ctx, app, uni, aux, block_rows, rank, nranks, root_rounds, rounds, r0, r1, 1, rgb, stream);
 }
 int sbx_render_split_in_place(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
                               int nranks, int root_rounds, int rounds, float* frame, void* stream) {
@@ -649,6 +657,22 @@ int sbx_assemble_split(sbx_ctx* ctx, int width, int height, int block_rows, int 
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     launch_assemble(width, height, block_rows, nranks, root_rounds, rounds,
                     sbx_split_rows_max(height, block_rows, nranks, root_rounds, rounds), gathered, frame, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "assemble launch", e);
+    return SBX_OK;
+}
+int sbx_assemble_peers(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, int root_rounds, int rounds,
+                       int channels, const float* peers, float* frame, void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!frame || width <= 0 || !split_ok(height, block_rows, nranks, root_rounds, rounds) || (channels != 3 && channels != 4) ||
+        (nranks > 1 && !peers))
+        return fail(ctx, SBX_ERR_ARG, "bad assemble arguments");
+    if (nranks == 1) return SBX_OK;                           // no peers: the frame is the root's in-place render
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    launch_assemble_peers(width, height, block_rows, nranks, root_rounds, rounds,
+                          sbx_split_rows_max(height, block_rows, nranks, root_rounds, rounds), channels, peers, frame,
+                          (hipStream_t)stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "assemble launch", e);
     return SBX_OK;

@@ -49,8 +49,13 @@ inline dim3 grid_for(const RowMap& M) {
     constexpr int TH = 64 / TW, W = TW * TX;
     return dim3((M.width + W - 1) / W, (M.nrows + TH - 1) / TH);
 }
-__device__ __forceinline__ void store_rgba(float* out, size_t idx, v3 c) {
-    reinterpret_cast<float4*>(out)[idx] = make_float4(c.x, c.y, c.z, 1.0f);   // main.h:52
+__device__ __forceinline__ void store_rgba(const RowMap& M, float* out, size_t idx, v3 c) {
+    if (M.rgb) {                                                               // wave-uniform (a kernel argument)
+        float* o = out + idx * 3;                                              // 64 lanes: 768 contiguous bytes
+        o[0] = c.x; o[1] = c.y; o[2] = c.z;
+    } else {
+        reinterpret_cast<float4*>(out)[idx] = make_float4(c.x, c.y, c.z, 1.0f);   // main.h:52
+    }
 }
 
 // launchers (one per app), defined next to their kernels
@@ -75,6 +80,8 @@ void launch_clouds_ue4(const FrameCloudsUe4& F, const RowMap& M, float* out, hip
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_assemble(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
                      const float* gathered, float* frame, hipStream_t s);
+void launch_assemble_peers(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
+                           int channels, const float* peers, float* frame, hipStream_t s);
 void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);
 void launch_worley_volume(int size, float* out, hipStream_t s);

@@ -25,6 +25,8 @@ struct RowMap {
     int r0;      // first local row of this launch within the rank's slab (sub-range launches)
     int root_rounds, rounds;
     int in_place;   // 0: rows are written densely (slab row r); 1: at their global row y of a full-size frame
+    int rgb;        // 1: the output holds 3 floats per pixel (a peer's slab on its way to the root: alpha is the constant 1 of
+                    //    main.h:52 and need not cross xGMI); 0: float4 pixels
 };
 // blocks in one cycle, and the position of (round, rank) in it
 SBX_HD int split_cycle_blocks(int nranks, int root_rounds, int rounds) {

@@ -12,8 +12,18 @@ the gather is issued in `groups` pieces: slab rows are rendered group by group a
 started asynchronously (RCCL runs on its own stream) while the next group renders; only the last piece
 and the assembly kernel are exposed.  groups = 1 is the plain single gather.
 
-`renderer` is duck-typed (render_rank_rows / assemble / empty): shaderbox_amd.Renderer on GPUs; the CPU
-tests drive the same code over gloo with an oracle-backed stand-in.
+Two forms of that one exchange (`exchange=`):
+
+* "direct" (default): the root renders its own row-blocks IN PLACE into the frame and posts one grouped receive per piece
+  (`batch_isend_irecv`: one ncclGroup, the 7 peers arrive in parallel over their 7 links), the peers send their slabs
+  WITHOUT alpha — `channels=3`: alpha is the constant 1 that the caller of mainImage writes (src/main.h:52), so 12 instead
+  of 16 bytes per pixel cross xGMI and land in the root's HBM — and the root scatters the peers' rows into the frame
+  (`assemble_peers`, which writes the alpha).  No self-copy of the root's slab, no assembly of the root's rows.
+* "gather": `dist.gather` of equal RGBA slabs (the root's included) + `assemble` of all of them — round 1's form, kept for
+  comparison and as the fallback of backends without grouped point-to-point.
+
+`renderer` is duck-typed (render_rank_rows / render_rank_in_place / assemble / assemble_peers / empty):
+shaderbox_amd.Renderer on GPUs; the CPU tests drive the same code over gloo with an oracle-backed stand-in.
 """
 from . import shard
 
@@ -22,8 +32,15 @@ class FramePlan:
     """Buffers and schedule of one rank for repeated frames of a fixed size."""
 
     def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS, groups=1, root_rounds=1,
-                 rounds=1):
+                 rounds=1, exchange="direct", channels=3):
+        if exchange not in ("direct", "gather"):
+            raise ValueError("exchange must be 'direct' or 'gather'")
+        if exchange == "gather":
+            channels = 4
+        if channels not in (3, 4):
+            raise ValueError("channels must be 3 or 4")
         self.r, self.dist = renderer, dist
+        self.exchange, self.channels = exchange, int(channels)
         self.width, self.height, self.block_rows = int(width), int(height), int(block_rows)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
@@ -34,17 +51,50 @@ class FramePlan:
         # slab row ranges of the groups: whole blocks, as even as possible
         cuts = [((g * nblocks) // groups) * self.block_rows for g in range(groups + 1)]
         self.ranges = [(cuts[g], cuts[g + 1]) for g in range(groups) if cuts[g + 1] > cuts[g]]
-        self.slab = renderer.empty((self.rows_max, self.width, 4), zero=True)
-        if self.rank == 0:
-            self.gathered = renderer.empty((self.world, self.rows_max, self.width, 4))
-            self.glists = [[self.gathered[i, a:b] for i in range(self.world)] for a, b in self.ranges]
+        self.slab = self.gathered = self.peers = self.frame = None
+        self.glists = [None] * len(self.ranges)
+        if exchange == "gather":
+            self.slab = renderer.empty((self.rows_max, self.width, 4), zero=True)
+            if self.rank == 0:
+                self.gathered = renderer.empty((self.world, self.rows_max, self.width, 4))
+                self.glists = [[self.gathered[i, a:b] for i in range(self.world)] for a, b in self.ranges]
+                self.frame = renderer.empty((self.height, self.width, 4))
+        elif self.rank == 0:
             self.frame = renderer.empty((self.height, self.width, 4))
+            if self.world > 1:
+                self.peers = renderer.empty((self.world - 1, self.rows_max, self.width, self.channels), zero=True)
         else:
-            self.gathered = self.frame = None
-            self.glists = [None] * len(self.ranges)
+            self.slab = renderer.empty((self.rows_max, self.width, self.channels), zero=True)
 
     def render(self, app, time, mouse=(0.0, 0.0), aux=None):
         """All ranks call this; rank 0 returns the assembled [H, W, 4] frame, the others None."""
+        if self.exchange == "gather":
+            return self._render_gather(app, time, mouse, aux)
+        d = self.dist
+        works = []
+        if self.rank == 0:
+            # the receives first: they depend only on the previous use of `peers` (earlier on this stream), not on the
+            # root's own rendering, which then runs beside them
+            for a, b in self.ranges:
+                ops = [d.P2POp(d.irecv, self.peers[i - 1, a:b], i) for i in range(1, self.world)]
+                if ops:
+                    works += d.batch_isend_irecv(ops)
+            self.r.render_rank_in_place(app, self.width, self.height, time, self.block_rows, 0, self.world, self.frame,
+                                        mouse=mouse, aux=aux, root_rounds=self.root_rounds, rounds=self.rounds)
+            for w in works:
+                w.wait()
+            return self.r.assemble_peers(self.peers, self.width, self.height, self.block_rows, self.world, self.frame,
+                                         root_rounds=self.root_rounds, rounds=self.rounds)
+        for a, b in self.ranges:
+            self.r.render_rank_rows(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
+                                    a, b, self.slab, mouse=mouse, aux=aux, root_rounds=self.root_rounds,
+                                    rounds=self.rounds)
+            works += d.batch_isend_irecv([d.P2POp(d.isend, self.slab[a:b], 0)])
+        for w in works:
+            w.wait()          # stream-level on GPUs: the next frame's render into this slab is ordered after the send
+        return None
+
+    def _render_gather(self, app, time, mouse, aux):
         works = []
         last = len(self.ranges) - 1
         for g, (a, b) in enumerate(self.ranges):

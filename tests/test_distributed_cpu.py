@@ -1,6 +1,7 @@
 """The N>1 path on CPU: world_size 2 (and 3) over gloo, driving shaderbox_amd.distributed.FramePlan — the
 same code bench.py runs over RCCL — with an oracle-backed stand-in for the GPU renderer.  Checks that
-cyclic row-blocks + ONE gather + assembly reproduce the single-process frame bit-for-bit."""
+cyclic row-blocks + ONE exchange (the direct one: root in place, peers' slabs without alpha by grouped
+point-to-point; and round 1's dist.gather) + assembly reproduce the single-process frame bit-for-bit."""
 import os
 import socket
 
@@ -28,8 +29,28 @@ class OracleRenderer:
         rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)[r0:r1]
         if rows:
             img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
-            slab[r0:r0 + len(rows)] = torch.from_numpy(img)
+            slab[r0:r0 + len(rows)] = torch.from_numpy(img)[..., :slab.shape[-1]]      # 3-channel slabs: no alpha
         return slab
+
+    def render_rank_in_place(self, app, width, height, time, block_rows, rank, nranks, frame, mouse=(0.0, 0.0), aux=None,
+                             root_rounds=1, rounds=1):
+        from oracle.oracle import APP_IDS
+        from shaderbox_amd import shard
+        rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)
+        if rows:
+            img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
+            frame[rows] = torch.from_numpy(img)
+        return frame
+
+    def assemble_peers(self, peers, width, height, block_rows, nranks, frame, root_rounds=1, rounds=1):
+        from shaderbox_amd import shard          # mirror of k_assemble_peers (kern_util.hip)
+        ch = peers.shape[-1]
+        for y, (r, local) in enumerate(shard.slab_source(height, block_rows, nranks, root_rounds, rounds)):
+            if r > 0:
+                frame[y, :, :ch] = peers[r - 1, local]
+                if ch == 3:
+                    frame[y, :, 3] = 1.0
+        return frame
 
     def assemble(self, gathered, width, height, block_rows, nranks, out=None, root_rounds=1, rounds=1):
         from shaderbox_amd import shard          # mirror of k_assemble (kern_util.hip)
@@ -38,14 +59,17 @@ class OracleRenderer:
         return out
 
 
-def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1, 1)):
+def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1, 1), exchange="direct", channels=3):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from shaderbox_amd.distributed import FramePlan
-    plan = FramePlan(OracleRenderer(), dist, w, h, br, groups=groups, root_rounds=relief[0], rounds=relief[1])
+    plan = FramePlan(OracleRenderer(), dist, w, h, br, groups=groups, root_rounds=relief[0], rounds=relief[1],
+                     exchange=exchange, channels=channels)
     frame = None
     for _ in range(2):                       # buffers are reused across frames
+        if rank == 0:
+            plan.frame.fill_(-7.0)           # every pixel of the frame must be written again
         frame = plan.render(app, t)
     if rank == 0:
         np.save(result_path, frame.numpy())
@@ -63,26 +87,29 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("exchange,channels", [("direct", 3), ("direct", 4), ("gather", 4)])
 @pytest.mark.parametrize("world,app,w,h,br,groups", [(2, "clouds", 96, 54, 8, 1), (2, "egg", 64, 45, 8, 3),
                                                       (3, "raytracer", 64, 50, 5, 2), (2, "egg", 32, 20, 8, 4)])
-def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, app, w, h, br, groups):
+def test_gather_assembles_the_single_process_frame(tmp_path, oracle, world, app, w, h, br, groups, exchange, channels):
     from oracle.oracle import APP_IDS
     path = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, groups, path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, groups, path, (1, 1), exchange, channels),
+             nprocs=world, join=True)
     got = np.load(path)
     ref = oracle.render(APP_IDS[app], w, h, 0.37)
     assert got.shape == ref.shape
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("exchange", ["direct", "gather"])
 @pytest.mark.parametrize("world,app,w,h,br,groups,relief", [(2, "egg", 64, 45, 4, 1, (1, 3)), (3, "clouds", 96, 54, 2, 2, (2, 5)),
                                                              (3, "raytracer", 64, 50, 5, 1, (0, 2))])
-def test_gather_with_root_relief(tmp_path, oracle, world, app, w, h, br, groups, relief):
+def test_gather_with_root_relief(tmp_path, oracle, world, app, w, h, br, groups, relief, exchange):
     """the split that deals the gather's root fewer row-blocks (shard.py) assembles the same frame, incl. a root that
     renders nothing at all"""
     from oracle.oracle import APP_IDS
     path = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, groups, path, relief), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, groups, path, relief, exchange), nprocs=world, join=True)
     got = np.load(path)
     ref = oracle.render(APP_IDS[app], w, h, 0.37)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -351,3 +351,69 @@ def test_clouds_ue4_material_parameters(renderer, oracle):
     rows = list(range(20, H, 180))
     got = renderer.render("clouds_ue4", W, H, .37)[rows].cpu().numpy()
     assert compare(got, oracle.render_rows(APP_CLOUDS_UE4, W, H, .37, rows)) == (0.0, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the direct exchange of the one-process-per-GPU path: root in place, peers' slabs without alpha, peer-only assembly
+# ---------------------------------------------------------------------------------------------------------
+ALL_APPS = ["clouds", "egg", "raytracer", "atmosphere", "planet", "sdf_ao", "vinyl", "clouds_best", "clouds_ue4"]
+
+
+@pytest.mark.parametrize("app", ALL_APPS)
+def test_rgb_slab_is_the_rgba_slab_without_alpha(renderer, app):
+    """sbx_render_split_rgb writes the same three floats per pixel as sbx_render_split, densely (12 bytes per pixel), also for
+    sub-ranges of the slab rows; and every kernel's alpha is the constant 1 the RGB form drops."""
+    import torch
+    from shaderbox_amd import shard
+    w, h, br, n, rank = 200, 117, 8, 3, 1                    # ragged width and height
+    rmax = shard.rank_rows_max(h, br, n)
+    rows = shard.rank_rows(h, br, rank, n)
+    rgba = torch.full((rmax, w, 4), -3.0, device="cuda")
+    rgb = torch.full((rmax, w, 3), -3.0, device="cuda")
+    renderer.render_rank_rows(app, w, h, .37, br, rank, n, 0, rmax, rgba)
+    renderer.render_rank_rows(app, w, h, .37, br, rank, n, 0, 16, rgb)          # two launches: the second starts mid-slab
+    renderer.render_rank_rows(app, w, h, .37, br, rank, n, 16, rmax, rgb)
+    torch.cuda.synchronize()
+    a, b = rgba.cpu().numpy(), rgb.cpu().numpy()
+    assert np.array_equal(a[:rows, :, :3].view(np.uint32), b[:rows].view(np.uint32))
+    assert (a[:rows, :, 3] == 1.0).all()
+    assert (b[rows:] == -3.0).all() and (a[rows:] == -3.0).all()              # nothing written past the rank's rows
+
+
+@pytest.mark.parametrize("channels", [3, 4])
+@pytest.mark.parametrize("app,w,h,n,br,relief", [("clouds", 320, 180, 2, 8, (1, 1)), ("egg", 200, 117, 3, 8, (1, 2)),
+                                                 ("raytracer", 333, 90, 8, 4, (3, 4)), ("clouds", 3840, 2160, 8, 8, (3, 4)),
+                                                 ("planet", 256, 144, 4, 8, (0, 1)), ("sdf_ao", 64, 36, 1, 8, (1, 1))])
+def test_direct_exchange_emulated_on_one_gpu(renderer, app, w, h, n, br, relief, channels):
+    """N ranks on one device, the calls of distributed.FramePlan(exchange='direct') with the transfer replaced by the slab
+    already being where the receive would put it: root in place + peers' slabs + sbx_assemble_peers == one launch."""
+    import torch
+    from shaderbox_amd import shard
+    m0, m = relief
+    whole = renderer.render(app, w, h, .37)
+    rmax = shard.rank_rows_max(h, br, n, m0, m)
+    frame = torch.full((h, w, 4), float("nan"), device="cuda")
+    peers = torch.full((max(n - 1, 1), rmax, w, channels), float("nan"), device="cuda")
+    renderer.render_rank_in_place(app, w, h, .37, br, 0, n, frame, root_rounds=m0, rounds=m)
+    for r in range(1, n):
+        renderer.render_rank_rows(app, w, h, .37, br, r, n, 0, rmax, peers[r - 1], root_rounds=m0, rounds=m)
+    renderer.assemble_peers(peers, w, h, br, n, frame, root_rounds=m0, rounds=m)
+    torch.cuda.synchronize()
+    a, b = frame.view(torch.int32), whole.view(torch.int32)
+    assert int((a != b).any(dim=-1).sum().item()) == 0
+
+
+def test_assemble_peers_argument_errors(renderer):
+    import ctypes
+    import torch
+    import shaderbox_amd
+    lib = renderer.lib
+    frame = torch.zeros((16, 16, 4), device="cuda")
+    peers = torch.zeros((1, 8, 16, 3), device="cuda")
+    fp = lambda t: ctypes.cast(ctypes.c_void_p(t.data_ptr()), ctypes.POINTER(ctypes.c_float))
+    assert lib.sbx_assemble_peers(renderer.ctx, 16, 16, 8, 2, 1, 1, 5, fp(peers), fp(frame), None) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_assemble_peers(renderer.ctx, 16, 16, 8, 2, 1, 1, 3, None, fp(frame), None) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_assemble_peers(renderer.ctx, 16, 16, 8, 2, 2, 1, 3, fp(peers), fp(frame), None) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_assemble_peers(renderer.ctx, 16, 16, 8, 1, 1, 1, 3, None, fp(frame), None) == 0     # a lone rank has no peers
+    with pytest.raises(ValueError):
+        renderer.assemble_peers(torch.zeros((1, 4, 16, 3), device="cuda"), 16, 16, 8, 2, frame)

@@ -75,6 +75,33 @@ def frames_per_ms(fn):
     return (time.perf_counter() - t0) * 1e3 / K
 
 
+def emulate_direct(m0, m, ch=3):
+    """the direct exchange (distributed.FramePlan default): root in place, landing of 7 slabs without alpha, peer-only assembly"""
+    rows_max = shard.rank_rows_max(H, 8, n, m0, m)
+    bufs = [dict(slab=torch.empty((rows_max, W, ch), dtype=torch.float32, device="cuda"),
+                 src=torch.rand((n - 1, rows_max, W, ch), dtype=torch.float32, device="cuda"),
+                 peers=torch.empty((n - 1, rows_max, W, ch), dtype=torch.float32, device="cuda"),
+                 frame=torch.empty((H, W, 4), dtype=torch.float32, device="cuda")) for _ in range(2)]
+
+    def root_frame(i):
+        b = bufs[i % 2]
+        with torch.cuda.stream(streams[i % 2]):
+            R.render_rank_in_place(app, W, H, 0.37, 8, 0, n, b["frame"], root_rounds=m0, rounds=m)
+            b["peers"].copy_(b["src"])
+            R.assemble_peers(b["peers"], W, H, 8, n, b["frame"], root_rounds=m0, rounds=m)
+
+    def peer_frame(r):
+        def f(i):
+            with torch.cuda.stream(streams[i % 2]):
+                R.render_rank_rows(app, W, H, 0.37, 8, r, n, 0, rows_max, bufs[i % 2]["slab"], root_rounds=m0, rounds=m)
+        return f
+    root_ms = frames_per_ms(root_frame)
+    peer_ms = max(frames_per_ms(peer_frame(r)) for r in range(1, n))
+    worst = max(root_ms, peer_ms)
+    print("  DIRECT (%d channels), N=8, root sits out rounds >= %d of %d: root (in-place strip + landing + peer assembly) %.3f "
+          "ms/frame, slowest peer %.3f ms/frame -> %.2fx of the N=1 frame rate" % (ch, m0, m, root_ms, peer_ms, base / worst))
+
+
 def emulate(m0, m):
     rows_max = shard.rank_rows_max(H, 8, n, m0, m)
     bufs = [dict(slab=torch.empty((rows_max, W, 4), dtype=torch.float32, device="cuda"),
@@ -128,3 +155,8 @@ m0, m = shard.best_relief(H, 8, n, e / (n * t_s))
 print("  calibration: plain strip %.3f ms/frame, root-only work %.3f ms per frame -> relief %d/%d" % (t_s, e, m0, m))
 del src, g, sl
 emulate(m0, m)
+
+# the direct exchange (bench.py's default at N > 1), every candidate split of bench.py's calibration: it adopts the fastest
+for ch in (4, 3):
+    for m0, m in [(1, 1), (7, 8), (6, 7), (5, 6), (4, 5), (3, 4), (5, 7), (2, 3), (5, 8), (3, 5), (4, 7), (1, 2)]:
+        emulate_direct(m0, m, ch)
