@@ -115,26 +115,32 @@ __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float*
     float depth = -1e8f;                                    // :188, fresh per pixel
     v3 color = V3(.1f, .1f, .7f);                           // background :9-12
     float t = 0.f;
+    // The trace only FINDS the hit; what the reference does inside the loop at the hit (`:205-228`: depth, the 20-step shadow
+    // march of ground pixels, the flat colours, `break`) runs after the loop, once per wave with all of its hit lanes, instead of
+    // once per distinct hit iteration of the wave with the few lanes that hit in that iteration.  Per lane the same operations
+    // on the same values in the same order.
+    bool hit = false;
+    int mat = 0;
+    v3 hp = V3(0, 0, 0);
     for (int i = 0; i < 80; ++i) {                          // render_scene :190-231
         const v3 p = ro + rd * t;
         const D2 d = egg_sdf<CULL>(F, p);
         if (t > 15.f) break;
-        if (d.d < 0.001f) {
-            const int mat = (int)d.m;
-            if (mat == 1 || mat == 2) depth = fmax_(depth, p.z);
-            float s = 1.f;
-            if (mat == 3) {
-                const v3 sh_dir = V3(0, 1, 1);
-                s = egg_shadowmarch<CULL>(F, p + sh_dir * 0.05f, sh_dir);
-            }
-            v3 base = V3(1, 1, 1);                          // illuminate :29-35
-            if (mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
-            else if (mat == 1) base = V3(0.9f, 0.95f, 0.95f);
-            else if (mat == 2) base = V3(.2f, .2f, .2f);
-            color = base * s;
-            break;
-        }
+        if (d.d < 0.001f) { hit = true; mat = (int)d.m; hp = p; break; }
         t += d.d;
+    }
+    if (hit) {
+        if (mat == 1 || mat == 2) depth = fmax_(depth, hp.z);
+        float s = 1.f;
+        if (mat == 3) {
+            const v3 sh_dir = V3(0, 1, 1);
+            s = egg_shadowmarch<CULL>(F, hp + sh_dir * 0.05f, sh_dir);
+        }
+        v3 base = V3(1, 1, 1);                              // illuminate :29-35
+        if (mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
+        else if (mat == 1) base = V3(0.9f, 0.95f, 0.95f);
+        else if (mat == 2) base = V3(.2f, .2f, .2f);
+        color = base * s;
     }
     // bars overlay :233-251
     const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);

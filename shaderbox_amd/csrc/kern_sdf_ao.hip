@@ -91,12 +91,21 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
 
     v3 rgb = V3(.1f, .1f, .7f);                                   // background :9-12
     float t = 0.f;
+    // The trace only FINDS the hit; the reference's hit block (`:258-281`: 6-tap normal, 5-tap AO, lights, material, `break`)
+    // runs after the loop, once per wave with all of its hit lanes instead of once per distinct hit iteration of the wave.
+    // Per lane the same operations on the same values in the same order.
+    bool hit = false;
+    int mat = 0;
+    v3 p = V3(0, 0, 0);
     for (int i = 0; i < 70; ++i) {                                // render_impl :245-285
-        const v3 p = ro + rd * t;
-        const D2 d = ao_sdf<CULL>(F, p);
+        const v3 pi = ro + rd * t;
+        const D2 d = ao_sdf<CULL>(F, pi);
         if (t > 20.f) break;
-        if (d.d < .005f) {
-            const int mat = (int)d.m;
+        if (d.d < .005f) { hit = true; mat = (int)d.m; p = pi; break; }
+        t += d.d;
+    }
+    {
+        if (hit) {
             // sdf_normal :152-163
             const float e = 0.001f;
             const v3 n = normalize(V3(
@@ -132,9 +141,7 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
                 mat_c = mix3(mat_c - .15f * mat_c, mat_c + .15f * mat_c, cb);
             }
             rgb = accum * mat_c;
-            break;
         }
-        t += d.d;
     }
     // fog :287-311 (t is the march length at exit)
     const float fog_factor = F.fog_density * exp_(-ro.y * F.fog_falloff)

@@ -151,12 +151,21 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
 
     v3 color = V3(1, 1, 1);                                     // background :15-18
     float t = 0.f;
+    // The trace only FINDS the hit; the reference's hit block (`:436-452`: 20-step soft shadow, anisotropic or 6-tap-normal
+    // shading, `break`) runs after the loop, once per wave with all of its hit lanes instead of once per distinct hit iteration
+    // of the wave.  Per lane the same operations on the same values in the same order.
+    bool hit = false;
+    int mat = 0;
+    v3 p = V3(0, 0, 0);
     for (int i = 0; i < 60; ++i) {                              // render :427-455
-        const v3 p = ro + rd * t;
-        const D2 d = vinyl_sdf<CULL>(F, p);
+        const v3 pi = ro + rd * t;
+        const D2 d = vinyl_sdf<CULL>(F, pi);
         if (t > 40.f) break;
-        if (d.d < .005f) {
-            const int mat = (int)d.m;
+        if (d.d < .005f) { hit = true; mat = (int)d.m; p = pi; break; }
+        t += d.d;
+    }
+    {
+        if (hit) {
             // sdf_shadow :379-404
             float sh = 1.f;
             {
@@ -218,9 +227,7 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
                 lit = diffuse + specular;
             }
             color = lit * sh;
-            break;
         }
-        t += d.d;
     }
     store_rgba(M, out, px.idx, to_srgb(color));
 }
