@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_egg(FrameEgg F, RowMap M, float*
     // march of ground pixels, the flat colours, `break`) runs after the loop, once per wave with all of its hit lanes, instead of
     // once per distinct hit iteration of the wave with the few lanes that hit in that iteration.  Per lane the same operations
     // on the same values in the same order.  1920x1080: 0.54 -> 0.27 ms.  (Trace and shadow march as ONE loop around one copy of
-    // the sdf — lanes with a ground hit start their shadow march while neighbours still trace, 10 KB of code instead of 112 —
+    // the sdf — lanes with a ground hit start their shadow march while neighbours still trace —
     // is slower: 0.283 vs 0.273 ms, 4K 0.68 vs 0.64; the per-lane phase logic costs more than the shorter waves save.)
     bool hit = false;
     int mat = 0;
