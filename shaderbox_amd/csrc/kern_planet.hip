@@ -57,9 +57,12 @@ __device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_
 #ifndef PL_BATCH
 #define PL_BATCH 2          // octaves fetched per cooperative batch: 4 at a time (round 1) peaked at 32 hash registers and spilled
 #endif
+#ifndef PL_BATCH_DETAIL
+#define PL_BATCH_DETAIL 2   // the 7-octave detail maps of the hit shading (6 per hit pixel)
+#endif
 template <int OCT, int MODE, int START>
 __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacunarity, float& H, float gain, float& t, bool on, int lane) {
-    constexpr int B = PL_BATCH;
+    constexpr int B = (OCT == 7) ? PL_BATCH_DETAIL : PL_BATCH;
 #pragma unroll
     for (int base = START; base < OCT; base += B) {
         if (base + B <= OCT) {
@@ -89,30 +92,42 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
 
 // clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
 // SKIP = false (sbx_set_variant 1) evaluates everything: the reference form, kept for the parity sweeps
+// The density part of clouds_map: false = nothing would change for any committing lane of the wave (see below), else
+// dens and T_i = exp(-30.034 dens t_step) of every lane are set.
 template <bool SKIP>
-__device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, bool on, int lane) {
+__device__ __forceinline__ bool clouds_density(WaveCache& S, v3 pos, float height, float t_step, bool on, int lane, float& dens_out,
+                                               float& T_i_out) {
     // The cloud shell is the height band (.2, .65): outside it band() is exactly +0, so dens = fbm * 0 = +0,
     // T_i = exp(-0) = 1, and the three updates below are `*= 1`, `+= 0`, `+= 0 * (1 - alpha)`: nothing changes.
     // When that holds for every committing lane of the wave the noise is not evaluated at all (most steps of the
     // 75-step march and 2-3 of the 5 shadow steps).  A NaN height compares unequal and takes the full path.
-    const float bd = band(c.height);
-    if (SKIP && !wave_any(on && bd != 0.f)) return;
+    const float bd = band(height);
+    if (SKIP && !wave_any(on && bd != 0.f)) return false;
     // fbm of |2 noise - 1| in [0, 1], gains .5 .25 .125 .0625: evaluated in stages {0,1}, {2}, {3}; once the part so far
     // plus the largest possible rest is below the coverage edge for every committing lane, smoothstep(cov, ..) is
     // exactly 0, the density +0, and nothing below would change anything.
     const float cov = .29475675f, fuzzy = .0335f;
-    v3 q = c.pos * 3.2343f + V3(.35f, 13.35f, 2.67f);
+    v3 q = pos * 3.2343f + V3(.35f, 13.35f, 2.67f);
     float H = .5f, dens = 0.f;
     coop_fbm_range<2, 1, 0>(S, q, 2.0276f, H, .5f, dens, on, lane);
-    if (SKIP && !wave_any(on && !(dens + .1876f < cov))) return;
+    if (SKIP && !wave_any(on && !(dens + .1876f < cov))) return false;
     coop_fbm_range<3, 1, 2>(S, q, 2.0276f, H, .5f, dens, on, lane);
-    if (SKIP && !wave_any(on && !(dens + .06255f < cov))) return;
+    if (SKIP && !wave_any(on && !(dens + .06255f < cov))) return false;
     coop_fbm_range<4, 1, 3>(S, q, 2.0276f, H, .5f, dens, on, lane);
     dens *= SMOOTHSTEP_K(cov, cov + fuzzy, dens);
     dens *= bd;
     // dens is exactly +0 below the coverage edge as well (smoothstep = 0): same identities, skip the two exp
-    if (SKIP && !wave_any(on && dens != 0.f)) return;
-    const float T_i = exp_(-30.034f * dens * t_step);
+    if (SKIP && !wave_any(on && dens != 0.f)) return false;
+    dens_out = dens;
+    T_i_out = exp_(-30.034f * dens * t_step);
+    return true;
+}
+// clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
+// SKIP = false (sbx_set_variant 1) evaluates everything: the reference form, kept for the parity sweeps
+template <bool SKIP>
+__device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, bool on, int lane) {
+    float dens = 0.f, T_i = 1.f;
+    if (!clouds_density<SKIP>(S, c.pos, c.height, t_step, on, lane, dens, T_i)) return;
     if (on) {
         c.transmittance *= T_i;
         c.radiance += dens * div_by(exp_(c.height), 1.0 / (double).055f) * c.transmittance * t_step;
@@ -168,9 +183,19 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
 #ifndef PL_MIN_WAVES
 #define PL_MIN_WAVES 5
 #endif
+#ifndef PL_PARK
+#define PL_PARK 1          // the hit shading's state waits in LDS while the 6 detail terrain maps run
+#endif
+// (tools/ab_time.py, 7680x4320, same bits: no parking 7.36 ms, 112 B of scratch per lane, 1.72 GB of HBM traffic per frame
+//  against the 0.53 GB framebuffer; hit-shading parking 7.29 ms, 60 B, ~1.0 GB; parking the cloud march's ray and integrator
+//  as well: no spills there to remove, 7.66 ms; recomputing pixel and ray in the epilogue instead of keeping them: 7.54 ms)
+#define PL_PARK_N 10
 template <bool SKIP>
 __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
     __shared__ WaveCache cache[WG_THREADS / 64];
+#if PL_PARK
+    __shared__ float park[WG_THREADS / 64][PL_PARK_N * 64];
+#endif
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
     hc_init(S, lane);
@@ -199,6 +224,8 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
     }
     hit_atm = hit_atm && px.valid;
     v3 col = V3(0, 0, 0);
+    bool cloud_sky = false;                                      // atmosphere hit, no ground hit: background under the clouds
+    float sky_r = 0.f, sky_a = 0.f;
     if (wave_any(hit_atm)) {
         // terrain march :328-342
         float t = 0.f;
@@ -248,16 +275,38 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
         v3 c_hit = V3(0, 0, 0);
         if (wave_any(hitl)) {
             // illuminate :238-298
-            const float h = df.y;
-            const v3 w_normal = normalize(pos);
+            float h = df.y;
             const float e = 0.001f;
             float g[3];                                            // sdf_terrain_normal :201-212
+#if PL_PARK
+            // 6 x (7 + 7)-octave terrain_map: the second register peak.  What it does not need — the hit point, its height
+            // term, the ray, the cloud integrator (already in slots 1-2) — waits in LDS, and the three differences land there.
+            float* const pk = &park[threadIdx.x >> 6][lane];
+            pk[3 * 64] = pos.x; pk[4 * 64] = pos.y; pk[5 * 64] = pos.z; pk[6 * 64] = h;
+            pk[1 * 64] = cloud.radiance; pk[2 * 64] = cloud.alpha;
+            asm volatile("" ::: "memory");
+#pragma unroll 1
+            for (int ax = 0; ax < 3; ++ax) {                       // one code copy for the three central differences
+                const v3 d = V3(ax == 0 ? e : 0.f, ax == 1 ? e : 0.f, ax == 2 ? e : 0.f);
+                const float va = terrain_map<7, SKIP>(S, V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]) + d, hitl, lane).x;
+                asm volatile("" ::: "memory");
+                const float vb = terrain_map<7, SKIP>(S, V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]) - d, hitl, lane).x;
+                pk[(7 + ax) * 64] = va - vb;
+                asm volatile("" ::: "memory");
+            }
+            pos = V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]);
+            h = pk[6 * 64];
+            cloud.radiance = pk[1 * 64]; cloud.alpha = pk[2 * 64];
+            g[0] = pk[7 * 64]; g[1] = pk[8 * 64]; g[2] = pk[9 * 64];
+#else
 #pragma unroll 1
             for (int ax = 0; ax < 3; ++ax) {                       // one code copy for the three central differences
                 const v3 d = V3(ax == 0 ? e : 0.f, ax == 1 ? e : 0.f, ax == 2 ? e : 0.f);
                 const float v = terrain_map<7, SKIP>(S, pos + d, hitl, lane).x - terrain_map<7, SKIP>(S, pos - d, hitl, lane).x;
                 if (ax == 0) g[0] = v; else if (ax == 1) g[1] = v; else g[2] = v;
             }
+#endif
+            const v3 w_normal = normalize(pos);
             const v3 normal = normalize(V3(g[0], g[1], g[2]));
             const float N = dot(normal, w_normal);
             const v3 c_water = V3(.015f, .110f, .455f), c_grass = V3(.086f, .132f, .018f),
@@ -292,11 +341,16 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
             const float shadow = mix_(.7f, 1.f, step_(sh.alpha, 0.33f));
             c_hit = abs3(mix3(c_terr * shadow, V3s(c_cld), alpha));
         }
-        col = hitl ? c_hit : abs3(mix3(planet_background(rd), V3s(cloud.radiance), cloud.alpha));   // :364-366
+        cloud_sky = !hitl;
+        sky_r = cloud.radiance; sky_a = cloud.alpha;
+        col = c_hit;
     }
-    if (!px.valid) return;
-    if (!hit_atm) col = planet_background(rd);                   // :316-318
-    store_rgba(M, out, px.idx, to_srgb(col));
+    const Pixel pxe = px;
+    const v3 rde = rd;
+    if (!pxe.valid) return;
+    if (cloud_sky) col = abs3(mix3(planet_background(rde), V3s(sky_r), sky_a));   // :364-366
+    if (!hit_atm) col = planet_background(rde);                  // :316-318
+    store_rgba(M, out, pxe.idx, to_srgb(col));
 }
 
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant) {
