@@ -2,7 +2,7 @@
 """One-off soak (run on the GPU box): every app's shipped kernel against the CPU oracle on random times, mouse positions and
 odd frame sizes (the golden frames and the parity tests fix a handful of each).  EGG, SDF_AO, VINYL and PLANET additionally
 against their plain form (sbx_set_variant 1: no culling / no skips) at a larger size.
-    python tools/soak_apps.py [frames per app = 24] [seed = 1]"""
+    python tests/soak_apps.py [frames per app = 24] [seed = 1]"""
 import sys
 
 import numpy as np
