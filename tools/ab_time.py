@@ -54,6 +54,9 @@ if not os.path.exists(path):
 shaderbox_amd.LIB_PATH = path
 R = shaderbox_amd.Renderer(0)
 R.set_timing(True)
+if a.app == "clouds_tex":          # the two baked volumes of APP_CLOUDS' USE_NOISE_TEX build (128^3 shape, 64^3 detail)
+    R.set_noise_volumes(R.worley_volume(128), R.worley_volume(64))
+    torch.cuda.synchronize()
 out = torch.empty((a.height, a.width, 4), dtype=torch.float32, device="cuda")
 for _ in range(5):
     R.render(a.app, a.width, a.height, a.time, out=out)
