@@ -31,7 +31,9 @@ __device__ __forceinline__ Pixel pixel_of(const RowMap& M, int tid, int bx, int 
     Pixel p;
     p.x = bx * (TW * TX) + wave * TW + (lane % TW);
     // (dispatching the block rows from the middle of the launch outwards — heaviest tiles first for centred scenes — LOSES:
-    // EGG 1080p 0.54 -> 0.77 ms, VINYL 4K 3.73 -> 4.07: heavy waves that run together share their SIMDs' issue slots)
+    // EGG 1080p 0.54 -> 0.77 ms, VINYL 4K 3.73 -> 4.07: heavy waves that run together share their SIMDs' issue slots.
+    // Re-measured after the hit block left the trace loop: one EGG 1080p launch 0.269 -> 0.241 ms, but 0.160 -> 0.168 ms per
+    // frame with two in flight and 4K 0.632 -> 0.648 ms: a shorter tail, lower throughput.  Not in.)
     // (so does visiting the rows with a stride: APP_CLOUDS 4K 2.86 ms in row order, 2.87 / 2.91 / 3.41 with strides 7 / 37 / 269)
     const int by = TOP_FIRST ? (grid_y - 1 - by_in) : by_in;
     const int r = by * TH + (lane / TW);
