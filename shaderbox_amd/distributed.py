@@ -65,6 +65,14 @@ class FramePlan:
                 self.peers = renderer.empty((self.world - 1, self.rows_max, self.width, self.channels), zero=True)
         else:
             self.slab = renderer.empty((self.rows_max, self.width, self.channels), zero=True)
+        # the point-to-point descriptors of the direct exchange, built once (they only name fixed buffers and peers)
+        self.p2p = []
+        if exchange == "direct" and self.world > 1:
+            for a, b in self.ranges:
+                if self.rank == 0:
+                    self.p2p.append([dist.P2POp(dist.irecv, self.peers[i - 1, a:b], i) for i in range(1, self.world)])
+                else:
+                    self.p2p.append([dist.P2POp(dist.isend, self.slab[a:b], 0)])
 
     def render(self, app, time, mouse=(0.0, 0.0), aux=None):
         """All ranks call this; rank 0 returns the assembled [H, W, 4] frame, the others None."""
@@ -75,21 +83,19 @@ class FramePlan:
         if self.rank == 0:
             # the receives first: they depend only on the previous use of `peers` (earlier on this stream), not on the
             # root's own rendering, which then runs beside them
-            for a, b in self.ranges:
-                ops = [d.P2POp(d.irecv, self.peers[i - 1, a:b], i) for i in range(1, self.world)]
-                if ops:
-                    works += d.batch_isend_irecv(ops)
+            for ops in self.p2p:
+                works += d.batch_isend_irecv(ops)
             self.r.render_rank_in_place(app, self.width, self.height, time, self.block_rows, 0, self.world, self.frame,
                                         mouse=mouse, aux=aux, root_rounds=self.root_rounds, rounds=self.rounds)
             for w in works:
                 w.wait()
             return self.r.assemble_peers(self.peers, self.width, self.height, self.block_rows, self.world, self.frame,
                                          root_rounds=self.root_rounds, rounds=self.rounds)
-        for a, b in self.ranges:
+        for g, (a, b) in enumerate(self.ranges):
             self.r.render_rank_rows(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
                                     a, b, self.slab, mouse=mouse, aux=aux, root_rounds=self.root_rounds,
                                     rounds=self.rounds)
-            works += d.batch_isend_irecv([d.P2POp(d.isend, self.slab[a:b], 0)])
+            works += d.batch_isend_irecv(self.p2p[g])
         for w in works:
             w.wait()          # stream-level on GPUs: the next frame's render into this slab is ordered after the send
         return None
