@@ -46,6 +46,12 @@
 #else
 #define CL_EXP(x) exp_(x)
 #endif
+#ifndef CL_EXP_LDEXP
+#define CL_EXP_LDEXP 1
+#endif
+#ifndef CL_MAX3
+#define CL_MAX3 1
+#endif
 #ifndef CL_MIN_WAVES
 #define CL_MIN_WAVES 6     // waves per SIMD the register allocation is held to (__launch_bounds__): 80 VGPRs (78 used, no spills;
                            // 7 waves = 72 VGPRs spill 6 and lose 4 %)
@@ -79,7 +85,15 @@ __device__ __forceinline__ float cl_exp(float x, const double (&tab)[32]) {
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     const double y = p * tab[ki & 31];
+#if CL_EXP_LDEXP
+    // |x| <= 80 in the REG kernels (launch_clouds): y * 2^(ki >> 5) lies in [2^-117, 2^117], far inside binary32's normal range,
+    // so rounding y to binary32 first and scaling by the power of two afterwards gives the same bits (a power-of-two scale
+    // commutes with rounding when nothing underflows or overflows; NaN stays NaN): v_cvt + v_ashr + v_ldexp instead of the
+    // 64-bit exponent insertion (shift, mask, 64-bit add) + v_cvt
+    return __builtin_ldexpf((float)y, ki >> 5);
+#else
     return (float)u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
+#endif
 }
 #define CL_EXP_REG(x) cl_exp((x), etab)
 #else
@@ -452,7 +466,11 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             qzv[k] = qz;
             if (REG) {
                 az[k] = qz - curz[k];                         // general form's first sample: curz is NaN -> az NaN -> "moved"
+#if !CL_MAX3
                 mk[k] = wave_mask(f2u(az[k]) >= 0x3f800000u);              // not (+0 <= az < 1)
+#else
+                mk[k] = 0;
+#endif
             } else {
                 const float pz = floor_(qz);
                 az[k] = qz - pz;
@@ -462,7 +480,23 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             moved_mask |= mk[k];
             qz = qz * 2.64f;
         }
+#if CL_MAX3
+        if (REG) {
+            // "some octave left its cell" from ONE compare: the largest of the four bit patterns (two v_max instead of three more
+            // v_cmp, all half-rate, and no mask arithmetic); which octaves, only when that happened
+            unsigned mx, m4;
+            asm("v_max3_u32 %0, %1, %2, %3" : "=v"(mx) : "v"(f2u(az[0])), "v"(f2u(az[1])), "v"(f2u(az[2])));
+            asm("v_max_u32 %0, %1, %2" : "=v"(m4) : "v"(mx), "v"(f2u(az[3])));
+            moved_mask = wave_mask(m4 >= 0x3f800000u);
+        }
+#endif
         if (wave_any_mask(moved_mask & lit_mask)) {
+#if CL_MAX3
+            if (REG) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mk[k] = wave_mask(f2u(az[k]) >= 0x3f800000u);
+            }
+#endif
 #ifdef SBX_CL_STATS
             if (lane == 0) S.stat[3] += 1.f;
 #endif
@@ -510,6 +544,19 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
         lp = lp + lstep;
     }
     return ltrans;
+}
+
+// The REG kernels' exp (cl_exp) as a standalone function for the exhaustive equivalence test against exp_ (sbx_math_eval
+// "exp_reg"; tests/test_gpu_round2.py): the same LDS table, the same instruction sequence as inside k_clouds.
+__global__ void __launch_bounds__(256) k_cl_exp_eval(const float* __restrict__ a, float* __restrict__ out, size_t n) {
+    __shared__ double etab[32];
+    if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = CL_EXP_REG(a[i]);
+}
+void launch_cl_exp_eval(const float* a, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_cl_exp_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, out, n);
 }
 
 // sky colour of a view direction (render_sky_color :36-46)

@@ -417,3 +417,23 @@ def test_assemble_peers_argument_errors(renderer):
     assert lib.sbx_assemble_peers(renderer.ctx, 16, 16, 8, 1, 1, 1, 3, None, fp(frame), None) == 0     # a lone rank has no peers
     with pytest.raises(ValueError):
         renderer.assemble_peers(torch.zeros((1, 4, 16, 3), device="cuda"), 16, 16, 8, 2, frame)
+
+
+def test_regular_frame_exp_equals_exp_on_its_whole_domain(renderer):
+    """cl_exp (kern_clouds.hip: no range guard, three-address v_fma_f64, power-of-two scaling after the rounding to binary32)
+    against exp_ of the math spec on EVERY binary32 argument the regular-frame kernels can produce: |x| <= 80 (launch_clouds
+    admits a frame only if |sigma * dt| <= 80 and the density is in [0, 1)), both signs, zeros, denormals; plus NaNs."""
+    import torch
+    lim = np.array([80.0], dtype=np.float32).view(np.uint32)[0]          # bit pattern of 80.0f: all patterns below are |x| < 80
+    chunk = 1 << 26
+    for sign in (0, 0x80000000):
+        for start in range(0, int(lim) + 1, chunk):
+            stop = min(start + chunk, int(lim) + 1)
+            bits = (torch.arange(start, stop, dtype=torch.int64, device="cuda") | sign).to(torch.int32)
+            x = bits.view(torch.float32)
+            a = renderer.math("exp_reg", x)
+            b = renderer.math("exp", x)
+            bad = a.view(torch.int32) != b.view(torch.int32)
+            assert not bool(bad.any()), "first mismatch at bits 0x%08x" % int(bits[bad][0].item() & 0xffffffff)
+    nan = torch.tensor([float("nan"), -float("nan")], device="cuda")
+    assert bool(torch.isnan(renderer.math("exp_reg", nan)).all())
