@@ -33,7 +33,14 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 // inside the atmosphere shell, so -height / H is in [-50.1, 0.001], far inside the guard's [-104, 89], and a NaN passes
 // through the guard unchanged.  exp(-tau) keeps its guard: grazing sun rays reach optical depths beyond 104 (measured: a ring
 // of 9 % of the pixels turns NaN / inf without it).
+#ifndef ATM_EXP_REG
+#define ATM_EXP_REG 1      // the density terms through exp_reg_ (sbx_math.h) when the uniforms are finite
+#endif
+#if ATM_EXP_REG
+#define ATM_EXP_H(x) (FIN ? exp_reg_<false>((x), etab) : exp_tab_<true>((x), etab))
+#else
 #define ATM_EXP_H(x) exp_tab_<!FIN>((x), etab)
+#endif
 #define ATM_EXP(x) exp_tab_<true>((x), etab)
 
 template <bool FIN>

@@ -46,9 +46,6 @@
 #else
 #define CL_EXP(x) exp_(x)
 #endif
-#ifndef CL_EXP_LDEXP
-#define CL_EXP_LDEXP 1
-#endif
 #ifndef CL_MAX3
 #define CL_MAX3 1
 #endif
@@ -59,43 +56,10 @@
 
 namespace sbx {
 
-// exp_tab_<false> (sbx_math.h) for the REG kernels with the middle of the Horner chain written as three-address v_fma_f64:
-// the compiler turns `p = fma(p, r, c)` with c in a VGPR pair into v_mov_b64 (copy c) + v_fmac_f64 (two-address), one extra
-// half-rate instruction per coefficient and exp.  Same operations, same operands, same order: identical bits
-// (tests: every REG frame against the per-lane kernel and the oracle).
+// The REG kernels' exp is exp_reg_ of sbx_math.h (|x| <= 80 shown on the host per launch): no range guard, three-address
+// v_fma_f64, power-of-two scaling after the rounding to binary32.  CL_EXP_ASM = 0 falls back to exp_tab_<false>.
 #if CL_EXP_ASM
-__device__ __forceinline__ double cl_fma64(double a, double b, double c) {
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ float cl_exp(float x, const double (&tab)[32]) {
-    const double xd = (double)x;
-    double kd = __builtin_fma(xd, 0x1.71547652b82fep+5, D_MAGIC);          // 32/ln2
-    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
-    kd = kd - D_MAGIC;
-    double r = __builtin_fma(kd, -0x1.62e42fefa0000p-6, xd);               // ln2/32, high 38 bits
-    r = __builtin_fma(kd, -0x1.cf79abc9e3b3ap-45, r);                      // ln2/32 - high
-    double p, c6 = 0x1.6c16c16c16c17p-10, c5 = 0x1.1111111111111p-7;         // 1/6!, 1/5!
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(c6), "v"(r), "v"(c5));
-    double c4 = 0x1.5555555555555p-5, c3 = 0x1.5555555555555p-3;
-    p = cl_fma64(p, r, c4);
-    p = cl_fma64(p, r, c3);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    const double y = p * tab[ki & 31];
-#if CL_EXP_LDEXP
-    // |x| <= 80 in the REG kernels (launch_clouds): y * 2^(ki >> 5) lies in [2^-117, 2^117], far inside binary32's normal range,
-    // so rounding y to binary32 first and scaling by the power of two afterwards gives the same bits (a power-of-two scale
-    // commutes with rounding when nothing underflows or overflows; NaN stays NaN): v_cvt + v_ashr + v_ldexp instead of the
-    // 64-bit exponent insertion (shift, mask, 64-bit add) + v_cvt
-    return __builtin_ldexpf((float)y, ki >> 5);
-#else
-    return (float)u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
-#endif
-}
-#define CL_EXP_REG(x) cl_exp((x), etab)
+#define CL_EXP_REG(x) exp_reg_((x), etab)
 #else
 #define CL_EXP_REG(x) exp_tab_<false>((x), etab)
 #endif
@@ -548,15 +512,18 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
 
 // The REG kernels' exp (cl_exp) as a standalone function for the exhaustive equivalence test against exp_ (sbx_math_eval
 // "exp_reg"; tests/test_gpu_round2.py): the same LDS table, the same instruction sequence as inside k_clouds.
+template <bool ASM>
 __global__ void __launch_bounds__(256) k_cl_exp_eval(const float* __restrict__ a, float* __restrict__ out, size_t n) {
     __shared__ double etab[32];
     if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = CL_EXP_REG(a[i]);
+    if (i < n) out[i] = ASM ? CL_EXP_REG(a[i]) : exp_reg_<false>(a[i], etab);     // k_clouds' form / k_atmosphere's form
 }
-void launch_cl_exp_eval(const float* a, float* out, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_cl_exp_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, out, n);
+void launch_cl_exp_eval(const float* a, float* out, size_t n, hipStream_t s, bool plain) {
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (plain) hipLaunchKernelGGL(k_cl_exp_eval<false>, grid, block, 0, s, a, out, n);
+    else hipLaunchKernelGGL(k_cl_exp_eval<true>, grid, block, 0, s, a, out, n);
 }
 
 // sky colour of a view direction (render_sky_color :36-46)

@@ -261,6 +261,50 @@ SBX_HD float exp_tab_(float x, const Tab& tab) {
     return (float)u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
 }
 SBX_HD float exp_(float x) { return exp_tab_(x, kExp2Tab); }
+#if defined(__HIPCC__)
+// exp_tab_<false> for callers that have shown |x| <= 80 (or NaN) for every argument they can produce — the regular-frame
+// k_clouds (|sigma * dt| <= 80 checked per launch) and APP_ATMOSPHERE's density terms (-height / H in [-50.1, 0.001]) — in
+// the cheapest instruction sequence found on gfx950, same operations on the same operands:
+//  * the middle of the Horner chain as three-address v_fma_f64: the compiler turns `p = fma(p, r, c)` with c in a VGPR pair
+//    into v_mov_b64 (copy c) + v_fmac_f64 (two-address), one extra half-rate instruction per coefficient;
+//  * the scaling by 2^(k >> 5) AFTER the rounding to binary32 (v_cvt + v_ashr + v_ldexp_f32 instead of shift, mask and a
+//    64-bit add before the v_cvt): y * 2^e lies in [2^-117, 2^117], far inside binary32's normal range, where a
+//    power-of-two scale commutes with the rounding; NaN stays NaN.
+// tests/test_gpu_round2.py::test_regular_frame_exp_equals_exp_on_its_whole_domain compares it with exp_ on EVERY binary32
+// argument with |x| <= 80 (sbx_math_eval "exp_reg"): identical.
+__device__ __forceinline__ double fma64_3addr(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// ASM = false keeps the compiler's own Horner chain (APP_ATMOSPHERE: with its two unrolled sample loops the asm operands in VGPR
+// pairs raise the kernel from 54 to 128 VGPRs and 4.53 to 4.72 ms).
+template <bool ASM = true, class Tab>
+__device__ __forceinline__ float exp_reg_(float x, const Tab& tab) {
+    const double xd = (double)x;
+    double kd = __builtin_fma(xd, 0x1.71547652b82fep+5, D_MAGIC);          // 32/ln2
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - D_MAGIC;
+    double r = __builtin_fma(kd, -0x1.62e42fefa0000p-6, xd);               // ln2/32, high 38 bits
+    r = __builtin_fma(kd, -0x1.cf79abc9e3b3ap-45, r);                      // ln2/32 - high
+    double p, c6 = 0x1.6c16c16c16c17p-10, c5 = 0x1.1111111111111p-7;         // 1/6!, 1/5!
+    const double c4 = 0x1.5555555555555p-5, c3 = 0x1.5555555555555p-3;
+    if (ASM) {
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(c6), "v"(r), "v"(c5));
+        p = fma64_3addr(p, r, c4);
+        p = fma64_3addr(p, r, c3);
+    } else {
+        p = __builtin_fma(c6, r, c5);
+        p = __builtin_fma(p, r, c4);
+        p = __builtin_fma(p, r, c3);
+    }
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double y = p * tab[ki & 31];
+    return __builtin_ldexpf((float)y, ki >> 5);
+}
+#endif
 // The former pow (atanh-series log2 with a binary64 division, 13-term 2^t), kept as the test hook "pow_h": the table
 // form below agrees with it except on a ~1e-8 fraction of inputs that sit on a binary32 rounding boundary to within
 // the ~1e-16 accuracy of either binary64 value (tests/test_gpu_parity.py::test_pow_table_vs_series).

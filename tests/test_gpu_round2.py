@@ -431,9 +431,10 @@ def test_regular_frame_exp_equals_exp_on_its_whole_domain(renderer):
             stop = min(start + chunk, int(lim) + 1)
             bits = (torch.arange(start, stop, dtype=torch.int64, device="cuda") | sign).to(torch.int32)
             x = bits.view(torch.float32)
-            a = renderer.math("exp_reg", x)
             b = renderer.math("exp", x)
-            bad = a.view(torch.int32) != b.view(torch.int32)
-            assert not bool(bad.any()), "first mismatch at bits 0x%08x" % int(bits[bad][0].item() & 0xffffffff)
+            for form in ("exp_reg", "exp_reg_plain"):                   # k_clouds' and k_atmosphere's instruction sequences
+                a = renderer.math(form, x)
+                bad = a.view(torch.int32) != b.view(torch.int32)
+                assert not bool(bad.any()), "%s: first mismatch at bits 0x%08x" % (form, int(bits[bad][0].item() & 0xffffffff))
     nan = torch.tensor([float("nan"), -float("nan")], device="cuda")
-    assert bool(torch.isnan(renderer.math("exp_reg", nan)).all())
+    assert bool(torch.isnan(renderer.math("exp_reg", nan)).all()) and bool(torch.isnan(renderer.math("exp_reg_plain", nan)).all())
