@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, ".")
 import shaderbox_amd
 
+if len(sys.argv) > 1:                      # an A/B library of tools/ab_build.py instead of the shipped one
+    shaderbox_amd.LIB_PATH = sys.argv[1]
 R = shaderbox_amd.Renderer(0)
 R.set_timing(True)
 W, H = 3840, 2160
