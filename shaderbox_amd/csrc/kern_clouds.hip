@@ -46,6 +46,10 @@
 #else
 #define CL_EXP(x) exp_(x)
 #endif
+#ifndef CL_NOTAB_GEN
+#define CL_NOTAB_GEN 1       // 1: the table-less kernels (more march steps than the y table's rows) at CL_MIN_WAVES_GEN too
+                             //    (1100 steps without a table at 4K: 48.1 ms at 6 waves, 42.7 at 5)
+#endif
 #ifndef CL_MIN_WAVES_GEN
 #define CL_MIN_WAVES_GEN 5   // the instantiations with the general light march (a sun off the z axis): 3840x2160 6.20 ms at 6 waves (92 B of
                              // scratch per lane), 5.31 at 5 (28 B), 5.53 at 4 (104 VGPRs, none)
@@ -560,7 +564,7 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
 // march a scalar load: 3.5 -> 4.0 ms.)
 struct ClArgs { FrameClouds F; RowMap M; float* out; const YRow* ytab; };
 template <bool YTAB, bool REG, bool ZL>
-__global__ void __launch_bounds__(64 * CL_TX, ZL ? CL_MIN_WAVES : CL_MIN_WAVES_GEN) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out_arg,
+__global__ void __launch_bounds__(64 * CL_TX, (ZL && (YTAB || !CL_NOTAB_GEN)) ? CL_MIN_WAVES : CL_MIN_WAVES_GEN) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out_arg,
                                                           const YRow* __restrict__ ytab) {
     __shared__ WaveCache cache[CL_TX];
 #if CL_PARK

@@ -63,7 +63,8 @@ __device__ __forceinline__ void store_rgba(const RowMap& M, float* out, size_t i
 // launchers (one per app), defined next to their kernels
 void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows,
                    bool build_table);
-constexpr int CLOUDS_YTAB_ROWS = 1024;      // march steps covered by the per-frame y table
+constexpr int CLOUDS_YTAB_ROWS = 4096;      // march steps covered by the per-frame y table (192 KB per table; beyond it the
+                                            // table-less kernels run: 1100 steps at 4K took 48 ms without a table)
 constexpr int CLOUDS_YTAB_BYTES = CLOUDS_YTAB_ROWS * 48;
 constexpr int CLOUDS_YTAB_RING = 8;         // eager tables: one per REBUILD (key change), round robin; reuse of a slot waits
                                             // for the launches that may still read it (sbx_capi.hip render_clouds)

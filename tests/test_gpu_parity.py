@@ -322,6 +322,8 @@ def test_clouds_aux_corners(renderer, oracle):
     W, H = 96, 54
     cases = []
     a = shaderbox_amd.clouds_defaults(); a.cld_march_steps = 1100; a.cld_thick = 137.5; cases.append((a, 0.37))
+    a = shaderbox_amd.clouds_defaults(); a.cld_march_steps = 4200; a.cld_thick = 137.5; cases.append((a, 0.37))   # beyond the y table
+    a = shaderbox_amd.clouds_defaults(); a.cld_march_steps = 4100; a.sun_dir[0], a.sun_dir[2] = .6, -.8; cases.append((a, 1.1))
     a = shaderbox_amd.clouds_defaults(); a.wind_dir[1] = .05; a.wind_dir[0] = -.1; cases.append((a, 1.7))
     a = shaderbox_amd.clouds_defaults(); a.cld_coverage = .95; cases.append((a, 0.37))
     a = shaderbox_amd.clouds_defaults(); a.cld_coverage = .05; cases.append((a, 0.37))
