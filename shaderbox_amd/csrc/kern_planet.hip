@@ -186,6 +186,9 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
 #ifndef PL_PARK
 #define PL_PARK 1          // the hit shading's state waits in LDS while the 6 detail terrain maps run
 #endif
+// (6 waves per SIMD, 80 VGPRs, no parking — its LDS does not fit beside 32-slot tables then: 7.03 ms, but 176 B of scratch per lane,
+//  now inside the marches, and 4.3 GB of HBM traffic per frame: 4 % of time bought with 4x the traffic; not taken.  7 waves with
+//  16-slot tables: 7.21 ms.)
 // (tools/ab_time.py, 7680x4320, same bits: no parking 7.36 ms, 112 B of scratch per lane, 1.72 GB of HBM traffic per frame
 //  against the 0.53 GB framebuffer; hit-shading parking 7.29 ms, 60 B, ~1.0 GB; parking the cloud march's ray and integrator
 //  as well: no spills there to remove, 7.66 ms; recomputing pixel and ray in the epilogue instead of keeping them: 7.54 ms)
