@@ -19,10 +19,10 @@
 
 namespace sbx {
 
-// waves per SIMD (tools/ab_time.py, 3840x2160, same bits): 4 (100 VGPRs) 2.00 ms, 5 1.80, 6 (80 VGPRs) 1.76, 6 with 16-slot tables 1.81,
-// 7 1.89, 8 2.78
+// waves per SIMD (tools/ab_time.py, 3840x2160, same bits): 4 (100 VGPRs) 2.00 ms; 5 (96 VGPRs, no scratch, HBM traffic = the frame)
+// 1.80; 6 (80 VGPRs, 60 B of scratch per lane, 0.5 GB of traffic for a 0.13 GB frame) 1.76; 6 with 16-slot tables 1.81; 7 1.89; 8 2.78
 #ifndef UE4_MIN_WAVES
-#define UE4_MIN_WAVES 6
+#define UE4_MIN_WAVES 5
 #endif
 __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameCloudsUe4 F, RowMap M, float* __restrict__ out) {
     __shared__ WaveCache cache[WG_THREADS / 64];
