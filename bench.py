@@ -117,6 +117,24 @@ def launch_check(args):
     return 0
 
 
+_emit = None
+
+
+def claim_stdout():
+    """The contract: stdout carries ONE JSON line.  Libraries inside this process must not add to it — RCCL prints a version
+    banner to the C stdout, flushed at exit, i.e. AFTER the line — so descriptor 1 is pointed at stderr for the life of the
+    process and the line goes to the saved descriptor."""
+    global _emit
+    if _emit is None:
+        sys.stdout.flush()
+        real = os.dup(1)
+        os.dup2(2, 1)
+
+        def _emit(line):
+            os.write(real, (line + "\n").encode())
+    return _emit
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +179,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.engine == "lib" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        claim_stdout()
         sys.exit(bench_lib(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (the driver's command shape at N = 1, 2, 4, 8)
@@ -171,6 +190,7 @@ def main():
         raise SystemExit("bench.py --gpus %d runs under WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    claim_stdout()
 
     # HIP maps streams onto a few hardware queues (4 by default); two streams that share a queue do not overlap at all,
     # and this process uses up to four (default, two frame streams, RCCL's): ask for more queues before HIP starts.
@@ -333,8 +353,7 @@ def main():
             out["other_configs"] = other_configs(R, torch, dev, streams, t, check_rows=0 if args.no_cpu_baseline else 16)
             if any(c["parity"] and not (c["parity"]["max_abs_diff"] <= 1e-4) for c in out["other_configs"]):
                 status = 3
-        print(json.dumps(out))
-        sys.stdout.flush()
+        claim_stdout()(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -392,7 +411,7 @@ def bench_lib(args):
                                      % (args.block_rows, n, devices, "RCCL send/recv per row-block into the final rows" if M.uses_rccl
                                         else "device copies per row-block (ranks share devices: emulation, not a scaling number)")},
            "parity": {"against": "one-launch render of the same frame", "rows": H, "mismatching_pixels": bad}}
-    print(json.dumps(out))
+    claim_stdout()(json.dumps(out))
     M.close()
     return 3 if bad else 0
 

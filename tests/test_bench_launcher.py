@@ -20,6 +20,9 @@ def run_bench(*args, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode == 0:
+        # the contract: ONE JSON line on stdout and nothing else (RCCL's version banner, flushed at exit, used to follow it)
+        assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-600:]
     return r, (json.loads(lines[-1]) if lines else None)
 
 
