@@ -111,8 +111,8 @@ def launch_check(args):
     dist.all_reduce(t)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
-                          "self_launched": os.environ.get("SBX_BENCH_SELF_LAUNCHED") == "1"}))
+        claim_stdout()(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
+                                   "self_launched": os.environ.get("SBX_BENCH_SELF_LAUNCHED") == "1"}))
     dist.destroy_process_group()
     return 0
 
@@ -185,6 +185,7 @@ def main():
         # plain `python bench.py --gpus N`: become the launcher of N ranks (the driver's command shape at N = 1, 2, 4, 8)
         sys.exit(self_launch(args, sys.argv[1:]))
     if args.launch_check:
+        claim_stdout()
         sys.exit(launch_check(args))
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         raise SystemExit("bench.py --gpus %d runs under WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
