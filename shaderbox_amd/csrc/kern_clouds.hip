@@ -23,6 +23,9 @@
 #ifndef CL_LIPSKIP
 #define CL_LIPSKIP 1       // skip main samples proved clear by the Lipschitz bound (coop_density_row)
 #endif
+#ifndef CL_LIPSKIP2
+#define CL_LIPSKIP2 1      // the Lipschitz skip also where the SECOND stage fails
+#endif
 #ifndef CL_EPILOGUE_RELOAD
 #define CL_EPILOGUE_RELOAD 1
 #endif
@@ -363,8 +366,33 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
         }
         return 0.f;
     }
+#ifdef SBX_CL_STATS
+    if (lane == 0) S.stat[4] += 1.f;
+#endif
     row_octaves<2, 3>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
-    if (!wave_any_mask(active_mask & wave_mask(!(t + .06255f < F.cov)))) return 0.f;
+    if (!wave_any_mask(active_mask & wave_mask(!(t + .06255f < F.cov)))) {
+#if CL_LIPSKIP2
+        if (LIP) {
+            // the same proof one octave further: s3 = s + .125 N(q2) moves by at most j * 1.5 * (.5 + .25 * 2.64 + .125 * 2.64^2) D
+            // = j * 3.0468 D over j steps, and a sample with s3 + .06255 < cov is clear.  1 / c3 = (1 / c) * 1.74 / 3.0468
+            // (.571, rounded down); gap = (cov - .06255 - 1e-3) - s3.
+            float c = F.cov;
+            asm volatile("" : "+v"(c));
+            const float r = (((c - .06355f) - t) * *lip_slot) * .571f;
+            if (!wave_any_mask(active_mask & wave_mask(!(r >= 1.f)))) {
+                skip = 1;
+                if (!wave_any_mask(active_mask & wave_mask(!(r >= 2.f)))) {
+                    skip = 2;
+                    if (!wave_any_mask(active_mask & wave_mask(!(r >= 4.f)))) skip = 4;
+                }
+            }
+        }
+#endif
+        return 0.f;
+    }
+#ifdef SBX_CL_STATS
+    if (lane == 0) S.stat[5] += 1.f;
+#endif
     row_octaves<3, 4>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
     return t * smoothstep_rd(F.cov, F.cov_rd, t);        // :83-84
 }
@@ -579,7 +607,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (ZL && (YTAB || !CL_NOTAB_GEN)) ? 
     if (CL_TX > 1) __syncthreads();
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
 #ifdef SBX_CL_STATS
-    if (lane < 4) S.stat[lane] = 0.f;
+    if (lane < 8) S.stat[lane] = 0.f;
 #endif
     __builtin_amdgcn_wave_barrier();
 
@@ -751,7 +779,8 @@ __global__ void __launch_bounds__(64 * CL_TX, (ZL && (YTAB || !CL_NOTAB_GEN)) ? 
 #ifdef SBX_CL_STATS
     __builtin_amdgcn_wave_barrier();
     if (lane == 1) { st_steps = S.stat[0]; st_lit = S.stat[1]; st_alive = S.stat[2]; st_litl = S.stat[3]; }
-    reinterpret_cast<float4*>(out)[px.idx] = make_float4(st_steps, st_lit, (lane == 2) ? st_skipped : st_alive, st_litl);
+    if (lane == 2) { st_steps = S.stat[4]; st_lit = S.stat[5]; st_alive = st_skipped; }
+    reinterpret_cast<float4*>(out)[px.idx] = make_float4(st_steps, st_lit, st_alive, st_litl);
     return;
 #endif
     store_rgba(ME, out, px.idx, to_srgb(col));

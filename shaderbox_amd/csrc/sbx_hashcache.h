@@ -46,7 +46,8 @@ struct alignas(16) WaveCache {
     unsigned tag[4][HC_SLOTS];        // bits of n; 0x7fc00001 (a NaN) = empty
     unsigned ins_tag[8], ins_slot[8]; // cells being inserted in the current pass
 #ifdef SBX_CL_STATS
-    float stat[4];                    // census build only (tools/clouds_census.py): slow calls, passes, cells, re-lookups
+    float stat[8];                    // census build only (tools/clouds_census.py): slow calls, passes, cells, re-lookups,
+                                      // main samples past the first / second stage, Lipschitz-skipped steps
 #endif
 };
 
