@@ -438,3 +438,25 @@ def test_regular_frame_exp_equals_exp_on_its_whole_domain(renderer):
                 assert not bool(bad.any()), "%s: first mismatch at bits 0x%08x" % (form, int(bits[bad][0].item() & 0xffffffff))
     nan = torch.tensor([float("nan"), -float("nan")], device="cuda")
     assert bool(torch.isnan(renderer.math("exp_reg", nan)).all()) and bool(torch.isnan(renderer.math("exp_reg_plain", nan)).all())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# every pixel of the BASELINE.json frames
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("app,w,h", [("egg", 1920, 1080), ("raytracer", 3840, 2160), ("clouds", 3840, 2160),
+                                     ("atmosphere", 7680, 4320), ("planet", 7680, 4320)])
+def test_every_pixel_of_the_baseline_frames(renderer, oracle, app, w, h):
+    """C2 .. C5 of BASELINE.json at t = 0.37, mouse 0: the WHOLE frame against the CPU oracle, bit for bit (the other full-size
+    tests compare evenly spread rows).  About a minute of host time in total on the GPU box's 256 threads
+    (tests/full_frame_parity.py is the stand-alone form and also covers the §8f apps)."""
+    from oracle.oracle import APP_IDS
+    gpu = renderer.render(app, w, h, 0.37).cpu().numpy()
+    bad = 0
+    for y0 in range(0, h, 270):
+        rows = list(range(y0, min(y0 + 270, h)))
+        ref = oracle.render_rows(APP_IDS[app], w, h, 0.37, rows)
+        g = gpu[y0:y0 + len(rows)]
+        both_nan = np.isnan(g) & np.isnan(ref)
+        bad += int(((g.view(np.uint32) != ref.view(np.uint32)) & ~both_nan).any(-1).sum())
+    assert bad == 0
