@@ -23,8 +23,12 @@
 // in the 4 MB L2 of each XCD), neighbouring pixels of a wave tile sample neighbouring texels, and the straight
 // per-lane kernel below needs few registers, so 8 waves per SIMD hide the L2 latency.  HBM traffic stays the
 // framebuffer (16 B/pixel) plus one pass over the volumes; roofline and FETCH_SIZE in DESIGN.md §4.8.
+#include <cmath>
 #include "sbx_device.h"
 
+#ifndef TEX_ZL
+#define TEX_ZL 1           // 0: never use the z-only light march (A/B timing)
+#endif
 #ifndef TEX_MIN_WAVES
 #define TEX_MIN_WAVES 5
 #endif
@@ -97,6 +101,52 @@ __device__ __forceinline__ float tex3d_r(const NoiseTex& T, v3 p) {     // Sampl
     return mix_(mix_(a, b, fy), mix_(c, d, fy), fz);
 }
 
+// ---- the z-only light march (ZL kernels: power-of-two volumes, light step without x and y component) --------------------
+// illuminate_volume's samples (:106-113) are lp = pos + (j + 1) * L dt.  With L dt = (0, 0, lz) — the reference's default sun
+// (0, 0, -1), src/uniform_buffer.h:42 — lp.x = pos.x + 0 and lp.y = pos.y + 0 are the main sample's own coordinates (a -0 turned
+// +0 changes no result bit: the next operation is `* fsize - .5`), so for BOTH volumes the x and y texel indices and weights of
+// all light samples of a step are the main sample's, and as long as a light sample stays in the main sample's z cell
+// (one light step is dt * .001 * size = .16 texels of the 128^3 volume) so are its two bilinear plane values
+//     p0 = mix(mix(t000, t100, fx), mix(t010, t110, fx), fy),   p1 = the same in plane z1:
+// the sample is mix(p0, p1, fz) with only fz new — the same operations on the same values as tex3d_r, 2 instead of ~110
+// instructions and no loads.  A lane that leaves its cell fetches the two planes of its new cell (per-lane branch).
+struct TexCell { unsigned x0, x1, a0, a1; float fx, fy, fl, p0, p1; };   // a0/a1: y * size; fl = floor(uz) of the planes held
+
+__device__ __forceinline__ void tex_planes(const NoiseTex& T, TexCell& c, float fl) {      // power-of-two sizes, |fl| < 2^31
+    const int mask = T.size - 1;
+    const unsigned k = (unsigned)T.lg;
+    const int z0 = (int)fl & mask, z1 = (z0 + 1) & mask;
+    const unsigned r0 = (unsigned)z0 << (2 * k), r1 = (unsigned)z1 << (2 * k);
+    const float t000 = T.r[r0 + c.a0 + c.x0], t100 = T.r[r0 + c.a0 + c.x1];
+    const float t010 = T.r[r0 + c.a1 + c.x0], t110 = T.r[r0 + c.a1 + c.x1];
+    const float t001 = T.r[r1 + c.a0 + c.x0], t101 = T.r[r1 + c.a0 + c.x1];
+    const float t011 = T.r[r1 + c.a1 + c.x0], t111 = T.r[r1 + c.a1 + c.x1];
+    c.p0 = mix_(mix_(t000, t100, c.fx), mix_(t010, t110, c.fx), c.fy);
+    c.p1 = mix_(mix_(t001, t101, c.fx), mix_(t011, t111, c.fx), c.fy);
+    c.fl = fl;
+}
+// tex3d_r<true>'s fast form, keeping what the light march reuses.  The caller has made the range test.
+__device__ __forceinline__ float tex3d_seed(const NoiseTex& T, v3 p, TexCell& c) {
+    const int mask = T.size - 1;
+    const unsigned k = (unsigned)T.lg;
+    const float ux = p.x * T.fsize - .5f, uy = p.y * T.fsize - .5f, uz = p.z * T.fsize - .5f;
+    const float lx = floor_(ux), ly = floor_(uy), lz = floor_(uz);
+    c.fx = ux - lx; c.fy = uy - ly;
+    const float fz = uz - lz;
+    const int x0 = (int)lx & mask, y0 = (int)ly & mask;
+    c.x0 = (unsigned)x0; c.x1 = (unsigned)((x0 + 1) & mask);
+    c.a0 = (unsigned)y0 << k; c.a1 = (unsigned)((y0 + 1) & mask) << k;
+    tex_planes(T, c, lz);
+    return mix_(c.p0, c.p1, fz);
+}
+// a light sample: z only
+__device__ __forceinline__ float tex3d_z(const NoiseTex& T, float pz, TexCell& c) {
+    const float uz = pz * T.fsize - .5f;
+    const float lz = floor_(uz);
+    if (lz != c.fl) tex_planes(T, c, lz);
+    return mix_(c.p0, c.p1, uz - lz);
+}
+
 __device__ __forceinline__ float remap_(float v, float omin, float omax, float nmin, float nmax) {   // util.h:127-138
     return nmin + (((v - omin) / (omax - omin)) * (nmax - nmin));
 }
@@ -115,7 +165,7 @@ __device__ __forceinline__ float hg_phase_tex(float mu, float g) {   // volumetr
     return (1.f - g * g) / ((4.f + 3.14159265359f) * pow_(1.f + g * g - 2.f * g * mu, 1.5f));
 }
 
-template <bool POW2>
+template <bool POW2, bool ZL>      // ZL (decided on the host): POW2 and the light step has no x and no y component
 __global__ void __launch_bounds__(WG_THREADS, TEX_MIN_WAVES) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out,
                                                             NoiseTex T1, NoiseTex T2, double rsteps, double rlsteps) {
     // rsteps = recip64(float(steps)), rlsteps = recip64(float(lsteps)): `i / steps` and `j / lsteps` as exact multiplies
@@ -144,12 +194,46 @@ __global__ void __launch_bounds__(WG_THREADS, TEX_MIN_WAVES) k_clouds_tex(FrameC
             const float height = div_by((float)i, rsteps);      // :183  i / steps
             const v3 pos = origin + t * projection;
             t += F.dt;
-            const float density = tex_density<POW2>(F, T1, T2, pos, height);
+            // ZL: the main sample through the seeding form of the filter when every coordinate of the wave — and the far end of its
+            // light march — is inside the fast form's range (wave-uniform; otherwise this step runs the general code below)
+            TexCell c1, c2;
+            bool fast = false;
+            float density;
+            if (ZL) {
+                const v3 q = pos * .001f;
+                const float zend = (pos.z + (float)(F.lsteps + 1) * lstep.z) * .001f;
+                const float lim = fmin_(1073741824.0f / T1.fsize, 1073741824.0f / T2.fsize) * .5f;
+                fast = !tex_wave_any(!(abs_(q.x) < lim) || !(abs_(q.y) < lim) || !(abs_(q.z) < lim) || !(abs_(zend) < lim));
+                if (fast) {
+                    float shape = tex3d_seed(T1, q, c1);                            // tex_density with the cells kept
+                    const float w = tex3d_seed(T2, q, c2);
+                    const float ww = mix_(w, 1.f - w, height);
+                    shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
+                    density = shape * smoothstep_rd(F.cov, F.cov_rd, shape);
+                } else {
+                    density = tex_density<POW2>(F, T1, T2, pos, height);
+                }
+            } else {
+                density = tex_density<POW2>(F, T1, T2, pos, height);
+            }
             if (!(density < .005f)) {                          // integrate_volume :132
                 const float T_i = exp_(-density * F.sigma * F.dt);
                 transmittance *= T_i;
                 v3 lp = pos + lstep;                           // illuminate_volume :91-123
                 float ltrans = 1.f;
+                if (ZL && fast) {
+                    for (int j = 0; j < F.lsteps; ++j) {
+                        const float lh = div_by((float)j, rlsteps);                 // :108  j / lsteps
+                        const float qz = lp.z * .001f;
+                        float shape = tex3d_z(T1, qz, c1);
+                        const float w = tex3d_z(T2, qz, c2);
+                        const float ww = mix_(w, 1.f - w, lh);
+                        shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
+                        const float d = shape * smoothstep_rd(F.cov, F.cov_rd, shape);
+                        ltrans *= exp_(-d * F.sigma * F.dt);
+                        lp.z = lp.z + lstep.z;
+                    }
+                } else
                 for (int j = 0; j < F.lsteps; ++j) {
                     const float lh = div_by((float)j, rlsteps);                     // :108  j / lsteps
                     const float d = tex_density<POW2>(F, T1, T2, lp, lh);
@@ -204,8 +288,11 @@ void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStr
     const NoiseTex T2{detail_r, detail_size, (float)detail_size, recip64((float)detail_size), lg2(detail_size)};
     const bool pow2 = (shape_size & (shape_size - 1)) == 0 && (detail_size & (detail_size - 1)) == 0;
     const double rs = recip64((float)F.steps), rl = recip64((float)F.lsteps);     // loops with 0 steps never use them
-    if (pow2) hipLaunchKernelGGL(k_clouds_tex<true>, grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2, rs, rl);
-    else hipLaunchKernelGGL(k_clouds_tex<false>, grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2, rs, rl);
+    const v3 lstep = F.sun_dir * F.dt;                           // the kernel's own expression
+    const bool zl = pow2 && lstep.x == 0.f && lstep.y == 0.f && std::isfinite(lstep.z) && TEX_ZL;
+    if (zl) hipLaunchKernelGGL((k_clouds_tex<true, true>), grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2, rs, rl);
+    else if (pow2) hipLaunchKernelGGL((k_clouds_tex<true, false>), grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2, rs, rl);
+    else hipLaunchKernelGGL((k_clouds_tex<false, false>), grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2, rs, rl);
 }
 
 }  // namespace sbx

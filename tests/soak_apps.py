@@ -16,7 +16,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 R = shaderbox_amd.Renderer(0)
 O = Oracle()
-APPS = ["egg", "sdf_ao", "vinyl", "raytracer", "atmosphere", "planet", "clouds", "clouds_best", "clouds_ue4"]
+APPS = ["egg", "sdf_ao", "vinyl", "raytracer", "atmosphere", "planet", "clouds", "clouds_best", "clouds_ue4", "clouds_tex"]
+# APP_CLOUDS' USE_NOISE_TEX build: two small baked volumes (32^3 shape, 16^3 detail) bound on both sides
+_v1, _v2 = R.worley_volume(32), R.worley_volume(16)
+R.set_noise_volumes(_v1, _v2)
+O.set_noise_volumes(_v1.cpu().numpy(), _v2.cpu().numpy())
 SIZES = [(160, 90), (97, 61), (128, 128), (211, 40), (64, 150)]
 total_bad = 0
 for app in APPS:
@@ -26,8 +30,20 @@ for app in APPS:
         t = float(rng.uniform(0, 60)) if i % 3 else float(rng.uniform(0, 3))
         mouse = (float(rng.uniform(0, W)), float(rng.uniform(0, H))) if i % 2 else (0.0, 0.0)
         R.set_variant(0)
-        g = R.render(app, W, H, t, mouse=mouse).cpu().numpy()
-        ref = O.render(APP_IDS[app], W, H, t, mouse=mouse)
+        aux = None
+        if app == "clouds_tex" and i % 2:                     # the aux block's code paths: z-only suns of any sign and length
+            aux = shaderbox_amd.clouds_defaults(R.lib)        # (the z-only light march), general suns, coverage, step counts
+            aux.cld_coverage = float(rng.uniform(.2, .8))
+            aux.cld_march_steps = int(rng.integers(10, 140))
+            aux.illum_march_steps = int(rng.integers(0, 10))
+            aux.cld_thick = float(rng.choice([rng.uniform(40, 300), -rng.uniform(10, 200)], p=[.85, .15]))
+            if i % 4 == 1:
+                aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = 0.0, 0.0, float(rng.choice([-2.0, 1.0, .3, 0.0]))
+            else:
+                d = rng.standard_normal(3); d /= np.linalg.norm(d)
+                aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = [float(x) for x in d]
+        g = R.render(app, W, H, t, mouse=mouse, aux=aux).cpu().numpy()
+        ref = O.render(APP_IDS[app], W, H, t, mouse=mouse, aux=aux)
         both_nan = np.isnan(g) & np.isnan(ref)
         diff = ((g.view(np.uint32) != ref.view(np.uint32)) & ~both_nan).any(-1)
         if diff.any():
