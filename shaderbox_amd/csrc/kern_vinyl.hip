@@ -13,13 +13,38 @@
 #define VI_MIN_WAVES 5     // 3840x2160: 3 waves (134 VGPRs) 4.03 ms, 4 waves 3.85, 5 waves (96 VGPRs, spills outside the march) 3.71
 #endif
 
+#ifndef VI_LDS_FRAME
+#define VI_LDS_FRAME 1
+#endif
+
 namespace sbx {
+
+// FV(field): a member of the frame block where it is used.  With VI_LDS_FRAME the block lives in LDS (k_vinyl) and the read is
+// volatile — emitted at the use, never hoisted out of the march loops or kept across them — so its ~220 floats neither occupy
+// SGPRs (they do not fit: the compiler parked them in VGPR lanes, 1 500 v_readlane) nor stay in VGPRs.
+#if VI_LDS_FRAME
+// (the reference is into the kernel's __shared__ block: the cast names the LDS address space, else the volatile read is a flat load)
+#define VI_LDS_PTR(T, r) ((const volatile __attribute__((address_space(3))) T*)(&(r)))
+__device__ __forceinline__ float vi_ld(const float& r) { return *VI_LDS_PTR(float, r); }
+__device__ __forceinline__ double vi_ld(const double& r) { return *VI_LDS_PTR(double, r); }
+__device__ __forceinline__ v2 vi_ld(const v2& r) { return V2(vi_ld(r.x), vi_ld(r.y)); }
+__device__ __forceinline__ v3 vi_ld(const v3& r) { return V3(vi_ld(r.x), vi_ld(r.y), vi_ld(r.z)); }
+__device__ __forceinline__ m3 vi_ld(const m3& r) { return m3{vi_ld(r.c0), vi_ld(r.c1), vi_ld(r.c2)}; }
+__device__ __forceinline__ BezierFrame vi_ld(const BezierFrame& r) {
+    return BezierFrame{vi_ld(r.b), vi_ld(r.u), vi_ld(r.v), vi_ld(r.w), vi_ld(r.a2), vi_ld(r.c2), vi_ld(r.bc), vi_ld(r.br)};
+}
+__device__ __forceinline__ CylFrame vi_ld(const CylFrame& r) { return CylFrame{vi_ld(r.dir), vi_ld(r.len1), vi_ld(r.len0)}; }
+#else
+template <class T>
+__device__ __forceinline__ const T& vi_ld(const T& r) { return r; }
+#endif
+#define FV(x) vi_ld(F.x)
 
 __device__ __forceinline__ float vinyl_logo(const FrameVinyl& F, v3 pos, float thick) {       // :68-85
     const v3 b = V3(.25f, thick, 1.2f), d = V3(.7f, 0, 0);
-    v3 p = mul(pos, F.ry30);
+    v3 p = mul(pos, FV(ry30));
     const float v1 = sd_box(p - d, b);
-    p = mul(pos, F.rym30);
+    p = mul(pos, FV(rym30));
     const float v2 = sd_box(p + d, b);
     const float x = sd_box(pos, V3(1.5f, thick, 1.35f));
     return fmax_(fmin_(v1, v2), x);                              // op_intersect(op_add(v1, v2), x)
@@ -74,18 +99,19 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
         }
     }
 
-    const v3 p = mul(pos, F.wobble);
+    const v3 p = mul(pos, FV(wobble));
     const float R = .1f;
-    const float arm1 = sd_capsule_f(p, F.arm1.a, F.arm1.ab, F.arm1.rd, R);
-    const float arm2 = sd_capsule_f(p, F.arm2.a, F.arm2.ab, F.arm2.rd, R);
-    const float arm3 = sd_capsule_f(p, F.arm3.a, F.arm3.ab, F.arm3.rd, R);
+    const float arm1 = sd_capsule_f(p, FV(arm1.a), FV(arm1.ab), FV(arm1.rd), R);
+    const float arm2 = sd_capsule_f(p, FV(arm2.a), FV(arm2.ab), FV(arm2.rd), R);
+    const float arm3 = sd_capsule_f(p, FV(arm3.a), FV(arm3.ab), FV(arm3.rd), R);
     const float arm_link1 = fmin_(arm1, arm2);
     const float arm_link2 = fmin_(arm_link1, arm3);
     const float dmin2 = fmin_(fmin_(dmin, base.d), arm_link2);
-    const float armb = (CULL && bezier_far(F.armb, p, R, dmin2)) ? inf : sd_bezier_x(F.armb, p, R);
+    const BezierFrame abz = FV(armb);
+    const float armb = (CULL && bezier_far(abz, p, R, dmin2)) ? inf : sd_bezier_x(abz, p, R);
     const D2 arm = {fmin_(arm_link2, armb), 5.f};
     {
-        const v3 q = p - F.a3;
+        const v3 q = p - FV(a3);
         const float K = (dmin2 + 1e-3f) * 1.74f + 1.35f;
         if (CULL && dmin2 >= 0.f && dot(q, q) > K * K) {
             const D2 tone1 = op_add2(base, arm);
@@ -93,26 +119,26 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
         }
     }
 
-    const v3 clr_p = p - F.a3;
+    const v3 clr_p = p - FV(a3);
     const float clr_r = R * 1.5f;
-    const float collar = sd_cylinder0(F.collar, clr_p, clr_r);
+    const float collar = sd_cylinder0(FV(collar), clr_p, clr_r);
     const float fl_w = .045f, fl_h = .020f;
     const float fl_len1 = clr_r * 1.f;
     const float fl_len2 = fl_len1 * 1.2f;
-    const v3 fl_p = mul(clr_p - F.fl_sub1 - F.fl_sub2, F.fl_rot);
+    const v3 fl_p = mul(clr_p - FV(fl_sub1) - FV(fl_sub2), FV(fl_rot));
     const float fl1 = sd_box(fl_p, V3(fl_w, fl_h, fl_len1));
-    const float fl2 = sd_box(mul(fl_p - V3(0, 0, fl_len1), F.fl_rot2) - V3(0, 0, fl_len2), V3(fl_w, fl_h, fl_len2));
+    const float fl2 = sd_box(mul(fl_p - V3(0, 0, fl_len1), FV(fl_rot2)) - V3(0, 0, fl_len2), V3(fl_w, fl_h, fl_len2));
     const float finger_lift = fmin_(fl1, fl2);
     const D2 headshell = {fmin_(collar, finger_lift), 5.f};
 
     const float ctg_w = .05f, ctg_h = .05f, ctg_len1 = .3f, ctg_len2 = .5f;
-    const v3 ctg_p = mul(clr_p, F.arm_xform);
+    const v3 ctg_p = mul(clr_p, FV(arm_xform));
     const float ctg1 = sd_box(ctg_p, V3(ctg_len1, ctg_h, ctg_w));
-    const v3 ctg2_p = mul(ctg_p - V3(ctg_len1, 0, 0), F.ctg_rot) - V3(ctg_len2 - 0.03f, -.01f, 0);
+    const v3 ctg2_p = mul(ctg_p - V3(ctg_len1, 0, 0), FV(ctg_rot)) - V3(ctg_len2 - 0.03f, -.01f, 0);
     const float ctg2 = sd_box(ctg2_p, V3(ctg_len2, ctg_h, ctg_w));
-    const float cut = sd_box(mul(mul(ctg2_p, F.cut_rx10) - V3(0, .05f, .175f), F.cut_rym5),
+    const float cut = sd_box(mul(mul(ctg2_p, FV(cut_rx10)) - V3(0, .05f, .175f), FV(cut_rym5)),
                              V3(ctg_len2 * 2.f, ctg_h * 3.f, ctg_w * 3.2f));
-    const float cut2 = sd_box(mul(ctg2_p - V3(.3f, .2f, 0), F.cut2_rz10), V3(.4f, .2f, .3f));
+    const float cut2 = sd_box(mul(ctg2_p - V3(.3f, .2f, 0), FV(cut2_rz10)), V3(.4f, .2f, .3f));
     const float ctg12 = fmin_(ctg1, ctg2);
     const float ctg12c = fmax_(ctg12, -cut);
     const D2 cartridge = {fmax_(ctg12c, -cut2), 5.f};
@@ -123,7 +149,7 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
 }
 template <bool CULL>
 __device__ __forceinline__ D2 vinyl_sdf(const FrameVinyl& F, v3 pos) {                         // :257-265
-    const D2 plat = vinyl_platter(F, mul(pos, F.platter_rot));
+    const D2 plat = vinyl_platter(F, mul(pos, FV(platter_rot)));
     const D2 arm = vinyl_tonearm<CULL>(F, pos, plat.d);
     return op_add2(plat, arm);
 }
@@ -144,6 +170,28 @@ __device__ __forceinline__ v3 vinyl_base_color(int mat) {                       
 
 template <bool CULL>
 __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
+#if VI_LDS_FRAME
+    // The frame block (~220 floats of rotations and primitive frames) does not fit the SGPR file: kept in kernel arguments the
+    // compiler parks it in VGPR lanes (1 500 v_readlane in this kernel) and every use as an SGPR operand makes its fp32
+    // instruction half-rate (profiles/r02_ubench_issue.txt).  A copy in LDS instead, read where it is used (all lanes read one
+    // address: a broadcast), arrives in VGPRs; the reads are volatile (FV above) so that they stay at their uses.
+    __shared__ FrameVinyl Fs;
+    {
+        const float* ka = (const float*)__builtin_amdgcn_kernarg_segment_ptr();      // FrameVinyl is the first argument
+        float* dst = reinterpret_cast<float*>(&Fs);
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(FrameVinyl) / 4); i += WG_THREADS) dst[i] = ka[i];
+        __syncthreads();
+    }
+#define VI_F(ptr) Fs
+#define VI_LAUNDER(ptr)
+    const FrameVinyl* fp = nullptr;
+    (void)fp;
+#else
+#define VI_F(ptr) F
+#define VI_LAUNDER(ptr)
+    const FrameVinyl* fp = nullptr;
+    (void)fp;
+#endif
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
@@ -159,7 +207,8 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
     v3 p = V3(0, 0, 0);
     for (int i = 0; i < 60; ++i) {                              // render :427-455
         const v3 pi = ro + rd * t;
-        const D2 d = vinyl_sdf<CULL>(F, pi);
+        VI_LAUNDER(fp);
+        const D2 d = vinyl_sdf<CULL>(VI_F(fp), pi);
         if (t > 40.f) break;
         if (d.d < .005f) { hit = true; mat = (int)d.m; p = pi; break; }
         t += d.d;
@@ -172,7 +221,8 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
                 const v3 so = p + F.sun_dir * 0.05f;
                 float ts = 0.f;
                 for (int k = 0; k < 20; ++k) {
-                    const D2 ds = vinyl_sdf<CULL>(F, so + F.sun_dir * ts);
+                    VI_LAUNDER(fp);
+                    const D2 ds = vinyl_sdf<CULL>(VI_F(fp), so + F.sun_dir * ts);
                     if (ts > 5.f) break;
                     if (ds.d < .005f) { sh = .05f; break; }
                     ts += ds.d;
@@ -218,9 +268,9 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
             } else {
                 const float e = 0.001f;                              // sdf_normal :267-278
                 const v3 n = normalize(V3(
-                    vinyl_sdf<CULL>(F, p + V3(e, 0, 0)).d - vinyl_sdf<CULL>(F, p - V3(e, 0, 0)).d,
-                    vinyl_sdf<CULL>(F, p + V3(0, e, 0)).d - vinyl_sdf<CULL>(F, p - V3(0, e, 0)).d,
-                    vinyl_sdf<CULL>(F, p + V3(0, 0, e)).d - vinyl_sdf<CULL>(F, p - V3(0, 0, e)).d));
+                    vinyl_sdf<CULL>(VI_F(fp), p + V3(e, 0, 0)).d - vinyl_sdf<CULL>(VI_F(fp), p - V3(e, 0, 0)).d,
+                    vinyl_sdf<CULL>(VI_F(fp), p + V3(0, e, 0)).d - vinyl_sdf<CULL>(VI_F(fp), p - V3(0, e, 0)).d,
+                    vinyl_sdf<CULL>(VI_F(fp), p + V3(0, 0, e)).d - vinyl_sdf<CULL>(VI_F(fp), p - V3(0, 0, e)).d));
                 const v3 diffuse = base * fmax_(0.f, dot(L, n));
                 const v3 H = normalize(V + L);
                 const v3 specular = pow_(fmax_(0.f, dot(H, n)), 50.f) * V3(1, 1, 1);
