@@ -6,6 +6,7 @@
 // (platter and wobble rotations, the tonearm's constant-angle rotations, capsule/Bezier/cylinder frames) is in
 // FrameVinyl.  SURVEY.md §8f row 4; the reference has no known answers for this app (parity vs oracle only).
 #include "sbx_device.h"
+#include "sbx_ldsframe.h"
 #include "sbx_sdf.h"
 #include "sbx_noise.h"
 
@@ -19,26 +20,12 @@
 
 namespace sbx {
 
-// FV(field): a member of the frame block where it is used.  With VI_LDS_FRAME the block lives in LDS (k_vinyl) and the read is
-// volatile — emitted at the use, never hoisted out of the march loops or kept across them — so its ~220 floats neither occupy
-// SGPRs (they do not fit: the compiler parked them in VGPR lanes, 1 500 v_readlane) nor stay in VGPRs.
+// FV(field): a member of the frame block where it is used (sbx_ldsframe.h: the block lives in LDS, the read is volatile).
 #if VI_LDS_FRAME
-// (the reference is into the kernel's __shared__ block: the cast names the LDS address space, else the volatile read is a flat load)
-#define VI_LDS_PTR(T, r) ((const volatile __attribute__((address_space(3))) T*)(&(r)))
-__device__ __forceinline__ float vi_ld(const float& r) { return *VI_LDS_PTR(float, r); }
-__device__ __forceinline__ double vi_ld(const double& r) { return *VI_LDS_PTR(double, r); }
-__device__ __forceinline__ v2 vi_ld(const v2& r) { return V2(vi_ld(r.x), vi_ld(r.y)); }
-__device__ __forceinline__ v3 vi_ld(const v3& r) { return V3(vi_ld(r.x), vi_ld(r.y), vi_ld(r.z)); }
-__device__ __forceinline__ m3 vi_ld(const m3& r) { return m3{vi_ld(r.c0), vi_ld(r.c1), vi_ld(r.c2)}; }
-__device__ __forceinline__ BezierFrame vi_ld(const BezierFrame& r) {
-    return BezierFrame{vi_ld(r.b), vi_ld(r.u), vi_ld(r.v), vi_ld(r.w), vi_ld(r.a2), vi_ld(r.c2), vi_ld(r.bc), vi_ld(r.br)};
-}
-__device__ __forceinline__ CylFrame vi_ld(const CylFrame& r) { return CylFrame{vi_ld(r.dir), vi_ld(r.len1), vi_ld(r.len0)}; }
+#define FV(x) lds_ld(F.x)
 #else
-template <class T>
-__device__ __forceinline__ const T& vi_ld(const T& r) { return r; }
+#define FV(x) (F.x)
 #endif
-#define FV(x) vi_ld(F.x)
 
 __device__ __forceinline__ float vinyl_logo(const FrameVinyl& F, v3 pos, float thick) {       // :68-85
     const v3 b = V3(.25f, thick, 1.2f), d = V3(.7f, 0, 0);
@@ -171,17 +158,9 @@ __device__ __forceinline__ v3 vinyl_base_color(int mat) {                       
 template <bool CULL>
 __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
 #if VI_LDS_FRAME
-    // The frame block (~220 floats of rotations and primitive frames) does not fit the SGPR file: kept in kernel arguments the
-    // compiler parks it in VGPR lanes (1 500 v_readlane in this kernel) and every use as an SGPR operand makes its fp32
-    // instruction half-rate (profiles/r02_ubench_issue.txt).  A copy in LDS instead, read where it is used (all lanes read one
-    // address: a broadcast), arrives in VGPRs; the reads are volatile (FV above) so that they stay at their uses.
+    // the frame block (~220 floats of rotations and primitive frames) in LDS: sbx_ldsframe.h
     __shared__ FrameVinyl Fs;
-    {
-        const float* ka = (const float*)__builtin_amdgcn_kernarg_segment_ptr();      // FrameVinyl is the first argument
-        float* dst = reinterpret_cast<float*>(&Fs);
-        for (int i = (int)threadIdx.x; i < (int)(sizeof(FrameVinyl) / 4); i += WG_THREADS) dst[i] = ka[i];
-        __syncthreads();
-    }
+    lds_frame_fill<FrameVinyl, WG_THREADS>(Fs);
 #define VI_F(ptr) Fs
 #define VI_LAUNDER(ptr)
     const FrameVinyl* fp = nullptr;
