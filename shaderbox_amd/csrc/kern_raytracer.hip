@@ -7,8 +7,25 @@
 // slots, the light) is frame-constant: it is built on the host (setup_scene :18-36 +
 // setup_cornell_box cornell_box.h:39-87) and arrives as kernel arguments in SGPRs.
 #include "sbx_device.h"
+#include "sbx_ldsframe.h"
+
+#ifndef RT_LDS_FRAME
+#define RT_LDS_FRAME 1      // the scene block (130 floats: does not fit the SGPR file) in LDS, read at its uses (sbx_ldsframe.h)
+#endif
 
 namespace sbx {
+
+#if RT_LDS_FRAME
+__device__ __forceinline__ RtPlane rt_ld(const RtPlane& r) { return RtPlane{lds_ld(r.n), lds_ld(r.d), lds_ld(r.mat)}; }
+__device__ __forceinline__ RtSphere rt_ld(const RtSphere& r) { return RtSphere{lds_ld(r.o), lds_ld(r.r), lds_ld(r.mat), lds_ld(r.rr)}; }
+__device__ __forceinline__ RtMaterial rt_ld(const RtMaterial& r) {
+    return RtMaterial{lds_ld(r.base_color), lds_ld(r.roughness), lds_ld(r.ior), lds_ld(r.reflectivity), lds_ld(r.r0)};
+}
+__device__ __forceinline__ v3 rt_ld(const v3& r) { return lds_ld(r); }
+__device__ __forceinline__ int rt_ld(const int& r) { return lds_ld(r); }
+#else
+template <class T> __device__ __forceinline__ const T& rt_ld(const T& r) { return r; }
+#endif
 
 struct Hit { float t; int mat; v3 n, o; };
 
@@ -53,10 +70,10 @@ __device__ __forceinline__ Hit trace(const FrameRaytracer& F, v3 ro, v3 rd, int 
     Hit hit;
     hit.t = (float)(1e8f + 1e1f); hit.mat = -1; hit.n = V3(0, 0, 0); hit.o = V3(0, 0, 0);   // no_hit def.h:78-83
 #pragma unroll
-    for (int i = 0; i < 6; ++i) hit_plane(ro, rd, F.planes[i], hit);
+    for (int i = 0; i < 6; ++i) hit_plane(ro, rd, rt_ld(F.planes[i]), hit);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-        if (F.spheres[i].mat != mat_to_ignore) hit_sphere(ro, rd, F.spheres[i], hit);
+        if (rt_ld(F.spheres[i].mat) != mat_to_ignore) hit_sphere(ro, rd, rt_ld(F.spheres[i]), hit);
     return hit;
 }
 // get_material: linear scan; an id outside 0..7 yields the zero-initialised material (App. B5)
@@ -64,9 +81,13 @@ __device__ __forceinline__ RtMaterial material_of(const FrameRaytracer& F, int i
     RtMaterial m;
     m.base_color = V3(0, 0, 0); m.roughness = 0.f; m.ior = 0.f; m.reflectivity = 0.f;
     m.r0 = 1.f;                                                  // ior 0: ((1 - 0) / (1 + 0))^2
+#if RT_LDS_FRAME
+    if (id >= 0 && id < 8) m = rt_ld(F.mats[id]);               // one LDS read per member at the lane's own address
+#else
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         if (i == id) m = F.mats[i];
+#endif
     return m;
 }
 __device__ __forceinline__ v3 cook_torrance(v3 V, v3 L, const Hit& hit, const RtMaterial& mat) {   // light.h:64-92
@@ -86,15 +107,22 @@ __device__ __forceinline__ v3 cook_torrance(v3 V, v3 L, const Hit& hit, const Rt
 }
 __device__ __forceinline__ v3 rt_illuminate(const FrameRaytracer& F, v3 eye, const Hit& hit) {   // :46-68
     const RtMaterial mat = material_of(F, hit.mat);
-    if (hit.mat == 0) return F.mats[0].base_color;               // mat_debug: flat
+    if (hit.mat == 0) return rt_ld(F.mats[0].base_color);        // mat_debug: flat
     v3 accum = V3(.01f, .01f, .01f);                              // ambient_light light.h:16
     const v3 V = normalize(eye - hit.o);
-    const v3 L = normalize(F.light - hit.o);                      // point light, light.h:18-27
+    const v3 L = normalize(rt_ld(F.light) - hit.o);               // point light, light.h:18-27
     accum = accum + cook_torrance(V, L, hit, mat);
     return accum;
 }
 
 __global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowMap M, float* __restrict__ out) {
+#if RT_LDS_FRAME
+    __shared__ FrameRaytracer Fs;
+    lds_frame_fill<FrameRaytracer, WG_THREADS>(Fs);
+#define RT_F Fs
+#else
+#define RT_F F
+#endif
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
@@ -103,20 +131,20 @@ __global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowM
 
     v3 color = V3(0, 0, 0), accum = V3(1, 1, 1);
     for (int i = 0; i < 2; ++i) {                                 // :96-133
-        const Hit hit = trace(F, ro, rd, -1);
+        const Hit hit = trace(RT_F, ro, rd, -1);
         if (hit.t >= 1e8f) {
             color = color + accum * V3(0, 0, 0);                  // background :13-16
             break;
         }
         const float f = fresnel_factor(1.f, 1.f, dot(hit.n, -rd));
-        color = color + (1.f - f) * accum * rt_illuminate(F, eye, hit);   // primary origin on every bounce (:105)
+        color = color + (1.f - f) * accum * rt_illuminate(RT_F, eye, hit);   // primary origin on every bounce (:105)
         if (i == 0) {                                             // shadow ray :108-121
-            const v3 shadow_line = F.light - hit.o;
+            const v3 shadow_line = rt_ld(RT_F.light) - hit.o;
             const v3 shadow_dir = normalize(shadow_line);
-            const Hit sh = trace(F, hit.o + shadow_dir * 1e-4f, shadow_dir, 0);
+            const Hit sh = trace(RT_F, hit.o + shadow_dir * 1e-4f, shadow_dir, 0);
             if (sh.t < length(shadow_line)) color = color * 0.1f;
         }
-        const RtMaterial mat = material_of(F, hit.mat);
+        const RtMaterial mat = material_of(RT_F, hit.mat);
         if (mat.reflectivity > 0.f) {
             accum = accum * f;
             // reflect(hit.normal, ray.direction): arguments swapped in the reference (:127), kept
