@@ -17,26 +17,34 @@ N = 1 : the frame is one kernel launch.
 N > 1 : one process per GPU (torch.distributed / RCCL).  `python bench.py --gpus N` launched as a plain command starts
         its own N ranks (re-executes itself under torch.distributed.run on 127.0.0.1); launched by torch.distributed.run
         it uses the ranks it is given.  The SAME frame is sharded as cyclic 8-row blocks (shaderbox_amd/shard.py), every
-        rank renders its blocks, ONE gather over xGMI brings the slabs to rank 0, and one small kernel scatters them to
+        rank renders its blocks, ONE exchange over xGMI brings the slabs to rank 0, and one small kernel scatters them to
         their rows.  Total work is fixed -> "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
+        The line also carries `phases` (per rank: render_ms / exchange_wait_ms / assemble_ms of serial frames timed with
+        events after the timed region) and `steady_state` (frames between the completion of the first and the last
+        timed frame on rank 0: the pipeline's rate without the un-overlapped tail of the last frame).
 
 Extra objects on the JSON line (N = 1 unless noted):
   roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel of HBM traffic),
-                 so bound = "valu":
-                   achieved / frac      algorithmic scalar fp ops per launch (SURVEY.md §8d per-pixel count x pixels)
-                                        / mean UN-OVERLAPPED launch duration (HIP events on the launch stream, measured
-                                        after the timed region one launch at a time) against the 157.3 TFLOP/s fp32
-                                        vector peak.  This is a USEFUL-WORK ratio: the count is of the REFERENCE
-                                        algorithm's operations, most of which the kernel no longer executes.
-                   valu_issue_frac      the HARDWARE view: VALU wave-instructions the kernel actually issued
-                                        (SQ_INSTS_VALU) x 2 cycles (wave64 on a SIMD-32) / (1024 SIMDs x the shader
-                                        cycles the launch was active = GRBM_GUI_ACTIVE / 8 XCDs, same pass).
-                   valu_busy_pct        rocprofv3's VALUBusy halved (its gfx94x formula assumes 4-cycle issue).
-                   traffic              HBM bytes per launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction of
-                                        MI355X_MICROARCH.md), separate PMC passes.
-                 The three PMC-derived fields are measured in this run (`--pmc auto`: rocprofv3 is started on a short
-                 serial run of this script, one counter group per pass; `pmc_source` says so) or, when rocprofv3 is not
-                 usable, taken from the committed summary under profiles/ (named in `pmc_source`), or null.
+                 so bound = "valu", and the object reports EXECUTED work, which cannot exceed the peak:
+                   achieved            VALU lane-operations the kernel actually issued per second: SQ_INSTS_VALU x 64 lanes /
+                                       the launch's duration in the same rocprofv3 pass
+                   peak                1024 SIMD-32 x 32 lanes x the shader clock of that pass (GRBM_GUI_ACTIVE / 8 XCDs /
+                                       duration; DVFS holds this kernel near 2.1 GHz); peak_at_2p4ghz = 78.6 T lane-ops/s is
+                                       the same at the nominal clock (MI355X_MICROARCH.md: 4 SIMD-32 per CU, 2-cycle wave64 issue)
+                   frac                achieved / peak = SQ_INSTS_VALU x 2 issue cycles / (1024 SIMDs x active cycles): the share
+                                       of the VALU issue slots that carried an instruction; frac_at_2p4ghz = the same against
+                                       the nominal-clock peak with the UN-profiled launch duration (HIP events)
+                   useful_work_ratio   NOT a utilisation figure: the REFERENCE algorithm's scalar fp ops per launch (SURVEY.md
+                                       §8d per-pixel count x pixels) / un-overlapped launch duration / 157.3 TFLOP/s.  It can
+                                       exceed 1 because the kernel executes far fewer operations than the reference algorithm
+                                       (hashes shared per wave, clear samples proved away) for the same bits.
+                   valu_busy_pct       rocprofv3's VALUBusy halved (its gfx94x formula assumes 4-cycle issue).
+                   traffic             HBM bytes per launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction of
+                                       MI355X_MICROARCH.md), separate PMC passes.
+                 The PMC-derived fields are measured in this run (`--pmc auto`: rocprofv3 is started on a short serial run
+                 of this script, one counter group per pass; `pmc_source` says so) or, when rocprofv3 is not usable or N > 1,
+                 derived from the committed per-launch instruction count under profiles/ (named in `pmc_source`) at the
+                 nominal clock.
   roofline_hbm : the same kernel against HBM (16 B/pixel written once): far from the bound by design.
   serial       : Mpixels/s of one un-overlapped launch (SURVEY.md §8d defines the metric per launch; `value` has
                  `frames_in_flight` launches overlapping).
@@ -44,7 +52,9 @@ Extra objects on the JSON line (N = 1 unless noted):
                  renders): max |diff| and pixels with any differing bit.  > 1e-4 -> non-zero exit status.
                  N > 1: the assembled frame against a one-launch render of the same frame on rank 0 (bit-identical).
   cpu_baseline : the CPU oracle (kind "port") timed on this host's cores on a bounded sample of the same frame (every
-                 k-th row, dealt to the threads in 64-pixel tiles), strict build (g++ -O2 -ffp-contract=off).
+                 k-th row, dealt to the threads in 64-pixel tiles), strict build (g++ -O2 -ffp-contract=off).  `cores` = the
+                 threads used; `affinity`, `cgroup_cpu_max` and the one-thread rate say what those threads could get.  Printed
+                 for every N (rank 0, after the timed region).
   cpu_baseline_speed : the same sample with the optimisation level of the reference's own C++ build
                  (-O3 -march=native -funroll-loops, /root/reference/src/Makefile:12-13), compiled on this host at run time.
   other_configs: the other BASELINE.json GPU configs, timed the same way (pipelined frames + un-overlapped kernel time), each
@@ -68,11 +78,13 @@ sys.path.insert(0, ROOT)
 OPS_PER_PIXEL = {"clouds": 60248.0, "egg": 15276.0, "raytracer": 564.0, "atmosphere": 2493.0,
                  "planet": 21253.0, "sdf_ao": 7255.0}       # (no survey count for vinyl / clouds_best / clouds_tex)
 PEAK_FP32_VECTOR_TFLOPS = 157.3
-SCALAR_ISSUE_TLANEOPS = 39.3        # 256 CU x 64 lanes x 2.4 GHz: one non-packed, non-FMA lane-op per lane per cycle (SURVEY.md §8d ii)
 PEAK_HBM_GBPS = 8000.0
 N_SIMD = 1024                       # 256 CU x 4
 VALU_ISSUE_CYCLES = 2.0             # wave64 VALU instruction on a SIMD-32 (MI355X_MICROARCH.md)
 NOMINAL_CLOCK_HZ = 2.4e9
+LANES_PER_SIMD_CYCLE = 32           # a SIMD-32 retires half a wave64 instruction per cycle
+PEAK_LANEOPS_NOMINAL_T = N_SIMD * LANES_PER_SIMD_CYCLE * NOMINAL_CLOCK_HZ / 1e12     # 78.6 T lane-ops/s
+PMC_ROUND = "r03"                   # committed per-launch counters: profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json
 # the other BASELINE.json configs that fit one GPU: (app, W, H) — C2, C3, C5 (both apps)
 OTHER_CONFIGS = [("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320)]
 KERNEL_OF = {"clouds": "k_clouds", "egg": "k_egg", "raytracer": "k_raytracer", "atmosphere": "k_atmosphere",
@@ -174,6 +186,9 @@ def main():
                     help="N>1: 'dist' = one process per GPU (torch.distributed / RCCL gather, the contract's launch shape); 'lib' = ONE "
                          "process drives the N GPUs through the library's own multi-GPU path (sbx_multi_*: RCCL send/recv per "
                          "row-block straight into the final rows, no assembly pass); with fewer GPUs than N the ranks share devices")
+    ap.add_argument("--lib-exchange", choices=["slabs", "blocks"], default="slabs",
+                    help="--engine lib: 'slabs' = one send/receive per peer of its whole 3-channel slab + one scatter kernel on the "
+                         "root (default); 'blocks' = one send/receive pair per row-block straight into the final rows (round 2)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -262,9 +277,14 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
+    step_done = [None, None]                 # completion of the first and of the last timed frame (events, rank 0's view)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+        if i == 0 or i == args.steps - 1:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(streams[i % ns])
+            step_done[0 if i == 0 else 1] = ev
     sync()
     elapsed = time.perf_counter() - t0
     # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region, one launch at a time,
@@ -287,33 +307,30 @@ def main():
     else:
         kmean = sum(kernel_ms) / len(kernel_ms)
 
+    # N > 1: what each rank's frame consists of, timed with events on serial frames (outside the timed region)
+    phases = steady = None
+    if use_dist:
+        phases = dist_phases(plans[0], torch, dist, dev, app, t, world, rank)
     status = 0
     if rank == 0:
         pixels = W * H
         ms_per_step = elapsed * 1e3 / args.steps
         value = pixels / (ms_per_step * 1e-3) / 1e6
-        ops = OPS_PER_PIXEL.get(app)
-        launch_pixels = pixels if not use_dist else shard.rank_rows(H, br, 0, world, relief[0], relief[1]) * W
-        roofline = roofline_hbm = None
-        if ops is not None:
-            achieved = ops * launch_pixels / (kmean * 1e-3) / 1e12
-            roofline = {"bound": "valu", "kernel": KERNEL_OF.get(app, "k_" + app), "achieved": round(achieved, 4),
-                        "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5),
-                        "frac_is": "useful-work ratio: reference-algorithm ops / kernel time / fp32 vector peak (the kernel executes "
-                                   "far fewer operations than the reference algorithm); hardware utilisation is valu_issue_frac",
-                        "frac_of_scalar_issue_ceiling": round(achieved / SCALAR_ISSUE_TLANEOPS, 4),
-                        "ops_per_pixel": ops, "pixels_per_launch": launch_pixels,
-                        "kernel_ms": round(kmean, 4), "kernel_ms_min": round(min(kernel_ms), 4),
-                        "traffic": None, "valu_issue_frac": None, "valu_busy_pct": None, "pmc_source": None}
-            hbm = 16.0 * launch_pixels / (kmean * 1e-3) / 1e9
-            roofline_hbm = {"bound": "hbm", "kernel": KERNEL_OF.get(app, "k_" + app), "achieved": round(hbm, 2),
-                            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBPS, 5),
-                            "bytes_per_pixel": 16, "traffic": None}
-            if world == 1 and not use_dist and args.pmc != "off":
-                pmc = pmc_counters(args, app, W, H, t)
-                if pmc:
-                    fill_pmc(roofline, roofline_hbm, pmc, kmean)
+        launch_pixels = pixels if not use_dist else max(shard.rank_rows(H, br, r, world, relief[0], relief[1]) for r in range(world)) * W
+        pmc = None
+        if world == 1 and not use_dist and args.pmc != "off":
+            pmc = pmc_counters(args, app, W, H, t)
+        elif args.pmc != "off":
+            pmc = pmc_committed(app, W, H)                      # N > 1: per-pixel instruction count of the committed profile
+        roofline, roofline_hbm = rooflines(app, launch_pixels, W * H, kmean, min(kernel_ms), pmc)
+        if roofline is not None and use_dist:
+            roofline["rank"] = "slowest (max over ranks of the un-overlapped launch duration; %d pixels)" % launch_pixels
+        if step_done[0] is not None and args.steps > 1:
+            span_ms = step_done[0].elapsed_time(step_done[1])
+            steady = {"value": round(pixels * (args.steps - 1) / (span_ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
+                      "ms_per_step": round(span_ms / (args.steps - 1), 4),
+                      "what": "rank 0: %d frames between the completion of the first and of the last timed frame (the last "
+                              "frame's un-overlapped drain / exchange / assembly tail is the same in both, i.e. excluded)" % (args.steps - 1)}
         out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(value, 3),
                "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
@@ -329,8 +346,10 @@ def main():
                                          args.gather_groups)},
                "serial": {"value": round(launch_pixels / (kmean * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
                           "what": "one un-overlapped launch (HIP events), %d pixels" % launch_pixels},
+               "steady_state": steady,
                "roofline": roofline, "roofline_hbm": roofline_hbm}
         if use_dist:
+            out["phases"] = phases
             # the assembled frame of the multi-GPU path against a one-launch render of the same frame: same bits
             whole = R.render(app, W, H, t)
             a, b = plans[(args.steps - 1) % ns].frame.view(torch.int32), whole.view(torch.int32)
@@ -339,6 +358,13 @@ def main():
                              "mismatching_pixels": bad}
             if bad:
                 status = 3
+            if not args.no_cpu_baseline:
+                base, rows, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
+                out["cpu_baseline"] = base
+                par = parity(plans[(args.steps - 1) % ns].frame[rows].cpu().numpy(), ref, len(rows))
+                out["parity"]["oracle"] = par
+                if not (par["max_abs_diff"] <= 1e-4):
+                    status = 3
         elif not args.no_cpu_baseline:
             base, rows, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
             out["cpu_baseline"] = base
@@ -351,7 +377,8 @@ def main():
             if speed is not None:
                 out["cpu_baseline_speed"] = speed
         if world == 1 and not use_dist and not args.no_other_configs and app == "clouds":
-            out["other_configs"] = other_configs(R, torch, dev, streams, t, check_rows=0 if args.no_cpu_baseline else 16)
+            out["other_configs"] = other_configs(R, torch, dev, streams, t, check_rows=0 if args.no_cpu_baseline else 16,
+                                                 pmc_mode=args.pmc)
             if any(c["parity"] and not (c["parity"]["max_abs_diff"] <= 1e-4) for c in out["other_configs"]):
                 status = 3
         claim_stdout()(json.dumps(out))
@@ -373,6 +400,7 @@ def bench_lib(args):
     M = shaderbox_amd.MultiRenderer(devices)
     m0, m = (1, 1) if args.root_rounds == "auto" else tuple(int(v) for v in args.root_rounds.split("/"))
     M.set_split(args.block_rows, m0, m)
+    M.set_exchange(args.lib_exchange)
     W, H, app, t = args.width, args.height, args.app, args.time
     dev = torch.device("cuda", devices[0])
     torch.cuda.set_device(dev)
@@ -393,28 +421,65 @@ def bench_lib(args):
     for i in range(args.warmup):
         step(i)
     sync()
+    step_done = [None, None]
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+        if i == 0 or i == args.steps - 1:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(streams[i % ns])
+            step_done[0 if i == 0 else 1] = ev
     sync()
     elapsed = time.perf_counter() - t0
     R = shaderbox_amd.Renderer(devices[0])
+    R.set_timing(True)
     whole = R.render(app, W, H, t)
     a, b = frames[(args.steps - 1) % ns].view(torch.int32), whole.view(torch.int32)
     bad = int((a != b).any(dim=-1).sum().item())
+    # the slowest rank's un-overlapped launch (rank 1 has the most rows of a plain split)
+    from shaderbox_amd import shard
+    rows = [shard.rank_rows(H, args.block_rows, r, n, m0, m) for r in range(n)]
+    slow = max(range(n), key=lambda r: rows[r])
+    slab = torch.empty((shard.rank_rows_max(H, args.block_rows, n, m0, m), W, 4), dtype=torch.float32, device=dev)
+    km = []
+    for _ in range(5):
+        R.render_rank(app, W, H, t, args.block_rows, slow, n, out=slab, root_rounds=m0, rounds=m)
+        km.append(R.last_kernel_ms())
+    torch.cuda.synchronize(dev)
+    roofline, roofline_hbm = rooflines(app, rows[slow] * W, W * H, sum(km) / len(km), min(km),
+                                       pmc_committed(app, W, H) if args.pmc != "off" else None)
+    if roofline is not None:
+        roofline["rank"] = "slowest (rank %d: %d rows), one un-overlapped launch on device %d" % (slow, rows[slow], devices[0])
     ms_per_step = elapsed * 1e3 / args.steps
+    steady = None
+    if step_done[1] is not None and args.steps > 1:
+        span_ms = step_done[0].elapsed_time(step_done[1])
+        steady = {"value": round(W * H * (args.steps - 1) / (span_ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
+                  "ms_per_step": round(span_ms / (args.steps - 1), 4),
+                  "what": "%d frames between the completion of the first and of the last timed frame" % (args.steps - 1)}
     out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(W * H / (ms_per_step * 1e-3) / 1e6, 3),
            "unit": "Mpixels/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)" % (app.upper(), W, H, t),
                       "frames_in_flight": ns, "engine": "lib (one process, sbx_multi_*)",
                       "parallelism": "cyclic %d-row blocks over %d ranks on devices %s, %s, root renders in place"
-                                     % (args.block_rows, n, devices, "RCCL send/recv per row-block into the final rows" if M.uses_rccl
-                                        else "device copies per row-block (ranks share devices: emulation, not a scaling number)")},
+                                     % (args.block_rows, n, devices,
+                                        ("%s, %s" % ("RCCL send/recv" if M.uses_rccl else
+                                                     "device copies (ranks share devices: emulation, not a scaling number)",
+                                                     "one per peer of its whole 3-channel slab + one scatter kernel" if args.lib_exchange == "slabs"
+                                                     else "one per row-block into the final rows")))},
+           "steady_state": steady, "roofline": roofline, "roofline_hbm": roofline_hbm,
            "parity": {"against": "one-launch render of the same frame", "rows": H, "mismatching_pixels": bad}}
+    status = 3 if bad else 0
+    if not args.no_cpu_baseline:
+        base, crow, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
+        out["cpu_baseline"] = base
+        out["parity"]["oracle"] = parity(frames[(args.steps - 1) % ns][crow].cpu().numpy(), ref, len(crow))
+        if not (out["parity"]["oracle"]["max_abs_diff"] <= 1e-4):
+            status = 3
     claim_stdout()(json.dumps(out))
     M.close()
-    return 3 if bad else 0
+    return status
 
 
 def parity(gpu, ref, nrows):
@@ -427,7 +492,7 @@ def parity(gpu, ref, nrows):
             "max_abs_diff": float(d.max()), "mismatching_pixels": int(bits.any(axis=-1).sum()), "tolerance": 1e-4}
 
 
-def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_rows=0):
+def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_rows=0, pmc_mode="off"):
     """pipelined frames (as the headline) + un-overlapped kernel time of one config"""
     ns = len(streams)
     frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
@@ -457,20 +522,28 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
         par = parity(frames[0][rows].cpu().numpy(), ref, len(rows))
     del frames
     kmean = sum(k) / len(k)
-    ops = OPS_PER_PIXEL.get(app)
-    achieved = ops * W * H / (kmean * 1e-3) / 1e12 if ops else None
+    pmc = None
+    if pmc_mode in ("auto", "live"):
+        tmp = tempfile.mkdtemp(prefix="sbx_pmc_")
+        try:
+            pmc = run_pmc_pass(PMC_PASSES[0][1], app, W, H, t, os.path.join(tmp, "valu"))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        if pmc:
+            pmc["source"] = "live: one rocprofv3 --kernel-trace --pmc pass of `bench.py --app %s --steps 4 --warmup 1 --streams 1` in this run" % app
+    if not pmc and pmc_mode != "off":
+        pmc = pmc_committed(app, W, H)
+    roofline, _ = rooflines(app, W * H, W * H, kmean, min(k), pmc)
     return {"workload": "APP_%s %dx%d u_time=%g" % (app.upper(), W, H, t), "value": round(W * H / (ms * 1e-3) / 1e6, 2),
             "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "steps": steps, "frames_in_flight": ns,
             "kernel": KERNEL_OF.get(app), "kernel_ms": round(kmean, 4),
             "serial_value": round(W * H / (kmean * 1e-3) / 1e6, 2),
-            "roofline": None if achieved is None else
-            {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 5), "ops_per_pixel": ops},
+            "roofline": roofline,
             "hbm_store_gbps": round(16.0 * W * H / (kmean * 1e-3) / 1e9, 1), "parity": par}
 
 
-def other_configs(R, torch, dev, streams, t, check_rows=16):
-    return [time_config(R, torch, dev, streams, a, w, h, t, check_rows=check_rows) for a, w, h in OTHER_CONFIGS]
+def other_configs(R, torch, dev, streams, t, check_rows=16, pmc_mode="auto"):
+    return [time_config(R, torch, dev, streams, a, w, h, t, check_rows=check_rows, pmc_mode=pmc_mode) for a, w, h in OTHER_CONFIGS]
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -534,9 +607,20 @@ def run_pmc_pass(counters, app, W, H, t, outdir, timeout=100):
     return res or None
 
 
+def pmc_committed(app, W, H):
+    """the committed per-launch counters of this config (profiles/<round>_pmc_<app>_<W>x<H>.json), or None"""
+    for rnd in (PMC_ROUND, "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s_%dx%d.json" % (rnd, app, W, H))
+        if os.path.exists(path):
+            got = json.load(open(path))
+            got["source"] = "committed: profiles/" + os.path.basename(path)
+            got["committed"] = True
+            return got
+    return None
+
+
 def pmc_counters(args, app, W, H, t):
-    """{counter: per-launch mean} + 'source'.  live: rocprofv3 passes now; profiles: profiles/r02_pmc_<app>_<W>x<H>.json"""
-    committed = os.path.join(ROOT, "profiles", "r02_pmc_%s_%dx%d.json" % (app, W, H))
+    """{counter: per-launch mean} + 'source'.  live: rocprofv3 passes now; else the committed summary"""
     if args.pmc in ("auto", "live"):
         tmp = tempfile.mkdtemp(prefix="sbx_pmc_")
         got = {}
@@ -554,38 +638,98 @@ def pmc_counters(args, app, W, H, t):
             return got
         if args.pmc == "live":
             return None
-    if os.path.exists(committed):
-        got = json.load(open(committed))
-        got["source"] = "committed: profiles/" + os.path.basename(committed)
-        return got
-    return None
+    return pmc_committed(app, W, H)
 
 
-def fill_pmc(roofline, roofline_hbm, pmc, kmean_ms):
-    roofline["pmc_source"] = pmc.get("source")
-    if "WRITE_SIZE" in pmc and "FETCH_SIZE" in pmc:      # KB; gfx950: FETCH_SIZE counts half of a wide streaming read
+def rooflines(app, launch_pixels, frame_pixels, kmean_ms, kmin_ms, pmc):
+    """(roofline, roofline_hbm) of one launch of `launch_pixels` pixels.  `pmc`: per-launch counters of a FULL frame of
+    `frame_pixels` pixels (live pass or committed file) or None."""
+    kernel = KERNEL_OF.get(app, "k_" + app)
+    ops = OPS_PER_PIXEL.get(app)
+    hbm = 16.0 * launch_pixels / (kmean_ms * 1e-3) / 1e9
+    roofline_hbm = {"bound": "hbm", "kernel": kernel, "achieved": round(hbm, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(hbm / PEAK_HBM_GBPS, 5), "bytes_per_pixel": 16, "traffic": None}
+    r = {"bound": "valu", "kernel": kernel, "achieved": None, "peak": None, "unit": "T lane-ops/s", "frac": None,
+         "frac_is": "executed work: VALU lane-operations issued (SQ_INSTS_VALU x 64) / time, against 1024 SIMD-32 x 32 lanes x "
+                    "shader clock = share of the VALU issue slots that carried an instruction (<= 1 by construction)",
+         "peak_at_2p4ghz": round(PEAK_LANEOPS_NOMINAL_T, 2), "frac_at_2p4ghz": None,
+         "pixels_per_launch": launch_pixels, "kernel_ms": round(kmean_ms, 4), "kernel_ms_min": round(kmin_ms, 4),
+         "traffic": None, "valu_busy_pct": None, "pmc_source": pmc.get("source") if pmc else None}
+    if ops is not None:
+        alg = ops * launch_pixels / (kmean_ms * 1e-3) / 1e12
+        r["useful_work_ratio"] = {"value": round(alg / PEAK_FP32_VECTOR_TFLOPS, 5), "achieved": round(alg, 4),
+                                  "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s", "ops_per_pixel": ops,
+                                  "what": "reference-algorithm scalar fp ops (SURVEY.md 8d) / un-overlapped launch time / fp32 vector "
+                                          "peak: a speed-up measure, NOT utilisation (the kernel executes far fewer operations than "
+                                          "the reference algorithm for the same bits, so it may exceed 1)"}
+    if not pmc or "SQ_INSTS_VALU" not in pmc:
+        return r, roofline_hbm
+    scale = launch_pixels / float(frame_pixels)                  # counters are per FULL-frame launch
+    insts = pmc["SQ_INSTS_VALU"] * scale
+    r["valu_insts_per_launch"] = round(insts)
+    r["valu_insts_per_pixel"] = round(pmc["SQ_INSTS_VALU"] / frame_pixels, 2)
+    nominal = insts * 64.0 / (kmean_ms * 1e-3) / 1e12
+    r["frac_at_2p4ghz"] = round(nominal / PEAK_LANEOPS_NOMINAL_T, 4)
+    live = not pmc.get("committed") and scale == 1.0 and "GRBM_GUI_ACTIVE" in pmc and pmc.get("kernel_ms_profiled")
+    if live:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = shader cycles the profiled launch was active, whatever the clock
+        active = pmc["GRBM_GUI_ACTIVE"] / 8.0
+        dur = pmc["kernel_ms_profiled"] * 1e-3
+        clock = active / dur
+        r["achieved"] = round(insts * 64.0 / dur / 1e12, 3)
+        r["peak"] = round(N_SIMD * LANES_PER_SIMD_CYCLE * clock / 1e12, 3)
+        r["frac"] = round(insts * VALU_ISSUE_CYCLES / (N_SIMD * active), 4)
+        r["shader_clock_ghz_profiled"] = round(clock / 1e9, 3)
+        r["kernel_ms_profiled"] = round(pmc["kernel_ms_profiled"], 4)
+    else:
+        # no counters of THIS launch (rocprofv3 unusable, or a rank's strip at N > 1): the committed profile's instruction count
+        # per pixel x this launch's pixels, against the nominal-clock peak
+        r["achieved"] = round(nominal, 3)
+        r["peak"] = round(PEAK_LANEOPS_NOMINAL_T, 2)
+        r["frac"] = r["frac_at_2p4ghz"]
+        r["frac_is"] += "; here from the committed per-pixel instruction count x this launch's pixels at the nominal 2.4 GHz"
+    if "WRITE_SIZE" in pmc and "FETCH_SIZE" in pmc and scale == 1.0:      # KB; gfx950: FETCH_SIZE counts half of a wide streaming read
         traffic = int(pmc["WRITE_SIZE"] * 1024 + 2 * pmc["FETCH_SIZE"] * 1024)
-        roofline["traffic"] = roofline_hbm["traffic"] = traffic
-        roofline["traffic_over_algorithmic"] = round(traffic / (16.0 * roofline["pixels_per_launch"]), 4)
-    if "SQ_INSTS_VALU" in pmc:
-        insts = pmc["SQ_INSTS_VALU"]
-        roofline["valu_insts_per_launch"] = insts
-        if "GRBM_GUI_ACTIVE" in pmc:
-            # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = shader cycles the profiled launch was active, whatever the clock
-            active = pmc["GRBM_GUI_ACTIVE"] / 8.0
-            roofline["valu_issue_frac"] = round(insts * VALU_ISSUE_CYCLES / (N_SIMD * active), 4)
-            roofline["valu_issue_frac_what"] = ("SQ_INSTS_VALU x %g issue cycles / (%d SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): share of "
-                                                "the VALU issue slots of the launch's active cycles that carried an instruction"
-                                                % (VALU_ISSUE_CYCLES, N_SIMD))
-            if pmc.get("kernel_ms_profiled"):
-                roofline["shader_clock_ghz_profiled"] = round(active / (pmc["kernel_ms_profiled"] * 1e-3) / 1e9, 3)
-                roofline["kernel_ms_profiled"] = round(pmc["kernel_ms_profiled"], 4)
-        roofline["valu_issue_frac_at_2p4ghz"] = round(insts * VALU_ISSUE_CYCLES / (N_SIMD * kmean_ms * 1e-3 * NOMINAL_CLOCK_HZ), 4)
+        r["traffic"] = roofline_hbm["traffic"] = traffic
+        r["traffic_over_algorithmic"] = round(traffic / (16.0 * launch_pixels), 4)
     if "VALUBusy" in pmc:
-        roofline["valu_busy_pct"] = round(pmc["VALUBusy"] / 2.0, 2)      # gfx94x formula assumes 4-cycle issue; gfx950 issues in 2
-        roofline["valu_busy_pct_raw_rocprof"] = round(pmc["VALUBusy"], 2)
+        r["valu_busy_pct"] = round(pmc["VALUBusy"] / 2.0, 2)      # gfx94x formula assumes 4-cycle issue; gfx950 issues in 2
+        r["valu_busy_pct_raw_rocprof"] = round(pmc["VALUBusy"], 2)
     if "VALUUtilization" in pmc:
-        roofline["valu_lane_utilization_pct"] = round(pmc["VALUUtilization"], 2)
+        r["valu_lane_utilization_pct"] = round(pmc["VALUUtilization"], 2)
+    return r, roofline_hbm
+
+
+def dist_phases(plan, torch, dist, dev, app, t, world, rank, reps=5):
+    """N > 1: per-rank render_ms / exchange_wait_ms / assemble_ms of SERIAL frames (events on the frame's stream, one frame at a
+    time, outside the timed region), gathered to rank 0: what a rank's frame consists of when nothing overlaps it."""
+    acc = {}
+    for _ in range(reps):
+        marks = []
+
+        def mark(name):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+            marks.append((name, ev))
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        mark("start")
+        plan.render(app, t, mark=mark)
+        mark("end")
+        torch.cuda.synchronize(dev)
+        for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
+            acc.setdefault(name, []).append(e0.elapsed_time(e1))
+    names = ["render", "exchange", "assemble", "end"]
+    mine = torch.tensor([sum(acc.get(n, [0.0])) / max(len(acc.get(n, [0.0])), 1) for n in names], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    if rank != 0:
+        return None
+    return {"what": "serial frames, events on the frame's stream: render = the rank's own launch(es), exchange_wait = until its "
+                    "send is out / the root's receives have landed (the root posts them before its render, so this is what the "
+                    "render did not hide), assemble = the root's scatter kernel",
+            "per_rank": [{"rank": i, "render_ms": round(float(v[0]), 4), "exchange_wait_ms": round(float(v[1]), 4),
+                          "assemble_ms": round(float(v[2] + v[3]), 4)} for i, v in enumerate(allr)]}
 
 
 def relief_candidates(max_rounds=8):
@@ -672,20 +816,60 @@ def cpu_rows(H, stride, cores):
     return stride, list(range(stride // 2, H, stride))
 
 
+def host_cpu_facts():
+    """what the threads of the CPU leg can actually get: scheduler affinity and the cgroup CPU quota of this process"""
+    facts = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        facts["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        facts["affinity"] = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().strip()
+        except OSError:
+            continue
+        if path.endswith("cpu.max"):
+            quota = txt                                   # "max 100000" or "<quota_us> <period_us>"
+        else:
+            try:
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            except OSError:
+                period = "?"
+            quota = "%s %s" % (txt, period)
+        break
+    facts["cgroup_cpu_max"] = quota
+    return facts
+
+
 def cpu_baseline(app, W, H, t, stride):
     """The CPU oracle ('port' of the reference path, oracle/) on this host's cores, bounded sample.  Returns the
     baseline object, the row indices and the rendered rows (the parity check reuses them)."""
     from oracle.oracle import APP_IDS, Oracle
     o = Oracle()
-    cores = os.cpu_count() or 1
+    facts = host_cpu_facts()
+    cores = facts["affinity"] or facts["os_cpu_count"]   # threads used = CPUs this process may run on
     stride, rows = cpu_rows(H, stride, cores)
     o.render_rows(APP_IDS[app], W, H, t, rows[:max(1, cores // 60)], threads=cores)   # warm the threads/caches
     t0 = time.perf_counter()
     ref = o.render_rows(APP_IDS[app], W, H, t, rows, threads=cores)
     dt = time.perf_counter() - t0
-    return ({"value": round(len(rows) * W / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+    # one thread on a few of the same rows: the per-thread rate the all-thread figure can be read against
+    one_rows = rows[len(rows) // 2:len(rows) // 2 + 2]
+    t0 = time.perf_counter()
+    o.render_rows(APP_IDS[app], W, H, t, one_rows, threads=1)
+    dt1 = time.perf_counter() - t0
+    value, one = len(rows) * W / dt / 1e6, len(one_rows) * W / dt1 / 1e6
+    return ({"value": round(value, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
              "sample": "%d of %d rows (every %dth row) of the same %dx%d frame in 64-pixel tiles, %.1f s, g++ -O2 -ffp-contract=off"
-                       % (len(rows), H, stride, W, H, dt)}, rows, ref)
+                       % (len(rows), H, stride, W, H, dt),
+             "affinity": facts["affinity"], "os_cpu_count": facts["os_cpu_count"], "cgroup_cpu_max": facts["cgroup_cpu_max"],
+             "one_thread": {"value": round(one, 5), "unit": "Mpixels/s", "sample": "%d rows, %.1f s" % (len(one_rows), dt1)},
+             "thread_equivalents": round(value / one, 1) if one > 0 else None,
+             "note": "the port evaluates sin/cos/exp/pow in binary64 by the sbx math spec (correctly rounded); the reference's own "
+                     "headers over glibc libm ran about 2x faster per thread in the survey's probe (BASELINE.md: 0.112 vs 0.056 "
+                     "Mpixels/s on the same 8 vCPU), so this understates the reference's C++ path by about that factor; "
+                     "cpu_baseline_speed is the same port at the reference Makefile's optimisation level"}, rows, ref)
 
 
 def cpu_baseline_speed(app, W, H, t, rows):
@@ -695,7 +879,8 @@ def cpu_baseline_speed(app, W, H, t, rows):
         o = Oracle(variant="_speed", subdir="_speed", rebuild=True)
     except Exception:
         return None
-    cores = os.cpu_count() or 1
+    facts = host_cpu_facts()
+    cores = facts["affinity"] or facts["os_cpu_count"]
     o.render_rows(APP_IDS[app], W, H, t, rows[:max(1, cores // 60)], threads=cores)
     t0 = time.perf_counter()
     o.render_rows(APP_IDS[app], W, H, t, rows, threads=cores)

@@ -36,9 +36,24 @@ static int app_from_name(const std::string& s) {
     return -1;
 }
 
+// A file-name pattern may hold ONE integer conversion (%d, %4d, %04d ...) and any number of "%%"; anything else (%s, %n, a
+// second %d) would make the user's string an snprintf format with undefined behaviour, so it is rejected up front.
+static bool pattern_ok(const std::string& p) {
+    int conversions = 0;
+    for (size_t i = 0; i < p.size(); ++i) {
+        if (p[i] != '%') continue;
+        if (i + 1 < p.size() && p[i + 1] == '%') { ++i; continue; }
+        size_t j = i + 1;
+        while (j < p.size() && p[j] >= '0' && p[j] <= '9') ++j;      // flag 0 and a width
+        if (j >= p.size() || p[j] != 'd' || j - i > 4) return false;
+        ++conversions;
+        i = j;
+    }
+    return conversions <= 1;
+}
 static std::string frame_name(const std::string& pattern, int f, int frames) {
     char buf[4096];
-    if (pattern.find('%') != std::string::npos) { snprintf(buf, sizeof(buf), pattern.c_str(), f); return buf; }
+    if (pattern.find('%') != std::string::npos) { snprintf(buf, sizeof(buf), pattern.c_str(), f); return buf; }   // checked in main
     if (frames <= 1) return pattern;
     const size_t dot = pattern.rfind('.');
     snprintf(buf, sizeof(buf), "%s_%04d%s", pattern.substr(0, dot).c_str(), f, dot == std::string::npos ? "" : pattern.substr(dot).c_str());
@@ -107,6 +122,8 @@ int main(int argc, char** argv) {
     const int id = app_from_name(app);
     if (id < 0) { fprintf(stderr, "unknown app %s\n", app.c_str()); return 2; }
     if (frames < 1 || gpus < 1) { fprintf(stderr, "--frames and --gpus must be >= 1\n"); return 2; }
+    for (const std::string* p : {&ppm, &f32})
+        if (!pattern_ok(*p)) { fprintf(stderr, "bad file pattern %s: one %%d / %%0Nd conversion at most, a literal percent as %%%%\n", p->c_str()); return 2; }
     const void* aux = nullptr;
     if ((id == SBX_APP_CLOUDS || id == SBX_APP_CLOUDS_TEX) && have_ac) aux = &ac;
     if (id == SBX_APP_SDF_AO && have_as) aux = &as;
@@ -122,7 +139,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < gpus; ++i) devs[i] = ndev >= gpus ? i : i % (ndev > 0 ? ndev : 1);
         if (ndev < gpus) fprintf(stderr, "note: %d GPU(s) visible, running the %d-rank schedule with ranks sharing devices\n", ndev, gpus);
         rc = sbx_multi_create(gpus, devs.data(), &multi);
-        if (rc != SBX_OK) { fprintf(stderr, "sbx_multi_create failed (%d)\n", rc); return 1; }
+        if (rc != SBX_OK) { fprintf(stderr, "sbx_multi_create failed (%d): %s\n", rc, sbx_multi_create_error()); return 1; }
         printf("%d ranks, transfers by %s\n", gpus, sbx_multi_uses_rccl(multi) ? "RCCL send/recv" : "device copies");
     }
     (void)hipSetDevice(0);
@@ -149,6 +166,9 @@ int main(int argc, char** argv) {
         (void)hipDeviceSynchronize();
         (void)hipFree(d1); (void)hipFree(d2);
     }
+    // the frame, the 8-bit copy and the timing events belong to rank 0's device (the sbx_multi_* calls leave it current;
+    // set again here so that nothing below depends on that)
+    (void)hipSetDevice(0);
     const size_t n = (size_t)W * H * 4, npx = (size_t)W * H;
     float* dev = nullptr;
     unsigned char* dev8 = nullptr;

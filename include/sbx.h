@@ -237,12 +237,20 @@ int sbx_tex3d_eval(sbx_ctx* ctx, int size, const float* rgba, const float* xyz, 
 /* ---- Multi-GPU frames inside the library (SURVEY.md §8b "Ownership", §8e "Collective") -----------------------------
  * One process drives `nranks` ranks; devices[i] is the HIP device of rank i, rank 0 owns the frame.  With all devices
  * distinct the library creates its communicator with ncclCommInitAll (rccl.h:236; librccl is dlopen'ed here, not linked)
- * and every peer's row-blocks travel by grouped ncclSend / ncclRecv (rccl.h:700,722) straight into their rows of the
- * root's frame — no staging slab, no assembly pass; rank 0 renders its own blocks in place.  Devices may repeat (several
- * ranks on one GPU — how the N-rank schedule runs on fewer GPUs than ranks): those transfers are device copies.
- * The split is the cyclic row-block split of sbx_render_split (default 8-row blocks, no root relief). */
+ * and every peer's slab travels by ONE ncclSend / ncclRecv pair (rccl.h:700,722; all pairs of a frame in one group, N-1 distinct
+ * xGMI links) into a landing area on rank 0, from where one small kernel scatters the rows into the frame; rank 0 renders its
+ * own blocks in place.  Devices may repeat (several ranks on one GPU — how the N-rank schedule runs on fewer GPUs than
+ * ranks): those transfers are device copies.  The split is the cyclic row-block split of sbx_render_split (default 8-row
+ * blocks, no root relief).  Every sbx_multi_* call leaves rank 0's device current (hipSetDevice). */
 typedef struct sbx_multi sbx_multi;
 int sbx_multi_create(int nranks, const int* devices, sbx_multi** out);
+/* Why the last sbx_multi_create of this process failed (e.g. the dlopen / dlsym text for librccl); "" after a success. */
+const char* sbx_multi_create_error(void);
+/* How the peers' rows reach rank 0: SLABS (default) = one send / receive per peer of its whole 3-channel slab + one scatter
+ * kernel; BLOCKS = one send / receive pair per row-block straight into the final rows (no landing area, no scatter kernel,
+ * but (N-1) x blocks point-to-point operations per frame in one group). */
+enum { SBX_MULTI_EXCHANGE_SLABS = 0, SBX_MULTI_EXCHANGE_BLOCKS = 1 };
+int sbx_multi_set_exchange(sbx_multi* m, int mode);
 void sbx_multi_destroy(sbx_multi* m);
 int sbx_multi_ranks(const sbx_multi* m);
 int sbx_multi_uses_rccl(const sbx_multi* m);             /* 1: RCCL send/recv, 0: device / peer copies */

@@ -124,6 +124,9 @@ def load_library(path=None):
     lib.sbx_multi_uses_rccl.argtypes = [vp]
     lib.sbx_multi_set_split.argtypes = [vp, ci, ci, ci]
     lib.sbx_multi_set_variant.argtypes = [vp, ci]
+    lib.sbx_multi_set_exchange.argtypes = [vp, ci]
+    lib.sbx_multi_create_error.argtypes = []
+    lib.sbx_multi_create_error.restype = ctypes.c_char_p
     lib.sbx_multi_set_noise_volumes.argtypes = [vp, ci, fp, ci, fp]
     lib.sbx_multi_render.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, fp, vp]
     lib.sbx_multi_rccl_selftest.argtypes = [ci, ctypes.POINTER(ci)]
@@ -388,7 +391,7 @@ class MultiRenderer:
         h = ctypes.c_void_p()
         rc = self.lib.sbx_multi_create(len(self.devices), arr, ctypes.byref(h))
         if rc != SBX_OK:
-            raise SbxError(rc, "sbx_multi_create failed")
+            raise SbxError(rc, "sbx_multi_create failed: " + (self.lib.sbx_multi_create_error() or b"").decode())
         self.m = h
         self.tdev = torch.device("cuda", self.devices[0])
 
@@ -416,6 +419,11 @@ class MultiRenderer:
 
     def set_variant(self, variant):
         self._check(self.lib.sbx_multi_set_variant(self.m, int(variant)))
+
+    def set_exchange(self, mode):
+        """'slabs' (default): one send / receive per peer of its whole 3-channel slab + one scatter kernel on rank 0;
+        'blocks': one send / receive pair per row-block straight into the final rows (the round-2 form)."""
+        self._check(self.lib.sbx_multi_set_exchange(self.m, {"slabs": 0, "blocks": 1}[mode] if isinstance(mode, str) else int(mode)))
 
     def set_noise_volumes(self, shape_rgba, detail_rgba):
         self._check(self.lib.sbx_multi_set_noise_volumes(self.m, int(shape_rgba.shape[0]), ctypes.c_void_p(shape_rgba.data_ptr()),

@@ -28,19 +28,42 @@ SOURCES = ["kern_clouds.hip", "kern_clouds_tex.hip", "kern_egg.hip", "kern_raytr
 # in ~4.7 cycles against 2 x 2.9 for the scalar pair (profiles/r01_ubench_valu.txt), needs its constants in
 # VGPR pairs (no literals), and the extra live registers cost a wave of occupancy.
 EXTRA = {}
-HEADERS = ["sbx_math.h", "sbx_vec.h", "sbx_frame.h", "sbx_device.h", "sbx_noise.h", "sbx_hashcache.h", "sbx_sdf.h", "../../include/sbx.h"]
+
+
+def _headers():
+    """Every header a translation unit can see: all of csrc/*.h (a glob, not a hand-kept list: round 2's list missed
+    sbx_ldsframe.h) and the public include/*.h."""
+    import glob
+    inc = os.path.join(HERE, "..", "include")
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(inc, "*.h")))
+
+
+_HIPCC_VERSION = None
+
+
+def _hipcc_version():
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            _HIPCC_VERSION = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+        except OSError:
+            _HIPCC_VERSION = "?"
+    return _HIPCC_VERSION
 
 
 def _key(src):
-    """Content key of one translation unit: the source, every shared header, the flags and the compiler path.  Staleness is
+    """Content key of one translation unit: the source, every header under csrc/ and include/, the flags, the compiler path
+    and the compiler's version string.  Staleness is
     decided by CONTENT, not by mtime: objects and the library travel to the GPU box outside git (an mtime rule can
     ship a stale binary after a checkout or a copy)."""
     import hashlib
     h = hashlib.sha256()
-    for path in [os.path.join(CSRC, src)] + [os.path.join(CSRC, x) for x in HEADERS]:
+    for path in [os.path.join(CSRC, src)] + _headers():
         with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode())
             h.update(f.read())
     h.update(" ".join([HIPCC] + FLAGS + EXTRA.get(src, [])).encode())
+    h.update(_hipcc_version().encode())
     return h.hexdigest()
 
 

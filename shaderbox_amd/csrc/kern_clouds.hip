@@ -335,8 +335,15 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
 // With gap = (cov - .1876 - 1e-3) - s(i) and c = 1.01 * 1.74 D (rounded up, per lane, fixed for the march), the next
 // floor(gap / c) samples of that lane satisfy the stage-1 test; the minimum over the alive lanes (taken as the largest of
 // 1, 2, 4, 8, 16 that every alive lane allows) is the number of main samples the wave skips entirely: each would have
-// returned density 0, which integrate_volume ignores (src/app_clouds.h:132), so only `t += dt` remains of them.  The 1e-3
-// and the 1 % dominate every rounding on the way (positions ~3e3 +- 1e-4, t <= 125 +- 4e-4, noise +- 2e-6).
+// returned density 0, which integrate_volume ignores (src/app_clouds.h:132), so only `t += dt` remains of them.
+// DOMAIN of the proof (clouds_lip_domain, checked on the host per launch; F.lip_ok = 0 turns the skip off and nothing else).
+// The bound is about the real-valued noise; the kernel evaluates it at ROUNDED positions.  With every march position
+// |pos.{x,y,z}| <= 2^17 (ulp <= 2^-6): pos, pos * .001 and * 2.03 each round by half an ulp, i.e. q0 is off by <= 5e-5 and
+// q1 = 2.64 q0 by <= 1.6e-4, the lattice index n <= 271 * 2^17 * .00203 * 2.64^3 = 1.3e6 < 2^24 is an exact integer (cells
+// share their corner hashes, the blend is continuous across faces), and s moves by <= 1.5 * 2 * (.5 * 5e-5 + .25 * 1.6e-4)
+// = 2e-4 per end point (s3: 4e-4): the 1e-3 in the gaps covers both ends, the 1 % in c the rounding of t and D.  Positions
+// are eye + proj * 150 + wind_dir * u_time * 1000 + t * proj with |proj.x|, |proj.z| <= 20 (dir.y >= .05) — unbounded in
+// u_time and wind_dir, both caller-set: at |wind_off| = 2e7 (ulp 2) the bound fails numerically, hence the check.
 template <bool LIP>
 __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
                                                   unsigned long long active_mask, WaveCache& S, int lane,
@@ -648,10 +655,12 @@ __global__ void __launch_bounds__(64 * CL_TX, (ZL && (YTAB || !CL_NOTAB_GEN)) ? 
             // 1 / c of coop_density_row's skip bound; c = 1.01 * 1.74 * D, D = dt * .001 * 2.03 * (|proj.x| + 1 + |proj.z|)
             const float lip_inv = 1.0f / ((1.01f * 1.74f) * ((F.dt * (.001f * 2.03f)) * ((abs_(projection.x) + 1.0f) + abs_(projection.z))));
 #if CL_PARK
-            if (LIP) pk[9 * 64] = lip_inv;                // lives in LDS: it is needed only where a first stage fails
+            if (LIP) pk[9 * 64] = F.lip_ok ? lip_inv : 0.f;   // lives in LDS: it is needed only where a first stage fails
+                                                              // (0: r = gap * 0 is 0 or NaN, never >= 1: no sample is skipped)
             const float* lip_slot = &pk[9 * 64];
 #else
-            const float* lip_slot = &lip_inv;
+            const float lip_inv_ok = F.lip_ok ? lip_inv : 0.f;
+            const float* lip_slot = &lip_inv_ok;
 #endif
             int skip = 0;
             float vsigma = F.sigma, vdt = F.dt, vcov = F.cov;
@@ -796,8 +805,21 @@ static bool clouds_regular(const FrameClouds& F) {
            sd <= 80.0;
 }
 
-void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows,
+// Domain of the Lipschitz sample skip (coop_density_row): every coordinate of every MAIN march position stays within 2^17.
+// pos = (eye + proj * 150 + wind_off) + t * proj, |proj.x|, |proj.z| <= 1 / .05 (+ rounding: 21), proj.y = 1,
+// |t| <= steps * |dt| (+ its accumulated rounding, covered by the factor 22).  NaN / inf anywhere fails the test.
+static bool clouds_lip_domain(const FrameClouds& F) {
+    const double reach = 21.0 * 150.0 + 22.0 * std::fabs((double)F.dt) * (double)F.steps;
+    const double e = std::fmax(std::fabs((double)F.cam.eye.x), std::fmax(std::fabs((double)F.cam.eye.y), std::fabs((double)F.cam.eye.z)));
+    const double w = std::fmax(std::fabs((double)F.wind_off.x), std::fmax(std::fabs((double)F.wind_off.y), std::fabs((double)F.wind_off.z)));
+    const double far = e + w + reach;
+    return std::isfinite(F.wind_off.x) && std::isfinite(F.wind_off.y) && std::isfinite(F.wind_off.z) && far <= 131072.0;   // NaN compares false
+}
+
+void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows,
                    bool build_table) {
+    FrameClouds F = F_in;
+    F.lip_ok = clouds_lip_domain(F) ? 1 : 0;
     const bool reg = clouds_regular(F);
     const dim3 grid = grid_for<CL_TW, CL_TX>(M), block(64 * CL_TX);
 #ifdef SBX_CL_OCC_SWEEP

@@ -91,6 +91,7 @@ static FrameClouds build_clouds(const sbx_uniforms& U, const sbx_aux_clouds& A) 
     F.cov = 1.f - A.cld_coverage;                                      // :83
     F.cov_hi = F.cov + .0135f;                                         // :84
     F.cov_rd = recip64(F.cov_hi - F.cov);
+    F.lip_ok = 0;                                                      // decided per launch (launch_clouds)
     return F;
 }
 
@@ -446,6 +447,16 @@ static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, fl
     return SBX_OK;
 }
 
+// Domain of the margin-based culls of EGG / SDF_AO / VINYL (bounding spheres and boxes around members placed by rotations) and
+// of PLANET's |o|^2 band test (a rotation preserves the norm): their proofs take the frame's rotations to BE rotations.  The
+// spec's sin / cos reduce their argument with a two-term pi, which is accurate while |angle| < 2^30 or so; the fastest angle
+// of any app is 400 degrees = 7 rad per second of u_time (src/app_egg.h:73), so |u_time| <= 1e8 keeps every matrix entry the
+// correctly rounded sin / cos of its angle (orthonormal to 2e-7; the margins are >= 3e-4 relative).  Beyond that, and for
+// NaN / inf, the reduction returns what it returns (the oracle's does the same) and the PLAIN kernels run: same operations
+// as the reference on whatever the matrices are.  (APP_CLOUDS has its own per-launch checks: clouds_regular,
+// clouds_lip_domain in kern_clouds.hip.)
+static bool tame_time(float t) { return std::fabs(t) <= 1e8f; }      // NaN compares false
+
 static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, const RowMap& M,
                          float* rgba, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -478,20 +489,21 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         (void)hipEventRecord(tp->ev0, s);
     }
     int rc = SBX_OK;
+    const int cull_variant = tame_time(uni->u_time) ? ctx->variant : 1;
     switch (app) {
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
     case SBX_APP_CLOUDS_TEX: launch_clouds_tex(build_clouds(*uni, AC), M, rgba, s, ctx->noise_tex, ctx->noise_tex_size, ctx->noise_tex2, ctx->noise_tex2_size); break;
-    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, ctx->variant); break;
+    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, cull_variant); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
     case SBX_APP_SDF_AO: {
         sbx_aux_sdf_ao A;
         if (aux) A = *(const sbx_aux_sdf_ao*)aux; else sbx_aux_sdf_ao_defaults(&A);
-        launch_sdf_ao(build_sdf_ao(*uni, A), M, rgba, s, ctx->variant);
+        launch_sdf_ao(build_sdf_ao(*uni, A), M, rgba, s, cull_variant);
         break;
     }
-    case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s, ctx->variant); break;
-    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s, ctx->variant); break;
+    case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s, cull_variant); break;
+    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s, cull_variant); break;
     case SBX_APP_CLOUDS_BEST: launch_clouds_best(build_clouds_best(*uni), M, rgba, s); break;
     case SBX_APP_CLOUDS_UE4: {
         sbx_aux_clouds_ue4 A;

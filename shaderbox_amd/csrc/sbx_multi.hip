@@ -6,9 +6,13 @@
 // second process.  The frame shards as the same cyclic row-blocks as the per-process path (sbx_split_*):
 //
 //   rank 0 (the owner of the frame) renders its blocks IN PLACE into the caller's frame (sbx_render_split_in_place);
-//   rank i > 0 renders its blocks densely into a slab on its own GPU, then sends every block to the row it belongs to:
-//       grouped ncclSend / ncclRecv (rccl.h:700,722), one pair per row-block, received straight into the final rows —
-//       no staging slab on the root and no assembly kernel.  xGMI is point-to-point: the N-1 peers use N-1 distinct links.
+//   rank i > 0 renders its blocks densely into a slab on its own GPU (3 floats per pixel: alpha is the constant 1 of
+//       src/main.h:52) and sends the WHOLE slab with ONE ncclSend (rccl.h:700); the root posts ONE ncclRecv per peer (:722)
+//       into a staging area, all in one group — N-1 point-to-point transfers over N-1 distinct xGMI links — and one small
+//       kernel (k_assemble_peers) scatters the rows and writes the alpha.  (SBX_MULTI_EXCHANGE_BLOCKS, the round-2 form:
+//       one send/recv pair per 8-row block straight into the final rows, no staging and no scatter, but ~34 x (N-1)
+//       point-to-point operations in one group per 4K frame — kept behind sbx_multi_set_exchange for comparison on a node.)
+// Every entry point leaves RANK 0's device current (hipSetDevice), whatever devices it visited.
 //
 // Two frames may be in flight (double-buffered slabs and two stream sets per rank, alternating per call) so that the
 // drain of one frame's kernels overlaps the next frame, exactly as bench.py pipelines the per-process path.
@@ -39,14 +43,22 @@ struct RcclApi {
     nccl_result_t (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     nccl_result_t (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(nccl_result_t) = nullptr;
+    bool loaded = false;
+    std::string load_error;
     bool load(std::string& err) {
-        if (handle) return true;
+        if (loaded) return true;
+        if (handle) { (void)dlclose(handle); handle = nullptr; }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (handle) break;
         }
-        if (!handle) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
-        auto sym = [&](const char* n) { void* p = dlsym(handle, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        if (!handle) {
+            const char* de = dlerror();
+            err = load_error = std::string("cannot load librccl: ") + (de ? de : "?");
+            return false;
+        }
+        std::string missing;
+        auto sym = [&](const char* n) { void* p = dlsym(handle, n); if (!p) { missing += missing.empty() ? "" : ", "; missing += n; } return p; };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
@@ -54,7 +66,17 @@ struct RcclApi {
         Send = (decltype(Send))sym("ncclSend");
         Recv = (decltype(Recv))sym("ncclRecv");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+        if (!missing.empty()) {
+            // a half-resolved table must never be reachable: the next load() starts from scratch
+            CommInitAll = nullptr; CommDestroy = nullptr; GroupStart = nullptr; GroupEnd = nullptr; Send = nullptr; Recv = nullptr;
+            GetErrorString = nullptr;
+            (void)dlclose(handle);
+            handle = nullptr;
+            err = load_error = "librccl lacks " + missing;
+            return false;
+        }
+        loaded = true;
+        return true;
     }
 };
 RcclApi g_rccl;
@@ -70,8 +92,12 @@ struct Rank {
     hipEvent_t recv_done[kInFlight] = {};
     float* slab[kInFlight] = {nullptr, nullptr};
     size_t slab_floats = 0;
+    float* stage[kInFlight] = {nullptr, nullptr};         // rank 0 only: where the peers' slabs land (slab exchange)
+    size_t stage_floats = 0;
     nccl_comm_t comm = nullptr;
 };
+
+std::string g_create_error;
 
 }  // namespace
 
@@ -79,6 +105,7 @@ struct sbx_multi {
     std::vector<Rank> ranks;
     bool use_rccl = false;
     int block_rows = 8, root_rounds = 1, rounds = 1;
+    int exchange = SBX_MULTI_EXCHANGE_SLABS;
     unsigned calls = 0;
     hipEvent_t start[kInFlight] = {};
     std::string err;
@@ -102,6 +129,7 @@ void sbx_multi_destroy(sbx_multi* m) {
         if (r.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r.comm);
         for (int k = 0; k < kInFlight; ++k) {
             if (r.slab[k]) (void)hipFree(r.slab[k]);
+            if (r.stage[k]) (void)hipFree(r.stage[k]);
             if (r.render[k]) (void)hipStreamDestroy(r.render[k]);
             if (r.recv[k]) (void)hipStreamDestroy(r.recv[k]);
             if (r.done[k]) (void)hipEventDestroy(r.done[k]);
@@ -116,15 +144,18 @@ void sbx_multi_destroy(sbx_multi* m) {
     delete m;
 }
 
+const char* sbx_multi_create_error(void) { return g_create_error.c_str(); }
+
 int sbx_multi_create(int nranks, const int* devices, sbx_multi** out) {
     if (!out) return SBX_ERR_ARG;
     *out = nullptr;
-    if (nranks < 1 || nranks > 64 || !devices) return SBX_ERR_ARG;
+    g_create_error.clear();
+    if (nranks < 1 || nranks > 64 || !devices) { g_create_error = "bad rank count or NULL device list"; return SBX_ERR_ARG; }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SBX_ERR_NO_DEVICE;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device"; return SBX_ERR_NO_DEVICE; }
     bool distinct = true;
     for (int i = 0; i < nranks; ++i) {
-        if (devices[i] < 0 || devices[i] >= ndev) return SBX_ERR_ARG;
+        if (devices[i] < 0 || devices[i] >= ndev) { g_create_error = "device id out of range"; return SBX_ERR_ARG; }
         for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) distinct = false;
     }
     sbx_multi* m = new sbx_multi();
@@ -133,7 +164,7 @@ int sbx_multi_create(int nranks, const int* devices, sbx_multi** out) {
         Rank& r = m->ranks[i];
         r.device = devices[i];
         int rc = sbx_create(r.device, &r.ctx);
-        if (rc != SBX_OK) { sbx_multi_destroy(m); return rc; }
+        if (rc != SBX_OK) { g_create_error = "sbx_create failed on a rank's device"; sbx_multi_destroy(m); return rc; }
         hipError_t e = hipSetDevice(r.device);
         for (int k = 0; k < kInFlight && e == hipSuccess; ++k) {
             if ((e = hipStreamCreateWithFlags(&r.render[k], hipStreamNonBlocking)) != hipSuccess) break;
@@ -144,7 +175,7 @@ int sbx_multi_create(int nranks, const int* devices, sbx_multi** out) {
                 if ((e = hipEventCreateWithFlags(&m->start[k], hipEventDisableTiming)) != hipSuccess) break;
             }
         }
-        if (e != hipSuccess) { sbx_multi_destroy(m); return SBX_ERR_HIP; }
+        if (e != hipSuccess) { g_create_error = std::string("stream / event creation: ") + hipGetErrorString(e); sbx_multi_destroy(m); return SBX_ERR_HIP; }
     }
     // peers write into the root's frame (copy mode) / RCCL sets its own peer mappings up: enable peer access where possible
     for (int i = 1; i < nranks; ++i) {
@@ -160,13 +191,18 @@ int sbx_multi_create(int nranks, const int* devices, sbx_multi** out) {
     const char* no_rccl = getenv("SBX_MULTI_NO_RCCL");      // diagnostic: peer copies instead of RCCL
     if (distinct && nranks > 1 && !(no_rccl && no_rccl[0] == '1')) {
         std::string err;
-        if (!g_rccl.load(err)) { sbx_multi_destroy(m); return SBX_ERR_UNSUPPORTED; }
+        if (!g_rccl.load(err)) { g_create_error = err; fprintf(stderr, "libsbx: %s\n", err.c_str()); sbx_multi_destroy(m); return SBX_ERR_UNSUPPORTED; }
         std::vector<nccl_comm_t> comms(nranks, nullptr);
         const nccl_result_t rc = g_rccl.CommInitAll(comms.data(), nranks, devices);
-        if (rc != 0) { sbx_multi_destroy(m); return SBX_ERR_HIP; }
+        if (rc != 0) {
+            g_create_error = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc);
+            sbx_multi_destroy(m);
+            return SBX_ERR_HIP;
+        }
         for (int i = 0; i < nranks; ++i) m->ranks[i].comm = comms[i];
         m->use_rccl = true;
     }
+    (void)hipSetDevice(m->ranks[0].device);                  // the caller continues on the frame owner's device
     *out = m;
     return SBX_OK;
 }
@@ -231,6 +267,13 @@ int sbx_multi_set_split(sbx_multi* m, int block_rows, int root_rounds, int round
     return SBX_OK;
 }
 
+int sbx_multi_set_exchange(sbx_multi* m, int mode) {
+    if (!m) return SBX_ERR_ARG;
+    if (mode != SBX_MULTI_EXCHANGE_SLABS && mode != SBX_MULTI_EXCHANGE_BLOCKS) return mfail(m, SBX_ERR_ARG, "unknown exchange mode");
+    m->exchange = mode;
+    return SBX_OK;
+}
+
 int sbx_multi_set_variant(sbx_multi* m, int variant) {
     if (!m) return SBX_ERR_ARG;
     for (Rank& r : m->ranks) {
@@ -244,6 +287,7 @@ int sbx_multi_set_noise_volumes(sbx_multi* m, int shape_size, const float* shape
     if (!m) return SBX_ERR_ARG;
     if (!shape_rgba || !detail_rgba || shape_size <= 0 || detail_size <= 0) return mfail(m, SBX_ERR_ARG, "bad noise volume arguments");
     Rank& root = m->ranks[0];
+    struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{root.device};   // whatever path returns
     const size_t b1 = (size_t)shape_size * shape_size * shape_size * 16, b2 = (size_t)detail_size * detail_size * detail_size * 16;
     for (Rank& r : m->ranks) {
         hipError_t e = hipSetDevice(r.device);
@@ -293,7 +337,23 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
     if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
     // everything this frame does starts after what the caller has already enqueued on `stream` (e.g. the last reader of `frame`)
     if ((e = hipEventRecord(m->start[k], user)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
-    const size_t row_floats = (size_t)W * 4;
+    struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{root.device};   // whatever path returns
+    const bool slabs = m->exchange == SBX_MULTI_EXCHANGE_SLABS;
+    const int ch = slabs ? 3 : 4;                                   // floats per pixel of a peer's slab
+    const size_t row_floats = (size_t)W * 4, slab_row = (size_t)W * ch;
+    const int rows_max = sbx_split_rows_max(H, br, n, m0, mr);
+    if (rows_max < 0) return mfail(m, SBX_ERR_ARG, "bad split");
+    if (n > 1 && slabs) {                                           // the root's landing area: (n - 1) slabs of rows_max rows
+        const size_t need = (size_t)(n - 1) * rows_max * slab_row;
+        if (need > root.stage_floats) {
+            for (int q = 0; q < kInFlight; ++q) {
+                if (root.stage[q]) (void)hipFree(root.stage[q]);
+                root.stage[q] = nullptr;
+                if ((e = hipMalloc((void**)&root.stage[q], need * sizeof(float))) != hipSuccess) { root.stage_floats = 0; return mfail(m, SBX_ERR_HIP, "hipMalloc stage", e); }
+            }
+            root.stage_floats = need;
+        }
+    }
     // ---- every rank renders its share -------------------------------------------------------------------
     for (int i = 0; i < n; ++i) {
         Rank& r = m->ranks[i];
@@ -303,9 +363,7 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
         if (i == 0) {
             rc = sbx_render_split_in_place(r.ctx, app, uni, aux, br, 0, n, m0, mr, frame, r.render[k]);
         } else {
-            const int rows = sbx_split_rank_rows(H, br, i, n, m0, mr);
-            if (rows < 0) return mfail(m, SBX_ERR_ARG, "bad split");
-            const size_t need = (size_t)(rows > 0 ? rows : 1) * row_floats;
+            const size_t need = (size_t)rows_max * row_floats;       // sized for either exchange
             if (need > r.slab_floats) {
                 for (int q = 0; q < kInFlight; ++q) {
                     if (r.slab[q]) (void)hipFree(r.slab[q]);          // hipFree waits for the device: nothing reads the old slab
@@ -314,20 +372,28 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
                 }
                 r.slab_floats = need;
             }
-            rc = sbx_render_split(r.ctx, app, uni, aux, br, i, n, m0, mr, 0, 0x7fffffff, r.slab[k], r.render[k]);
+            rc = slabs ? sbx_render_split_rgb(r.ctx, app, uni, aux, br, i, n, m0, mr, 0, 0x7fffffff, r.slab[k], r.render[k])
+                       : sbx_render_split(r.ctx, app, uni, aux, br, i, n, m0, mr, 0, 0x7fffffff, r.slab[k], r.render[k]);
         }
         if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(r.ctx));
     }
-    // ---- the one exchange step: every peer's row-blocks to their rows of the root's frame -------------------
+    // ---- the one exchange step ----------------------------------------------------------------------------
     if (n > 1) {
+        if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+        if ((e = hipStreamWaitEvent(root.recv[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
         if (m->use_rccl) {
-            if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
-            if ((e = hipStreamWaitEvent(root.recv[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
             nccl_result_t nr = g_rccl.GroupStart();
             for (int i = 1; i < n && nr == 0; ++i) {
                 Rank& r = m->ranks[i];
                 const int rows = sbx_split_rank_rows(H, br, i, n, m0, mr);
-                for (int lr = 0, lb = 0; lr < rows && nr == 0; lr += br, ++lb) {
+                if (slabs) {                                        // one send / one receive per peer: the whole slab
+                    if (rows <= 0) continue;
+                    const size_t floats = (size_t)rows * slab_row;
+                    nr = g_rccl.Send(r.slab[k], floats, kNcclFloat, 0, r.comm, r.render[k]);
+                    if (nr == 0) nr = g_rccl.Recv(root.stage[k] + (size_t)(i - 1) * rows_max * slab_row, floats, kNcclFloat, i, root.comm, root.recv[k]);
+                    continue;
+                }
+                for (int lr = 0, lb = 0; lr < rows && nr == 0; lr += br, ++lb) {       // one pair per row-block, into the final rows
                     const int y = global_block(lb, i, n, m0, mr) * br;
                     const int cnt = (y + br <= H) ? br : (H - y);
                     const size_t floats = (size_t)cnt * row_floats;
@@ -337,24 +403,45 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
             }
             const nccl_result_t ne = g_rccl.GroupEnd();
             if (nr != 0 || ne != 0) return mfail(m, SBX_ERR_HIP, std::string("RCCL send/recv: ") + g_rccl.GetErrorString(nr != 0 ? nr : ne));
-            if ((e = hipEventRecord(root.recv_done[k], root.recv[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
         } else {
             for (int i = 1; i < n; ++i) {
                 Rank& r = m->ranks[i];
                 if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
                 const int rows = sbx_split_rank_rows(H, br, i, n, m0, mr);
-                for (int lr = 0, lb = 0; lr < rows; lr += br, ++lb) {
-                    const int y = global_block(lb, i, n, m0, mr) * br;
-                    const int cnt = (y + br <= H) ? br : (H - y);
-                    const size_t bytes = (size_t)cnt * row_floats * sizeof(float);
-                    if (r.device == root.device)
-                        e = hipMemcpyAsync(frame + (size_t)y * row_floats, r.slab[k] + (size_t)lr * row_floats, bytes, hipMemcpyDeviceToDevice, r.render[k]);
-                    else
-                        e = hipMemcpyPeerAsync(frame + (size_t)y * row_floats, root.device, r.slab[k] + (size_t)lr * row_floats, r.device, bytes, r.render[k]);
-                    if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "row-block copy", e);
+                if (slabs) {
+                    if (rows > 0) {
+                        float* dst = root.stage[k] + (size_t)(i - 1) * rows_max * slab_row;
+                        const size_t bytes = (size_t)rows * slab_row * sizeof(float);
+                        if (r.device == root.device) e = hipMemcpyAsync(dst, r.slab[k], bytes, hipMemcpyDeviceToDevice, r.render[k]);
+                        else e = hipMemcpyPeerAsync(dst, root.device, r.slab[k], r.device, bytes, r.render[k]);
+                        if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "slab copy", e);
+                    }
+                } else {
+                    for (int lr = 0, lb = 0; lr < rows; lr += br, ++lb) {
+                        const int y = global_block(lb, i, n, m0, mr) * br;
+                        const int cnt = (y + br <= H) ? br : (H - y);
+                        const size_t bytes = (size_t)cnt * row_floats * sizeof(float);
+                        if (r.device == root.device)
+                            e = hipMemcpyAsync(frame + (size_t)y * row_floats, r.slab[k] + (size_t)lr * row_floats, bytes, hipMemcpyDeviceToDevice, r.render[k]);
+                        else
+                            e = hipMemcpyPeerAsync(frame + (size_t)y * row_floats, root.device, r.slab[k] + (size_t)lr * row_floats, r.device, bytes, r.render[k]);
+                        if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "row-block copy", e);
+                    }
                 }
+                // the copies of this peer are complete at this point of its stream: the root's scatter waits for it
+                if ((e = hipEventRecord(r.done[k], r.render[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
             }
+            if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+            if (slabs)
+                for (int i = 1; i < n; ++i)
+                    if ((e = hipStreamWaitEvent(root.recv[k], m->ranks[i].done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
         }
+        if (slabs) {
+            // the peers' rows to their places, alpha = 1 (rank 0's rows, rendered in place beside this, are not touched)
+            const int rc = sbx_assemble_peers(root.ctx, W, H, br, n, m0, mr, 3, root.stage[k], frame, root.recv[k]);
+            if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(root.ctx));
+        }
+        if ((e = hipEventRecord(root.recv_done[k], root.recv[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
     }
     // ---- the caller's stream continues when every part of the frame is in place ---------------------------------
     for (int i = 0; i < n; ++i) {
@@ -365,7 +452,7 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
     if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
     for (int i = 0; i < n; ++i)
         if ((e = hipStreamWaitEvent(user, m->ranks[i].done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
-    if (n > 1 && m->use_rccl)
+    if (n > 1)
         if ((e = hipStreamWaitEvent(user, root.recv_done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
     return SBX_OK;
 }

@@ -74,10 +74,13 @@ class FramePlan:
                 else:
                     self.p2p.append([dist.P2POp(dist.isend, self.slab[a:b], 0)])
 
-    def render(self, app, time, mouse=(0.0, 0.0), aux=None):
-        """All ranks call this; rank 0 returns the assembled [H, W, 4] frame, the others None."""
+    def render(self, app, time, mouse=(0.0, 0.0), aux=None, mark=None):
+        """All ranks call this; rank 0 returns the assembled [H, W, 4] frame, the others None.  `mark(name)`, if given, is
+        called after the rank's rendering ("render"), after the waits of its exchange ("exchange") and after the root's
+        assembly ("assemble"): bench.py records stream events there to time the phases of a frame."""
+        mark = mark or (lambda name: None)
         if self.exchange == "gather":
-            return self._render_gather(app, time, mouse, aux)
+            return self._render_gather(app, time, mouse, aux, mark)
         d = self.dist
         works = []
         if self.rank == 0:
@@ -87,20 +90,26 @@ class FramePlan:
                 works += d.batch_isend_irecv(ops)
             self.r.render_rank_in_place(app, self.width, self.height, time, self.block_rows, 0, self.world, self.frame,
                                         mouse=mouse, aux=aux, root_rounds=self.root_rounds, rounds=self.rounds)
+            mark("render")
             for w in works:
                 w.wait()
-            return self.r.assemble_peers(self.peers, self.width, self.height, self.block_rows, self.world, self.frame,
-                                         root_rounds=self.root_rounds, rounds=self.rounds)
+            mark("exchange")
+            frame = self.r.assemble_peers(self.peers, self.width, self.height, self.block_rows, self.world, self.frame,
+                                          root_rounds=self.root_rounds, rounds=self.rounds)
+            mark("assemble")
+            return frame
         for g, (a, b) in enumerate(self.ranges):
             self.r.render_rank_rows(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
                                     a, b, self.slab, mouse=mouse, aux=aux, root_rounds=self.root_rounds,
                                     rounds=self.rounds)
             works += d.batch_isend_irecv(self.p2p[g])
+        mark("render")
         for w in works:
             w.wait()          # stream-level on GPUs: the next frame's render into this slab is ordered after the send
+        mark("exchange")
         return None
 
-    def _render_gather(self, app, time, mouse, aux):
+    def _render_gather(self, app, time, mouse, aux, mark):
         works = []
         last = len(self.ranges) - 1
         for g, (a, b) in enumerate(self.ranges):
@@ -111,9 +120,13 @@ class FramePlan:
             w = self.dist.gather(self.slab[a:b], self.glists[g], dst=0, async_op=(g != last))
             if w is not None:
                 works.append(w)
+        mark("render")
         for w in works:
             w.wait()          # stream-level wait on GPUs: the slab/gathered buffers are safe to reuse/read after it
+        mark("exchange")
         if self.rank == 0:
-            return self.r.assemble(self.gathered, self.width, self.height, self.block_rows, self.world,
-                                   out=self.frame, root_rounds=self.root_rounds, rounds=self.rounds)
+            frame = self.r.assemble(self.gathered, self.width, self.height, self.block_rows, self.world,
+                                    out=self.frame, root_rounds=self.root_rounds, rounds=self.rounds)
+            mark("assemble")
+            return frame
         return None

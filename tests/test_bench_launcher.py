@@ -54,7 +54,12 @@ def test_bench_line_contract_and_parity():
         assert k in line, k
     assert line["parity"]["mismatching_pixels"] == 0 and line["parity"]["max_abs_diff"] == 0.0 and line["parity"]["rows"] == 45
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["value"] > 0
-    assert line["roofline"]["bound"] == "valu" and 0 < line["roofline"]["frac"]
+    rf = line["roofline"]
+    assert rf["bound"] == "valu" and rf["unit"] == "T lane-ops/s" and "frac_of_scalar_issue_ceiling" not in rf
+    assert rf["useful_work_ratio"]["value"] > 0 and rf["useful_work_ratio"]["ops_per_pixel"] == 60248.0
+    assert rf["frac"] is None or 0 < rf["frac"] <= 1.0            # --pmc off: no counters, or the committed file's (<= 1 either way)
+    assert line["cpu_baseline"]["one_thread"]["value"] > 0 and "affinity" in line["cpu_baseline"] and "cgroup_cpu_max" in line["cpu_baseline"]
+    assert line["steady_state"]["value"] > 0
     assert [c["kernel"] for c in line["other_configs"]] == ["k_egg", "k_raytracer", "k_atmosphere", "k_planet"]
     assert all(c["value"] > 0 and c["kernel_ms"] > 0 for c in line["other_configs"])
     assert all(c["parity"]["rows"] == 16 and c["parity"]["mismatching_pixels"] == 0 for c in line["other_configs"])
@@ -66,6 +71,13 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
     r, line = run_bench("--force-dist", "--steps", "3", "--warmup", "1", "--width", "640", "--height", "360")
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 1 and line["parity"]["mismatching_pixels"] == 0 and line["parity"]["rows"] == 360
+    # the N > 1 line: per-rank phases, the steady-state rate beside the strict value, a roofline and the CPU baseline
+    ph = line["phases"]["per_rank"]
+    assert len(ph) == 1 and ph[0]["render_ms"] > 0 and ph[0]["exchange_wait_ms"] >= 0 and ph[0]["assemble_ms"] >= 0
+    assert line["steady_state"]["value"] > 0 and line["steady_state"]["ms_per_step"] > 0
+    assert line["roofline"]["bound"] == "valu" and (line["roofline"]["frac"] is None or line["roofline"]["frac"] <= 1.0)
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    assert line["parity"]["oracle"]["mismatching_pixels"] == 0
 
 
 @pytest.mark.gpu
@@ -74,3 +86,7 @@ def test_bench_library_engine_on_one_gpu():
     r, line = run_bench("--gpus", "4", "--engine", "lib", "--steps", "4", "--warmup", "1", "--width", "640", "--height", "360")
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 4 and line["parity"]["mismatching_pixels"] == 0 and "sbx_multi" in line["config"]["engine"]
+    assert line["steady_state"]["value"] > 0 and line["cpu_baseline"]["value"] > 0 and line["roofline"]["bound"] == "valu"
+    r2, line2 = run_bench("--gpus", "4", "--engine", "lib", "--lib-exchange", "blocks", "--steps", "4", "--warmup", "1", "--width", "640",
+                          "--height", "360", "--no-cpu-baseline")
+    assert r2.returncode == 0 and line2["parity"]["mismatching_pixels"] == 0 and "per row-block" in line2["config"]["parallelism"]

@@ -255,9 +255,12 @@ def test_library_multi_gpu_frame_equals_single_gpu(renderer, nranks):
         full = renderer.render(app, w, h, t)
         for split in [(8, 1, 1)] + ([(8, 3, 4), (4, 0, 2)] if nranks > 1 else []):
             m.set_split(*split)
-            got = m.render(app, w, h, t)
-            torch.cuda.synchronize()
-            assert torch.equal(got.view(torch.int32), full.view(torch.int32)), (app, w, h, nranks, split)
+            for mode in ("slabs", "blocks"):           # one transfer per peer + scatter kernel / one per row-block in place
+                m.set_exchange(mode)
+                got = m.render(app, w, h, t)
+                torch.cuda.synchronize()
+                assert torch.equal(got.view(torch.int32), full.view(torch.int32)), (app, w, h, nranks, split, mode)
+    m.set_exchange("slabs")
     # two frames in flight on two streams, different times
     m.set_split(8, 1, 1)
     s = [torch.cuda.Stream(), torch.cuda.Stream()]

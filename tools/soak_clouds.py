@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak (run on the GPU box): the shipped k_clouds against the plain per-lane kernel (sbx_set_variant 1) on random
 uniforms and aux blocks, with the ranges stretched over the borders of the kernel's special cases: sigma * dt across the REG
-limit of 80, z-only suns of any length and general suns (ZL on / off), wind with a y component (y-table key changes every
+limit of 80, positions far from the origin (u_time to 3e6, wind to 50: across and beyond the Lipschitz skip's domain), z-only suns of any length and general suns (ZL on / off), wind with a y component (y-table key changes every
 frame), tiny / huge / negative thickness, 1..300 march steps, 0..12 light steps, coverage 0..1.
     python tools/soak_clouds.py [frames=2000] [seed=1] [scale=1]"""
 import sys
@@ -21,6 +21,8 @@ kinds = {"reg_zl": 0, "reg_gen": 0, "noreg": 0}
 for i in range(n):
     aux = shaderbox_amd.clouds_defaults(R.lib)
     t = float(rng.uniform(0, 100)) if i % 3 else float(rng.uniform(0, 3))
+    if i % 7 == 0:                       # far from the origin: either side of the Lipschitz skip's domain (|wind_off| ~ 2^17) and beyond
+        t = float(rng.choice([rng.uniform(400, 900), 10.0 ** rng.uniform(3, 6.5), -1e9]))
     mouse = (float(rng.uniform(0, 6.3)), 0.0) if i % 2 else (0.0, 0.0)
     aux.cld_coverage = float(rng.choice([rng.uniform(0.3, 0.8), rng.uniform(0, 1), 0.0, 1.0], p=[.6, .3, .05, .05]))
     aux.cld_march_steps = int(rng.choice([rng.integers(20, 160), rng.integers(1, 300)]))
@@ -30,6 +32,8 @@ for i in range(n):
     aux.sigma_scattering = float(rng.choice([rng.uniform(.02, .6), rng.uniform(1, 200), 0.0], p=[.75, .2, .05]))
     if i % 4 == 0:
         aux.wind_dir[0], aux.wind_dir[1], aux.wind_dir[2] = [float(x) for x in rng.uniform(-.3, .3, 3)]
+    if i % 28 == 0:
+        aux.wind_dir[0], aux.wind_dir[1], aux.wind_dir[2] = [float(x) for x in rng.uniform(-50, 50, 3)]
     k = i % 6
     if k == 0:
         d = rng.standard_normal(3); d /= np.linalg.norm(d)
