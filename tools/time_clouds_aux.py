@@ -49,6 +49,9 @@ ref = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 for _ in range(40):                       # clocks up before the first case
     R.render("clouds", W, H, .37, out=buf)
 torch.cuda.synchronize()
+import os
+if os.environ.get("SBX_AUX_ONLY"):
+    CASES = [c for c in CASES if any(k in c[0] for k in os.environ["SBX_AUX_ONLY"].split(","))]
 for name, a, t, m in CASES:
     R.set_variant(0)
     R.render("clouds", W, H, t, mouse=m, aux=a, out=buf); torch.cuda.synchronize()
