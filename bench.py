@@ -839,6 +839,15 @@ def host_cpu_facts():
             quota = "%s %s" % (txt, period)
         break
     facts["cgroup_cpu_max"] = quota
+    # CPUs this process can actually keep busy: the affinity mask capped by the cgroup quota (quota_us / period_us)
+    eff = facts["affinity"] or facts["os_cpu_count"]
+    try:
+        q, per = (quota or "max 0").split()[:2]
+        if q != "max" and float(q) > 0 and float(per) > 0:
+            eff = max(1, min(eff, int(-(-float(q) // float(per)))))
+    except ValueError:
+        pass
+    facts["effective_cpus"] = eff
     return facts
 
 
@@ -848,7 +857,7 @@ def cpu_baseline(app, W, H, t, stride):
     from oracle.oracle import APP_IDS, Oracle
     o = Oracle()
     facts = host_cpu_facts()
-    cores = facts["affinity"] or facts["os_cpu_count"]   # threads used = CPUs this process may run on
+    cores = facts["effective_cpus"]                      # threads used = CPUs this process may run on AND is allowed to keep busy
     stride, rows = cpu_rows(H, stride, cores)
     o.render_rows(APP_IDS[app], W, H, t, rows[:max(1, cores // 60)], threads=cores)   # warm the threads/caches
     t0 = time.perf_counter()
@@ -864,6 +873,7 @@ def cpu_baseline(app, W, H, t, stride):
              "sample": "%d of %d rows (every %dth row) of the same %dx%d frame in 64-pixel tiles, %.1f s, g++ -O2 -ffp-contract=off"
                        % (len(rows), H, stride, W, H, dt),
              "affinity": facts["affinity"], "os_cpu_count": facts["os_cpu_count"], "cgroup_cpu_max": facts["cgroup_cpu_max"],
+             "cores_is": "threads used = min(scheduler affinity, cgroup CPU quota rounded up)",
              "one_thread": {"value": round(one, 5), "unit": "Mpixels/s", "sample": "%d rows, %.1f s" % (len(one_rows), dt1)},
              "thread_equivalents": round(value / one, 1) if one > 0 else None,
              "note": "the port evaluates sin/cos/exp/pow in binary64 by the sbx math spec (correctly rounded); the reference's own "
@@ -880,7 +890,7 @@ def cpu_baseline_speed(app, W, H, t, rows):
     except Exception:
         return None
     facts = host_cpu_facts()
-    cores = facts["affinity"] or facts["os_cpu_count"]
+    cores = facts["effective_cpus"]
     o.render_rows(APP_IDS[app], W, H, t, rows[:max(1, cores // 60)], threads=cores)
     t0 = time.perf_counter()
     o.render_rows(APP_IDS[app], W, H, t, rows, threads=cores)

@@ -8,6 +8,9 @@ import shaderbox_amd
 from shaderbox_amd import shard
 
 app = sys.argv[1] if len(sys.argv) > 1 else "clouds"
+import os
+if os.environ.get("SBX_LIB"):              # an A/B library of tools/ab_build.py instead of the shipped one
+    shaderbox_amd.LIB_PATH = os.environ["SBX_LIB"]
 W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160)
 R = shaderbox_amd.Renderer(0)
 R.set_timing(True)
@@ -57,6 +60,9 @@ for n in (1, 2, 4, 8):
         base = worst
     print("  2 streams, N=%d: slowest rank %.3f ms/frame -> compute-only speed-up %.2fx" % (n, worst, base / worst))
 
+import os
+if os.environ.get("SBX_STRIP_QUICK"):
+    sys.exit(0)
 # the ROOT's frame at N = 8, emulated on one GPU: its own strip + a 7-slab device copy standing in for the data RCCL's
 # receive kernels write into its HBM + the assembly kernel, two frames in flight as in bench.py — for the plain cyclic
 # split and for the split with root relief that bench.py's calibration picks (shard.relief_rounds)
