@@ -32,11 +32,34 @@
 #ifndef TEX_MIN_WAVES
 #define TEX_MIN_WAVES 5
 #endif
+#ifndef TEX_TW
+#define TEX_TW 32          // wave tile TEX_TW x 64/TEX_TW pixels
+#endif
+#ifndef TEX_SKIP
+#define TEX_SKIP 1         // REG frames: no exp of a zero density
+#endif
+#ifndef TEX_YTAB
+#define TEX_YTAB 1         // the y terms of the main march (and of the z-only light march) from a per-workgroup table in LDS
+#endif
+#ifndef TEX_TX
+#define TEX_TX 4           // waves per workgroup
+#endif
+#ifndef TEX_YROWS_N
+#define TEX_YROWS_N 256
+#endif
+constexpr int TEX_YROWS = TEX_YROWS_N;   // march steps the LDS table covers (8 KB per workgroup); more steps: the per-lane form
 
 namespace sbx {
 
 struct NoiseTex { const float* r; int size; float fsize; double rsize; int lg; };   // rsize = recip64(fsize): fl / size as an exact multiply
                                                                                   // (sbx_math.h div_by); lg = log2(size) when size is a power of two
+
+// One texel of a power-of-two volume by its 32-bit BYTE offset (size <= 512: at most 2^29 bytes): the address is the uniform base
+// plus a zero-extended 32-bit register, which is exactly what global_load_dword's scalar-base form takes — written as T.r[index]
+// the compiler builds a 64-bit address per texel (v_lshl_add_u64, 16 per density sample).
+__device__ __forceinline__ float texel_b(const NoiseTex& T, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(T.r) + byte_off);
+}
 
 __device__ __forceinline__ void tex_axis(float c, const NoiseTex& T, int& i0, int& i1, float& f) {
     const float u = c * T.fsize - .5f;
@@ -83,10 +106,18 @@ __device__ __forceinline__ float tex3d_r(const NoiseTex& T, v3 p) {     // Sampl
     // 32-bit texel indices from one base pointer (a volume has at most 2^30 texels).  Power-of-two sizes: shifts and ORs (the
     // three fields do not overlap) instead of v_mul_lo_u32, a quarter-rate instruction, six times per sample.
     unsigned r0, r1, a0, a1;
-    if (POW2) {
+    if (POW2) {                                                // byte offsets (texel_b): the POW2 kernels run for sizes <= 512 only
         const unsigned k = (unsigned)T.lg;
-        r0 = (unsigned)z0 << (2 * k); r1 = (unsigned)z1 << (2 * k);
-        a0 = (unsigned)y0 << k; a1 = (unsigned)y1 << k;
+        const unsigned b0 = (unsigned)x0 << 2, b1 = (unsigned)x1 << 2;
+        r0 = (unsigned)z0 << (2 * k + 2); r1 = (unsigned)z1 << (2 * k + 2);
+        a0 = (unsigned)y0 << (k + 2); a1 = (unsigned)y1 << (k + 2);
+        const float t000 = texel_b(T, r0 + a0 + b0), t100 = texel_b(T, r0 + a0 + b1);
+        const float t010 = texel_b(T, r0 + a1 + b0), t110 = texel_b(T, r0 + a1 + b1);
+        const float t001 = texel_b(T, r1 + a0 + b0), t101 = texel_b(T, r1 + a0 + b1);
+        const float t011 = texel_b(T, r1 + a1 + b0), t111 = texel_b(T, r1 + a1 + b1);
+        const float a = mix_(t000, t100, fx), b = mix_(t010, t110, fx);
+        const float c = mix_(t001, t101, fx), d = mix_(t011, t111, fx);
+        return mix_(mix_(a, b, fy), mix_(c, d, fy), fz);
     } else {
         const unsigned s1 = (unsigned)T.size;
         r0 = (unsigned)z0 * s1 * s1; r1 = (unsigned)z1 * s1 * s1;
@@ -110,40 +141,53 @@ __device__ __forceinline__ float tex3d_r(const NoiseTex& T, v3 p) {     // Sampl
 //     p0 = mix(mix(t000, t100, fx), mix(t010, t110, fx), fy),   p1 = the same in plane z1:
 // the sample is mix(p0, p1, fz) with only fz new — the same operations on the same values as tex3d_r, 2 instead of ~110
 // instructions and no loads.  A lane that leaves its cell fetches the two planes of its new cell (per-lane branch).
-struct TexCell { unsigned x0, x1, a0, a1; float fx, fy, fl, p0, p1; };   // a0/a1: y * size; fl = floor(uz) of the planes held
+struct TexCell { unsigned x0, x1, a0, a1; float fx, fy, fl, p0, p1; };   // x0/x1, a0/a1: BYTE offsets x * 4, y * size * 4; fl = floor(uz) of the planes held
 
-__device__ __forceinline__ void tex_planes(const NoiseTex& T, TexCell& c, float fl) {      // power-of-two sizes, |fl| < 2^31
-    const int mask = T.size - 1;
+// (fs, mask: the volume's size as a float and size - 1, handed in by the caller in VGPRs — an SGPR source halves the issue rate of
+//  a VALU instruction on gfx950, profiles/r02_ubench_issue.txt, and these are used ~10 times per sample)
+__device__ __forceinline__ void tex_planes(const NoiseTex& T, TexCell& c, float fl, int mask) {      // power-of-two sizes, |fl| < 2^31
     const unsigned k = (unsigned)T.lg;
     const int z0 = (int)fl & mask, z1 = (z0 + 1) & mask;
-    const unsigned r0 = (unsigned)z0 << (2 * k), r1 = (unsigned)z1 << (2 * k);
-    const float t000 = T.r[r0 + c.a0 + c.x0], t100 = T.r[r0 + c.a0 + c.x1];
-    const float t010 = T.r[r0 + c.a1 + c.x0], t110 = T.r[r0 + c.a1 + c.x1];
-    const float t001 = T.r[r1 + c.a0 + c.x0], t101 = T.r[r1 + c.a0 + c.x1];
-    const float t011 = T.r[r1 + c.a1 + c.x0], t111 = T.r[r1 + c.a1 + c.x1];
+    const unsigned r0 = (unsigned)z0 << (2 * k + 2), r1 = (unsigned)z1 << (2 * k + 2);
+    const float t000 = texel_b(T, r0 + c.a0 + c.x0), t100 = texel_b(T, r0 + c.a0 + c.x1);
+    const float t010 = texel_b(T, r0 + c.a1 + c.x0), t110 = texel_b(T, r0 + c.a1 + c.x1);
+    const float t001 = texel_b(T, r1 + c.a0 + c.x0), t101 = texel_b(T, r1 + c.a0 + c.x1);
+    const float t011 = texel_b(T, r1 + c.a1 + c.x0), t111 = texel_b(T, r1 + c.a1 + c.x1);
     c.p0 = mix_(mix_(t000, t100, c.fx), mix_(t010, t110, c.fx), c.fy);
     c.p1 = mix_(mix_(t001, t101, c.fx), mix_(t011, t111, c.fx), c.fy);
     c.fl = fl;
 }
 // tex3d_r<true>'s fast form, keeping what the light march reuses.  The caller has made the range test.
-__device__ __forceinline__ float tex3d_seed(const NoiseTex& T, v3 p, TexCell& c) {
-    const int mask = T.size - 1;
+__device__ __forceinline__ float tex3d_seed(const NoiseTex& T, v3 p, TexCell& c, float fs, int mask) {
     const unsigned k = (unsigned)T.lg;
-    const float ux = p.x * T.fsize - .5f, uy = p.y * T.fsize - .5f, uz = p.z * T.fsize - .5f;
+    const float ux = p.x * fs - .5f, uy = p.y * fs - .5f, uz = p.z * fs - .5f;
     const float lx = floor_(ux), ly = floor_(uy), lz = floor_(uz);
     c.fx = ux - lx; c.fy = uy - ly;
     const float fz = uz - lz;
     const int x0 = (int)lx & mask, y0 = (int)ly & mask;
-    c.x0 = (unsigned)x0; c.x1 = (unsigned)((x0 + 1) & mask);
-    c.a0 = (unsigned)y0 << k; c.a1 = (unsigned)((y0 + 1) & mask) << k;
-    tex_planes(T, c, lz);
+    c.x0 = (unsigned)x0 << 2; c.x1 = (unsigned)((x0 + 1) & mask) << 2;
+    c.a0 = (unsigned)y0 << (k + 2); c.a1 = (unsigned)((y0 + 1) & mask) << (k + 2);
+    tex_planes(T, c, lz, mask);
+    return mix_(c.p0, c.p1, fz);
+}
+// the same with the y terms of the step given (frame constants: the march's y is the same for every pixel, see k_clouds_tex)
+__device__ __forceinline__ float tex3d_seed_y(const NoiseTex& T, float px, float pz, float fy, unsigned a0, unsigned a1, TexCell& c,
+                                              float fs, int mask) {
+    const float ux = px * fs - .5f, uz = pz * fs - .5f;
+    const float lx = floor_(ux), lz = floor_(uz);
+    c.fx = ux - lx; c.fy = fy;
+    const float fz = uz - lz;
+    const int x0 = (int)lx & mask;
+    c.x0 = (unsigned)x0 << 2; c.x1 = (unsigned)((x0 + 1) & mask) << 2;
+    c.a0 = a0; c.a1 = a1;
+    tex_planes(T, c, lz, mask);
     return mix_(c.p0, c.p1, fz);
 }
 // a light sample: z only
-__device__ __forceinline__ float tex3d_z(const NoiseTex& T, float pz, TexCell& c) {
-    const float uz = pz * T.fsize - .5f;
+__device__ __forceinline__ float tex3d_z(const NoiseTex& T, float pz, TexCell& c, float fs, int mask) {
+    const float uz = pz * fs - .5f;
     const float lz = floor_(uz);
-    if (lz != c.fl) tex_planes(T, c, lz);
+    if (lz != c.fl) tex_planes(T, c, lz, mask);
     return mix_(c.p0, c.p1, uz - lz);
 }
 
@@ -165,12 +209,42 @@ __device__ __forceinline__ float hg_phase_tex(float mu, float g) {   // volumetr
     return (1.f - g * g) / ((4.f + 3.14159265359f) * pow_(1.f + g * g - 2.f * g * mu, 1.5f));
 }
 
-template <bool POW2, bool ZL>      // ZL (decided on the host): POW2 and the light step has no x and no y component
-__global__ void __launch_bounds__(WG_THREADS, TEX_MIN_WAVES) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out,
-                                                            NoiseTex T1, NoiseTex T2, double rsteps, double rlsteps) {
+// REG (decided on the host per launch, clouds_tex_regular): the coverage edge, sigma and dt are finite.  Then, and only then,
+//      a zero density needs no exp: -(+-0) * sigma * dt = -+0 and exp(-+0) = 1 exactly, so `ltrans *= 1` is skipped;
+//      (Deciding a zero density from the SHAPE sample alone — with a detail volume known to lie in [0, 1], a shape value below
+//      the coverage edge cannot be lifted over it by the remap — was built and measured: per lane +8 %, per wave +5 % at
+//      3840x2160; the detail sample is cheap next to the branch.  Not in.)
+// YT (decided on the host: power-of-two volumes, steps <= TEX_YROWS, the march's y range inside the fast filter's domain):
+//      render_clouds marches along dir / dir.y, whose y component is exactly 1 (:165), from origin.y = (eye.y + 150) + wind.y, so
+//      the height of main step i, `i / steps`, and per volume floor / fract of uy and the two row offsets are the same for
+//      every pixel: each workgroup computes them once into LDS (thread i the row of step i, the operations a lane would do) and
+//      the march reads the row with two broadcast loads.  The z-only light march keeps x and y of its main sample: same row.
+struct TexArgs { NoiseTex T1, T2; double rsteps, rlsteps; };
+template <bool POW2, bool ZL, bool REG, bool YT>      // ZL (decided on the host): POW2 and the light step has no x and no y component
+__global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out, TexArgs A) {
     // rsteps = recip64(float(steps)), rlsteps = recip64(float(lsteps)): `i / steps` and `j / lsteps` as exact multiplies
     // (sbx_math.h div_by: the IEEE quotient, bit for bit; ~13 instead of ~42 issue cycles, 230 times per marching pixel)
-    const Pixel px = pixel_of_thread<8>(M);
+    const NoiseTex& T1 = A.T1;
+    const NoiseTex& T2 = A.T2;
+    const double rsteps = A.rsteps, rlsteps = A.rlsteps;
+    __shared__ float4 yrow_f[YT ? TEX_YROWS : 1];          // {height, fy of volume 1, fy of volume 2, -}
+    __shared__ uint4 yrow_i[YT ? TEX_YROWS : 1];           // {a0, a1 of volume 1, a0, a1 of volume 2}: byte offsets y0 * size * 4, y1 * size * 4
+    if (YT) {
+        for (int i = threadIdx.x; i < F.steps; i += 64 * TEX_TX) {
+            float t = 0.f;
+            for (int j = 0; j < i; ++j) t += F.dt;                              // t after i steps of `t += dt` (:186)
+            const float origin_y = (F.cam.eye.y + 1.0f * 150.f) + F.wind_off.y;  // :166-167 with projection.y = 1
+            const float qy = (origin_y + t * 1.0f) * .001f;                      // :185, :66
+            const float u1 = qy * T1.fsize - .5f, u2 = qy * T2.fsize - .5f;      // tex3d_seed's y terms, both volumes
+            const float l1 = floor_(u1), l2 = floor_(u2);
+            const int y1 = (int)l1 & (T1.size - 1), y2 = (int)l2 & (T2.size - 1);
+            yrow_f[i] = make_float4(div_by((float)i, rsteps), u1 - l1, u2 - l2, 0.f);
+            yrow_i[i] = make_uint4((unsigned)y1 << (T1.lg + 2), (unsigned)((y1 + 1) & (T1.size - 1)) << (T1.lg + 2),
+                                   (unsigned)y2 << (T2.lg + 2), (unsigned)((y2 + 1) & (T2.size - 1)) << (T2.lg + 2));
+        }
+        if (TEX_TX > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    }
+    const Pixel px = pixel_of_thread<TEX_TW, TEX_TX>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 dir = primary_dir(F.cam, pc);
@@ -189,9 +263,23 @@ __global__ void __launch_bounds__(WG_THREADS, TEX_MIN_WAVES) k_clouds_tex(FrameC
         origin = origin + F.wind_off;
         const float phase = hg_phase_tex(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
         const v3 lstep = F.sun_dir * F.dt;
+        float fs1 = T1.fsize, fs2 = T2.fsize;
+        int m1 = T1.size - 1, m2 = T2.size - 1;
+        float vcov = F.cov, vsig = F.sigma, vdt = F.dt;
+        asm volatile("" : "+v"(fs1), "+v"(fs2), "+v"(m1), "+v"(m2), "+v"(vcov), "+v"(vsig), "+v"(vdt));   // VGPR-resident (full-rate operands)
+        const float lim = fmin_(1073741824.0f / T1.fsize, 1073741824.0f / T2.fsize) * .5f;
+        // YT: the fast filter's range test once per pixel instead of once per step — x and z of the march are monotone in t, so
+        // both ends inside (with the light march's reach in z) puts every sample inside; y is the table's (checked on the host)
+        bool fast_all = false;
+        if (YT) {
+            const float tend = (float)F.steps * abs_(F.dt) * 1.001f;
+            const float zreach = (float)(F.lsteps + 1) * abs_(lstep.z);
+            const float ex = fmax_(abs_(origin.x), abs_(origin.x + tend * projection.x)) + tend * 1e-3f;
+            const float ez = fmax_(abs_(origin.z), abs_(origin.z + tend * projection.z)) + zreach + tend * 1e-3f;
+            fast_all = !tex_wave_any(!(ex * .001f < lim * .5f) || !(ez * .001f < lim * .5f));
+        }
         float transmittance = 1.f, radiance = 0.f, alpha = 0.f, t = 0.f;
         for (int i = 0; i < F.steps; ++i) {
-            const float height = div_by((float)i, rsteps);      // :183  i / steps
             const v3 pos = origin + t * projection;
             t += F.dt;
             // ZL: the main sample through the seeding form of the filter when every coordinate of the wave — and the far end of its
@@ -199,22 +287,36 @@ __global__ void __launch_bounds__(WG_THREADS, TEX_MIN_WAVES) k_clouds_tex(FrameC
             TexCell c1, c2;
             bool fast = false;
             float density;
-            if (ZL) {
-                const v3 q = pos * .001f;
-                const float zend = (pos.z + (float)(F.lsteps + 1) * lstep.z) * .001f;
-                const float lim = fmin_(1073741824.0f / T1.fsize, 1073741824.0f / T2.fsize) * .5f;
-                fast = !tex_wave_any(!(abs_(q.x) < lim) || !(abs_(q.y) < lim) || !(abs_(q.z) < lim) || !(abs_(zend) < lim));
-                if (fast) {
-                    float shape = tex3d_seed(T1, q, c1);                            // tex_density with the cells kept
-                    const float w = tex3d_seed(T2, q, c2);
-                    const float ww = mix_(w, 1.f - w, height);
-                    shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
-                    density = shape * smoothstep_rd(F.cov, F.cov_rd, shape);
+            float height;
+            if (YT && fast_all) {
+                const float4 rf = yrow_f[i];                                        // all lanes one address: a broadcast
+                const uint4 ri = yrow_i[i];
+                height = rf.x;
+                fast = true;
+                const float qx = pos.x * .001f, qz = pos.z * .001f;
+                float shape = tex3d_seed_y(T1, qx, qz, rf.y, ri.x, ri.y, c1, fs1, m1);
+                const float w = tex3d_seed_y(T2, qx, qz, rf.z, ri.z, ri.w, c2, fs2, m2);
+                const float ww = mix_(w, 1.f - w, height);
+                shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
+                density = REG ? x_smoothstep_rd_med3(vcov, F.cov_rd, shape) : shape * smoothstep_rd(F.cov, F.cov_rd, shape);
+            } else {
+                height = div_by((float)i, rsteps);                                  // :183  i / steps
+                if (ZL) {
+                    const v3 q = pos * .001f;
+                    const float zend = (pos.z + (float)(F.lsteps + 1) * lstep.z) * .001f;
+                    fast = !tex_wave_any(!(abs_(q.x) < lim) || !(abs_(q.y) < lim) || !(abs_(q.z) < lim) || !(abs_(zend) < lim));
+                    if (fast) {
+                        float shape = tex3d_seed(T1, q, c1, fs1, m1);                            // tex_density with the cells kept
+                        const float w = tex3d_seed(T2, q, c2, fs2, m2);
+                        const float ww = mix_(w, 1.f - w, height);
+                        shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
+                        density = shape * smoothstep_rd(F.cov, F.cov_rd, shape);
+                    } else {
+                        density = tex_density<POW2>(F, T1, T2, pos, height);
+                    }
                 } else {
                     density = tex_density<POW2>(F, T1, T2, pos, height);
                 }
-            } else {
-                density = tex_density<POW2>(F, T1, T2, pos, height);
             }
             if (!(density < .005f)) {                          // integrate_volume :132
                 const float T_i = exp_(-density * F.sigma * F.dt);
@@ -223,22 +325,24 @@ __global__ void __launch_bounds__(WG_THREADS, TEX_MIN_WAVES) k_clouds_tex(FrameC
                 float ltrans = 1.f;
                 if (ZL && fast) {
                     for (int j = 0; j < F.lsteps; ++j) {
-                        const float lh = div_by((float)j, rlsteps);                 // :108  j / lsteps
                         const float qz = lp.z * .001f;
-                        float shape = tex3d_z(T1, qz, c1);
-                        const float w = tex3d_z(T2, qz, c2);
+                        float shape = tex3d_z(T1, qz, c1, fs1, m1);
+                        lp.z = lp.z + lstep.z;
+                        const float lh = div_by((float)j, rlsteps);                 // :108  j / lsteps
+                        const float w = tex3d_z(T2, qz, c2, fs2, m2);
                         const float ww = mix_(w, 1.f - w, lh);
                         shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
-                        const float d = shape * smoothstep_rd(F.cov, F.cov_rd, shape);
-                        ltrans *= exp_(-d * F.sigma * F.dt);
-                        lp.z = lp.z + lstep.z;
+                        const float d = REG ? x_smoothstep_rd_med3(vcov, F.cov_rd, shape) : shape * smoothstep_rd(F.cov, F.cov_rd, shape);
+                        if (REG && TEX_SKIP && d == 0.f) continue;                  // exp(-+0) = 1
+                        ltrans *= exp_(-d * vsig * vdt);
                     }
                 } else
                 for (int j = 0; j < F.lsteps; ++j) {
                     const float lh = div_by((float)j, rlsteps);                     // :108  j / lsteps
                     const float d = tex_density<POW2>(F, T1, T2, lp, lh);
-                    ltrans *= exp_(-d * F.sigma * F.dt);
                     lp = lp + lstep;
+                    if (REG && TEX_SKIP && d == 0.f) continue;                      // exp(-+0) = 1
+                    ltrans *= exp_(-d * F.sigma * F.dt);
                 }
                 radiance += (density * F.sigma) * (ltrans * F.sun_power * phase) * transmittance * F.dt;
                 alpha += (1.f - T_i) * (1.f - alpha);
@@ -281,18 +385,41 @@ void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out
     hipLaunchKernelGGL(k_tex3d_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, size, rgba, xyz, out, n);
 }
 
+// "regular frame" for the REG shortcuts of k_clouds_tex: everything they rely on is checked here, per launch
+static bool clouds_tex_regular(const FrameClouds& F) {
+    return std::isfinite(F.cov) && std::isfinite(F.cov_rd) && F.cov_rd > 0.0 && std::isfinite(F.sigma) && std::isfinite(F.dt);
+}
 void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, const float* shape_r, int shape_size,
                        const float* detail_r, int detail_size) {
     auto lg2 = [](int n) { int k = 0; while ((1 << k) < n) ++k; return k; };
     const NoiseTex T1{shape_r, shape_size, (float)shape_size, recip64((float)shape_size), lg2(shape_size)};
     const NoiseTex T2{detail_r, detail_size, (float)detail_size, recip64((float)detail_size), lg2(detail_size)};
-    const bool pow2 = (shape_size & (shape_size - 1)) == 0 && (detail_size & (detail_size - 1)) == 0;
+    const bool pow2 = (shape_size & (shape_size - 1)) == 0 && (detail_size & (detail_size - 1)) == 0 &&
+                      shape_size <= 512 && detail_size <= 512;   // 32-bit byte offsets (texel_b): 2^29 bytes at most
     const double rs = recip64((float)F.steps), rl = recip64((float)F.lsteps);     // loops with 0 steps never use them
     const v3 lstep = F.sun_dir * F.dt;                           // the kernel's own expression
     const bool zl = pow2 && lstep.x == 0.f && lstep.y == 0.f && std::isfinite(lstep.z) && TEX_ZL;
-    if (zl) hipLaunchKernelGGL((k_clouds_tex<true, true>), grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2, rs, rl);
-    else if (pow2) hipLaunchKernelGGL((k_clouds_tex<true, false>), grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2, rs, rl);
-    else hipLaunchKernelGGL((k_clouds_tex<false, false>), grid_for<8>(M), dim3(WG_THREADS), 0, s, F, M, out, T1, T2, rs, rl);
+    const bool reg = clouds_tex_regular(F);
+    // the LDS y table: the march's y range (the kernel's own expressions for its two ends) inside the fast filter's domain
+    bool yt = false;
+    if (TEX_YTAB && pow2 && F.steps > 0 && F.steps <= TEX_YROWS && std::isfinite(F.dt)) {
+        const float origin_y = (F.cam.eye.y + 1.0f * 150.f) + F.wind_off.y;
+        const float far = std::fabs(origin_y) + (float)F.steps * std::fabs(F.dt) * 1.001f;
+        const float lim = std::fmin(1073741824.0f / T1.fsize, 1073741824.0f / T2.fsize) * .25f;
+        yt = far * .001f < lim;                                  // NaN compares false
+    }
+    const TexArgs A{T1, T2, rs, rl};
+    const dim3 grid = grid_for<TEX_TW, TEX_TX>(M), block(64 * TEX_TX);
+#define SBX_TEX_LAUNCH(P, Z) do {                                                                                          \
+        if (reg && yt) hipLaunchKernelGGL((k_clouds_tex<P, Z, true, true>), grid, block, 0, s, F, M, out, A);               \
+        else if (reg) hipLaunchKernelGGL((k_clouds_tex<P, Z, true, false>), grid, block, 0, s, F, M, out, A);              \
+        else if (yt) hipLaunchKernelGGL((k_clouds_tex<P, Z, false, true>), grid, block, 0, s, F, M, out, A);               \
+        else hipLaunchKernelGGL((k_clouds_tex<P, Z, false, false>), grid, block, 0, s, F, M, out, A);                      \
+    } while (0)
+    if (zl) SBX_TEX_LAUNCH(true, true);
+    else if (pow2) SBX_TEX_LAUNCH(true, false);
+    else hipLaunchKernelGGL((k_clouds_tex<false, false, false, false>), grid, block, 0, s, F, M, out, A);
+#undef SBX_TEX_LAUNCH
 }
 
 }  // namespace sbx

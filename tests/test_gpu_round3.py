@@ -85,3 +85,48 @@ def test_culled_kernels_at_extreme_times(renderer, oracle, app):
         assert compare(a, b) == (0.0, 0), (app, t)
         ref = oracle.render(APP_IDS[app], w, h, t)
         assert compare(a, ref) == (0.0, 0), (app, t)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k_clouds_tex: the LDS y table, the REG shortcuts and their fall-backs
+# ---------------------------------------------------------------------------------------------------------
+def test_clouds_tex_instantiations(renderer, oracle):
+    """Every (ZL, REG, YT) instantiation of k_clouds_tex and the per-wave fall-backs inside them against the oracle: steps within
+    / beyond the LDS y table's rows, wind with a y component (the table's y origin moves), a sun off the z axis, non-finite
+    sigma (non-REG), a y range outside the fast filter's domain (host turns the table off), x / z ranges outside it (the wave
+    falls back per step), zero and negative thickness, zero light steps."""
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS_TEX
+    v1, v2 = renderer.worley_volume(32), renderer.worley_volume(16)
+    renderer.set_noise_volumes(v1, v2)
+    oracle.set_noise_volumes(v1.cpu().numpy(), v2.cpu().numpy())
+    w, h = 192, 108
+
+    def case(t=.37, mouse=(0.0, 0.0), **kw):
+        aux = shaderbox_amd.clouds_defaults()
+        for k, v in kw.items():
+            if isinstance(v, tuple):
+                for i, x in enumerate(v):
+                    getattr(aux, k)[i] = x
+            else:
+                setattr(aux, k, v)
+        gpu = renderer.render("clouds_tex", w, h, t, mouse=mouse, aux=aux).cpu().numpy()
+        ref = oracle.render(APP_CLOUDS_TEX, w, h, t, mouse=mouse, aux=aux)
+        assert compare(gpu, ref) == (0.0, 0), (t, mouse, kw)
+
+    case()                                                       # ZL, REG, YT
+    case(t=2.5, mouse=(2.0, 0.0))
+    case(cld_march_steps=256)                                    # the table's last row
+    case(cld_march_steps=257)                                    # beyond it: per-lane y terms
+    case(cld_march_steps=1, illum_march_steps=0)
+    case(wind_dir=(.1, .3, .2), t=1.5)                           # y origin moves with time
+    case(wind_dir=(0.0, 4.0e6, 0.0), t=1.0)                      # y far outside the fast filter's domain: no table, general wrap
+    case(wind_dir=(3.0e7, 0.0, 1.0), t=1.0)                      # x outside it: the wave's per-step fall-back
+    case(sun_dir=(.3, .5, -.8))                                  # general light march (not ZL), REG + YT
+    case(sun_dir=(0.0, 0.0, 2.5), illum_march_steps=9)           # z-only, long step, other sign
+    case(sigma_scattering=float("inf"))                          # not REG
+    case(cld_coverage=float("nan"))
+    case(cld_thick=-60.0)
+    case(cld_thick=0.0)
+    case(cld_coverage=1.0)
+    case(cld_coverage=0.0, cld_march_steps=40)
