@@ -60,6 +60,12 @@
 #ifndef CL_MAX3
 #define CL_MAX3 1
 #endif
+#ifndef CL_MIN_WAVES_YZ
+#define CL_MIN_WAVES_YZ 5    // the instantiations with the y-z light march
+#endif
+#ifndef CL_YZ_MARCH
+#define CL_YZ_MARCH 1        // 0: suns in the y-z plane take the general march (A/B timing)
+#endif
 #ifndef CL_MIN_WAVES
 #define CL_MIN_WAVES 6     // waves per SIMD the register allocation is held to (__launch_bounds__): 80 VGPRs (78 used, no spills;
                            // 7 waves = 72 VGPRs spill 6 and lose 4 %)
@@ -553,6 +559,95 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
     return ltrans;
 }
 
+// illuminate_volume's march (:106-113) when the light step L * dt has no x component (REG + YTAB kernels) — a sun anywhere in the
+// y-z plane: the default (0, 0, -1) raised or lowered, the "sun elevation" edit of hlsltoy's panel.  lp.x = pos.x + 0 never changes,
+// so per octave the x fract / smoothstep weight are the main sample's (mfx, as in light_march_z) and, while a light sample stays
+// in its lattice cell, the four x-mixes of the blend (noise_iq.h:20-21)
+//     a = h000 gx + h100 fx,  b = h010 gx + h110 fx,  c = h001 gx + h101 fx,  d = h011 gx + h111 fx
+// are the SAME binary32 values for every sample: they are kept in registers (16), and a sample costs the y and z terms, the
+// two y-mixes and the z-mix: ~140 instructions against ~250 for the general march and 85 for the z-only one.  "Still in the cell"
+// is decided as in light_march_z, for y and z: a = q - cur is the reference's fract iff 0 <= RN(q - cur) < 1, one unsigned compare
+// of the larger bit pattern against 1.0f.  The kept x-mixes are register values: nothing the cache does can invalidate them.
+// A sample that leaves a cell looks that octave up in the general form (floor / index / tag check / cooperative insert).
+template <bool REG>
+__device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
+                                                WaveCache& S, int lane, const float (&mfx)[4], const double (&etab)[32],
+                                                float vsigma, float vdt, float vcov) {
+    float xa[4], xb[4], xc[4], xd[4], cy[4], cz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cy[k] = cz[k] = u2f(0x7fc00001u); xa[k] = xb[k] = xc[k] = xd[k] = 0.f; }
+    const float qx0 = (lp.x * .001f) * 2.03f;             // the same for every sample of the march (lp.x + 0)
+    float ltrans = 1.f;
+    for (int j = 0; j < F.lsteps; ++j) {
+        float ay[4], az[4], qyv[4], qzv[4];
+        unsigned m[4];
+        float qy = (lp.y * .001f) * 2.03f, qz = (lp.z * .001f) * 2.03f;                  // :66,72
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            qyv[k] = qy; qzv[k] = qz;
+            ay[k] = qy - cy[k]; az[k] = qz - cz[k];        // first sample: cur is NaN -> "moved"
+            asm("v_max_u32 %0, %1, %2" : "=v"(m[k]) : "v"(f2u(ay[k])), "v"(f2u(az[k])));
+            qy = qy * 2.64f; qz = qz * 2.64f;                                            // fbm.h:6
+        }
+        unsigned m3, mall;
+        asm("v_max3_u32 %0, %1, %2, %3" : "=v"(m3) : "v"(m[0]), "v"(m[1]), "v"(m[2]));
+        asm("v_max_u32 %0, %1, %2" : "=v"(mall) : "v"(m3), "v"(m[3]));
+        if (wave_any_mask(wave_mask(mall >= 0x3f800000u) & lit_mask)) {                  // some lit lane left a cell in y or z
+#ifdef SBX_CL_STATS
+            if (lane == 0) S.stat[3] += 1.f;
+#endif
+            float qx = qx0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float qxk = qx;
+                qx = qx * 2.64f;
+                if (!wave_any_mask(wave_mask(m[k] >= 0x3f800000u) & lit_mask)) continue;
+                // the general form for every lane (noise_iq.h:14-19)
+                const float px = floor_(qxk), py = floor_(qyv[k]), pz = floor_(qzv[k]);
+                ay[k] = qyv[k] - py; az[k] = qzv[k] - pz;
+                cy[k] = py; cz[k] = pz;
+                const float n = px + py * 157.0f + 113.0f * pz;
+                const unsigned nbits = f2u(n);
+                const int slot = (int)n & (HC_SLOTS - 1);
+                const bool ne = (S.tag[k][slot] != nbits);
+                H8 h;
+                if (wave_any(lit && ne)) {
+                    h = hc_slow(S, k, nbits, slot, lit, lane);
+                } else {
+                    h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot][0]);
+                    h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
+                }
+                const float fx = mfx[k], gx = 1.0f - fx;
+                xa[k] = h.lo.x * gx + h.lo.y * fx;
+                xb[k] = h.lo.z * gx + h.lo.w * fx;
+                xc[k] = h.hi.x * gx + h.hi.y * fx;
+                xd[k] = h.hi.z * gx + h.hi.w * fx;
+            }
+        }
+        float t = 0.f, H = .5f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float fy = ay[k] * ay[k] * (3.0f - 2.0f * ay[k]);
+            const float fz = az[k] * az[k] * (3.0f - 2.0f * az[k]);
+            const float gy = 1.0f - fy, gz = 1.0f - fz;
+            const float ab = xa[k] * gy + xb[k] * fy;
+            const float cd = xc[k] * gy + xd[k] * fy;
+            const float term = (ab * gz + cd * fz) * H;
+            t = (REG && k == 0) ? term : t + term;         // 0 + x == x for x >= +0 or NaN (see light_march_z)
+            H *= .5f;
+        }
+        if (REG) {
+            const float d = x_smoothstep_rd_med3(vcov, F.cov_rd, t);
+            ltrans *= CL_EXP_REG(-d * vsigma * vdt);
+        } else {
+            const float d = t * smoothstep_rd(F.cov, F.cov_rd, t);
+            ltrans *= CL_EXP(-d * F.sigma * F.dt);
+        }
+        lp = lp + lstep;
+    }
+    return ltrans;
+}
+
 // The REG kernels' exp (cl_exp) as a standalone function for the exhaustive equivalence test against exp_ (sbx_math_eval
 // "exp_reg"; tests/test_gpu_round2.py): the same LDS table, the same instruction sequence as inside k_clouds.
 template <bool ASM>
@@ -598,8 +693,10 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
 // order at their natural alignment, exactly like this struct.  (Passing ONE struct argument instead made every use in the
 // march a scalar load: 3.5 -> 4.0 ms.)
 struct ClArgs { FrameClouds F; RowMap M; float* out; const YRow* ytab; };
-template <bool YTAB, bool REG, bool ZL>
-__global__ void __launch_bounds__(64 * CL_TX, (ZL && (YTAB || !CL_NOTAB_GEN)) ? CL_MIN_WAVES : CL_MIN_WAVES_GEN) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out_arg,
+// LM, the light march (decided on the host from L * dt): 1 = no x and no y component (light_march_z), 2 = no x component
+// (light_march_yz; YTAB kernels only), 0 = general (coop_density per light sample)
+template <bool YTAB, bool REG, int LM>
+__global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN)) ? CL_MIN_WAVES : (LM == 2 ? CL_MIN_WAVES_YZ : CL_MIN_WAVES_GEN)) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out_arg,
                                                           const YRow* __restrict__ ytab) {
     __shared__ WaveCache cache[CL_TX];
 #if CL_PARK
@@ -699,7 +796,8 @@ __global__ void __launch_bounds__(64 * CL_TX, (ZL && (YTAB || !CL_NOTAB_GEN)) ? 
                     float T_i = REG ? CL_EXP_REG(-density * vsigma * vdt) : CL_EXP(-density * F.sigma * F.dt);
                     v3 lp = pos + lstep;                           // illuminate_volume :91-123
                     float ltrans = 1.f;
-                    if (ZL) {                                      // lstep.x == 0 && lstep.y == 0 (launch_clouds): z-only light step
+                    constexpr bool ZL = LM == 1 || (LM == 2 && YTAB);   // the marches that run with the march state parked
+                    if (ZL) {                                      // lstep.x == 0 (&& lstep.y == 0) (launch_clouds)
 #if CL_PARK
                         // what the march does not need while a light march runs: parked for that time (slots 0-4, 9-11)
                         pk[0 * 64] = origin.x; pk[1 * 64] = origin.z; pk[2 * 64] = projection.x; pk[3 * 64] = projection.z;
@@ -708,7 +806,8 @@ __global__ void __launch_bounds__(64 * CL_TX, (ZL && (YTAB || !CL_NOTAB_GEN)) ? 
                         asm volatile("" ::: "memory");     // the reloads below cannot be forwarded from these stores: the values
                                                            // are dead across the light march
 #endif
-                        ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
+                        if (LM == 1) ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
+                        else ltrans = light_march_yz<REG>(F, lp, lstep, lit, lit_mask, S, lane, mfx, etab, vsigma, vdt, vcov);
 #if CL_PARK
                         asm volatile("" ::: "memory");
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
@@ -831,22 +930,25 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
 #endif
     const v3 lstep = F.sun_dir * F.dt;                          // the kernel's own expression
     const bool zl = lstep.x == 0.f && lstep.y == 0.f;
+    const bool yz = !zl && lstep.x == 0.f && CL_YZ_MARCH;        // NaN compares false: the general march
     if (variant == 1) {
         hipLaunchKernelGGL(k_clouds_perlane, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out);
     } else if (ytab && F.steps <= ytab_rows && F.steps > 0) {
         YRow* tab = reinterpret_cast<YRow*>(ytab);
         if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
         const YRow* ct = tab;
-        if (reg && zl) hipLaunchKernelGGL((k_clouds<true, true, true>), grid, block, pad, s, F, M, out, ct);
-        else if (reg) hipLaunchKernelGGL((k_clouds<true, true, false>), grid, block, 0, s, F, M, out, ct);
-        else if (zl) hipLaunchKernelGGL((k_clouds<true, false, true>), grid, block, 0, s, F, M, out, ct);
-        else hipLaunchKernelGGL((k_clouds<true, false, false>), grid, block, 0, s, F, M, out, ct);
+        if (reg && zl) hipLaunchKernelGGL((k_clouds<true, true, 1>), grid, block, pad, s, F, M, out, ct);
+        else if (reg && yz) hipLaunchKernelGGL((k_clouds<true, true, 2>), grid, block, 0, s, F, M, out, ct);
+        else if (reg) hipLaunchKernelGGL((k_clouds<true, true, 0>), grid, block, 0, s, F, M, out, ct);
+        else if (zl) hipLaunchKernelGGL((k_clouds<true, false, 1>), grid, block, 0, s, F, M, out, ct);
+        else if (yz) hipLaunchKernelGGL((k_clouds<true, false, 2>), grid, block, 0, s, F, M, out, ct);
+        else hipLaunchKernelGGL((k_clouds<true, false, 0>), grid, block, 0, s, F, M, out, ct);
     } else {
         const YRow* ct = nullptr;
-        if (reg && zl) hipLaunchKernelGGL((k_clouds<false, true, true>), grid, block, 0, s, F, M, out, ct);
-        else if (reg) hipLaunchKernelGGL((k_clouds<false, true, false>), grid, block, 0, s, F, M, out, ct);
-        else if (zl) hipLaunchKernelGGL((k_clouds<false, false, true>), grid, block, 0, s, F, M, out, ct);
-        else hipLaunchKernelGGL((k_clouds<false, false, false>), grid, block, 0, s, F, M, out, ct);
+        if (reg && zl) hipLaunchKernelGGL((k_clouds<false, true, 1>), grid, block, 0, s, F, M, out, ct);
+        else if (reg) hipLaunchKernelGGL((k_clouds<false, true, 0>), grid, block, 0, s, F, M, out, ct);
+        else if (zl) hipLaunchKernelGGL((k_clouds<false, false, 1>), grid, block, 0, s, F, M, out, ct);
+        else hipLaunchKernelGGL((k_clouds<false, false, 0>), grid, block, 0, s, F, M, out, ct);
     }
 }
 

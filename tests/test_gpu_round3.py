@@ -130,3 +130,37 @@ def test_clouds_tex_instantiations(renderer, oracle):
     case(cld_thick=0.0)
     case(cld_coverage=1.0)
     case(cld_coverage=0.0, cld_march_steps=40)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k_clouds: suns in the y-z plane (light_march_yz)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sun", [(0.0, .3, -1.0), (0.0, -.6, -.8), (0.0, 1.0, 0.0), (0.0, 1e-9, -1.0), (0.0, 5.0, 2.0), (-0.0, .5, .5)])
+def test_clouds_sun_in_the_yz_plane(renderer, oracle, sun):
+    """L * dt without an x component: the light march keeps the four x-mixes of its lattice cells (kern_clouds.hip
+    light_march_yz).  Default kernel == per-lane kernel == oracle, also with mouse rotation, wind and other step counts."""
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS
+    w, h = 384, 216
+    for t, mouse, extra in [(.37, (0.0, 0.0), {}), (12.5, (2.2, 0.0), {"illum_march_steps": 11}),
+                            (1.0, (0.0, 0.0), {"cld_march_steps": 33, "cld_thick": 200.0, "wind_dir": (.2, .1, -.3)})]:
+        aux = shaderbox_amd.clouds_defaults()
+        aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = sun
+        for k, v in extra.items():
+            if isinstance(v, tuple):
+                for i, x in enumerate(v):
+                    getattr(aux, k)[i] = x
+            else:
+                setattr(aux, k, v)
+        a, b = both_variants(renderer, "clouds", w, h, t, mouse=mouse, aux=aux)
+        assert compare(a, b) == (0.0, 0), (sun, t)
+        ref = oracle.render(APP_CLOUDS, w, h, t, mouse=mouse, aux=aux)
+        assert compare(a, ref) == (0.0, 0), (sun, t)
+
+
+def test_clouds_sun_in_the_yz_plane_4k(renderer):
+    import shaderbox_amd
+    aux = shaderbox_amd.clouds_defaults()
+    aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = 0.0, .28734788, -.95782629
+    a, b = both_variants(renderer, "clouds", 3840, 2160, .37, aux=aux)
+    assert compare(a, b) == (0.0, 0)

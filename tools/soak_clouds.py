@@ -17,7 +17,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 R = shaderbox_amd.Renderer(0)
 bad = 0
-kinds = {"reg_zl": 0, "reg_gen": 0, "noreg": 0}
+kinds = {"reg_zl": 0, "reg_yz": 0, "reg_gen": 0, "noreg": 0}
 for i in range(n):
     aux = shaderbox_amd.clouds_defaults(R.lib)
     t = float(rng.uniform(0, 100)) if i % 3 else float(rng.uniform(0, 3))
@@ -40,10 +40,13 @@ for i in range(n):
         aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = [float(x) for x in d]
     elif k == 1:
         aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = 0.0, 0.0, float(rng.choice([-2.0, 1.0, .3, -1e-3]))
+    elif k == 2:                        # the y-z plane (light_march_yz)
+        aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = 0.0, float(rng.choice([rng.uniform(-1, 1), 1e-6, 3.0])), float(rng.uniform(-1, 1))
     dt = aux.cld_thick / max(aux.cld_march_steps, 1)
     reg = abs(aux.sigma_scattering * dt) <= 80
     zl = aux.sun_dir[0] * dt == 0 and aux.sun_dir[1] * dt == 0
-    kinds["noreg" if not reg else ("reg_zl" if zl else "reg_gen")] += 1
+    yz = not zl and aux.sun_dir[0] * dt == 0
+    kinds["noreg" if not reg else ("reg_zl" if zl else ("reg_yz" if yz else "reg_gen"))] += 1
     W, H = [(320, 180), (333, 187), (160, 284)][i % 3]
     W, H = W * scale, H * scale
     R.set_variant(0); a = R.render("clouds", W, H, t, mouse=mouse, aux=aux).clone()

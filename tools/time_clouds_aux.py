@@ -36,6 +36,8 @@ CASES = [("default", None, .37, (0, 0)),
          ("mouse (.3,.6)", None, .37, (.3 * W, .6 * H)),
          ("sun (.3,.5,.8)", aux(sun_dir=norm((.3, .5, .8))), .37, (0, 0)),
          ("sun (0,1,.2)", aux(sun_dir=norm((0, 1, .2))), .37, (0, 0)),
+         ("sun (0,.3,-1)", aux(sun_dir=norm((0, .3, -1))), .37, (0, 0)),          # raised in the y-z plane: light_march_yz
+         ("sun (0,-.6,-.8)", aux(sun_dir=(0., -.6, -.8)), .37, (0, 0)),
          ("coverage .7", aux(cld_coverage=.7), .37, (0, 0)),
          ("coverage .3", aux(cld_coverage=.3), .37, (0, 0)),
          ("thick 150", aux(cld_thick=150.), .37, (0, 0)),
