@@ -27,8 +27,9 @@
 #include "../include/sbx.h"
 
 static int app_from_name(const std::string& s) {
-    const char* names[] = {"planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best", "clouds_tex", "clouds_ue4"};
-    const int n = 10;
+    const char* names[] = {"planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best", "clouds_tex", "clouds_ue4",
+                           "clouds_sky", "vinyl_gpu"};
+    const int n = 12;
     std::string low;
     for (char c : s) low += (char)tolower(c);
     for (int i = 0; i < n; ++i)
@@ -125,7 +126,7 @@ int main(int argc, char** argv) {
     for (const std::string* p : {&ppm, &f32})
         if (!pattern_ok(*p)) { fprintf(stderr, "bad file pattern %s: one %%d / %%0Nd conversion at most, a literal percent as %%%%\n", p->c_str()); return 2; }
     const void* aux = nullptr;
-    if ((id == SBX_APP_CLOUDS || id == SBX_APP_CLOUDS_TEX) && have_ac) aux = &ac;
+    if ((id == SBX_APP_CLOUDS || id == SBX_APP_CLOUDS_TEX || id == SBX_APP_CLOUDS_SKY) && have_ac) aux = &ac;
     if (id == SBX_APP_SDF_AO && have_as) aux = &as;
 
     sbx_ctx* ctx = nullptr;

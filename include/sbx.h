@@ -55,7 +55,16 @@ typedef enum sbx_app {
        Unreal material, not a mainImage shader.  Host mapping of this build: cam_dir = the primary-ray direction of
        APP_CLOUDS' camera, time = u_time, parameters = the TWEAK defaults (:4-17) or an sbx_aux_clouds_ue4 block, result
        through main.h's sRGB epilogue.  No reference-held answers: parity unpinned. */
-    SBX_APP_CLOUDS_UE4 = 9
+    SBX_APP_CLOUDS_UE4 = 9,
+    /* APP_CLOUDS compiled with SKY_SPHERE (src/app_clouds.h:8,14-19,154-162; intersect_sphere_from_inside src/intersect.h:35-53):
+       the march starts where the view ray meets the sphere ((0, atm_ground_y, 0), atm_radius) — which makes those two fields
+       of the aux block live — runs along the view ray itself, the layer turns with rotate_around_x(u_time) and
+       cld_noise_factor is 10 / atm_radius.  Same aux block as APP_CLOUDS (wind_dir is not read).  Parity unpinned (no
+       reference-held answers; bit-identical to the oracle's restatement). */
+    SBX_APP_CLOUDS_SKY = 10,
+    /* APP_VINYL with the march length of its GLSL / HLSL builds: 180 steps instead of the C++ build's 60
+       (src/app_vinyl.h:411-416).  Everything else as SBX_APP_VINYL. */
+    SBX_APP_VINYL_GPU = 11
 } sbx_app;
 
 typedef enum sbx_status {

@@ -219,8 +219,16 @@ struct AppClouds {
     /* USE_NOISE_TEX build (app_clouds.h:9): both set -> density_func samples the volumes instead of the fBm */
     noise_tex_t tex_noise, tex_noise_2;
     bool use_noise_tex() const { return tex_noise.rgba != nullptr && tex_noise_2.rgba != nullptr; }
+    /* SKY_SPHERE build (app_clouds.h:8,14-19,154-162): the march starts on a sphere around the viewer and runs along the view ray */
+    bool sky_sphere = false;
+    sphere_t atmosphere() const {                               /* app_clouds.h:15-17 */
+        sphere_t s; s.origin = vec3(0, A.atm_ground_y, 0); s.radius = A.atm_radius; s.material = 0;
+        return s;
+    }
     static constexpr float hg_g = .2f;                         /* app_clouds.h:5 */
-    static constexpr float cld_noise_factor = .001f;           /* app_clouds.h:20 */
+    float cld_noise_factor() const {                            /* app_clouds.h:18 / :20 */
+        return sky_sphere ? ((1.f / atmosphere().radius) * 10.f) : .001f;
+    }
 
     float fov() const { return 1.f; }                          /* app_clouds.h:219 */
     void setup_scene() {}
@@ -243,7 +251,7 @@ struct AppClouds {
     }
     /* app_clouds.h:62-86 */
     float density_func(vec3 pos_in, float height) const {
-        vec3 pos = pos_in * cld_noise_factor;
+        vec3 pos = pos_in * cld_noise_factor();
         float shape;
         if (use_noise_tex()) {                                  /* #ifdef USE_NOISE_TEX :69-70, :74-81 */
             shape = tex3d_sample_r(tex_noise, pos);
@@ -280,9 +288,20 @@ struct AppClouds {
     }
     /* app_clouds.h:153-202 */
     vec4 render_clouds(const ray_t& eye) const {
-        vec3 projection = eye.direction / eye.direction.y;
-        vec3 origin = eye.origin + projection * 150.f;
-        origin += A.wind_dir * U.u_time * (1.f / cld_noise_factor);
+        vec3 projection, origin;
+        if (sky_sphere) {                                       /* #ifdef SKY_SPHERE :154-162 */
+            hit_t hit = no_hit();
+            const sphere_t atm = atmosphere();
+            intersect_sphere_from_inside(eye, atm, hit);
+            projection = eye.direction;
+            origin = hit.origin;
+            mat3 rot = rotate_around_x(U.u_time);
+            origin = mul(rot, origin - atm.origin);
+        } else {                                                /* #else :163-167 */
+            projection = eye.direction / eye.direction.y;
+            origin = eye.origin + projection * 150.f;
+            origin += A.wind_dir * U.u_time * (1.f / cld_noise_factor());
+        }
         volume_sampler_t cloud = construct_volume(origin);
         float t = 0.f;
         const float dt = A.cld_thick / (float)A.cld_march_steps;
@@ -925,6 +944,7 @@ struct AppPlanet {
 /* =================================================================================== */
 struct AppVinyl {
     uniforms_t U;
+    int march_steps = 60;                                    /* :411-416: the __cplusplus value; 180 = the GLSL / HLSL builds */
     enum { num_materials = 8, mat_debug = 0, mat_groove = 1, mat_dead_wax, mat_label, mat_logo, mat_shiny }; /* :20-24 */
     material_t materials[num_materials];                     /* material.h:17 */
     mat3 platter_rot;                                        /* :66 (_mutable, assigned in render before use) */
@@ -1139,7 +1159,7 @@ struct AppVinyl {
     }
     /* :406-457 */
     vec3 render(const ray_t& ray, vec3 /*point_cam*/) {
-        const int steps = 60;                                 /* the __cplusplus value, :411-416 */
+        const int steps = march_steps;                        /* 60 under __cplusplus, 180 otherwise :411-416 */
         const float end = 40.f;
         float rot = U.u_time * 200.f;
         platter_rot = mul(rotate_around_y(rot), rotate_around_x(m_sin(U.u_time) * .1f));

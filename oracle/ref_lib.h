@@ -227,6 +227,20 @@ static inline void intersect_sphere(const ray_t& ray, const sphere_t& sphere, hi
     hit.origin = impact;
     hit.normal = (impact - sphere.origin) / sphere.radius;
 }
+/* intersect.h:35-53 (no early-outs: t0 = tca - thc is taken whatever its sign, sqrt of a negative number is NaN and flows on) */
+static inline void intersect_sphere_from_inside(const ray_t& ray, const sphere_t& sphere, hit_t& hit) {
+    vec3 rc = sphere.origin - ray.origin;
+    float radius2 = sphere.radius * sphere.radius;
+    float tca = dot(rc, ray.direction);
+    float d2 = dot(rc, rc) - tca * tca;
+    float thc = m_sqrt(radius2 - d2);
+    float t0 = tca - thc;
+    vec3 impact = ray.origin + ray.direction * t0;
+    hit.t = t0;
+    hit.material_id = sphere.material;
+    hit.origin = impact;
+    hit.normal = (impact - sphere.origin) / sphere.radius;
+}
 /* intersect.h:61-77 */
 static inline void intersect_plane(const ray_t& ray, const plane_t& p, hit_t& hit) {
     float denom = dot(p.direction, ray.direction);

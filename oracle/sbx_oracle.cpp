@@ -28,7 +28,9 @@ using namespace sbxref;
 enum { APP_PLANET = 0, APP_CLOUDS = 1, APP_VINYL = 2, APP_EGG = 3, APP_RAYTRACER = 4, APP_ATMOSPHERE = 5, APP_SDF_AO = 6,
        APP_CLOUDS_BEST = 7 /* src/app_clouds_best.h: not an APP_* define of the reference, numbered after them */,
        APP_CLOUDS_TEX = 8  /* APP_CLOUDS compiled with USE_NOISE_TEX (src/app_clouds.h:9,51-56,69-81) */,
-       APP_CLOUDS_UE4 = 9  /* ue4/volumetric_clouds/Shaders/app_clouds.usf under the build's host mapping (ref_apps.h) */ };
+       APP_CLOUDS_UE4 = 9  /* ue4/volumetric_clouds/Shaders/app_clouds.usf under the build's host mapping (ref_apps.h) */,
+       APP_CLOUDS_SKY = 10 /* APP_CLOUDS compiled with SKY_SPHERE (src/app_clouds.h:8,14-19,154-162) */,
+       APP_VINYL_GPU = 11  /* APP_VINYL with the march length of its non-C++ builds: 180 steps (src/app_vinyl.h:411-416) */ };
 
 /* the two bound 3-D textures of the USE_NOISE_TEX build (t1, t2): set by sbxo_set_noise_volumes, owned by the caller */
 static noise_tex_t g_tex_noise, g_tex_noise_2;
@@ -67,6 +69,7 @@ static bool pixel(int app, const uniforms_t& U, const void* aux, float fx, float
     switch (app) {
     case APP_EGG: { AppEgg a; a.U = U; c = main_image(a, fc); break; }
     case APP_CLOUDS: { AppClouds a; a.U = U; a.A = parse_clouds_aux(aux); c = main_image(a, fc); break; }
+    case APP_CLOUDS_SKY: { AppClouds a; a.U = U; a.A = parse_clouds_aux(aux); a.sky_sphere = true; c = main_image(a, fc); break; }
     case APP_CLOUDS_TEX: {
         if (!g_tex_noise.rgba || !g_tex_noise_2.rgba) return false;
         AppClouds a; a.U = U; a.A = parse_clouds_aux(aux); a.tex_noise = g_tex_noise; a.tex_noise_2 = g_tex_noise_2;
@@ -76,6 +79,7 @@ static bool pixel(int app, const uniforms_t& U, const void* aux, float fx, float
     case APP_SDF_AO: { AppSdfAo a; a.U = U; a.A = parse_sdf_ao_aux(aux); c = main_image(a, fc); break; }
     case APP_PLANET: { AppPlanet a; a.U = U; c = main_image(a, fc); break; }
     case APP_VINYL: { AppVinyl a; a.U = U; c = main_image(a, fc); break; }
+    case APP_VINYL_GPU: { AppVinyl a; a.U = U; a.march_steps = 180; c = main_image(a, fc); break; }
     case APP_CLOUDS_BEST: { AppCloudsBest a; a.U = U; c = main_image(a, fc); break; }
     case APP_CLOUDS_UE4: {
         AppCloudsUe4 a; a.U = U;

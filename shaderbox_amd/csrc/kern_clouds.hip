@@ -82,7 +82,7 @@ namespace sbx {
 #endif
 
 __device__ __forceinline__ float clouds_density(const FrameClouds& F, v3 pos_in) {
-    v3 pos = pos_in * .001f;                                   // cld_noise_factor, :20,66
+    v3 pos = pos_in * F.nf;                                    // cld_noise_factor, :18,20,66 (.001 unless SKY_SPHERE)
     float shape = fbm<4>(pos * 2.03f, 2.64f, .5f, .5f, [](v3 p) { return noise_iq(p); });   // :72
     return shape * smoothstep_(F.cov, F.cov_hi, shape);        // :83-84 (per-lane cross-check kernel keeps the IEEE division)
 }
@@ -126,9 +126,21 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, Ro
     v3 col = sky;
     if (!(cutoff < 0.05f)) {                                   // :212
         // render_clouds :153-202
-        const v3 projection = dir / dir.y;
+        v3 projection = dir / dir.y;
         v3 origin = F.cam.eye + projection * 150.f;
         origin = origin + F.wind_off;
+        if (F.sky) {                                           // #ifdef SKY_SPHERE :154-162, intersect_sphere_from_inside intersect.h:35-53
+            const v3 ac = V3(0, F.atm_y, 0);
+            const v3 rc = ac - F.cam.eye;
+            const float radius2 = F.atm_r * F.atm_r;
+            const float tca = dot(rc, dir);
+            const float d2 = dot(rc, rc) - tca * tca;
+            const float thc = sqrt_(radius2 - d2);
+            const float t0 = tca - thc;
+            const v3 impact = F.cam.eye + dir * t0;
+            projection = dir;
+            origin = mul(F.sky_rot, impact - ac);
+        }
         const float phase = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
         float transmittance = 1.f, radiance = 0.f, alpha = 0.f, t = 0.f;
         for (int i = 0; i < F.steps; ++i) {
@@ -205,8 +217,10 @@ __global__ void __launch_bounds__(64) k_clouds_ytab(FrameClouds F, YRow* __restr
     tab[i].py157 = make_float4(p157[0], p157[1], p157[2], p157[3]);
 }
 
+// NFL: the noise factor is the literal .001 (the y-table kernels, which never run SKY_SPHERE frames); else F.nf
+template <bool NFL>
 __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, bool active, WaveCache& S, int lane) {
-    v3 p = (pos_in * .001f) * 2.03f;                     // :66,72
+    v3 p = (pos_in * (NFL ? .001f : F.nf)) * 2.03f;      // :66,72
     float fx[4], fy[4], fz[4];
     unsigned nbits[4];
     int slot[4];
@@ -451,7 +465,8 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             ab[k] = mab[k]; cd[k] = mcd[k];
         }
     } else {
-        float qx = (lp.x * .001f) * 2.03f, qy = (lp.y * .001f) * 2.03f;
+        const float nf0 = F.nf;                              // (YTAB = false: .001, or SKY_SPHERE's factor)
+        float qx = (lp.x * nf0) * 2.03f, qy = (lp.y * nf0) * 2.03f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float px = floor_(qx);
@@ -473,7 +488,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
         // fixed), and then ab/cd still hold its x/y blends whatever happened to the cache since: no lookup at all.
         float az[4], pzv[4], qzv[4];
         unsigned long long moved_mask = 0, mk[4];
-        float qz = (lp.z * .001f) * 2.03f;
+        float qz = (lp.z * (YTAB ? .001f : F.nf)) * 2.03f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             qzv[k] = qz;
@@ -740,6 +755,19 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
         if (wave_any(alive)) {                                    // wave-uniform
             v3 projection = dir / dir.y;                          // render_clouds :153-202
             v3 origin = (F.cam.eye + projection * 150.f) + F.wind_off;
+            if (!YTAB && F.sky) {                                 // #ifdef SKY_SPHERE :154-162 (wave-uniform: a kernel argument)
+                // intersect_sphere_from_inside (intersect.h:35-53): t0 = tca - thc whatever its sign, NaN flows on
+                const v3 ac = V3(0, F.atm_y, 0);
+                const v3 rc = ac - F.cam.eye;
+                const float radius2 = F.atm_r * F.atm_r;
+                const float tca = dot(rc, dir);
+                const float d2 = dot(rc, rc) - tca * tca;
+                const float thc = sqrt_(radius2 - d2);
+                const float t0 = tca - thc;
+                const v3 impact = F.cam.eye + dir * t0;
+                projection = dir;
+                origin = mul(F.sky_rot, impact - ac);
+            }
 #if CL_PARK
             pk[8 * 64] = hg_phase(clamp_(dot(F.sun_dir, dir), 0.f, 1.f), .2f);
 #else
@@ -786,7 +814,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
                 float mab[4] = {0.f, 0.f, 0.f, 0.f}, mcd[4] = {0.f, 0.f, 0.f, 0.f};
                 float mpz[4] = {u2f(0x7fc00001u), u2f(0x7fc00001u), u2f(0x7fc00001u), u2f(0x7fc00001u)};
                 float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, mab, mcd, mpz, lip_slot, skip)
-                                           : coop_density(F, pos, alive, S, lane);
+                                           : coop_density<false>(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
                 if (wave_any_mask(lit_mask)) {
@@ -816,7 +844,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
 #endif
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
-                            const float d = coop_density(F, lp, lit, S, lane);
+                            const float d = coop_density<YTAB>(F, lp, lit, S, lane);
                             ltrans *= REG ? CL_EXP_REG(-d * vsigma * vdt) : CL_EXP(-d * F.sigma * F.dt);
                             lp = lp + lstep;
                         }
@@ -931,9 +959,10 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
     const v3 lstep = F.sun_dir * F.dt;                          // the kernel's own expression
     const bool zl = lstep.x == 0.f && lstep.y == 0.f;
     const bool yz = !zl && lstep.x == 0.f && CL_YZ_MARCH;        // NaN compares false: the general march
+    // (SKY_SPHERE frames: the march does not run along dir / dir.y, so no y table — the table-less kernels, F.nf, F.sky)
     if (variant == 1) {
         hipLaunchKernelGGL(k_clouds_perlane, grid_for<32>(M), dim3(WG_THREADS), 0, s, F, M, out);
-    } else if (ytab && F.steps <= ytab_rows && F.steps > 0) {
+    } else if (!F.sky && ytab && F.steps <= ytab_rows && F.steps > 0) {
         YRow* tab = reinterpret_cast<YRow*>(ytab);
         if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
         const YRow* ct = tab;

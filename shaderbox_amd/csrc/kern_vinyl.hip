@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
     bool hit = false;
     int mat = 0;
     v3 p = V3(0, 0, 0);
-    for (int i = 0; i < 60; ++i) {                              // render :427-455
+    for (int i = 0; i < F.steps; ++i) {                           // render :427-455; 60 (C++ build) or 180 steps :411-416
         const v3 pi = ro + rd * t;
         VI_LAUNDER(fp);
         const D2 d = vinyl_sdf<CULL>(VI_F(fp), pi);

@@ -72,7 +72,7 @@ static int fail(sbx_ctx* ctx, int code, const char* what, hipError_t e = hipSucc
 // ---------------------------------------------------------------------------------------------
 // frame builders: the frame-constant part of setup_camera()/setup_scene()/sdf() per app
 // ---------------------------------------------------------------------------------------------
-static FrameClouds build_clouds(const sbx_uniforms& U, const sbx_aux_clouds& A) {
+static FrameClouds build_clouds(const sbx_uniforms& U, const sbx_aux_clouds& A, bool sky_sphere = false) {
     FrameClouds F;
     // setup_camera app_clouds.h:23-30
     const v3 eye = V3(0, -.5f, 0);
@@ -92,6 +92,12 @@ static FrameClouds build_clouds(const sbx_uniforms& U, const sbx_aux_clouds& A) 
     F.cov_hi = F.cov + .0135f;                                         // :84
     F.cov_rd = recip64(F.cov_hi - F.cov);
     F.lip_ok = 0;                                                      // decided per launch (launch_clouds)
+    // SKY_SPHERE (:8,14-19,154-162)
+    F.sky = sky_sphere ? 1 : 0;
+    F.atm_y = A.atm_ground_y;
+    F.atm_r = A.atm_radius;
+    F.nf = sky_sphere ? ((1.f / A.atm_radius) * 10.f) : .001f;        // cld_noise_factor :18 / :20
+    F.sky_rot = rotate_around_x(U.u_time);                            // :160
     return F;
 }
 
@@ -227,8 +233,9 @@ static Capsule capsule(v3 a, v3 b) {                                   // sdf.h:
     c.rd = recip64(dot(c.ab, c.ab));
     return c;
 }
-static FrameVinyl build_vinyl(const sbx_uniforms& U) {
+static FrameVinyl build_vinyl(const sbx_uniforms& U, int steps) {
     FrameVinyl F;
+    F.steps = steps;                                                   // :411-416
     const float t = U.u_time;
     F.cam = make_camera(U.u_res[0], U.u_res[1], 1.f, V3(0, 5.75f, 6.75f), V3(0, -2.5f, 0));   // app_vinyl.h:56-64,459
     F.platter_rot = mul(rotate_around_y(t * 200.f), rotate_around_x(sin_(t) * .1f));          // :417,424-426
@@ -464,9 +471,9 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     if (M.nrows == 0) return SBX_OK;
     // argument checks come before anything is enqueued or recorded
-    if (app < SBX_APP_PLANET || app > SBX_APP_CLOUDS_UE4) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
+    if (app < SBX_APP_PLANET || app > SBX_APP_VINYL_GPU) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
     sbx_aux_clouds AC;
-    if (app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX) {
+    if (app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX || app == SBX_APP_CLOUDS_SKY) {
         if (aux) AC = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&AC);
         if (AC.cld_march_steps < 0 || AC.illum_march_steps < 0) return fail(ctx, SBX_ERR_ARG, "negative march steps");
     }
@@ -492,6 +499,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     const int cull_variant = tame_time(uni->u_time) ? ctx->variant : 1;
     switch (app) {
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
+    case SBX_APP_CLOUDS_SKY: launch_clouds(build_clouds(*uni, AC, true), M, rgba, s, ctx->variant, nullptr, 0, false); break;
     case SBX_APP_CLOUDS_TEX: launch_clouds_tex(build_clouds(*uni, AC), M, rgba, s, ctx->noise_tex, ctx->noise_tex_size, ctx->noise_tex2, ctx->noise_tex2_size); break;
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, cull_variant); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
@@ -503,7 +511,8 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         break;
     }
     case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s, cull_variant); break;
-    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni), M, rgba, s, cull_variant); break;
+    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni, 60), M, rgba, s, cull_variant); break;
+    case SBX_APP_VINYL_GPU: launch_vinyl(build_vinyl(*uni, 180), M, rgba, s, cull_variant); break;
     case SBX_APP_CLOUDS_BEST: launch_clouds_best(build_clouds_best(*uni), M, rgba, s); break;
     case SBX_APP_CLOUDS_UE4: {
         sbx_aux_clouds_ue4 A;
@@ -545,7 +554,7 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
                    float fragColor[4]) {
     if (!ctx) return SBX_ERR_ARG;
     if (!uni || !fragCoord || !fragColor) return fail(ctx, SBX_ERR_ARG, "NULL argument");
-    const int aux_bytes = !aux ? 0 : ((app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX) ? (int)sizeof(sbx_aux_clouds)
+    const int aux_bytes = !aux ? 0 : ((app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX || app == SBX_APP_CLOUDS_SKY) ? (int)sizeof(sbx_aux_clouds)
                                       : (app == SBX_APP_SDF_AO ? (int)sizeof(sbx_aux_sdf_ao)
                                       : (app == SBX_APP_CLOUDS_UE4 ? (int)sizeof(sbx_aux_clouds_ue4) : 0)));
     const bool hit = ctx->mi_valid && ctx->mi_app == app && std::memcmp(&ctx->mi_uni, uni, sizeof(*uni)) == 0 &&

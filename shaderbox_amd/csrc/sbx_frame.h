@@ -90,6 +90,12 @@ struct FrameClouds {
     double cov_rd;        // recip64(cov_hi - cov): the smoothstep division becomes an exact multiply
     int lip_ok;           // 1: the march positions are small enough for k_clouds' Lipschitz sample skip (set per launch by
                           //    launch_clouds / clouds_lip_domain; 0 disables the skip, nothing else)
+    // SKY_SPHERE build (app_clouds.h:8,14-19,154-162; SBX_APP_CLOUDS_SKY): the march starts where the view ray meets a sphere
+    // around the viewer (intersect_sphere_from_inside) and runs along the view ray itself; the table-less kernels only
+    int sky;              // 1: SKY_SPHERE
+    float nf;             // cld_noise_factor: .001, or (1 / atm_radius) * 10 for SKY_SPHERE            app_clouds.h:18,20
+    float atm_y, atm_r;   // atmosphere = sphere((0, atm_ground_y, 0), atm_radius)                     app_clouds.h:15-17
+    m3 sky_rot;           // rotate_around_x(u_time)                                                   app_clouds.h:160
 };
 
 // ---- APP_EGG (src/app_egg.h) ----------------------------------------------------------------
@@ -189,6 +195,7 @@ struct FrameVinyl {
     m3 arm_xform, fl_rot, fl_rot2, ctg_rot, cut_rx10, cut_rym5, cut2_rz10;   // :163-232
     v3 fl_sub1, fl_sub2;       // arm_right * clr_r, arm_up * clr_r                           :191-193
     CylFrame collar;           // sd_cylinder(., 0, arm_fwd * .05, .)                         :173-176
+    int steps;                 // march steps: 60 (the C++ build) or 180 (the GLSL / HLSL builds, SBX_APP_VINYL_GPU)   :411-416
 };
 
 }  // namespace sbx

@@ -164,3 +164,51 @@ def test_clouds_sun_in_the_yz_plane_4k(renderer):
     aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = 0.0, .28734788, -.95782629
     a, b = both_variants(renderer, "clouds", 3840, 2160, .37, aux=aux)
     assert compare(a, b) == (0.0, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# compile-time variants inside the cited line ranges: SKY_SPHERE (app_clouds.h:8,14-19,154-162), VINYL's 180-step march (:411-416)
+# ---------------------------------------------------------------------------------------------------------
+def test_clouds_sky_sphere_matches_oracle(renderer, oracle):
+    """APP_CLOUDS + SKY_SPHERE: atm_radius / atm_ground_y are live, the march runs along the view ray from the sphere, the layer
+    turns with u_time.  Default kernel == per-lane kernel == oracle for default and edited aux blocks."""
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS_SKY, APP_CLOUDS
+    w, h = 256, 144
+    frames = []
+    for t, mouse, kw in [(.37, (0.0, 0.0), {}), (0.0, (0.0, 0.0), {}), (40.0, (1.3, 0.0), {}),
+                         (2.5, (0.0, 0.0), {"atm_radius": 3000.0, "atm_ground_y": 2900.0, "cld_march_steps": 60, "cld_thick": 400.0}),
+                         (1.0, (0.0, 0.0), {"atm_radius": 100.0, "atm_ground_y": 500.0}),          # the viewer OUTSIDE the sphere: sqrt of a negative number
+                         (1.0, (0.0, 0.0), {"sun_dir": (.3, .5, -.8), "cld_coverage": .6}),
+                         (1.0, (0.0, 0.0), {"sun_dir": (0.0, .5, -.8), "cld_march_steps": 5000})]:  # more steps than the y table has rows: same kernels
+        aux = shaderbox_amd.clouds_defaults()
+        for k, v in kw.items():
+            if isinstance(v, tuple):
+                for i, x in enumerate(v):
+                    getattr(aux, k)[i] = x
+            else:
+                setattr(aux, k, v)
+        if kw.get("cld_march_steps") == 5000:
+            w2, h2 = 48, 27
+        else:
+            w2, h2 = w, h
+        a, b = both_variants(renderer, "clouds_sky", w2, h2, t, mouse=mouse, aux=aux)
+        assert compare(a, b) == (0.0, 0), (t, kw)
+        ref = oracle.render(APP_CLOUDS_SKY, w2, h2, t, mouse=mouse, aux=aux)
+        assert compare(a, ref) == (0.0, 0), (t, kw)
+        frames.append(a)
+    plain = renderer.render("clouds", w, h, .37).cpu().numpy()
+    assert compare(frames[0], plain)[1] > 1000                  # it IS another build of the shader
+    assert np.isfinite(frames[0]).all() and frames[0][h - 1].std() > 0
+
+
+def test_vinyl_180_steps_matches_oracle(renderer, oracle):
+    from oracle.oracle import APP_VINYL_GPU
+    w, h = 192, 108
+    for t in (0.0, .37, 2.5):
+        a, b = both_variants(renderer, "vinyl_gpu", w, h, t)
+        assert compare(a, b) == (0.0, 0), t
+        ref = oracle.render(APP_VINYL_GPU, w, h, t)
+        assert compare(a, ref) == (0.0, 0), t
+    # (at this size every ray converges or leaves within 60 steps, so the frames equal SBX_APP_VINYL's; the longer march only
+    #  matters for rays that graze the record)

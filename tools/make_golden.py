@@ -18,7 +18,7 @@ from oracle.oracle import APP_IDS, Oracle  # noqa: E402
 
 CASES = {"egg": (64, 64), "clouds": (96, 54), "raytracer": (64, 64), "atmosphere": (64, 36),
          "sdf_ao": (64, 36), "planet": (64, 36), "vinyl": (64, 36), "clouds_best": (96, 54),
-         "clouds_ue4": (96, 54), "clouds_tex": (96, 54)}
+         "clouds_ue4": (96, 54), "clouds_tex": (96, 54), "clouds_sky": (96, 54), "vinyl_gpu": (64, 36)}
 TIMES = (0.0, 0.37, 2.5)
 
 
@@ -39,7 +39,10 @@ if __name__ == "__main__":
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     o.set_noise_volumes(*fixture_volumes())
+    only = set(sys.argv[1:])                  # python tools/make_golden.py [app ...]: only these fixtures
     for app, (w, h) in CASES.items():
+        if only and app not in only:
+            continue
         frames = {"t%g" % t: o.render(APP_IDS[app], w, h, t) for t in TIMES}
         np.savez_compressed(os.path.join(out, "%s_%dx%d.npz" % (app, w, h)), **frames)
         print(app, w, h, {k: float(np.nanmean(v[..., :3])) for k, v in frames.items()})
