@@ -810,9 +810,14 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
     return (int(pick[0].item()), int(pick[1].item()))
 
 
-def cpu_rows(H, stride, cores):
+def cpu_rows(H, stride, cores, rows_per_s=None, target_s=12.0):
+    """every stride-th row of the frame.  stride 0 = choose: from a measured rate (rows per second of this host, this app) so
+    that the sample is ~target_s of wall time, else from the core count"""
     if stride <= 0:
-        stride = 8 if cores <= 16 else (4 if cores <= 64 else 2)
+        if rows_per_s:
+            stride = max(1, min(16, int(H / max(rows_per_s * target_s, 1.0))))
+        else:
+            stride = 8 if cores <= 16 else (4 if cores <= 64 else 2)
     return stride, list(range(stride // 2, H, stride))
 
 
@@ -858,8 +863,11 @@ def cpu_baseline(app, W, H, t, stride):
     o = Oracle()
     facts = host_cpu_facts()
     cores = facts["effective_cpus"]                      # threads used = CPUs this process may run on AND is allowed to keep busy
-    stride, rows = cpu_rows(H, stride, cores)
-    o.render_rows(APP_IDS[app], W, H, t, rows[:max(1, cores // 60)], threads=cores)   # warm the threads/caches
+    # calibration (also warms threads and caches): 8 rows spread over the frame -> rows per second -> a ~12 s sample
+    cal = [int((k + .5) * H / 8) for k in range(8)]
+    t0 = time.perf_counter()
+    o.render_rows(APP_IDS[app], W, H, t, cal, threads=cores)
+    stride, rows = cpu_rows(H, stride, cores, rows_per_s=len(cal) / max(time.perf_counter() - t0, 1e-6))
     t0 = time.perf_counter()
     ref = o.render_rows(APP_IDS[app], W, H, t, rows, threads=cores)
     dt = time.perf_counter() - t0
