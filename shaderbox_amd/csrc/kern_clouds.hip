@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, Ro
 // per-lane variant evaluates 32 sin per lane per density_func; this one ~0.1).  Control flow around the
 // cross-lane steps is wave-uniform: lanes never exit early, they carry `alive`/`lit` predicates.
 // (The first cooperative version re-elected the distinct cells of every sample: 11.6 ms per 4K frame,
-// of which 2.3 ms election and 2.0 ms hash passes; see DESIGN.md §4.1.)
+// of which 2.3 ms election and 2.0 ms hash passes; see DESIGN.md §5.1.)
 // ---------------------------------------------------------------------------------------------
 // ---- y terms of the main march --------------------------------------------------------------------
 // render_clouds marches along projection = dir / dir.y (:165), whose y component is dir.y / dir.y = 1 exactly,
@@ -450,7 +450,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
     float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4], curz[4];
     if (YTAB) {
         // lp.x = pos.x + 0 and lp.y = pos.y + 0: the x terms are the main sample's own (same operations on
-        // the same value; a -0 turned +0 by the addition changes no result bit, DESIGN.md §4.1), the y terms
+        // the same value; a -0 turned +0 by the addition changes no result bit, DESIGN.md §5.1), the y terms
         // are the step's row of the frame table.
         const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
         const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};

@@ -22,7 +22,7 @@
 // uses (8.4 MB per 128^3 volume instead of 33.5 MB: both volumes sit in the 256 MB Infinity Cache and mostly
 // in the 4 MB L2 of each XCD), neighbouring pixels of a wave tile sample neighbouring texels, and the straight
 // per-lane kernel below needs few registers, so 8 waves per SIMD hide the L2 latency.  HBM traffic stays the
-// framebuffer (16 B/pixel) plus one pass over the volumes; roofline and FETCH_SIZE in DESIGN.md §4.8.
+// framebuffer (16 B/pixel) plus one pass over the volumes; roofline and FETCH_SIZE in DESIGN.md §5.6.
 #include <cmath>
 #include "sbx_device.h"
 

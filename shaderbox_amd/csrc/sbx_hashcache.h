@@ -8,7 +8,7 @@
 // Lookups are per lane (lanes of a tile mostly read the same slot: LDS broadcast); misses are served by the
 // whole wave together (leader election with ballot/readlane, then lane (r, c) hashes corner c of pending
 // cell r).  Every hash is hash1() of the same binary32 argument as in a per-lane evaluation, so results
-// are bit-identical by construction.  DESIGN.md §4.1 has the measurements and the compiler hazards.
+// are bit-identical by construction.  DESIGN.md §5.1 has the measurements and the compiler hazards.
 #pragma once
 #include "sbx_device.h"
 #include "sbx_noise.h"

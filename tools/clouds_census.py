@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/clouds_census.py — wave-level census of the APP_CLOUDS 4K frame (DESIGN.md §4.1).
+"""tools/clouds_census.py — wave-level census of the APP_CLOUDS 4K frame (DESIGN.md §5.1).
 
 Step 1 (here, no GPU):   python tools/clouds_census.py --build     -> build/libsbx_stats.so (-DSBX_CL_STATS)
 Step 2 (on the GPU box): PYTHONPATH=. python tools/clouds_census.py
