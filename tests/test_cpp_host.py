@@ -27,6 +27,18 @@ def test_hosts_build_and_fail_loudly_without_gpu(built):
         assert r.returncode == 1 and "no CPU path" in r.stderr
 
 
+def test_cli_rejects_bad_file_patterns(built):
+    """--ppm / --f32 patterns are snprintf formats: anything but one %d / %0Nd conversion (and %%) is refused before any GPU work
+    (`out_%s.ppm`, `%n`, two conversions were undefined behaviour)"""
+    exe = os.path.join(built, "sbx_render")
+    for bad in ("out_%s.ppm", "a%n.ppm", "f_%d_%d.ppm", "x%", "p%5.2f.ppm", "q%123456d.ppm"):
+        r = subprocess.run([exe, "--app", "egg", "--res", "32x32", "--ppm", bad], capture_output=True, text=True)
+        assert r.returncode == 2 and "bad file pattern" in r.stderr, (bad, r.returncode, r.stderr)
+    for good in ("out_%04d.ppm", "plain.ppm", "100%%_%d.ppm"):
+        r = subprocess.run([exe, "--app", "egg", "--res", "32x32", "--ppm", good], capture_output=True, text=True)
+        assert "bad file pattern" not in r.stderr, good
+
+
 @pytest.mark.gpu
 def test_cli_and_mainimage_dropin_match_oracle(built, oracle, tmp_path):
     from oracle.oracle import APP_IDS

@@ -212,3 +212,34 @@ def test_vinyl_180_steps_matches_oracle(renderer, oracle):
         assert compare(a, ref) == (0.0, 0), t
     # (at this size every ray converges or leaves within 60 steps, so the frames equal SBX_APP_VINYL's; the longer march only
     #  matters for rays that graze the record)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bench.py's N > 1 start-up code on one GPU: the relief calibration of rank 0 with a fake 8-rank world
+# ---------------------------------------------------------------------------------------------------------
+def test_bench_relief_calibration_runs_for_eight_ranks(renderer):
+    """choose_relief('auto') only runs with world > 1, i.e. never on a 1-GPU box through bench.py itself: drive rank 0's
+    measuring loop (in-place strip + landing of 7 slabs + peer assembly, and the peers' strips, for every candidate split)
+    with world = 8 and a stand-in for the broadcast; the result is one of the candidates and a valid split."""
+    import importlib.util
+    import os
+    import torch
+    from shaderbox_amd import shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class FakeDist:
+        @staticmethod
+        def broadcast(t, src=0):
+            return None
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for exchange, ch in (("direct", 3), ("gather", 4)):
+        m0, m = bench.choose_relief("auto", renderer, FakeDist, torch, dev, "clouds", 960, 540, .37, 8, 8, 0, streams, exchange, ch)
+        assert (m0, m) in bench.relief_candidates() and 1 <= m0 <= m
+        rows = [shard.rank_rows(540, 8, r, 8, m0, m) for r in range(8)]
+        assert sum(rows) == 540 and rows[0] <= max(rows[1:])
+    assert bench.choose_relief("3/4", renderer, FakeDist, torch, dev, "clouds", 960, 540, .37, 8, 8, 0, streams) == (3, 4)
+    assert bench.choose_relief("auto", renderer, FakeDist, torch, dev, "clouds", 960, 540, .37, 8, 1, 0, streams) == (1, 1)
