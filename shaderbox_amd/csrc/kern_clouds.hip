@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(64) k_clouds_ytab(FrameClouds F, YRow* __restr
     for (int k = 0; k < 4; ++k) {
         const float py = floor_(q);
         const float ay = q - py;
-        fy[k] = ay * ay * (3.0f - 2.0f * ay);
+        fy[k] = ay * ay * tm2_(ay);
         gy[k] = 1.0f - fy[k];
         p157[k] = py * 157.0f;
         q = q * 2.64f;
@@ -230,9 +230,9 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
     for (int k = 0; k < 4; ++k) {                        // lattice part of noise_iq.h:14-19, all octaves first
         const float px = floor_(p.x), py = floor_(p.y), pz = floor_(p.z);
         const float ax = p.x - px, ay = p.y - py, az = p.z - pz;
-        fx[k] = ax * ax * (3.0f - 2.0f * ax);
-        fy[k] = ay * ay * (3.0f - 2.0f * ay);
-        fz[k] = az * az * (3.0f - 2.0f * az);
+        fx[k] = ax * ax * tm2_(ax);
+        fy[k] = ay * ay * tm2_(ay);
+        fz[k] = az * az * tm2_(az);
         const float n = px + py * 157.0f + 113.0f * pz;
         nbits[k] = f2u(n);
         slot[k] = (int)n & (HC_SLOTS - 1);
@@ -297,8 +297,8 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
     for (int k = K0; k < K1; ++k) {
         const float px = floor_(qx), pz = floor_(qz);
         const float ax = qx - px, az = qz - pz;
-        fx[k] = ax * ax * (3.0f - 2.0f * ax);
-        fz[k] = az * az * (3.0f - 2.0f * az);
+        fx[k] = ax * ax * tm2_(ax);
+        fz[k] = az * az * tm2_(az);
         nxy[k] = px + rpy[k];
         mpz[k] = pz;
         const float n = nxy[k] + 113.0f * pz;            // p.x + p.y*157 + 113*p.z, noise_iq.h:19
@@ -441,6 +441,10 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 // unsigned compare of az's bits against those of 1.0f replaces v_floor + v_cmp (both half-rate instructions on gfx950,
 // profiles/r02_ubench_issue.txt).  The test is conservative (a fract that rounds up to 1.0 is treated as a move);
 // a move recomputes floor / fract / lookups exactly as the general form does.
+#ifndef CL_PRESCALE
+#define CL_PRESCALE 1
+#endif
+__device__ __forceinline__ constexpr float hk_(int k) { return CL_PRESCALE ? (k == 0 ? .5f : (k == 1 ? .25f : (k == 2 ? .125f : .0625f))) : 1.0f; }
 template <bool YTAB, bool REG>
 __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                WaveCache& S, int lane, const YRow& row, const float (&mfx)[4],
@@ -462,7 +466,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             // of every octave, so the first light sample needs a lookup only where it has left that cell, like every later one
             // (a lit main sample has always evaluated all four octaves).
             curz[k] = CL_SEED ? mpz[k] : u2f(0x7fc00001u);
-            ab[k] = mab[k]; cd[k] = mcd[k];
+            ab[k] = mab[k] * hk_(k); cd[k] = mcd[k] * hk_(k);      // pre-scaled by the octave's gain (CL_PRESCALE, below)
         }
     } else {
         const float nf0 = F.nf;                              // (YTAB = false: .001, or SKY_SPHERE's factor)
@@ -471,10 +475,10 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
         for (int k = 0; k < 4; ++k) {
             const float px = floor_(qx);
             const float ax = qx - px;
-            fx[k] = ax * ax * (3.0f - 2.0f * ax);
+            fx[k] = ax * ax * tm2_(ax);
             const float py = floor_(qy);
             const float ay = qy - py;
-            fy[k] = ay * ay * (3.0f - 2.0f * ay);
+            fy[k] = ay * ay * tm2_(ay);
             gy[k] = 1.0f - fy[k];
             nxy[k] = px + py * 157.0f;
             curz[k] = u2f(0x7fc00001u);
@@ -550,14 +554,20 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
                     h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
                 }
                 hc_blend_xy(h.lo, h.hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
+                ab[k] *= hk_(k); cd[k] *= hk_(k);
             }
         }
         float t = 0.f, H = .5f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float fz = az[k] * az[k] * (3.0f - 2.0f * az[k]);
+            const float fz = az[k] * az[k] * tm2_(az[k]);
             const float gz = 1.0f - fz;
-            const float term = (ab[k] * gz + cd[k] * fz) * H;
+            // fbm's `t += noise * H` with H = 2^-(k+1) folded into the kept x/y blends: (ab gz + cd fz) H == (ab H) gz + (cd H) fz
+            // bit for bit — a power-of-two scale commutes with every rounding on the way — unless an intermediate is subnormal,
+            // i.e. below 2^-122; a term that small is either absorbed by the other octaves' terms or, if they are all that
+            // small, t < 2^-98 and d = t * smoothstep(..) underflows to exactly +-0 either way.  One multiply less per octave
+            // and sample (CL_PRESCALE = 0: the scale per sample).
+            const float term = CL_PRESCALE ? (ab[k] * gz + cd[k] * fz) : (ab[k] * gz + cd[k] * fz) * H;
             // fbm's t = 0; t += ...: a blend of hashes in [0, 1) with weights in [0, 1] is >= +0 (or NaN), and 0 + x == x then
             t = (REG && k == 0) ? term : t + term;
             H *= .5f;
@@ -642,8 +652,8 @@ __device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 
         float t = 0.f, H = .5f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float fy = ay[k] * ay[k] * (3.0f - 2.0f * ay[k]);
-            const float fz = az[k] * az[k] * (3.0f - 2.0f * az[k]);
+            const float fy = ay[k] * ay[k] * tm2_(ay[k]);
+            const float fz = az[k] * az[k] * tm2_(az[k]);
             const float gy = 1.0f - fy, gz = 1.0f - fz;
             const float ab = xa[k] * gy + xb[k] * fy;
             const float cd = xc[k] * gy + xd[k] * fy;

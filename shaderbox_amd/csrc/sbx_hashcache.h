@@ -150,9 +150,9 @@ __device__ __forceinline__ void coop_noise_n(WaveCache& S, const v3 (&p)[N], con
     for (int i = 0; i < N; ++i) {
         const float px = floor_(p[i].x), py = floor_(p[i].y), pz = floor_(p[i].z);
         const float ax = p[i].x - px, ay = p[i].y - py, az = p[i].z - pz;
-        fx[i] = ax * ax * (3.0f - 2.0f * ax);
-        fy[i] = ay * ay * (3.0f - 2.0f * ay);
-        fz[i] = az * az * (3.0f - 2.0f * az);
+        fx[i] = ax * ax * tm2_(ax);
+        fy[i] = ay * ay * tm2_(ay);
+        fz[i] = az * az * tm2_(az);
         const float n = px + py * 157.0f + 113.0f * pz;
         nbits[i] = f2u(n);
         slot[i] = (int)n & (HC_SLOTS - 1);

@@ -13,9 +13,9 @@ __device__ __forceinline__ float hash1(float n) { return fract_(sin_(n) * 753.54
 __device__ __forceinline__ float noise_iq(v3 x) {
     const float px = floor_(x.x), py = floor_(x.y), pz = floor_(x.z);
     float fx = x.x - px, fy = x.y - py, fz = x.z - pz;        // fract = x - floor(x)
-    fx = fx * fx * (3.0f - 2.0f * fx);
-    fy = fy * fy * (3.0f - 2.0f * fy);
-    fz = fz * fz * (3.0f - 2.0f * fz);
+    fx = fx * fx * tm2_(fx);
+    fy = fy * fy * tm2_(fy);
+    fz = fz * fz * tm2_(fz);
     const float n = px + py * 157.0f + 113.0f * pz;
     const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
     const float h000 = hash1(n + 0.0f), h100 = hash1(n + 1.0f);
