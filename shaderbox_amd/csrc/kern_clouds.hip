@@ -192,7 +192,12 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, Ro
 // per step, the same operations a lane would do) into a small table that the march reads with scalar loads:
 // the values arrive in SGPRs and ~9 VALU instructions per octave per sample disappear from every lane.
 // The z light march of a lit step (x, y unchanged) uses the same row.
-struct YRow { float4 fy, gy, py157; };     // per march step: 4 octaves each
+struct YRow { float4 fy, gy, py157; };     // per march step: 4 octaves each (fy, gy scaled by the octave's gain, see k_clouds_ytab)
+#ifndef CL_PRESCALE
+#define CL_PRESCALE 1
+#endif
+__device__ __forceinline__ constexpr float hk_(int k) { return CL_PRESCALE ? (k == 0 ? .5f : (k == 1 ? .25f : (k == 2 ? .125f : .0625f))) : 1.0f; }
+
 
 __global__ void __launch_bounds__(64) k_clouds_ytab(FrameClouds F, YRow* __restrict__ tab) {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -212,8 +217,12 @@ __global__ void __launch_bounds__(64) k_clouds_ytab(FrameClouds F, YRow* __restr
         p157[k] = py * 157.0f;
         q = q * 2.64f;
     }
-    tab[i].fy = make_float4(fy[0], fy[1], fy[2], fy[3]);
-    tab[i].gy = make_float4(gy[0], gy[1], gy[2], gy[3]);
+    // The y weights are stored PRE-SCALED by the octave's gain H = 2^-(k+1) (CL_PRESCALE): the y-mixes a gy + b fy then come out
+    // scaled, and with them the octave's term (ab gz + cd fz) H of fbm's `t += noise * H` — bit for bit, because a power-of-two
+    // scale commutes with every rounding on the way (see light_march_z for the subnormal corner) — so neither the main sample nor
+    // the z light march multiplies by H.
+    tab[i].fy = make_float4(fy[0] * hk_(0), fy[1] * hk_(1), fy[2] * hk_(2), fy[3] * hk_(3));
+    tab[i].gy = make_float4(gy[0] * hk_(0), gy[1] * hk_(1), gy[2] * hk_(2), gy[3] * hk_(3));
     tab[i].py157 = make_float4(p157[0], p157[1], p157[2], p157[3]);
 }
 
@@ -317,8 +326,8 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
         }
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
-            hc_blend_xy(lo[k], hi[k], fx[k], rfy[k], rgy[k], mab[k], mcd[k]);
-            t += (mab[k] * (1.0f - fz[k]) + mcd[k] * fz[k]) * H;
+            hc_blend_xy(lo[k], hi[k], fx[k], rfy[k], rgy[k], mab[k], mcd[k]);      // rfy, rgy carry the octave's gain (k_clouds_ytab)
+            t += CL_PRESCALE ? (mab[k] * (1.0f - fz[k]) + mcd[k] * fz[k]) : (mab[k] * (1.0f - fz[k]) + mcd[k] * fz[k]) * H;
             H *= .5f;
         }
     } else {
@@ -332,7 +341,7 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
                 h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
             }
             hc_blend_xy(h.lo, h.hi, fx[k], rfy[k], rgy[k], mab[k], mcd[k]);
-            t += (mab[k] * (1.0f - fz[k]) + mcd[k] * fz[k]) * H;
+            t += CL_PRESCALE ? (mab[k] * (1.0f - fz[k]) + mcd[k] * fz[k]) : (mab[k] * (1.0f - fz[k]) + mcd[k] * fz[k]) * H;
             H *= .5f;
         }
     }
@@ -441,10 +450,6 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 // unsigned compare of az's bits against those of 1.0f replaces v_floor + v_cmp (both half-rate instructions on gfx950,
 // profiles/r02_ubench_issue.txt).  The test is conservative (a fract that rounds up to 1.0 is treated as a move);
 // a move recomputes floor / fract / lookups exactly as the general form does.
-#ifndef CL_PRESCALE
-#define CL_PRESCALE 1
-#endif
-__device__ __forceinline__ constexpr float hk_(int k) { return CL_PRESCALE ? (k == 0 ? .5f : (k == 1 ? .25f : (k == 2 ? .125f : .0625f))) : 1.0f; }
 template <bool YTAB, bool REG>
 __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                WaveCache& S, int lane, const YRow& row, const float (&mfx)[4],
@@ -466,7 +471,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             // of every octave, so the first light sample needs a lookup only where it has left that cell, like every later one
             // (a lit main sample has always evaluated all four octaves).
             curz[k] = CL_SEED ? mpz[k] : u2f(0x7fc00001u);
-            ab[k] = mab[k] * hk_(k); cd[k] = mcd[k] * hk_(k);      // pre-scaled by the octave's gain (CL_PRESCALE, below)
+            ab[k] = mab[k]; cd[k] = mcd[k];                        // already scaled by the octave's gain: the row's fy, gy are
         }
     } else {
         const float nf0 = F.nf;                              // (YTAB = false: .001, or SKY_SPHERE's factor)
@@ -554,7 +559,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
                     h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
                 }
                 hc_blend_xy(h.lo, h.hi, fx[k], fy[k], gy[k], ab[k], cd[k]);
-                ab[k] *= hk_(k); cd[k] *= hk_(k);
+                if (!YTAB) { ab[k] *= hk_(k); cd[k] *= hk_(k); }          // (the table's fy, gy carry the gain already)
             }
         }
         float t = 0.f, H = .5f;
