@@ -5,14 +5,30 @@
 // per pixel, early exit on alpha, the per-step frame constants (FrameCloudsBest::row) read as scalars.
 // Bit-identical to oracle/ref_apps.h AppCloudsBest (same operations in the same order, no contraction).
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include "sbx_device.h"
 
 namespace sbx {
 
-__device__ __forceinline__ float sn_mod289(float x) { return x - floor_(x * (1.0f / 289.0f)) * 289.0f; }   // :460-466
-__device__ __forceinline__ float sn_permute(float x) { return sn_mod289(((x * 34.0f) + 1.0f) * x); }       // :469-471
+// XI ("exact integers", decided on the host per launch: every lattice coordinate of the frame is below 2^22 in magnitude): the
+// simplex noise's index arithmetic works on integer-valued floats, and wherever a product m * c of such values is EXACT
+// (an integer below 2^24) the reference's RN(x -+ RN(m * c)) equals RN(x -+ m * c), which is one fma.  That holds for
+//   mod289(x) = x - floor(x / 289) * 289          (floor(x / 289) * 289 <= |x| + 289 < 2^24)
+//   permute(x) = mod289((x * 34 + 1) * x)         (x < 600: x * 34 < 2^15)
+//   j = p - 49 * floor(..), y_ = floor(j - 7 * x_)  (p < 600)
+// and, for ANY finite value, for f * 2 + 1 (a power-of-two scale is exact) and b + s * sh with sh in {-0, -1}.
+// 51 of the ~250 instructions of a snoise; same bits (the oracle evaluates the plain forms).  Without XI (huge or non-finite
+// coordinates) the plain forms run.
+template <bool XI> __device__ __forceinline__ float sn_mod289(float x) {                                  // :460-466
+    const float q = floor_(x * (1.0f / 289.0f));
+    return XI ? __builtin_fmaf(-289.0f, q, x) : x - q * 289.0f;
+}
+template <bool XI> __device__ __forceinline__ float sn_permute(float x) {                                 // :469-471
+    return sn_mod289<XI>((XI ? __builtin_fmaf(x, 34.0f, 1.0f) : ((x * 34.0f) + 1.0f)) * x);
+}
 
 // snoise :478-551; vec4 quantities are 4 scalars, operations component-wise in source order
+template <bool XI>
 __device__ __forceinline__ float snoise(float vx, float vy, float vz) {
     const float Cx = 1.0f / 6.0f, Cy = 1.0f / 3.0f;
     const float s = (vx * Cy + vy * Cy) + vz * Cy;                         // dot(v, C.yyy)
@@ -26,17 +42,18 @@ __device__ __forceinline__ float snoise(float vx, float vy, float vz) {
     const float x1x = (x0x - i1x) + Cx, x1y = (x0y - i1y) + Cx, x1z = (x0z - i1z) + Cx;
     const float x2x = (x0x - i2x) + Cy, x2y = (x0y - i2y) + Cy, x2z = (x0z - i2z) + Cy;
     const float x3x = x0x - 0.5f, x3y = x0y - 0.5f, x3z = x0z - 0.5f;
-    ix = sn_mod289(ix); iy = sn_mod289(iy); iz = sn_mod289(iz);
+    ix = sn_mod289<XI>(ix); iy = sn_mod289<XI>(iy); iz = sn_mod289<XI>(iz);
     const float oz[4] = {0.0f, i1z, i2z, 1.0f}, oy[4] = {0.0f, i1y, i2y, 1.0f}, ox[4] = {0.0f, i1x, i2x, 1.0f};
     const float n_ = 0.142857142857f;
     const float nsx = n_ * 2.0f - 0.0f, nsy = n_ * 0.5f - 1.0f, nsz = n_ * 1.0f - 0.0f;
     float ax[4], ay[4], h[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float p = sn_permute((sn_permute((sn_permute(iz + oz[k]) + iy) + oy[k]) + ix) + ox[k]);
-        const float j = p - 49.0f * floor_(p * nsz * nsz);
+        const float p = sn_permute<XI>((sn_permute<XI>((sn_permute<XI>(iz + oz[k]) + iy) + oy[k]) + ix) + ox[k]);
+        const float m49 = floor_(p * nsz * nsz);
+        const float j = XI ? __builtin_fmaf(-49.0f, m49, p) : p - 49.0f * m49;
         const float x_ = floor_(j * nsz);
-        const float y_ = floor_(j - 7.0f * x_);
+        const float y_ = floor_(XI ? __builtin_fmaf(-7.0f, x_, j) : j - 7.0f * x_);
         ax[k] = x_ * nsx + nsy;
         ay[k] = y_ * nsx + nsy;
         h[k] = 1.0f - abs_(ax[k]) - abs_(ay[k]);
@@ -45,13 +62,16 @@ __device__ __forceinline__ float snoise(float vx, float vy, float vz) {
     float s0[4], s1[4], sh[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        s0[k] = floor_(b0[k]) * 2.0f + 1.0f;
-        s1[k] = floor_(b1[k]) * 2.0f + 1.0f;
+        s0[k] = __builtin_fmaf(floor_(b0[k]), 2.0f, 1.0f);       // f * 2 is exact: one rounding either way
+        s1[k] = __builtin_fmaf(floor_(b1[k]), 2.0f, 1.0f);
         sh[k] = -step_(h[k], 0.0f);
     }
     // a0 = b0.xzyw + s0.xzyw * sh.xxyy ; a1 = b1.xzyw + s1.xzyw * sh.zzww
-    const float a0x = b0[0] + s0[0] * sh[0], a0y = b0[2] + s0[2] * sh[0], a0z = b0[1] + s0[1] * sh[1], a0w = b0[3] + s0[3] * sh[1];
-    const float a1x = b1[0] + s1[0] * sh[2], a1y = b1[2] + s1[2] * sh[2], a1z = b1[1] + s1[1] * sh[3], a1w = b1[3] + s1[3] * sh[3];
+    // (sh is -0 or -1: s * sh is exact, so b + s * sh is one rounding either way)
+    const float a0x = __builtin_fmaf(s0[0], sh[0], b0[0]), a0y = __builtin_fmaf(s0[2], sh[0], b0[2]);
+    const float a0z = __builtin_fmaf(s0[1], sh[1], b0[1]), a0w = __builtin_fmaf(s0[3], sh[1], b0[3]);
+    const float a1x = __builtin_fmaf(s1[0], sh[2], b1[0]), a1y = __builtin_fmaf(s1[2], sh[2], b1[2]);
+    const float a1z = __builtin_fmaf(s1[1], sh[3], b1[1]), a1w = __builtin_fmaf(s1[3], sh[3], b1[3]);
     v3 p0 = V3(a0x, a0y, h[0]), p1 = V3(a0z, a0w, h[1]), p2 = V3(a1x, a1y, h[2]), p3 = V3(a1z, a1w, h[3]);
     p0 = p0 * (1.79284291400159f - 0.85373472095314f * dot(p0, p0));       // taylorInvSqrt :473-476
     p1 = p1 * (1.79284291400159f - 0.85373472095314f * dot(p1, p1));
@@ -65,6 +85,7 @@ __device__ __forceinline__ float snoise(float vx, float vy, float vz) {
     return 42.0f * ((((m0 * m0) * d0 + (m1 * m1) * d1) + (m2 * m2) * d2) + (m3 * m3) * d3);
 }
 
+template <bool XI>
 __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
@@ -95,7 +116,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, R
             float dens = 0.f, H = .5f;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                dens += abs_(snoise(qx, row.qy[k], qz)) * H;
+                dens = __builtin_fmaf(abs_(snoise<XI>(qx, row.qy[k], qz)), H, dens);   // |n| * 2^-(k+1) is exact: `dens += |n| * H` in one rounding
                 qx = qx * 2.6434f; qz = qz * 2.6434f;
                 H *= .5f;
             }
@@ -115,7 +136,14 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, R
 }
 
 void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_clouds_best, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    // XI: lattice coordinates below 2^22.  x, z: |pos| * .001 <= (|eye| + 20 * 100 + 20 * 50 * |march_step|) * .001, plus the
+    // wind offset, times 2.032 * 2.6434^4 (the finest octave), times 2 (the skew v + dot(v, 1/3)); y: the table's rows.
+    double far = (std::fabs((double)F.cam.eye.x) + std::fabs((double)F.cam.eye.y) + std::fabs((double)F.cam.eye.z) + 2100.0 +
+                  21.0 * CB_STEPS * std::fabs((double)F.march_step)) * .001 + std::fabs((double)F.wind_z);
+    for (int i = 0; i < CB_STEPS; ++i) far = std::fmax(far, std::fabs((double)F.row[i].qy[0]) / 2.032);
+    const bool xi = far * (2.032 * 48.83 * 2.0) < 4194304.0;       // NaN compares false
+    if (xi) hipLaunchKernelGGL(k_clouds_best<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_clouds_best<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

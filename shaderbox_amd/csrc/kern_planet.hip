@@ -38,8 +38,9 @@ __device__ __forceinline__ float band(float t) {                     // band(.2,
 template <int MODE>
 __device__ __forceinline__ float pl_basis(float n) {
     if (MODE == 0) return n;
-    if (MODE == 1) return abs_(n * 2.f - 1.f);
-    return 1.f - abs_(n * 2.f - 1.f);
+    // (n * 2 is exact, so n * 2 - 1 is one rounding: fma(n, 2, -1) has the reference's bits)
+    if (MODE == 1) return abs_(__builtin_fmaf(n, 2.f, -1.f));
+    return 1.f - abs_(__builtin_fmaf(n, 2.f, -1.f));
 }
 template <int OCT, int MODE>
 __device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_gain, float gain) {

@@ -243,3 +243,15 @@ def test_bench_relief_calibration_runs_for_eight_ranks(renderer):
         assert sum(rows) == 540 and rows[0] <= max(rows[1:])
     assert bench.choose_relief("3/4", renderer, FakeDist, torch, dev, "clouds", 960, 540, .37, 8, 8, 0, streams) == (3, 4)
     assert bench.choose_relief("auto", renderer, FakeDist, torch, dev, "clouds", 960, 540, .37, 8, 1, 0, streams) == (1, 1)
+
+
+def test_clouds_best_beyond_the_exact_integer_domain(renderer, oracle):
+    """k_clouds_best's one-fma index arithmetic (XI) needs lattice coordinates below 2^22; wind_z = -u_time * .2 leaves that
+    domain from u_time ~ 1e5 on, where the host launches the plain kernel.  Both sides of the edge, and far beyond, against the
+    oracle."""
+    from oracle.oracle import APP_CLOUDS_BEST
+    w, h = 192, 108
+    for t in (0.0, 2.5, 5e4, 1.0e5, 1.1e5, 3e5, 1e7, 1e12, -1e9, float("inf"), float("nan")):
+        gpu = renderer.render("clouds_best", w, h, t).cpu().numpy()
+        ref = oracle.render(APP_CLOUDS_BEST, w, h, t)
+        assert compare(gpu, ref) == (0.0, 0), t
