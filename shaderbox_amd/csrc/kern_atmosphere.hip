@@ -43,6 +43,7 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #endif
 #define ATM_EXP(x) exp_tab_<true>((x), etab)
 
+// (march_pos + 0.5 * march_step below is written fma(.5, march_step, march_pos): the half is exact, so it is one rounding either way)
 template <bool FIN>
 __device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, const double (&etab)[32]) {   // :50-76
     float t1;
@@ -50,7 +51,7 @@ __device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, 
     float march_pos = 0.f;
     const float march_step = t1 / 8.f;
     for (int i = 0; i < 8; ++i) {
-        const v3 s = ro + rd * (march_pos + 0.5f * march_step);
+        const v3 s = ro + rd * __builtin_fmaf(0.5f, march_step, march_pos);
         const float height = sqrt_n_(dot(s, s)) - ATM_EARTH_R;   // length(s), |s| ~ 6.4e6
         if (height < 0.f) return false;
         odR += ATM_EXP_H(div_by(-height, ATM_HR_RD)) * march_step;
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, Ro
         float odR = 0.f, odM = 0.f, march_pos = 0.f;
         v3 sumR = V3(0, 0, 0), sumM = V3(0, 0, 0);
         for (int i = 0; i < 16; ++i) {
-            const v3 s = ro + rd * (march_pos + 0.5f * march_step);
+            const v3 s = ro + rd * __builtin_fmaf(0.5f, march_step, march_pos);
             const float height = sqrt_n_(dot(s, s)) - ATM_EARTH_R;   // length(s)
             const float hr = ATM_EXP_H(div_by(-height, ATM_HR_RD)) * march_step;
             const float hm = ATM_EXP_H(div_by(-height, ATM_HM_RD)) * march_step;
