@@ -36,7 +36,12 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #ifndef ATM_EXP_REG
 #define ATM_EXP_REG 1      // the density terms through exp_reg_ (sbx_math.h) when the uniforms are finite
 #endif
-#if ATM_EXP_REG
+#ifndef ATM_EXP64
+#define ATM_EXP64 1        // ... in its 64-entry / degree-5 form (exp_reg64_: one binary64 fma less, exhaustively equal on |x| <= 80)
+#endif
+#if ATM_EXP_REG && ATM_EXP64
+#define ATM_EXP_H(x) (FIN ? exp_reg64_<false>((x), etab64) : exp_tab_<true>((x), etab))
+#elif ATM_EXP_REG
 #define ATM_EXP_H(x) (FIN ? exp_reg_<false>((x), etab) : exp_tab_<true>((x), etab))
 #else
 #define ATM_EXP_H(x) exp_tab_<!FIN>((x), etab)
@@ -45,7 +50,7 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 
 // (march_pos + 0.5 * march_step below is written fma(.5, march_step, march_pos): the half is exact, so it is one rounding either way)
 template <bool FIN>
-__device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, const double (&etab)[32]) {   // :50-76
+__device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, const double (&etab)[32], const double* etab64) {   // :50-76
     float t1;
     isect_atmosphere(ro, rd, t1);
     float march_pos = 0.f;
@@ -64,7 +69,9 @@ __device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, 
 template <bool FIN>
 __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
     __shared__ double etab[32];
+    __shared__ double etab64[FIN ? 64 : 1];             // the density terms' table (FIN kernels)
     if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    if (FIN && threadIdx.x < 64) etab64[threadIdx.x] = kExp2Tab64[threadIdx.x];
     __syncthreads();
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
@@ -96,7 +103,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, Ro
             odR += hr;
             odM += hm;
             float lR = 0.f, lM = 0.f;
-            if (sun_light<FIN>(s, F.sun_dir, lR, lM, etab)) {
+            if (sun_light<FIN>(s, F.sun_dir, lR, lM, etab, etab64)) {
                 const v3 tau = betaR * (odR + lR) + betaM * 1.1f * (odM + lM);
                 const v3 att = V3(ATM_EXP(-tau.x), ATM_EXP(-tau.y), ATM_EXP(-tau.z));
                 sumR = sumR + hr * att;

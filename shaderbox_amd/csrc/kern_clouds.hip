@@ -75,7 +75,12 @@ namespace sbx {
 
 // The REG kernels' exp is exp_reg_ of sbx_math.h (|x| <= 80 shown on the host per launch): no range guard, three-address
 // v_fma_f64, power-of-two scaling after the rounding to binary32.  CL_EXP_ASM = 0 falls back to exp_tab_<false>.
-#if CL_EXP_ASM
+#ifndef CL_EXP64
+#define CL_EXP64 1         // REG kernels: the 64-entry / degree-5 form of exp_reg_ (one binary64 fma less; exhaustively equal on |x| <= 80)
+#endif
+#if CL_EXP_ASM && CL_EXP64
+#define CL_EXP_REG(x) exp_reg64_((x), etab)
+#elif CL_EXP_ASM
 #define CL_EXP_REG(x) exp_reg_((x), etab)
 #else
 #define CL_EXP_REG(x) exp_tab_<false>((x), etab)
@@ -454,7 +459,7 @@ template <bool YTAB, bool REG>
 __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                WaveCache& S, int lane, const YRow& row, const float (&mfx)[4],
                                                const float (&mnxy)[4], const float (&mab)[4], const float (&mcd)[4],
-                                               const float (&mpz)[4], const double (&etab)[32], float vsigma, float vdt,
+                                               const float (&mpz)[4], const double* etab, float vsigma, float vdt,
                                                float vcov) {
     float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4], curz[4];
     if (YTAB) {
@@ -601,7 +606,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
 // A sample that leaves a cell looks that octave up in the general form (floor / index / tag check / cooperative insert).
 template <bool REG>
 __device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
-                                                WaveCache& S, int lane, const float (&mfx)[4], const double (&etab)[32],
+                                                WaveCache& S, int lane, const float (&mfx)[4], const double* etab,
                                                 float vsigma, float vdt, float vcov) {
     float xa[4], xb[4], xc[4], xd[4], cy[4], cz[4];
 #pragma unroll
@@ -686,11 +691,21 @@ __global__ void __launch_bounds__(256) k_cl_exp_eval(const float* __restrict__ a
     if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = ASM ? CL_EXP_REG(a[i]) : exp_reg_<false>(a[i], etab);     // k_clouds' form / k_atmosphere's form
+    if (i < n) out[i] = ASM ? exp_reg_<true>(a[i], etab) : exp_reg_<false>(a[i], etab);     // three-address asm form / the compiler's chain
 }
-void launch_cl_exp_eval(const float* a, float* out, size_t n, hipStream_t s, bool plain) {
+template <bool ASM>
+__global__ void __launch_bounds__(256) k_cl_exp64_eval(const float* __restrict__ a, float* __restrict__ out, size_t n) {
+    __shared__ double etab[64];
+    if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = exp_reg64_<ASM>(a[i], etab);
+}
+void launch_cl_exp_eval(const float* a, float* out, size_t n, hipStream_t s, int form) {     // 0 exp_reg asm, 1 plain, 2 / 3 the 64-entry forms
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (plain) hipLaunchKernelGGL(k_cl_exp_eval<false>, grid, block, 0, s, a, out, n);
+    if (form == 1) hipLaunchKernelGGL(k_cl_exp_eval<false>, grid, block, 0, s, a, out, n);
+    else if (form == 2) hipLaunchKernelGGL(k_cl_exp64_eval<true>, grid, block, 0, s, a, out, n);
+    else if (form == 3) hipLaunchKernelGGL(k_cl_exp64_eval<false>, grid, block, 0, s, a, out, n);
     else hipLaunchKernelGGL(k_cl_exp_eval<true>, grid, block, 0, s, a, out, n);
 }
 
@@ -734,10 +749,14 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
     // the fast memory: what the register allocator would otherwise send to scratch when the kernel is held to 96 VGPRs)
     __shared__ float park[CL_TX][CL_PARK_N][64];
 #endif
-    __shared__ double etab[32];                  // exp_'s 2^(j/32) table: per-lane reads come from LDS, not from the vector L1
+    // exp's table: per-lane reads come from LDS, not from the vector L1.  REG kernels: the 64 entries of exp_reg64_ (512 B: 5.8 KB per
+    // wave with the hash tables and the parked state — the 128-entry form's 6.3 KB is one allocation granule more and costs the
+    // sixth wave: 2.62 -> 2.71 ms); the others: exp_'s 32.
+    constexpr int ETAB_N = (REG && CL_EXP64 && CL_EXP_ASM) ? 64 : 32;
+    __shared__ double etab[ETAB_N];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
-    if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    for (int i = threadIdx.x; i < ETAB_N; i += 64 * CL_TX) etab[i] = (ETAB_N == 64) ? kExp2Tab64[i] : kExp2Tab[i];
     if (CL_TX > 1) __syncthreads();
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
 #ifdef SBX_CL_STATS

@@ -244,6 +244,29 @@ __constant__ const double kExp2Tab[32] = {SBX_EXP2_TAB_VALUES};
 #else
 constexpr double kExp2Tab[32] = {SBX_EXP2_TAB_VALUES};
 #endif
+// 2^(j/64), j = 0..63, correctly rounded to binary64 (tools/gen_math_coeffs.py --exp-table 64): the table of exp_reg64_
+#define SBX_EXP2_TAB64_VALUES \
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,  \
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,  \
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,  \
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,  \
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,  \
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,  \
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,  \
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,  \
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,  \
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,  \
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,  \
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,  \
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,  \
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,  \
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,  \
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0
+#if defined(__HIP_DEVICE_COMPILE__)
+__constant__ const double kExp2Tab64[64] = {SBX_EXP2_TAB64_VALUES};
+#else
+constexpr double kExp2Tab64[64] = {SBX_EXP2_TAB64_VALUES};
+#endif
 // exp with the 2^(j/32) table read through `tab` (the __constant__ table, or a copy a kernel keeps in LDS: the per-lane
 // table read is a dependent memory access in every call, ~4x shorter from LDS than from the vector L1)
 // CLAMP = false leaves the binary32 range guard out: only for callers that have shown |x| <= 89 (or x NaN, which the
@@ -309,6 +332,34 @@ __device__ __forceinline__ float exp_reg_(float x, const Tab& tab) {
     p = __builtin_fma(p, r, 1.0);
     const double y = p * tab[ki & 31];
     return __builtin_ldexpf((float)y, ki >> 5);
+}
+// The same with a 64-entry table: x = (k/64) ln2 + r, |r| <= ln2/128, and the degree-5 Taylor polynomial: ONE binary64 fma less
+// per call.  Not the spec (its truncation error r^6/720 <= 3.5e-17 is 10x the degree-6 / 32-entry form's): a kernel-internal form,
+// admitted because tests/test_gpu_round3.py::test_exp_reg64_equals_exp_on_its_whole_domain finds it equal to exp_ on EVERY
+// binary32 argument with |x| <= 80 (2.2e9 values; so is the 128-entry form, which costs k_clouds a wave of occupancy in LDS).
+// `tab` = kExp2Tab64 or a copy in LDS (512 B).
+template <bool ASM = true, class Tab>
+__device__ __forceinline__ float exp_reg64_(float x, const Tab& tab) {
+    const double xd = (double)x;
+    double kd = __builtin_fma(xd, 0x1.71547652b82fep+6, D_MAGIC);          // 64/ln2
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - D_MAGIC;
+    double r = __builtin_fma(kd, -0x1.62e42fefa0000p-7, xd);               // ln2/64, high 38 bits (|k| < 2^13: k * hi exact)
+    r = __builtin_fma(kd, -0x1.cf79abc9e3b3ap-46, r);                      // ln2/64 - high
+    double p, c5 = 0x1.1111111111111p-7;                                     // 1/5!
+    const double c4 = 0x1.5555555555555p-5, c3 = 0x1.5555555555555p-3;       // 1/4!, 1/3!
+    if (ASM) {
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(c5), "v"(r), "v"(c4));
+        p = fma64_3addr(p, r, c3);
+    } else {
+        p = __builtin_fma(c5, r, c4);
+        p = __builtin_fma(p, r, c3);
+    }
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double y = p * tab[ki & 63];
+    return __builtin_ldexpf((float)y, ki >> 6);
 }
 #endif
 // The former pow (atanh-series log2 with a binary64 division, 13-term 2^t), kept as the test hook "pow_h": the table

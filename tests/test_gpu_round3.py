@@ -255,3 +255,24 @@ def test_clouds_best_beyond_the_exact_integer_domain(renderer, oracle):
         gpu = renderer.render("clouds_best", w, h, t).cpu().numpy()
         ref = oracle.render(APP_CLOUDS_BEST, w, h, t)
         assert compare(gpu, ref) == (0.0, 0), t
+
+
+def test_exp_reg64_equals_exp_on_its_whole_domain(renderer):
+    """exp_reg64_ (sbx_math.h: 64-entry table, degree-5 polynomial — one binary64 fma less than the spec's form; with and
+    without the three-address asm) against exp_ of the math spec on EVERY binary32 argument with |x| < 80 — what the REG kernels
+    of APP_CLOUDS (|sigma * dt| <= 80, density in [0, 1)) and APP_ATMOSPHERE's density terms ([-50.1, .001]) can produce."""
+    import torch
+    lim = np.array([80.0], dtype=np.float32).view(np.uint32)[0]
+    chunk = 1 << 26
+    for sign in (0, 0x80000000):
+        for start in range(0, int(lim) + 1, chunk):
+            stop = min(start + chunk, int(lim) + 1)
+            bits = (torch.arange(start, stop, dtype=torch.int64, device="cuda") | sign).to(torch.int32)
+            x = bits.view(torch.float32)
+            b = renderer.math("exp", x)
+            for form in ("exp_reg64", "exp_reg64_plain"):
+                a = renderer.math(form, x)
+                bad = a.view(torch.int32) != b.view(torch.int32)
+                assert not bool(bad.any()), "%s: first mismatch at bits 0x%08x" % (form, int(bits[bad][0].item() & 0xffffffff))
+    nan = torch.tensor([float("nan"), -float("nan")], device="cuda")
+    assert bool(torch.isnan(renderer.math("exp_reg64", nan)).all()) and bool(torch.isnan(renderer.math("exp_reg64_plain", nan)).all())

@@ -138,8 +138,26 @@ def exp_table():
     print("// 1/n!, n = 2..6: " + ", ".join(float.hex(float(1 / mp.factorial(n))) for n in range(2, 7)))
 
 
+def exp_table_n(n):
+    """2^(j/n), j = 0..n-1, correctly rounded to binary64, and n/ln2, ln2/n split as in exp_table(): the constants of exp_reg64_"""
+    import struct
+    tab = [float(mp.mpf(2) ** (mp.mpf(j) / n)) for j in range(n)]
+    c = mp.log(2) / n
+    b = struct.unpack("<Q", struct.pack("<d", float(c)))[0] & ~((1 << 15) - 1)
+    hi = struct.unpack("<d", struct.pack("<Q", b))[0]
+    for i in range(0, n, 4):
+        print("    " + ", ".join(float.hex(v) for v in tab[i:i + 4]) + ",")
+    print("// %d/ln2 = %s ; ln2/%d = %s + %s" % (n, float.hex(float(n / mp.log(2))), n, float.hex(hi), float.hex(float(c - mp.mpf(hi)))))
+
+
 if __name__ == "__main__" and "--exp-table" in __import__("sys").argv:
-    exp_table()
+    a = __import__("sys").argv
+    i = a.index("--exp-table")
+    if i + 1 < len(a) and a[i + 1].isdigit():
+        mp.mp.prec = 200
+        exp_table_n(int(a[i + 1]))
+    else:
+        exp_table()
 
 
 def log2_table():
