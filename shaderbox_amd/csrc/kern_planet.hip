@@ -61,7 +61,7 @@ __device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_
 #ifndef PL_BATCH_DETAIL
 #define PL_BATCH_DETAIL 2   // the 7-octave detail maps of the hit shading (6 per hit pixel)
 #endif
-template <int OCT, int MODE, int START>
+template <int OCT, int MODE, int START, bool XI = false>
 __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacunarity, float& H, float gain, float& t, bool on, int lane) {
     constexpr int B = (OCT == 7) ? PL_BATCH_DETAIL : PL_BATCH;
 #pragma unroll
@@ -70,7 +70,7 @@ __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacuna
             v3 p[B]; int tab[B]; float nz[B];
 #pragma unroll
             for (int i = 0; i < B; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
-            coop_noise_n<B>(S, p, tab, on, lane, nz);
+            coop_noise_n<B, XI>(S, p, tab, on, lane, nz);
 #pragma unroll
             for (int i = 0; i < B; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         } else {
@@ -78,16 +78,16 @@ __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacuna
             v3 p[R > 0 ? R : 1]; int tab[R > 0 ? R : 1]; float nz[R > 0 ? R : 1];
 #pragma unroll
             for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
-            coop_noise_n<(R > 0 ? R : 1)>(S, p, tab, on, lane, nz);
+            coop_noise_n<(R > 0 ? R : 1), XI>(S, p, tab, on, lane, nz);
 #pragma unroll
             for (int i = 0; i < R; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         }
     }
 }
-template <int OCT, int MODE>
+template <int OCT, int MODE, bool XI = false>
 __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, float init_gain, float gain, bool on, int lane) {
     float H = init_gain, t = 0.f;
-    coop_fbm_range<OCT, MODE, 0>(S, q, lacunarity, H, gain, t, on, lane);
+    coop_fbm_range<OCT, MODE, 0, XI>(S, q, lacunarity, H, gain, t, on, lane);
     return t;
 }
 
@@ -110,11 +110,12 @@ __device__ __forceinline__ bool clouds_density(WaveCache& S, v3 pos, float heigh
     const float cov = .29475675f, fuzzy = .0335f;
     v3 q = pos * 3.2343f + V3(.35f, 13.35f, 2.67f);
     float H = .5f, dens = 0.f;
-    coop_fbm_range<2, 1, 0>(S, q, 2.0276f, H, .5f, dens, on, lane);
+    // (SKIP kernels run only for tame frames — sbx_capi.hip tame_time — where every lattice coordinate is a small integer: XI)
+    coop_fbm_range<2, 1, 0, SKIP>(S, q, 2.0276f, H, .5f, dens, on, lane);
     if (SKIP && !wave_any(on && !(dens + .1876f < cov))) return false;
-    coop_fbm_range<3, 1, 2>(S, q, 2.0276f, H, .5f, dens, on, lane);
+    coop_fbm_range<3, 1, 2, SKIP>(S, q, 2.0276f, H, .5f, dens, on, lane);
     if (SKIP && !wave_any(on && !(dens + .06255f < cov))) return false;
-    coop_fbm_range<4, 1, 3>(S, q, 2.0276f, H, .5f, dens, on, lane);
+    coop_fbm_range<4, 1, 3, SKIP>(S, q, 2.0276f, H, .5f, dens, on, lane);
     dens *= SMOOTHSTEP_K(cov, cov + fuzzy, dens);
     dens *= bd;
     // dens is exactly +0 below the coverage edge as well (smoothstep = 0): same identities, skip the two exp
@@ -139,19 +140,19 @@ __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, b
 // sdf_terrain_map / sdf_terrain_map_detail :175-199
 template <int OCT, bool SKIP>
 __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lane) {
-    const float h0 = coop_fbm<OCT, 0>(S, pos * 2.0987f, 2.0244f, .454f, .454f, on, lane);
+    const float h0 = coop_fbm<OCT, 0, SKIP>(S, pos * 2.0987f, 2.0244f, .454f, .454f, on, lane);
     const float n0 = SMOOTHSTEP_K(.35f, 1.f, h0);
     // Second fBm (ridged basis, values in [0, 1]): n1 = smoothstep(.6, 1, h1) is exactly +0 whenever h1 < .6.
     // After the first octave, h1 <= t + (.454^2 + ... + .454^OCT); when that bound is below .6 for every
     // committing lane of the wave the remaining octaves cannot change n1 = +0 and are not evaluated.
     v3 q = pos * 1.50987f + V3(1.9489f, 2.435f, .5483f);
     float H = .454f, h1 = 0.f;
-    coop_fbm_range<1, 2, 0>(S, q, 2.0244f, H, .454f, h1, on, lane);
+    coop_fbm_range<1, 2, 0, SKIP>(S, q, 2.0244f, H, .454f, h1, on, lane);
     constexpr float TAIL = (OCT == 3) ? .2998f : .3745f;       // sum of .454^k, k = 2..OCT, rounded up (OCT = 3 or 7)
     static_assert(OCT == 3 || OCT == 7, "tail bound tabulated for 3 and 7 octaves");
     float n1 = 0.f;
     if (!SKIP || wave_any(on && !(h1 + TAIL * 1.0001f < .6f))) {
-        coop_fbm_range<OCT, 2, 1>(S, q, 2.0244f, H, .454f, h1, on, lane);
+        coop_fbm_range<OCT, 2, 1, SKIP>(S, q, 2.0244f, H, .454f, h1, on, lane);
         n1 = SMOOTHSTEP_K(.6f, 1.f, h1);
     }
     const float n = n0 + n1;

@@ -137,7 +137,10 @@ __device__ __forceinline__ void hc_init(WaveCache& S, int lane) {
 // table, the insert that serves evaluation i could evict a cell evaluation j > i had seen present, and j would then read
 // another cell's hashes without looking at the tag again.  The callers pass (base + i) & 3 with N <= 4, or {0, 1, 2, 3};
 // the static_assert below holds N to the number of tables, the distinctness is the callers' contract.
-template <int N>
+// XI ("exact integers"): the caller guarantees lattice coordinates so small that n = px + 157 py + 113 pz is an integer below
+// 2^24 at every step (APP_PLANET: |p| <= 145 in the finest octave).  Both products are then exact, the reference's
+// RN(RN(px + RN(157 py)) + RN(113 pz)) has no rounding at all, and two fmas return the same integer.
+template <int N, bool XI = false>
 __device__ __forceinline__ void coop_noise_n(WaveCache& S, const v3 (&p)[N], const int (&tab)[N], bool active, int lane,
                                              float (&out)[N]) {
     static_assert(N >= 1 && N <= 4, "one table per evaluation: at most four per batch");
@@ -153,7 +156,7 @@ __device__ __forceinline__ void coop_noise_n(WaveCache& S, const v3 (&p)[N], con
         fx[i] = ax * ax * tm2_(ax);
         fy[i] = ay * ay * tm2_(ay);
         fz[i] = az * az * tm2_(az);
-        const float n = px + py * 157.0f + 113.0f * pz;
+        const float n = XI ? __builtin_fmaf(113.0f, pz, __builtin_fmaf(py, 157.0f, px)) : px + py * 157.0f + 113.0f * pz;
         nbits[i] = f2u(n);
         slot[i] = (int)n & (HC_SLOTS - 1);
         ne[i] = (S.tag[tab[i]][slot[i]] != nbits[i]);
