@@ -20,8 +20,8 @@ N > 1 : one process per GPU (torch.distributed / RCCL).  `python bench.py --gpus
         rank renders its blocks, ONE exchange over xGMI brings the slabs to rank 0, and one small kernel scatters them to
         their rows.  Total work is fixed -> "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
         The line also carries `phases` (per rank: render_ms / exchange_wait_ms / assemble_ms of serial frames timed with
-        events after the timed region) and `steady_state` (frames between the completion of the first and the last
-        timed frame on rank 0: the pipeline's rate without the un-overlapped tail of the last frame).
+        events after the timed region) and `steady_state` (the frames completed between the end of the first burst of
+        `frames_in_flight` frames and the start of the last one, rank 0: the pipeline's rate without ramp-in and drain).
 
 Extra objects on the JSON line (N = 1 unless noted):
   roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel of HBM traffic),
@@ -277,14 +277,11 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    step_done = [None, None]                 # completion of the first and of the last timed frame (events, rank 0's view)
+    step_done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]     # completion of every timed frame
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-        if i == 0 or i == args.steps - 1:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record(streams[i % ns])
-            step_done[0 if i == 0 else 1] = ev
+        step_done[i].record(streams[i % ns])
     sync()
     elapsed = time.perf_counter() - t0
     # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region, one launch at a time,
@@ -325,12 +322,7 @@ def main():
         roofline, roofline_hbm = rooflines(app, launch_pixels, W * H, kmean, min(kernel_ms), pmc)
         if roofline is not None and use_dist:
             roofline["rank"] = "slowest (max over ranks of the un-overlapped launch duration; %d pixels)" % launch_pixels
-        if step_done[0] is not None and args.steps > 1:
-            span_ms = step_done[0].elapsed_time(step_done[1])
-            steady = {"value": round(pixels * (args.steps - 1) / (span_ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
-                      "ms_per_step": round(span_ms / (args.steps - 1), 4),
-                      "what": "rank 0: %d frames between the completion of the first and of the last timed frame (the last "
-                              "frame's un-overlapped drain / exchange / assembly tail is the same in both, i.e. excluded)" % (args.steps - 1)}
+        steady = steady_state(step_done, ns, pixels)
         out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(value, 3),
                "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
@@ -421,14 +413,11 @@ def bench_lib(args):
     for i in range(args.warmup):
         step(i)
     sync()
-    step_done = [None, None]
+    step_done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-        if i == 0 or i == args.steps - 1:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record(streams[i % ns])
-            step_done[0 if i == 0 else 1] = ev
+        step_done[i].record(streams[i % ns])
     sync()
     elapsed = time.perf_counter() - t0
     R = shaderbox_amd.Renderer(devices[0])
@@ -451,12 +440,7 @@ def bench_lib(args):
     if roofline is not None:
         roofline["rank"] = "slowest (rank %d: %d rows), one un-overlapped launch on device %d" % (slow, rows[slow], devices[0])
     ms_per_step = elapsed * 1e3 / args.steps
-    steady = None
-    if step_done[1] is not None and args.steps > 1:
-        span_ms = step_done[0].elapsed_time(step_done[1])
-        steady = {"value": round(W * H * (args.steps - 1) / (span_ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
-                  "ms_per_step": round(span_ms / (args.steps - 1), 4),
-                  "what": "%d frames between the completion of the first and of the last timed frame" % (args.steps - 1)}
+    steady = steady_state(step_done, ns, W * H)
     out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(W * H / (ms_per_step * 1e-3) / 1e6, 3),
            "unit": "Mpixels/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -480,6 +464,23 @@ def bench_lib(args):
     claim_stdout()(json.dumps(out))
     M.close()
     return status
+
+
+def steady_state(step_done, ns, pixels):
+    """The pipeline's rate without its ramp-in and its drain: with ns frames in flight the frames complete in bursts of about
+    ns (they share the GPU), the first burst ends at ~ns frame times and the last burst drains on an emptying chip, so the
+    rate is taken between the end of the first burst (frame ns - 1) and the frame ns before the last one."""
+    K = len(step_done)
+    i1, i2 = ns - 1, K - 1 - ns
+    if i2 - i1 < 2:
+        return None
+    span_ms = step_done[i1].elapsed_time(step_done[i2])
+    if not span_ms > 0:
+        return None
+    return {"value": round(pixels * (i2 - i1) / (span_ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
+            "ms_per_step": round(span_ms / (i2 - i1), 4),
+            "what": "rank 0: the %d frames completed between timed frame %d and timed frame %d (events on the frames' streams): "
+                    "neither the ramp-in of the first %d frames nor the drain of the last %d is in it" % (i2 - i1, i1, i2, ns, ns)}
 
 
 def parity(gpu, ref, nrows):

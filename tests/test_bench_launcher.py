@@ -47,7 +47,7 @@ def test_under_torchrun_uses_the_given_ranks():
 
 @pytest.mark.gpu
 def test_bench_line_contract_and_parity():
-    r, line = run_bench("--steps", "3", "--warmup", "1", "--width", "640", "--height", "360", "--pmc", "off", "--cpu-row-stride", "8")
+    r, line = run_bench("--steps", "10", "--warmup", "1", "--width", "640", "--height", "360", "--pmc", "off", "--cpu-row-stride", "8")
     assert r.returncode == 0, r.stderr[-2000:]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_speed", "parity", "serial", "other_configs"):
@@ -68,7 +68,7 @@ def test_bench_line_contract_and_parity():
 @pytest.mark.gpu
 def test_bench_multi_gpu_code_path_on_one_gpu():
     """--force-dist runs render_rank + RCCL gather + assemble with one rank; the record carries the frame comparison"""
-    r, line = run_bench("--force-dist", "--steps", "3", "--warmup", "1", "--width", "640", "--height", "360")
+    r, line = run_bench("--force-dist", "--steps", "10", "--warmup", "1", "--width", "640", "--height", "360")
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 1 and line["parity"]["mismatching_pixels"] == 0 and line["parity"]["rows"] == 360
     # the N > 1 line: per-rank phases, the steady-state rate beside the strict value, a roofline and the CPU baseline (VERDICT r2)
@@ -83,7 +83,7 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
 @pytest.mark.gpu
 def test_bench_library_engine_on_one_gpu():
     """--engine lib: one process, the N-rank schedule of sbx_multi_* (ranks share the device on a 1-GPU box)"""
-    r, line = run_bench("--gpus", "4", "--engine", "lib", "--steps", "4", "--warmup", "1", "--width", "640", "--height", "360")
+    r, line = run_bench("--gpus", "4", "--engine", "lib", "--steps", "10", "--warmup", "1", "--width", "640", "--height", "360")
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 4 and line["parity"]["mismatching_pixels"] == 0 and "sbx_multi" in line["config"]["engine"]
     assert line["steady_state"]["value"] > 0 and line["cpu_baseline"]["value"] > 0 and line["roofline"]["bound"] == "valu"
