@@ -268,14 +268,14 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
         float vcov = F.cov, vsig = F.sigma, vdt = F.dt;
         asm volatile("" : "+v"(fs1), "+v"(fs2), "+v"(m1), "+v"(m2), "+v"(vcov), "+v"(vsig), "+v"(vdt));   // VGPR-resident (full-rate operands)
         const float lim = fmin_(1073741824.0f / T1.fsize, 1073741824.0f / T2.fsize) * .5f;
-        // YT: the fast filter's range test once per pixel instead of once per step — x and z of the march are monotone in t, so
-        // both ends inside (with the light march's reach in z) puts every sample inside; y is the table's (checked on the host)
+        // YT: the fast filter's range test once per pixel instead of once per step — |origin| + reach bounds every sample of the
+        // march (either sign of dt) and of its light march in z; y is the table's (checked on the host)
         bool fast_all = false;
         if (YT) {
             const float tend = (float)F.steps * abs_(F.dt) * 1.001f;
             const float zreach = (float)(F.lsteps + 1) * abs_(lstep.z);
-            const float ex = fmax_(abs_(origin.x), abs_(origin.x + tend * projection.x)) + tend * 1e-3f;
-            const float ez = fmax_(abs_(origin.z), abs_(origin.z + tend * projection.z)) + zreach + tend * 1e-3f;
+            const float ex = abs_(origin.x) + tend * abs_(projection.x) * 1.001f;           // |origin + t proj| for any t in [-tend, tend]
+            const float ez = abs_(origin.z) + tend * abs_(projection.z) * 1.001f + zreach;
             fast_all = !tex_wave_any(!(ex * .001f < lim * .5f) || !(ez * .001f < lim * .5f));
         }
         float transmittance = 1.f, radiance = 0.f, alpha = 0.f, t = 0.f;
