@@ -60,6 +60,7 @@
 #ifndef CL_MAX3
 #define CL_MAX3 1
 #endif
+
 #ifndef CL_MIN_WAVES_YZ
 #define CL_MIN_WAVES_YZ 5    // the instantiations with the y-z light march
 #endif
@@ -391,7 +392,9 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
     float lip_inv = 0.f;
     if (LIP) lip_inv = *lip_slot;                        // 1 / c of this lane, kept in LDS (read early, used after the first stage)
     row_octaves<0, 2>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
-    if (!wave_any_mask(active_mask & wave_mask(!(t + .1876f < F.cov)))) {                // NaN compares false: goes on
+    // (t + .1876 < cov written as t < cov - .1876 with the right side a frame constant: one instruction; the 1e-4 of slack over
+    //  .1875 covers the half ulp by which the two forms can differ, and a skipped sample is exactly 0 either way)
+    if (!wave_any_mask(active_mask & wave_mask(!(t < F.thr1)))) {                        // NaN compares false: goes on
         if (LIP) {
             float c = F.cov;
             asm volatile("" : "+v"(c));                  // (keeps cov - .1886 from being hoisted into a register held for the whole march)
@@ -411,7 +414,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
     if (lane == 0) S.stat[4] += 1.f;
 #endif
     row_octaves<2, 3>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
-    if (!wave_any_mask(active_mask & wave_mask(!(t + .06255f < F.cov)))) {
+    if (!wave_any_mask(active_mask & wave_mask(!(t < F.thr2)))) {
 #if CL_LIPSKIP2
         if (LIP) {
             // the same proof one octave further: s3 = s + .125 N(q2) moves by at most j * 1.5 * (.5 + .25 * 2.64 + .125 * 2.64^2) D
@@ -981,6 +984,8 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
                    bool build_table) {
     FrameClouds F = F_in;
     F.lip_ok = clouds_lip_domain(F) ? 1 : 0;
+    F.thr1 = F.cov - .1876f;                                     // coop_density_row's stage cut-offs
+    F.thr2 = F.cov - .06255f;
     const bool reg = clouds_regular(F);
     const dim3 grid = grid_for<CL_TW, CL_TX>(M), block(64 * CL_TX);
 #ifdef SBX_CL_OCC_SWEEP

@@ -92,6 +92,7 @@ static FrameClouds build_clouds(const sbx_uniforms& U, const sbx_aux_clouds& A, 
     F.cov_hi = F.cov + .0135f;                                         // :84
     F.cov_rd = recip64(F.cov_hi - F.cov);
     F.lip_ok = 0;                                                      // decided per launch (launch_clouds)
+    F.thr1 = F.thr2 = 0.f;                                             // set per launch (launch_clouds)
     // SKY_SPHERE (:8,14-19,154-162)
     F.sky = sky_sphere ? 1 : 0;
     F.atm_y = A.atm_ground_y;
