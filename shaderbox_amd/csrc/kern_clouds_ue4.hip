@@ -13,6 +13,9 @@
 #ifndef SBX_HC_SLOTS
 #define SBX_HC_SLOTS 32
 #endif
+#ifndef SBX_WG_WAVES
+#define SBX_WG_WAVES 1        // single-wave workgroups (one hash cache per wave, waves never talk): 1.78 -> 1.76 ms at 4K
+#endif
 #include "sbx_device.h"
 #include "sbx_noise.h"
 #include "sbx_hashcache.h"
