@@ -266,7 +266,7 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            t += hc_blend(lo[k], hi[k], fx[k], fy[k], fz[k]) * H;
+            t = __builtin_fmaf(hc_blend(lo[k], hi[k], fx[k], fy[k], fz[k]), H, t);    // noise * 2^-(k+1) is exact: `t += noise * H` in one rounding
             H *= .5f;
         }
     } else {
@@ -279,7 +279,7 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
                 h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
                 h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
             }
-            t += hc_blend(h.lo, h.hi, fx[k], fy[k], fz[k]) * H;
+            t = __builtin_fmaf(hc_blend(h.lo, h.hi, fx[k], fy[k], fz[k]), H, t);
             H *= .5f;
         }
     }
@@ -670,8 +670,9 @@ __device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 
             const float gy = 1.0f - fy, gz = 1.0f - fz;
             const float ab = xa[k] * gy + xb[k] * fy;
             const float cd = xc[k] * gy + xd[k] * fy;
-            const float term = (ab * gz + cd * fz) * H;
-            t = (REG && k == 0) ? term : t + term;         // 0 + x == x for x >= +0 or NaN (see light_march_z)
+            const float nz = ab * gz + cd * fz;
+            t = (REG && k == 0) ? nz * H : __builtin_fmaf(nz, H, t);   // 0 + x == x for x >= +0 or NaN (see light_march_z); noise * 2^-(k+1)
+                                                                       // is exact, so `t += noise * H` is one rounding: an fma
             H *= .5f;
         }
         if (REG) {
