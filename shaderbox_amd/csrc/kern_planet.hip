@@ -191,6 +191,9 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
 #ifndef PL_MIN_WAVES
 #define PL_MIN_WAVES 5
 #endif
+#ifndef PL_TW
+#define PL_TW 8              // wave tile PL_TW x 64/PL_TW pixels
+#endif
 #ifndef PL_PARK
 #define PL_PARK 1          // the hit shading's state waits in LDS while the 6 detail terrain maps run
 #endif
@@ -210,7 +213,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
     hc_init(S, lane);
-    const Pixel px = pixel_of_thread(M);
+    const Pixel px = pixel_of_thread<PL_TW>(M);
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
 
@@ -365,8 +368,8 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
 }
 
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant) {
-    if (variant == 1) hipLaunchKernelGGL(k_planet<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
-    else hipLaunchKernelGGL(k_planet<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    if (variant == 1) hipLaunchKernelGGL(k_planet<false>, grid_for<PL_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_planet<true>, grid_for<PL_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx
