@@ -609,13 +609,22 @@ def run_pmc_pass(counters, app, W, H, t, outdir, timeout=100):
 
 
 def pmc_committed(app, W, H):
-    """the committed per-launch counters of this config (profiles/<round>_pmc_<app>_<W>x<H>.json), or None"""
+    """the committed per-launch counters of this app (profiles/<round>_pmc_<app>_<W>x<H>.json): the file of this very frame
+    size if there is one, else any size's (the instruction count PER PIXEL is resolution independent to < 1 %, SURVEY.md 8d);
+    'frame_pixels' says which frame the counters belong to.  None if there is none."""
+    import glob
+    import re
     for rnd in (PMC_ROUND, "r02"):
-        path = os.path.join(ROOT, "profiles", "%s_pmc_%s_%dx%d.json" % (rnd, app, W, H))
-        if os.path.exists(path):
+        exact = os.path.join(ROOT, "profiles", "%s_pmc_%s_%dx%d.json" % (rnd, app, W, H))
+        paths = [exact] if os.path.exists(exact) else sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_pmc_%s_*x*.json" % (rnd, app))))
+        for path in paths:
+            m = re.search(r"_(\d+)x(\d+)\.json$", path)
+            if not m:
+                continue
             got = json.load(open(path))
             got["source"] = "committed: profiles/" + os.path.basename(path)
             got["committed"] = True
+            got["frame_pixels"] = int(m.group(1)) * int(m.group(2))
             return got
     return None
 
@@ -665,6 +674,7 @@ def rooflines(app, launch_pixels, frame_pixels, kmean_ms, kmin_ms, pmc):
                                           "the reference algorithm for the same bits, so it may exceed 1)"}
     if not pmc or "SQ_INSTS_VALU" not in pmc:
         return r, roofline_hbm
+    frame_pixels = pmc.get("frame_pixels", frame_pixels)       # (a committed file may be of another frame size)
     scale = launch_pixels / float(frame_pixels)                  # counters are per FULL-frame launch
     insts = pmc["SQ_INSTS_VALU"] * scale
     r["valu_insts_per_launch"] = round(insts)
