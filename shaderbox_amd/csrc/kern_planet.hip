@@ -64,12 +64,42 @@ __device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_
 #ifndef PL_BATCH
 #define PL_BATCH 2          // octaves fetched per cooperative batch: 4 at a time (round 1) peaked at 32 hash registers and spilled
 #endif
+#ifndef PL_ROLL_DETAIL
+#define PL_ROLL_DETAIL 1
+#endif
 #ifndef PL_BATCH_DETAIL
 #define PL_BATCH_DETAIL 2   // the 7-octave detail maps of the hit shading (6 per hit pixel)
 #endif
 template <int OCT, int MODE, int START, bool XI = false>
 __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacunarity, float& H, float gain, float& t, bool on, int lane) {
     constexpr int B = (OCT == 7) ? PL_BATCH_DETAIL : PL_BATCH;
+#if PL_ROLL_DETAIL
+    if (OCT == 7) {
+        // the 7-octave detail maps as a REAL loop over their batches (same operations in the same order): unrolled, the six maps of
+        // the hit shading are ~40 KB of straight-line code that the scheduler interleaves across octaves — the spills of the kernel
+        constexpr int NB = (OCT - START) / B;
+#pragma unroll 1
+        for (int b = 0; b < NB; ++b) {
+            const int base = START + b * B;
+            v3 p[B]; int tab[B]; float nz[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
+            coop_noise_n<B, XI>(S, p, tab, on, lane, nz);
+#pragma unroll
+            for (int i = 0; i < B; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
+        }
+        constexpr int R = (OCT - START) % B;
+        if (R > 0) {
+            v3 p[R > 0 ? R : 1]; int tab[R > 0 ? R : 1]; float nz[R > 0 ? R : 1];
+#pragma unroll
+            for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (START + NB * B + i) & 3; q = q * lacunarity; }
+            coop_noise_n<(R > 0 ? R : 1), XI>(S, p, tab, on, lane, nz);
+#pragma unroll
+            for (int i = 0; i < R; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int base = START; base < OCT; base += B) {
         if (base + B <= OCT) {
