@@ -79,7 +79,16 @@ namespace sbx {
 #ifndef CL_EXP64
 #define CL_EXP64 1         // REG kernels: the 64-entry / degree-5 form of exp_reg_ (one binary64 fma less; exhaustively equal on |x| <= 80)
 #endif
-#if CL_EXP_ASM && CL_EXP64
+#ifndef CL_EXP_SMALL
+#define CL_EXP_SMALL 1     // the SM instantiations (REG kernels with the y table, z-only or general light march): exp_small_ (no reduction, no
+#endif                     // table: 10 half-rate instructions instead of 17) on frames whose exp arguments all lie in [-0.205, -0] (decided per
+                           // launch, launch_clouds; the default frame's reach -0.1758): 3840x2160 2.637 -> 2.527 ms, same bits
+#ifndef CL_EXP_SMALL_ASM
+#define CL_EXP_SMALL_ASM 1
+#endif
+#if CL_EXP_ASM && CL_EXP64 && CL_EXP_SMALL
+#define CL_EXP_REG(x) (SM ? exp_small_<CL_EXP_SMALL_ASM != 0>(x) : exp_reg64_((x), etab))     // SM: a template parameter in scope
+#elif CL_EXP_ASM && CL_EXP64
 #define CL_EXP_REG(x) exp_reg64_((x), etab)
 #elif CL_EXP_ASM
 #define CL_EXP_REG(x) exp_reg_((x), etab)
@@ -458,7 +467,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 // unsigned compare of az's bits against those of 1.0f replaces v_floor + v_cmp (both half-rate instructions on gfx950,
 // profiles/r02_ubench_issue.txt).  The test is conservative (a fract that rounds up to 1.0 is treated as a move);
 // a move recomputes floor / fract / lookups exactly as the general form does.
-template <bool YTAB, bool REG>
+template <bool YTAB, bool REG, bool SM>
 __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                WaveCache& S, int lane, const YRow& row, const float (&mfx)[4],
                                                const float (&mnxy)[4], const float (&mab)[4], const float (&mcd)[4],
@@ -611,6 +620,7 @@ template <bool REG>
 __device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                 WaveCache& S, int lane, const float (&mfx)[4], const double* etab,
                                                 float vsigma, float vdt, float vcov) {
+    constexpr bool SM = false;          // (exp_small_ here: 24 -> 36 B of scratch at this kernel's 96 registers and 3.79 -> 3.86 ms)
     float xa[4], xb[4], xc[4], xd[4], cy[4], cz[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { cy[k] = cz[k] = u2f(0x7fc00001u); xa[k] = xb[k] = xc[k] = xd[k] = 0.f; }
@@ -705,9 +715,16 @@ __global__ void __launch_bounds__(256) k_cl_exp64_eval(const float* __restrict__
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = exp_reg64_<ASM>(a[i], etab);
 }
-void launch_cl_exp_eval(const float* a, float* out, size_t n, hipStream_t s, int form) {     // 0 exp_reg asm, 1 plain, 2 / 3 the 64-entry forms
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (form == 1) hipLaunchKernelGGL(k_cl_exp_eval<false>, grid, block, 0, s, a, out, n);
+template <bool ASM>
+__global__ void __launch_bounds__(256) k_cl_exp_small_eval(const float* __restrict__ a, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = exp_small_<ASM>(a[i]);
+}
+void launch_cl_exp_eval(const float* a, float* out, size_t n, hipStream_t s, int form) {     // 0 exp_reg asm, 1 plain, 2 / 3 the 64-entry forms,
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);                                // 4 / 5 exp_small_
+    if (form == 4) hipLaunchKernelGGL(k_cl_exp_small_eval<true>, grid, block, 0, s, a, out, n);
+    else if (form == 5) hipLaunchKernelGGL(k_cl_exp_small_eval<false>, grid, block, 0, s, a, out, n);
+    else if (form == 1) hipLaunchKernelGGL(k_cl_exp_eval<false>, grid, block, 0, s, a, out, n);
     else if (form == 2) hipLaunchKernelGGL(k_cl_exp64_eval<true>, grid, block, 0, s, a, out, n);
     else if (form == 3) hipLaunchKernelGGL(k_cl_exp64_eval<false>, grid, block, 0, s, a, out, n);
     else hipLaunchKernelGGL(k_cl_exp_eval<true>, grid, block, 0, s, a, out, n);
@@ -744,7 +761,7 @@ __device__ __forceinline__ v3 clouds_sky(const FrameClouds& F, v3 dir) {
 struct ClArgs { FrameClouds F; RowMap M; float* out; const YRow* ytab; };
 // LM, the light march (decided on the host from L * dt): 1 = no x and no y component (light_march_z), 2 = no x component
 // (light_march_yz; YTAB kernels only), 0 = general (coop_density per light sample)
-template <bool YTAB, bool REG, int LM>
+template <bool YTAB, bool REG, int LM, bool SM = false>   // SM: exp_small_ (launch_clouds: the frame's exp arguments lie in its domain)
 __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN)) ? CL_MIN_WAVES : (LM == 2 ? CL_MIN_WAVES_YZ : CL_MIN_WAVES_GEN)) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out_arg,
                                                           const YRow* __restrict__ ytab) {
     __shared__ WaveCache cache[CL_TX];
@@ -756,11 +773,11 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
     // exp's table: per-lane reads come from LDS, not from the vector L1.  REG kernels: the 64 entries of exp_reg64_ (512 B: 5.8 KB per
     // wave with the hash tables and the parked state — the 128-entry form's 6.3 KB is one allocation granule more and costs the
     // sixth wave: 2.62 -> 2.71 ms); the others: exp_'s 32.
-    constexpr int ETAB_N = (REG && CL_EXP64 && CL_EXP_ASM) ? 64 : 32;
+    constexpr int ETAB_N = SM ? 1 : (REG && CL_EXP64 && CL_EXP_ASM) ? 64 : 32;       // (exp_small_ reads no table)
     __shared__ double etab[ETAB_N];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
-    for (int i = threadIdx.x; i < ETAB_N; i += 64 * CL_TX) etab[i] = (ETAB_N == 64) ? kExp2Tab64[i] : kExp2Tab[i];
+    if (!SM) for (int i = threadIdx.x; i < ETAB_N; i += 64 * CL_TX) etab[i] = (ETAB_N == 64) ? kExp2Tab64[i] : kExp2Tab[i];
     if (CL_TX > 1) __syncthreads();
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
 #ifdef SBX_CL_STATS
@@ -872,7 +889,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
                         asm volatile("" ::: "memory");     // the reloads below cannot be forwarded from these stores: the values
                                                            // are dead across the light march
 #endif
-                        if (LM == 1) ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
+                        if (LM == 1) ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
                         else ltrans = light_march_yz<REG>(F, lp, lstep, lit, lit_mask, S, lane, mfx, etab, vsigma, vdt, vcov);
 #if CL_PARK
                         asm volatile("" ::: "memory");
@@ -985,6 +1002,9 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
                    bool build_table) {
     FrameClouds F = F_in;
     F.lip_ok = clouds_lip_domain(F) ? 1 : 0;
+    // exp_small_'s domain: x = -density * sigma * dt with 0 <= density <= .9375 (1 + 1e-6) (a blend of hashes in [0, 1] with weights
+    // in [0, 1], gains .5 + .25 + .125 + .0625, times a smoothstep in [0, 1]) lies in [-.205, -0] when sigma, dt >= 0 and:
+    F.exp_small = (F.sigma >= 0.f && F.dt >= 0.f && .94 * (double)F.sigma * (double)F.dt <= .2049) ? 1 : 0;   // NaN: 0
     F.thr1 = F.cov - .1876f;                                     // coop_density_row's stage cut-offs
     F.thr2 = F.cov - .06255f;
     const bool reg = clouds_regular(F);
@@ -1006,8 +1026,11 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
         YRow* tab = reinterpret_cast<YRow*>(ytab);
         if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
         const YRow* ct = tab;
-        if (reg && zl) hipLaunchKernelGGL((k_clouds<true, true, 1>), grid, block, pad, s, F, M, out, ct);
+        const bool sm = F.exp_small && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
+        if (reg && zl && sm) hipLaunchKernelGGL((k_clouds<true, true, 1, true>), grid, block, pad, s, F, M, out, ct);
+        else if (reg && zl) hipLaunchKernelGGL((k_clouds<true, true, 1>), grid, block, pad, s, F, M, out, ct);
         else if (reg && yz) hipLaunchKernelGGL((k_clouds<true, true, 2>), grid, block, 0, s, F, M, out, ct);
+        else if (reg && sm) hipLaunchKernelGGL((k_clouds<true, true, 0, true>), grid, block, 0, s, F, M, out, ct);
         else if (reg) hipLaunchKernelGGL((k_clouds<true, true, 0>), grid, block, 0, s, F, M, out, ct);
         else if (zl) hipLaunchKernelGGL((k_clouds<true, false, 1>), grid, block, 0, s, F, M, out, ct);
         else if (yz) hipLaunchKernelGGL((k_clouds<true, false, 2>), grid, block, 0, s, F, M, out, ct);

@@ -91,6 +91,8 @@ struct FrameClouds {
     float thr1, thr2;     // cov - .1876, cov - .06255: the staged main sample's two cut-offs (launch_clouds)
     int lip_ok;           // 1: the march positions are small enough for k_clouds' Lipschitz sample skip (set per launch by
                           //    launch_clouds / clouds_lip_domain; 0 disables the skip, nothing else)
+    int exp_small;        // 1: every exp argument of the REG kernels lies in [-0.205, -0] (sigma, dt >= 0, .94 sigma dt <= .205): they
+                          //    use exp_small_ of sbx_math.h instead of exp_reg64_ (set per launch by launch_clouds; same bits)
     // SKY_SPHERE build (app_clouds.h:8,14-19,154-162; SBX_APP_CLOUDS_SKY): the march starts where the view ray meets a sphere
     // around the viewer (intersect_sphere_from_inside) and runs along the view ray itself; the table-less kernels only
     int sky;              // 1: SKY_SPHERE

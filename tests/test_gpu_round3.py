@@ -257,6 +257,47 @@ def test_clouds_best_beyond_the_exact_integer_domain(renderer, oracle):
         assert compare(gpu, ref) == (0.0, 0), t
 
 
+def test_exp_small_equals_exp_on_its_whole_domain(renderer):
+    """exp_small_ (sbx_math.h: degree-8 minimax polynomial, no argument reduction, no table; with and without the three-address
+    asm) against exp_ of the math spec on EVERY binary32 argument in [-0.205, -0] and at +0 — what k_clouds' REG kernels can
+    produce when launch_clouds sets F.exp_small (sigma, dt >= 0, .94 sigma dt <= .2049; density in [0, .9375 (1 + 1e-6)])."""
+    import torch
+    lim = int(np.array([0.205], dtype=np.float32).view(np.uint32)[0])
+    chunk = 1 << 26
+    for start in range(0, lim + 1, chunk):
+        stop = min(start + chunk, lim + 1)
+        bits = (torch.arange(start, stop, dtype=torch.int64, device="cuda") | 0x80000000).to(torch.int32)
+        x = bits.view(torch.float32)
+        b = renderer.math("exp", x)
+        for form in ("exp_small", "exp_small_plain"):
+            a = renderer.math(form, x)
+            bad = a.view(torch.int32) != b.view(torch.int32)
+            assert not bool(bad.any()), "%s: first mismatch at bits 0x%08x" % (form, int(bits[bad][0].item() & 0xffffffff))
+    edge = torch.tensor([0.0, -0.0, -0.205, float("nan")], device="cuda")
+    for form in ("exp_small", "exp_small_plain"):
+        a, b = renderer.math(form, edge), renderer.math("exp", edge)
+        assert bool((a[:3].view(torch.int32) == b[:3].view(torch.int32)).all()) and bool(torch.isnan(a[3]))
+
+
+def test_clouds_exp_small_domain_edges(renderer, oracle):
+    """sigma * dt on both sides of exp_small_'s bound (.94 sigma dt <= .2049), a negative sigma and a negative thickness: the
+    default kernels (exp_small_ inside the bound, exp_reg64_ outside) against the per-lane kernel and the oracle."""
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS
+    w, h = 256, 144
+    cases = [dict(sigma_scattering=.1743), dict(sigma_scattering=.1744), dict(sigma_scattering=.17445), dict(cld_thick=145.3),
+             dict(cld_thick=145.4), dict(sigma_scattering=-.15), dict(cld_thick=-125.0), dict(sigma_scattering=0.0),
+             dict(cld_thick=0.0), dict(sigma_scattering=.2, cld_march_steps=150, illum_march_steps=4)]
+    for kw in cases:
+        aux = shaderbox_amd.clouds_defaults()
+        for k, v in kw.items():
+            setattr(aux, k, v)
+        for t in (.37, 2.5):
+            a, b = both_variants(renderer, "clouds", w, h, t, aux=aux)
+            assert compare(a, b) == (0.0, 0), (kw, t)
+            assert compare(a, oracle.render(APP_CLOUDS, w, h, t, aux=aux)) == (0.0, 0), (kw, t)
+
+
 def test_exp_reg64_equals_exp_on_its_whole_domain(renderer):
     """exp_reg64_ (sbx_math.h: 64-entry table, degree-5 polynomial — one binary64 fma less than the spec's form; with and
     without the three-address asm) against exp_ of the math spec on EVERY binary32 argument with |x| < 80 — what the REG kernels

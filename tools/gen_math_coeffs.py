@@ -191,3 +191,50 @@ def log2_table():
 
 if __name__ == "__main__" and "--log2-table" in __import__("sys").argv:
     log2_table()
+
+
+def exp_small(X="0.205", N=8):
+    """Coefficients of exp_small_ (sbx_math.h): p(x) = 1 + c1 x + ... + cN x^N minimising the RELATIVE error against e^x on
+    [-X, 0] (Remez exchange on a fine grid, 60 digits; p(0) = 1 is built in so that exp(-0) = exp(+0) = 1 exactly)."""
+    mp.mp.dps = 60
+    X = mp.mpf(X)
+    a, b = -X, mp.mpf(0)
+    m = N + 1
+
+    def err(c, x):
+        return (1 + sum(c[k] * x ** (k + 1) for k in range(N)) - mp.e ** x) / mp.e ** x
+    ref = [a + (b - a) * (1 - mp.cos(mp.pi * i / m)) / 2 for i in range(m)]          # (x = 0 is never a reference: the error is 0 there)
+    for _ in range(30):
+        A, rhs = mp.matrix(m, m), mp.matrix(m, 1)
+        for i, x in enumerate(ref):
+            for k in range(N):
+                A[i, k] = x ** (k + 1)
+            A[i, N] = -((-1) ** i) * mp.e ** x
+            rhs[i] = mp.e ** x - 1
+        sol = mp.lu_solve(A, rhs)
+        c, E = [sol[k] for k in range(N)], sol[N]
+        G = 4000
+        xs = [a + (b - a) * mp.mpf(i) / G for i in range(G + 1)]
+        es = [err(c, x) for x in xs]
+        ext = []
+        for i in range(G + 1):
+            if es[i] != 0 and (i == 0 or abs(es[i]) >= abs(es[i - 1])) and (i == G or abs(es[i]) >= abs(es[i + 1])):
+                if ext and (ext[-1][1] > 0) == (es[i] > 0):
+                    if abs(es[i]) > abs(ext[-1][1]):
+                        ext[-1] = (xs[i], es[i])
+                else:
+                    ext.append((xs[i], es[i]))
+        while len(ext) > m:
+            ext.pop(0 if abs(ext[0][1]) < abs(ext[-1][1]) else -1)
+        ref = [x for x, _ in ext]
+        if max(abs(v) for _, v in ext) / min(abs(v) for _, v in ext) < mp.mpf("1.0001"):
+            break
+    cr = [mp.mpf(float(ck)) for ck in c]
+    worst = max(abs(err(cr, a + (b - a) * mp.mpf(i) / 20000)) for i in range(20000))
+    print("// exp on [-%s, 0], degree %d: minimax relative error 2^%s; with the binary64 coefficients below 2^%s"
+          % (mp.nstr(X, 4), N, mp.nstr(mp.log(abs(E), 2), 5), mp.nstr(mp.log(worst, 2), 5)))
+    print("    " + ", ".join("c%d = %s" % (k + 1, float.hex(float(c[k]))) for k in reversed(range(N))))
+
+
+if __name__ == "__main__" and "--exp-small" in __import__("sys").argv:
+    exp_small()
