@@ -7,6 +7,7 @@
 // host from (0,1,0), i.e. it restarts from its initialiser for every pixel (GLSL semantics).
 // Magnitudes are ~6.4e6 in binary32, so the evaluation order below is part of the result.
 #include "sbx_device.h"
+#include "sbx_exp4k_table.h"
 #include <cmath>
 #ifndef ATM_NO_FIN
 #define ATM_NO_FIN 0
@@ -39,7 +40,19 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #ifndef ATM_EXP64
 #define ATM_EXP64 1        // ... in its 64-entry / degree-5 form (exp_reg64_: one binary64 fma less, exhaustively equal on |x| <= 80)
 #endif
-#if ATM_EXP_REG && ATM_EXP64
+#ifndef ATM_EXP4K
+#define ATM_EXP4K 1        // ... in its 4096-entry / degree-3 form (exp_reg4k_: two more fma and a register-pair move less, exhaustively equal
+#endif                     // on |x| <= 80).  The 32 KB table is read where it lies, in global memory through the vector L1: 7680x4320
+                           // 4.29 -> 4.03 ms.  (A copy in LDS per workgroup of 16 / 8 / 4 waves: 4.28 / 4.05 / 4.23 ms — 65 000 copies of
+                           // 32 KB, and a workgroup's LDS is held until its last wave ends; per-CU persistent workgroups that copy once
+                           // and walk through the tiles: the tile loop makes the compiler hoist the kernel's constants into registers,
+                           // 95 VGPRs / 5 waves or 84 B of scratch at 64, 4.66 ms.  profiles/r03_log.md)
+#ifndef ATM_TX
+#define ATM_TX 1           // waves per workgroup (1: 4.03 ms, 4: 4.06)
+#endif
+#if ATM_EXP_REG && ATM_EXP4K
+#define ATM_EXP_H(x) (FIN ? exp_reg4k_((x), kExp2Tab4096) : exp_tab_<true>((x), etab))
+#elif ATM_EXP_REG && ATM_EXP64
 #define ATM_EXP_H(x) (FIN ? exp_reg64_<false>((x), etab64) : exp_tab_<true>((x), etab))
 #elif ATM_EXP_REG
 #define ATM_EXP_H(x) (FIN ? exp_reg_<false>((x), etab) : exp_tab_<true>((x), etab))
@@ -47,6 +60,12 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #define ATM_EXP_H(x) exp_tab_<!FIN>((x), etab)
 #endif
 #define ATM_EXP(x) exp_tab_<true>((x), etab)
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const double kExp2Tab4096[4096] = {SBX_EXP2_TAB4096_VALUES};
+#else
+static const double kExp2Tab4096[1] = {1.0};          // (host pass: the kernel body only has to parse)
+#endif
 
 // (march_pos + 0.5 * march_step below is written fma(.5, march_step, march_pos): the half is exact, so it is one rounding either way)
 template <bool FIN>
@@ -67,13 +86,14 @@ __device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, 
 }
 
 template <bool FIN>
-__global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
+__global__ void __launch_bounds__(64 * ATM_TX) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
+    constexpr bool T64 = FIN && ATM_EXP_REG && ATM_EXP64 && !ATM_EXP4K;
     __shared__ double etab[32];
-    __shared__ double etab64[FIN ? 64 : 1];             // the density terms' table (FIN kernels)
+    __shared__ double etab64[T64 ? 64 : 1];               // exp_reg64_'s table (builds without exp_reg4k_)
     if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab[threadIdx.x];
-    if (FIN && threadIdx.x < 64) etab64[threadIdx.x] = kExp2Tab64[threadIdx.x];
-    __syncthreads();
-    const Pixel px = pixel_of_thread(M);
+    if (T64 && threadIdx.x < 64) etab64[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    if (ATM_TX > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    const Pixel px = pixel_of_thread<8, ATM_TX>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
 
@@ -116,6 +136,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_atmosphere(FrameAtmosphere F, Ro
     store_rgba(M, out, px.idx, to_srgb(col));
 }
 
+// exp_reg4k_ as a standalone function (sbx_math_eval "exp_reg4k"): the same table, read from global memory, the same instruction
+// sequence as inside k_atmosphere — for the exhaustive comparison with exp_
+__global__ void __launch_bounds__(256) k_exp4k_eval(const float* __restrict__ a, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = exp_reg4k_(a[i], kExp2Tab4096);
+}
+void launch_exp4k_eval(const float* a, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_exp4k_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, out, n);
+}
+
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s) {
     // FIN: camera and sun direction are finite numbers (they are for every finite u_res / u_time)
     const float chk[] = {F.cam.res_x, F.cam.res_y, F.cam.aspect_x, F.cam.fov, F.sun_dir.x, F.sun_dir.y, F.sun_dir.z,
@@ -125,8 +155,8 @@ void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hi
 #if ATM_NO_FIN
     fin = false;
 #endif
-    if (fin) hipLaunchKernelGGL(k_atmosphere<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
-    else hipLaunchKernelGGL(k_atmosphere<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    if (fin) hipLaunchKernelGGL(k_atmosphere<true>, (grid_for<8, ATM_TX>(M)), dim3(64 * ATM_TX), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_atmosphere<false>, (grid_for<8, ATM_TX>(M)), dim3(64 * ATM_TX), 0, s, F, M, out);
 }
 
 }  // namespace sbx

@@ -88,6 +88,7 @@ void launch_assemble_peers(int width, int height, int block_rows, int nranks, in
 void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);
 void launch_worley_volume(int size, float* out, hipStream_t s);
+void launch_exp4k_eval(const float* a, float* out, size_t n, hipStream_t s);
 int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t n, hipStream_t s);
 void launch_cl_exp_eval(const float* a, float* out, size_t n, hipStream_t s, int form);   // exp_reg_ / exp_reg128_ forms (kern_clouds.hip)
 

@@ -361,6 +361,25 @@ __device__ __forceinline__ float exp_reg64_(float x, const Tab& tab) {
     const double y = p * tab[ki & 63];
     return __builtin_ldexpf((float)y, ki >> 6);
 }
+// The same with a 4096-entry table (sbx_exp4k_table.h, 32 KB, read from global memory through the vector L1): x = (k/4096) ln2 + r,
+// |r| <= ln2/8192, and the degree-3 Taylor polynomial (truncation r^4/24 <= 2.1e-18): TWO binary64 fma less than exp_reg64_ and no
+// coefficient to move into a register pair.  A kernel-internal form like exp_reg64_, admitted on the same ground: equal to exp_ on
+// EVERY binary32 argument with |x| <= 80 (2.2e9 values; host: tests/test_exp_small.py against the oracle's m_exp; GPU:
+// tests/test_gpu_round3.py::test_exp_reg64_equals_exp_on_its_whole_domain).  (2048 entries: ONE argument of the 2.2e9 differs.)
+template <class Tab>
+__device__ __forceinline__ float exp_reg4k_(float x, const Tab& tab) {
+    const double xd = (double)x;
+    double kd = __builtin_fma(xd, 0x1.71547652b82fep+12, D_MAGIC);         // 4096/ln2
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - D_MAGIC;
+    double r = __builtin_fma(kd, -0x1.62e42fee00000p-13, xd);              // ln2/4096, high 32 bits (|k| < 2^19: k * hi exact)
+    r = __builtin_fma(kd, -0x1.a39ef35793c76p-45, r);                      // ln2/4096 - high
+    double p = __builtin_fma(0x1.5555555555555p-3, r, 0.5);                // 1/3!
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double y = p * tab[ki & 4095];
+    return __builtin_ldexpf((float)y, ki >> 12);
+}
 // exp on the SMALL NEGATIVE domain [-0.205, -0] (and +0): NO argument reduction, no table — the degree-8 minimax polynomial of
 // e^x on that interval (relative error 2^-55.6 with these binary64 coefficients, tools/gen_math_coeffs.py --exp-small), one Horner
 // chain: cvt + 8 fma + cvt = 10 half-rate instructions against the 17 of exp_reg64_ (magic-number rounding, two-step reduction,

@@ -53,3 +53,54 @@ def test_exp_small_equals_the_spec_exp_on_its_whole_domain(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout
     assert "mismatches 0" in r.stdout and "checked 1045556103" in r.stdout, r.stdout
+
+
+SRC4K = r"""
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include "%(root)s/oracle/sbx_math_ref.h"
+#include "%(root)s/shaderbox_amd/csrc/sbx_exp4k_table.h"
+using namespace sbxref;
+static const double TAB[4096] = {SBX_EXP2_TAB4096_VALUES};
+static inline float e4k(float x) {
+    const double xd = (double)x;
+    double kd = fma(xd, %(inv)s, SBX_D_MAGIC);
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - SBX_D_MAGIC;
+    double r = fma(kd, %(hi)s, xd);
+    r = fma(kd, %(lo)s, r);
+    double p = fma(%(c3)s, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexpf((float)(p * TAB[ki & 4095]), ki >> 12);
+}
+int main() {
+    const uint32_t lim = f2u(80.0f);
+    long bad = 0;
+    for (int sign = 0; sign < 2; ++sign)
+        for (uint32_t b = 0; b <= lim; ++b) {
+            const float x = u2f(b | (sign ? 0x80000000u : 0u));
+            if (f2u(e4k(x)) != f2u(m_exp(x))) { if (bad < 5) printf("x=%%a\n", x); ++bad; }
+        }
+    printf("checked %%u x 2 mismatches %%ld\n", lim + 1, bad);
+    return bad != 0;
+}
+"""
+
+
+def test_exp_reg4k_equals_the_spec_exp_for_all_arguments_up_to_80(tmp_path):
+    """exp_reg4k_ (sbx_math.h: 4096-entry table, degree 3 — k_atmosphere's density terms) restated in C with the constants read from
+    sbx_math.h and the table of sbx_exp4k_table.h, against the oracle's m_exp on every binary32 argument with |x| <= 80 (about 25 s)."""
+    text = open(os.path.join(ROOT, "shaderbox_amd", "csrc", "sbx_math.h")).read()
+    body = text[text.index("float exp_reg4k_(float x"):][:1200]
+    inv = re.search(r"fma\(xd, (0x[0-9a-f.]+p[-+]\d+), D_MAGIC\)", body).group(1)
+    hi, lo = re.findall(r"fma\(kd, (-0x[0-9a-f.]+p[-+]\d+),", body)
+    c3 = re.search(r"fma\((0x[0-9a-f.]+p[-+]\d+), r, 0\.5\)", body).group(1)
+    src = tmp_path / "exh4k.cpp"
+    src.write_text(SRC4K % dict(root=ROOT, inv=inv, hi=hi, lo=lo, c3=c3))
+    exe = tmp_path / "exh4k"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-msse4.1", "-o", str(exe), str(src)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout and "checked 1117782017 x 2" in r.stdout, r.stdout

@@ -300,7 +300,7 @@ def test_clouds_exp_small_domain_edges(renderer, oracle):
 
 def test_exp_reg64_equals_exp_on_its_whole_domain(renderer):
     """exp_reg64_ (sbx_math.h: 64-entry table, degree-5 polynomial — one binary64 fma less than the spec's form; with and
-    without the three-address asm) against exp_ of the math spec on EVERY binary32 argument with |x| < 80 — what the REG kernels
+    without the three-address asm) and exp_reg4k_ (4096-entry table, degree 3: k_atmosphere's density terms) against exp_ of the math spec on EVERY binary32 argument with |x| < 80 — what the REG kernels
     of APP_CLOUDS (|sigma * dt| <= 80, density in [0, 1)) and APP_ATMOSPHERE's density terms ([-50.1, .001]) can produce."""
     import torch
     lim = np.array([80.0], dtype=np.float32).view(np.uint32)[0]
@@ -311,9 +311,10 @@ def test_exp_reg64_equals_exp_on_its_whole_domain(renderer):
             bits = (torch.arange(start, stop, dtype=torch.int64, device="cuda") | sign).to(torch.int32)
             x = bits.view(torch.float32)
             b = renderer.math("exp", x)
-            for form in ("exp_reg64", "exp_reg64_plain"):
+            for form in ("exp_reg64", "exp_reg64_plain", "exp_reg4k"):
                 a = renderer.math(form, x)
                 bad = a.view(torch.int32) != b.view(torch.int32)
                 assert not bool(bad.any()), "%s: first mismatch at bits 0x%08x" % (form, int(bits[bad][0].item() & 0xffffffff))
     nan = torch.tensor([float("nan"), -float("nan")], device="cuda")
     assert bool(torch.isnan(renderer.math("exp_reg64", nan)).all()) and bool(torch.isnan(renderer.math("exp_reg64_plain", nan)).all())
+    assert bool(torch.isnan(renderer.math("exp_reg4k", nan)).all())

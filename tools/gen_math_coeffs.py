@@ -93,7 +93,7 @@ def hexf(x):
     return float(np.float32(x)).hex()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not any(a.startswith("--") for a in __import__("sys").argv[1:]):
     c, E = fit_sin()
     print("// sin(r) = r + r^3*(S0 + S1 s + S2 s^2 + S3 s^3 + S4 s^4), s=r^2 ; max rel err (exact arith) = %.3g" % E)
     for j, v in enumerate(c):
@@ -148,6 +148,29 @@ def exp_table_n(n):
     for i in range(0, n, 4):
         print("    " + ", ".join(float.hex(v) for v in tab[i:i + 4]) + ",")
     print("// %d/ln2 = %s ; ln2/%d = %s + %s" % (n, float.hex(float(n / mp.log(2))), n, float.hex(hi), float.hex(float(c - mp.mpf(hi)))))
+
+
+def exp_table_header(n, keep):
+    """shaderbox_amd/csrc/sbx_exp4k_table.h: 2^(j/n) correctly rounded to binary64 as one macro, with the constants of exp_reg4k_"""
+    import struct
+    mp.mp.prec = 200
+    tab = [float(mp.mpf(2) ** (mp.mpf(j) / n)) for j in range(n)]
+    c = mp.log(2) / n
+    b = struct.unpack("<Q", struct.pack("<d", float(c)))[0] & ~((1 << (53 - keep)) - 1)
+    hi = struct.unpack("<d", struct.pack("<Q", b))[0]
+    print("// shaderbox_amd/csrc/sbx_exp4k_table.h — GENERATED by `python tools/gen_math_coeffs.py --exp-table-header %d`: do not edit." % n)
+    print("// 2^(j/%d), j = 0..%d, correctly rounded to binary64 (mpmath, 200 bits): the table of exp_reg4k_ (sbx_math.h)." % (n, n - 1))
+    print("// %d/ln2 = %s ; ln2/%d = %s (high %d bits: k * hi is exact for |k| < 2^%d) + %s"
+          % (n, float.hex(float(n / mp.log(2))), n, float.hex(hi), keep, 53 - keep, float.hex(float(c - mp.mpf(hi)))))
+    print("#pragma once")
+    print("#define SBX_EXP2_TAB%d_VALUES \\" % n)
+    for i in range(0, n, 4):
+        print("    " + ", ".join(float.hex(v) for v in tab[i:i + 4]) + ("," if i + 4 < n else "") + (" \\" if i + 4 < n else ""))
+
+
+if __name__ == "__main__" and "--exp-table-header" in __import__("sys").argv:
+    exp_table_header(int(__import__("sys").argv[__import__("sys").argv.index("--exp-table-header") + 1]), 32)
+    raise SystemExit(0)
 
 
 if __name__ == "__main__" and "--exp-table" in __import__("sys").argv:
