@@ -61,12 +61,6 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #endif
 #define ATM_EXP(x) exp_tab_<true>((x), etab)
 
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ const double kExp2Tab4096[4096] = {SBX_EXP2_TAB4096_VALUES};
-#else
-static const double kExp2Tab4096[1] = {1.0};          // (host pass: the kernel body only has to parse)
-#endif
-
 // (march_pos + 0.5 * march_step below is written fma(.5, march_step, march_pos): the half is exact, so it is one rounding either way)
 template <bool FIN>
 __device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, const double (&etab)[32], const double* etab64) {   // :50-76

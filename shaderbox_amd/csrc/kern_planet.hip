@@ -19,6 +19,7 @@
 #include "sbx_device.h"
 #include "sbx_noise.h"
 #include "sbx_hashcache.h"
+#include "sbx_exp4k_table.h"
 
 // All noise_iq evaluations go through the per-wave lattice-hash cache (sbx_hashcache.h): octave k of any fBm
 // uses table k & 3.  The cross-lane steps of the cache need wave-uniform control flow, so lanes never leave
@@ -127,6 +128,15 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
     return t;
 }
 
+// The two exp of a cloud sample in the SKIP kernels: exp_reg4k_ of sbx_math.h (4096-entry table read through the vector L1, degree 3,
+// no range guard: 15 instructions against exp_'s 21), equal to exp_ for |x| <= 80.  The SKIP kernels run only for tame frames
+// (sbx_capi.hip tame_time: finite, bounded camera), where a sample lies within the atmosphere shell: the arguments are
+// -30.034 * dens * t_step with dens in [0, .94] and t_step <= .08, i.e. [-2.26, 0], and height = (|p| - 1) / .4 in [-2.5, 1.1]; a NaN
+// stays a NaN in both forms.  7680x4320: see profiles/r03_log.md.
+#ifndef PL_EXP4K
+#define PL_EXP4K 1
+#endif
+#define PL_EXP(x) ((SKIP && PL_EXP4K) ? exp_reg4k_((x), kExp2Tab4096) : exp_(x))
 // clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
 // SKIP = false (sbx_set_variant 1) evaluates everything: the reference form, kept for the parity sweeps
 // The density part of clouds_map: false = nothing would change for any committing lane of the wave (see below), else
@@ -157,7 +167,7 @@ __device__ __forceinline__ bool clouds_density(WaveCache& S, v3 pos, float heigh
     // dens is exactly +0 below the coverage edge as well (smoothstep = 0): same identities, skip the two exp
     if (SKIP && !wave_any(on && dens != 0.f)) return false;
     dens_out = dens;
-    T_i_out = exp_(-30.034f * dens * t_step);
+    T_i_out = PL_EXP(-30.034f * dens * t_step);
     return true;
 }
 // clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
@@ -168,7 +178,7 @@ __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, b
     if (!clouds_density<SKIP>(S, c.pos, c.height, t_step, on, lane, dens, T_i)) return;
     if (on) {
         c.transmittance *= T_i;
-        c.radiance += dens * div_by(exp_(c.height), 1.0 / (double).055f) * c.transmittance * t_step;
+        c.radiance += dens * div_by(PL_EXP(c.height), 1.0 / (double).055f) * c.transmittance * t_step;
         c.alpha += (1.f - T_i) * (1.f - c.alpha);
     }
 }

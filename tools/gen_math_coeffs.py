@@ -166,6 +166,11 @@ def exp_table_header(n, keep):
     print("#define SBX_EXP2_TAB%d_VALUES \\" % n)
     for i in range(0, n, 4):
         print("    " + ", ".join(float.hex(v) for v in tab[i:i + 4]) + ("," if i + 4 < n else "") + (" \\" if i + 4 < n else ""))
+    print("#if defined(__HIP_DEVICE_COMPILE__)")
+    print("static __device__ const double kExp2Tab%d[%d] = {SBX_EXP2_TAB%d_VALUES};      // one copy per translation unit that includes this" % (n, n, n))
+    print("#else")
+    print("static const double kExp2Tab%d[1] = {1.0};          // (host pass: kernel bodies only have to parse)" % n)
+    print("#endif")
 
 
 if __name__ == "__main__" and "--exp-table-header" in __import__("sys").argv:
