@@ -13,6 +13,7 @@
 #include "sbx_device.h"
 #include "sbx_noise.h"
 #include "sbx_hashcache.h"
+#include "sbx_exp4k_table.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -86,8 +87,19 @@ namespace sbx {
 #ifndef CL_EXP_SMALL_ASM
 #define CL_EXP_SMALL_ASM 1
 #endif
+#ifndef CL_YZ_SM
+#define CL_YZ_SM 1        // exp_small_ in the y-z light march's kernel as well
+#endif
+#ifndef CL_EXP4K
+#define CL_EXP4K 1         // the REG kernels outside exp_small_'s domain: exp_reg4k_ (4096-entry table through the vector L1, degree 3)
+#endif                     // instead of exp_reg64_ (64 entries in LDS, degree 5)
+#define CL_USES_4K (CL_EXP_ASM && CL_EXP64 && CL_EXP_SMALL && CL_EXP4K)
 #if CL_EXP_ASM && CL_EXP64 && CL_EXP_SMALL
-#define CL_EXP_REG(x) (SM ? exp_small_<CL_EXP_SMALL_ASM != 0>(x) : exp_reg64_((x), etab))     // SM: a template parameter in scope
+#if CL_EXP4K
+#define CL_EXP_REG(x) (SM ? exp_small_<CL_EXP_SMALL_ASM != 0>(x) : exp_reg4k_((x), kExp2Tab4096))     // SM: a template parameter in scope
+#else
+#define CL_EXP_REG(x) (SM ? exp_small_<CL_EXP_SMALL_ASM != 0>(x) : exp_reg64_((x), etab))
+#endif
 #elif CL_EXP_ASM && CL_EXP64
 #define CL_EXP_REG(x) exp_reg64_((x), etab)
 #elif CL_EXP_ASM
@@ -616,11 +628,10 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
 // is decided as in light_march_z, for y and z: a = q - cur is the reference's fract iff 0 <= RN(q - cur) < 1, one unsigned compare
 // of the larger bit pattern against 1.0f.  The kept x-mixes are register values: nothing the cache does can invalidate them.
 // A sample that leaves a cell looks that octave up in the general form (floor / index / tag check / cooperative insert).
-template <bool REG>
+template <bool REG, bool SM>
 __device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                 WaveCache& S, int lane, const float (&mfx)[4], const double* etab,
                                                 float vsigma, float vdt, float vcov) {
-    constexpr bool SM = false;          // (exp_small_ here: 24 -> 36 B of scratch at this kernel's 96 registers and 3.79 -> 3.86 ms)
     float xa[4], xb[4], xc[4], xd[4], cy[4], cz[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { cy[k] = cz[k] = u2f(0x7fc00001u); xa[k] = xb[k] = xc[k] = xd[k] = 0.f; }
@@ -773,11 +784,12 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
     // exp's table: per-lane reads come from LDS, not from the vector L1.  REG kernels: the 64 entries of exp_reg64_ (512 B: 5.8 KB per
     // wave with the hash tables and the parked state — the 128-entry form's 6.3 KB is one allocation granule more and costs the
     // sixth wave: 2.62 -> 2.71 ms); the others: exp_'s 32.
-    constexpr int ETAB_N = SM ? 1 : (REG && CL_EXP64 && CL_EXP_ASM) ? 64 : 32;       // (exp_small_ reads no table)
+    constexpr bool NOTAB = SM || (REG && CL_USES_4K);        // exp_small_ reads no table, exp_reg4k_ its own
+    constexpr int ETAB_N = NOTAB ? 1 : (REG && CL_EXP64 && CL_EXP_ASM) ? 64 : 32;
     __shared__ double etab[ETAB_N];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
-    if (!SM) for (int i = threadIdx.x; i < ETAB_N; i += 64 * CL_TX) etab[i] = (ETAB_N == 64) ? kExp2Tab64[i] : kExp2Tab[i];
+    if (!NOTAB) for (int i = threadIdx.x; i < ETAB_N; i += 64 * CL_TX) etab[i] = (ETAB_N == 64) ? kExp2Tab64[i] : kExp2Tab[i];
     if (CL_TX > 1) __syncthreads();
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;   // empty
 #ifdef SBX_CL_STATS
@@ -890,7 +902,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
                                                            // are dead across the light march
 #endif
                         if (LM == 1) ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
-                        else ltrans = light_march_yz<REG>(F, lp, lstep, lit, lit_mask, S, lane, mfx, etab, vsigma, vdt, vcov);
+                        else ltrans = light_march_yz<REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, mfx, etab, vsigma, vdt, vcov);
 #if CL_PARK
                         asm volatile("" ::: "memory");
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
@@ -1029,6 +1041,7 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
         const bool sm = F.exp_small && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
         if (reg && zl && sm) hipLaunchKernelGGL((k_clouds<true, true, 1, true>), grid, block, pad, s, F, M, out, ct);
         else if (reg && zl) hipLaunchKernelGGL((k_clouds<true, true, 1>), grid, block, pad, s, F, M, out, ct);
+        else if (reg && yz && sm && CL_YZ_SM) hipLaunchKernelGGL((k_clouds<true, true, 2, true>), grid, block, 0, s, F, M, out, ct);
         else if (reg && yz) hipLaunchKernelGGL((k_clouds<true, true, 2>), grid, block, 0, s, F, M, out, ct);
         else if (reg && sm) hipLaunchKernelGGL((k_clouds<true, true, 0, true>), grid, block, 0, s, F, M, out, ct);
         else if (reg) hipLaunchKernelGGL((k_clouds<true, true, 0>), grid, block, 0, s, F, M, out, ct);

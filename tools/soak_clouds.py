@@ -17,6 +17,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 R = shaderbox_amd.Renderer(0)
 bad = 0
+small = 0
 kinds = {"reg_zl": 0, "reg_yz": 0, "reg_gen": 0, "noreg": 0}
 for i in range(n):
     aux = shaderbox_amd.clouds_defaults(R.lib)
@@ -43,6 +44,9 @@ for i in range(n):
     elif k == 2:                        # the y-z plane (light_march_yz)
         aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = 0.0, float(rng.choice([rng.uniform(-1, 1), 1e-6, 3.0])), float(rng.uniform(-1, 1))
     dt = aux.cld_thick / max(aux.cld_march_steps, 1)
+    if i % 5 == 0 and dt > 0:           # sigma * dt on both sides of exp_small_'s bound (.94 sigma dt <= .2049, i.e. .218)
+        aux.sigma_scattering = float(rng.uniform(.12, .25)) / dt
+    small += int(aux.sigma_scattering >= 0 and dt >= 0 and .94 * aux.sigma_scattering * dt <= .2049)
     reg = abs(aux.sigma_scattering * dt) <= 80
     zl = aux.sun_dir[0] * dt == 0 and aux.sun_dir[1] * dt == 0
     yz = not zl and aux.sun_dir[0] * dt == 0
@@ -57,4 +61,4 @@ for i in range(n):
         print("MISMATCH frame %d: %d pixels; t=%g mouse=%s cov=%g steps=%d lsteps=%d thick=%g sigma=%g sun=%s wind=%s"
               % (i, int((~same).any(-1).sum()), t, mouse, aux.cld_coverage, aux.cld_march_steps, aux.illum_march_steps,
                  aux.cld_thick, aux.sigma_scattering, list(aux.sun_dir), list(aux.wind_dir)))
-print("soak: %d frames (%s), %d with differing pixels" % (n, kinds, bad))
+print("soak: %d frames (%s; %d of them inside exp_small_'s domain), %d with differing pixels" % (n, kinds, small, bad))
