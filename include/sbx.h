@@ -236,7 +236,9 @@ int sbx_worley_volume(sbx_ctx* ctx, int size, float* rgba, void* stream);
  * command line and binds with a MIN_MAG_MIP_LINEAR / WRAP sampler (util/hlsltoy/src/hlsltoy.cpp:227-249, 437).
  * Each is a size^3 RGBA32F volume in device memory, x fastest (the layout util/ddsvolgen writes, ddsvolgen.cpp:101-117;
  * sbx_worley_volume produces one).  The shader reads only .r: the call copies that channel into the context (R32F,
- * a quarter of the footprint), asynchronously on `stream`; the caller's buffers are not referenced afterwards.
+ * a quarter of the footprint) on `stream` and scans the copies for the range of the texel values (k_clouds_tex derives a bound on
+ * the density from it and uses a cheaper, equal form of exp inside that bound); the call returns when both have finished, and the
+ * caller's buffers are not referenced afterwards.  Inside a stream capture there is no scan and no wait.
  * SampleLevel is evaluated by the sbx texture-filter spec: texel centres at (i + .5) / size, WRAP,
  * trilinear blend with binary32 weights in x, y, z order.  Renders of SBX_APP_CLOUDS_TEX must be ordered after this
  * call (same stream, or an event). */

@@ -24,7 +24,9 @@
 // per-lane kernel below needs few registers, so 8 waves per SIMD hide the L2 latency.  HBM traffic stays the
 // framebuffer (16 B/pixel) plus one pass over the volumes; roofline and FETCH_SIZE in DESIGN.md §5.6.
 #include <cmath>
+#include <algorithm>
 #include "sbx_device.h"
+#include "sbx_exp4k_table.h"
 
 #ifndef TEX_ZL
 #define TEX_ZL 1           // 0: never use the z-only light march (A/B timing)
@@ -40,6 +42,12 @@
 #endif
 #ifndef TEX_YTAB
 #define TEX_YTAB 1         // the y terms of the main march (and of the z-only light march) from a per-workgroup table in LDS
+#endif
+#ifndef TEX_XB
+#define TEX_XB 1          // 0: never exp_reg4k_ (A/B timing)
+#endif
+#ifndef TEX_LH
+#define TEX_LH 1          // 0: `j / lsteps` computed per light sample (A/B timing)
 #endif
 #ifndef TEX_TX
 #define TEX_TX 4           // waves per workgroup
@@ -219,7 +227,12 @@ __device__ __forceinline__ float hg_phase_tex(float mu, float g) {   // volumetr
 //      the height of main step i, `i / steps`, and per volume floor / fract of uy and the two row offsets are the same for
 //      every pixel: each workgroup computes them once into LDS (thread i the row of step i, the operations a lane would do) and
 //      the march reads the row with two broadcast loads.  The z-only light march keeps x and y of its main sample: same row.
-struct TexArgs { NoiseTex T1, T2; double rsteps, rlsteps; };
+// xb (decided on the host, clouds_tex_exp_bound): REG, and the texel values of both volumes (scanned when they were bound) bound
+//      every density so that |density * sigma * dt| <= 80: the exps are exp_reg4k_ of sbx_math.h (no range guard, 4096-entry table,
+//      degree 3: 15 instructions against exp_'s 21), equal to exp_ on that whole range.
+struct TexArgs { NoiseTex T1, T2; double rsteps, rlsteps; int xb; };
+#define TEX_EXP(x) (A.xb ? exp_reg4k_((x), kExp2Tab4096) : exp_(x))
+constexpr int TEX_LH_N = 64;     // light steps whose `j / lsteps` comes from the workgroup's LDS table (more: computed per sample)
 template <bool POW2, bool ZL, bool REG, bool YT>      // ZL (decided on the host): POW2 and the light step has no x and no y component
 __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out, TexArgs A) {
     // rsteps = recip64(float(steps)), rlsteps = recip64(float(lsteps)): `i / steps` and `j / lsteps` as exact multiplies
@@ -227,6 +240,10 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
     const NoiseTex& T1 = A.T1;
     const NoiseTex& T2 = A.T2;
     const double rsteps = A.rsteps, rlsteps = A.rlsteps;
+    // illuminate_volume's height `j / lsteps` (:108) is the same for every pixel: once per workgroup into LDS, one broadcast read per
+    // light sample instead of cvt + binary64 multiply + cvt
+    __shared__ float lh_tab[TEX_LH_N];
+    if (threadIdx.x < TEX_LH_N) lh_tab[threadIdx.x] = div_by((float)(int)threadIdx.x, rlsteps);
     __shared__ float4 yrow_f[YT ? TEX_YROWS : 1];          // {height, fy of volume 1, fy of volume 2, -}
     __shared__ uint4 yrow_i[YT ? TEX_YROWS : 1];           // {a0, a1 of volume 1, a0, a1 of volume 2}: byte offsets y0 * size * 4, y1 * size * 4
     if (YT) {
@@ -242,8 +259,9 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
             yrow_i[i] = make_uint4((unsigned)y1 << (T1.lg + 2), (unsigned)((y1 + 1) & (T1.size - 1)) << (T1.lg + 2),
                                    (unsigned)y2 << (T2.lg + 2), (unsigned)((y2 + 1) & (T2.size - 1)) << (T2.lg + 2));
         }
-        if (TEX_TX > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     }
+    if (TEX_TX > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    const bool lh_lds = TEX_LH && F.lsteps <= TEX_LH_N;
     const Pixel px = pixel_of_thread<TEX_TW, TEX_TX>(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
@@ -319,7 +337,7 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
                 }
             }
             if (!(density < .005f)) {                          // integrate_volume :132
-                const float T_i = exp_(-density * F.sigma * F.dt);
+                const float T_i = TEX_EXP(-density * F.sigma * F.dt);
                 transmittance *= T_i;
                 v3 lp = pos + lstep;                           // illuminate_volume :91-123
                 float ltrans = 1.f;
@@ -328,21 +346,21 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
                         const float qz = lp.z * .001f;
                         float shape = tex3d_z(T1, qz, c1, fs1, m1);
                         lp.z = lp.z + lstep.z;
-                        const float lh = div_by((float)j, rlsteps);                 // :108  j / lsteps
+                        const float lh = lh_lds ? lh_tab[j] : div_by((float)j, rlsteps);   // :108  j / lsteps
                         const float w = tex3d_z(T2, qz, c2, fs2, m2);
                         const float ww = mix_(w, 1.f - w, lh);
                         shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
                         const float d = REG ? x_smoothstep_rd_med3(vcov, F.cov_rd, shape) : shape * smoothstep_rd(F.cov, F.cov_rd, shape);
                         if (REG && TEX_SKIP && d == 0.f) continue;                  // exp(-+0) = 1
-                        ltrans *= exp_(-d * vsig * vdt);
+                        ltrans *= TEX_EXP(-d * vsig * vdt);
                     }
                 } else
                 for (int j = 0; j < F.lsteps; ++j) {
-                    const float lh = div_by((float)j, rlsteps);                     // :108  j / lsteps
+                    const float lh = lh_lds ? lh_tab[j] : div_by((float)j, rlsteps);   // :108  j / lsteps
                     const float d = tex_density<POW2>(F, T1, T2, lp, lh);
                     lp = lp + lstep;
                     if (REG && TEX_SKIP && d == 0.f) continue;                      // exp(-+0) = 1
-                    ltrans *= exp_(-d * F.sigma * F.dt);
+                    ltrans *= TEX_EXP(-d * F.sigma * F.dt);
                 }
                 radiance += (density * F.sigma) * (ltrans * F.sun_power * phase) * transmittance * F.dt;
                 alpha += (1.f - T_i) * (1.f - alpha);
@@ -360,6 +378,27 @@ __global__ void __launch_bounds__(256) k_extract_r(const float4* __restrict__ rg
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) r[i] = rgba[i].x;
 }
+
+// min / max of the R32F copy (NaN texels set the flag): the bounds the host derives the exp form from (clouds_tex_exp_bound).
+// res[0] = min, res[1] = max as order-preserving unsigned keys, res[2] = 1 if a NaN was seen; initialised by the launcher.
+__device__ __forceinline__ unsigned f_key(float x) { const unsigned u = f2u(x); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__global__ void __launch_bounds__(256) k_minmax_r(const float* __restrict__ r, size_t n, unsigned* __restrict__ res) {
+    unsigned lo = 0xffffffffu, hi = 0u, nan = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = r[i];
+        if (v != v) { nan = 1u; continue; }
+        const unsigned k = f_key(v);
+        lo = k < lo ? k : lo; hi = k > hi ? k : hi;
+    }
+    atomicMin(&res[0], lo); atomicMax(&res[1], hi);
+    if (nan) atomicOr(&res[2], 1u);
+}
+void launch_minmax_r(const float* r, size_t n, unsigned* res, hipStream_t s) {      // res: 3 device words, set to {~0, 0, 0} here
+    (void)hipMemsetAsync(res, 0xff, sizeof(unsigned), s);
+    (void)hipMemsetAsync(res + 1, 0, 2 * sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_minmax_r, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, r, n, res);
+}
+float minmax_key_to_float(unsigned k) { return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 void launch_extract_r(const float* rgba, float* r, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_extract_r, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(rgba), r, n);
@@ -389,8 +428,21 @@ void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out
 static bool clouds_tex_regular(const FrameClouds& F) {
     return std::isfinite(F.cov) && std::isfinite(F.cov_rd) && F.cov_rd > 0.0 && std::isfinite(F.sigma) && std::isfinite(F.dt);
 }
+// |density| <= B for every sample, from the texel ranges [lo1, hi1] (shape) and [lo2, hi2] (detail): a trilinear blend is a convex
+// combination (binary32 weights in [0, 1]) and stays within the texels' range up to rounding; ww = mix(w, 1 - w, h) with h in [0, 1]
+// lies between min(lo2, 1 - hi2) and max(hi2, 1 - lo2); remap = (shape - .7 ww) / (1 - .7 ww); density = remap * smoothstep in [0, 1].
+// Returns < 0 when there is no bound (unknown or non-finite ranges, or 1 - .7 ww can come near 0).
+static double clouds_tex_density_bound(const float* b) {      // b = {lo1, hi1, lo2, hi2}
+    for (int i = 0; i < 4; ++i) if (!std::isfinite(b[i])) return -1.0;
+    const double wlo = std::min((double)b[2], 1.0 - b[3]), whi = std::max((double)b[3], 1.0 - b[2]);
+    const double olo = std::min(.7 * wlo, .7 * whi) - 1e-5, ohi = std::max(.7 * wlo, .7 * whi) + 1e-5;
+    const double bmin = 1.0 - ohi;
+    if (!(bmin >= 1e-3)) return -1.0;
+    const double amax = std::max(std::fabs(b[0] - ohi), std::fabs(b[1] - olo)) + 1e-5;
+    return amax / bmin * 1.001;
+}
 void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, const float* shape_r, int shape_size,
-                       const float* detail_r, int detail_size) {
+                       const float* detail_r, int detail_size, const float* bounds) {
     auto lg2 = [](int n) { int k = 0; while ((1 << k) < n) ++k; return k; };
     const NoiseTex T1{shape_r, shape_size, (float)shape_size, recip64((float)shape_size), lg2(shape_size)};
     const NoiseTex T2{detail_r, detail_size, (float)detail_size, recip64((float)detail_size), lg2(detail_size)};
@@ -408,7 +460,10 @@ void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStr
         const float lim = std::fmin(1073741824.0f / T1.fsize, 1073741824.0f / T2.fsize) * .25f;
         yt = far * .001f < lim;                                  // NaN compares false
     }
-    const TexArgs A{T1, T2, rs, rl};
+    // exp_reg4k_'s domain: |density * sigma * dt| <= 80 (bounds == nullptr: the volumes were bound without a scan)
+    const double dens_max = bounds ? clouds_tex_density_bound(bounds) : -1.0;
+    const int xb = (TEX_XB && reg && dens_max >= 0.0 && dens_max * std::fabs((double)F.sigma) * std::fabs((double)F.dt) * 1.001 <= 80.0) ? 1 : 0;
+    const TexArgs A{T1, T2, rs, rl, xb};
     const dim3 grid = grid_for<TEX_TW, TEX_TX>(M), block(64 * TEX_TX);
 #define SBX_TEX_LAUNCH(P, Z) do {                                                                                          \
         if (reg && yt) hipLaunchKernelGGL((k_clouds_tex<P, Z, true, true>), grid, block, 0, s, F, M, out, A);               \

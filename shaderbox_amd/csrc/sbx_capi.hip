@@ -49,6 +49,9 @@ struct sbx_ctx {
     float* noise_tex = nullptr;      // shape (t1)
     float* noise_tex2 = nullptr;     // detail (t2)
     int noise_tex_size = 0, noise_tex2_size = 0;
+    unsigned* tex_scan = nullptr;    // 6 device words: min / max keys and NaN flag of the two volumes (sbx_set_noise_volumes)
+    float tex_bounds[4] = {0, 0, 0, 0};   // {lo1, hi1, lo2, hi2} of the texels; valid only if tex_bounds_valid
+    bool tex_bounds_valid = false;
     // sbx_main_image: the frame of the last (app, uniforms, aux) seen, on the device and on the host
     float* mi_dev = nullptr;
     size_t mi_floats = 0;
@@ -384,6 +387,7 @@ void sbx_destroy(sbx_ctx* ctx) {
     if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
     if (ctx->noise_tex) (void)hipFree(ctx->noise_tex);
     if (ctx->noise_tex2) (void)hipFree(ctx->noise_tex2);
+    if (ctx->tex_scan) (void)hipFree(ctx->tex_scan);
     if (ctx->have_ytab_event) (void)hipEventDestroy(ctx->ytab_ready);
     for (auto& sl : ctx->slots) for (auto& u : sl.users) (void)hipEventDestroy(u.second);
     for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -502,7 +506,8 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     switch (app) {
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
     case SBX_APP_CLOUDS_SKY: launch_clouds(build_clouds(*uni, AC, true), M, rgba, s, ctx->variant, nullptr, 0, false); break;
-    case SBX_APP_CLOUDS_TEX: launch_clouds_tex(build_clouds(*uni, AC), M, rgba, s, ctx->noise_tex, ctx->noise_tex_size, ctx->noise_tex2, ctx->noise_tex2_size); break;
+    case SBX_APP_CLOUDS_TEX: launch_clouds_tex(build_clouds(*uni, AC), M, rgba, s, ctx->noise_tex, ctx->noise_tex_size, ctx->noise_tex2, ctx->noise_tex2_size,
+                                                    ctx->tex_bounds_valid ? ctx->tex_bounds : nullptr); break;
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, cull_variant); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
@@ -814,6 +819,23 @@ int sbx_set_noise_volumes(sbx_ctx* ctx, int shape_size, const float* shape_rgba,
     launch_extract_r(detail_rgba, ctx->noise_tex2, n2, (hipStream_t)stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "noise volume copy launch", e);
+    // The range of the texel values: k_clouds_tex derives a bound on the density from it and, inside that bound, uses the cheaper
+    // exp form that is equal to exp_ there (kern_clouds_tex.hip clouds_tex_density_bound).  The scan is read back here, so the call
+    // waits for its own copies; inside a stream capture nothing can be read back and the volumes stay without bounds (exp_ itself).
+    ctx->tex_bounds_valid = false;
+    if (!stream_is_capturing((hipStream_t)stream)) {
+        if (!ctx->tex_scan && (e = hipMalloc((void**)&ctx->tex_scan, 6 * sizeof(unsigned))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
+        launch_minmax_r(ctx->noise_tex, n1, ctx->tex_scan, (hipStream_t)stream);
+        launch_minmax_r(ctx->noise_tex2, n2, ctx->tex_scan + 3, (hipStream_t)stream);
+        unsigned h[6];
+        if ((e = hipMemcpyAsync(h, ctx->tex_scan, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream)) != hipSuccess ||
+            (e = hipStreamSynchronize((hipStream_t)stream)) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "noise volume scan", e);
+        if (!h[2] && !h[5] && h[0] <= h[1] && h[3] <= h[4]) {
+            ctx->tex_bounds[0] = minmax_key_to_float(h[0]); ctx->tex_bounds[1] = minmax_key_to_float(h[1]);
+            ctx->tex_bounds[2] = minmax_key_to_float(h[3]); ctx->tex_bounds[3] = minmax_key_to_float(h[4]);
+            ctx->tex_bounds_valid = true;
+        }
+    }
     return SBX_OK;
 }
 

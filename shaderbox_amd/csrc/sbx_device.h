@@ -70,7 +70,9 @@ constexpr int CLOUDS_YTAB_RING = 8;         // eager tables: one per REBUILD (ke
                                             // for the launches that may still read it (sbx_capi.hip render_clouds)
 constexpr int CLOUDS_YTAB_CAPTURE = 8;      // tables used only by launches recorded into a stream capture
 void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, const float* shape_r, int shape_size,
-                       const float* detail_r, int detail_size);
+                       const float* detail_r, int detail_size, const float* bounds);     // bounds: {lo1, hi1, lo2, hi2} of the texels, or NULL
+void launch_minmax_r(const float* r, size_t n, unsigned* res, hipStream_t s);
+float minmax_key_to_float(unsigned k);
 void launch_extract_r(const float* rgba, float* r, size_t n, hipStream_t s);
 void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out, size_t n, hipStream_t s);
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant);

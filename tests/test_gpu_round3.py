@@ -257,6 +257,47 @@ def test_clouds_best_beyond_the_exact_integer_domain(renderer, oracle):
         assert compare(gpu, ref) == (0.0, 0), t
 
 
+def test_clouds_tex_texel_ranges(renderer, oracle):
+    """sbx_set_noise_volumes scans the texels; k_clouds_tex uses exp_reg4k_ only where the range bounds |density sigma dt| by 80.
+    Volumes inside that bound (the baked ones), volumes whose range lets 1 - .7 ww reach 0 (no bound), huge values, a NaN texel, a
+    large sigma that breaks the bound, more light steps than the LDS table of j / lsteps holds: all against the oracle."""
+    import torch
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS_TEX
+    w, h = 160, 90
+    g = torch.Generator(device="cpu").manual_seed(5)
+
+    def vol(n, lo, hi):
+        v = torch.zeros((n, n, n, 4), dtype=torch.float32)
+        v[..., 0] = torch.rand((n, n, n), generator=g) * (hi - lo) + lo
+        return v.cuda()
+
+    def check(v1, v2, **kw):
+        renderer.set_noise_volumes(v1, v2)
+        oracle.set_noise_volumes(v1.cpu().numpy(), v2.cpu().numpy())
+        aux = shaderbox_amd.clouds_defaults()
+        for k, x in kw.items():
+            setattr(aux, k, x)
+        for t in (.37, 2.5):
+            gpu = renderer.render("clouds_tex", w, h, t, aux=aux).cpu().numpy()
+            assert compare(gpu, oracle.render(APP_CLOUDS_TEX, w, h, t, aux=aux)) == (0.0, 0), (kw, t)
+
+    baked1, baked2 = renderer.worley_volume(32), renderer.worley_volume(16)
+    check(baked1, baked2)                                           # bounded: exp_reg4k_
+    check(baked1, baked2, illum_march_steps=70)                     # beyond the 64 rows of the j / lsteps table
+    check(baked1, baked2, sigma_scattering=60.0)                    # 8.4 * 60 * 1.25 > 80: exp_
+    check(baked1, baked2, sigma_scattering=5.0)                     # large arguments inside the bound
+    check(vol(16, 0.0, 1.0), vol(8, 0.0, 1.0))                      # unit range
+    check(vol(16, -3.0, 3.0), vol(8, -3.0, 3.0))                    # 1 - .7 ww passes through 0: no bound
+    check(vol(16, 0.0, 1.0), vol(8, 1.42, 1.43))                    # 1 - .7 ww within 1e-3 of 0
+    check(vol(16, -1e30, 1e30), vol(8, 0.0, 1.0))                   # huge texels
+    v = vol(16, 0.0, 1.0)
+    v[3, 4, 5, 0] = float("nan")
+    check(v, vol(8, 0.0, 1.0))                                      # a NaN texel: no bound
+    renderer.set_noise_volumes(baked1, baked2)
+    oracle.set_noise_volumes(baked1.cpu().numpy(), baked2.cpu().numpy())
+
+
 def test_exp_small_equals_exp_on_its_whole_domain(renderer):
     """exp_small_ (sbx_math.h: degree-8 minimax polynomial, no argument reduction, no table; with and without the three-address
     asm) against exp_ of the math spec on EVERY binary32 argument in [-0.205, -0] and at +0 — what k_clouds' REG kernels can
