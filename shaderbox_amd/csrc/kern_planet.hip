@@ -136,6 +136,18 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
 #ifndef PL_EXP4K
 #define PL_EXP4K 1
 #endif
+// length() of a march position in the SKIP kernels: sqrt_n_ of sbx_math.h — v_sqrt_f32 and the two-sided fix-up WITHOUT the input
+// scaling and class tests of the compiler's IEEE expansion (~35 instead of ~60 issue cycles), bit-identical to it for every
+// argument that is 0, not finite, negative, or >= 2^-96 (all 2^32 run: test_sqrt_n_is_ieee_sqrt).  Here the argument is |p|^2 of a
+// point p = rot * (eye + s * rd) with the reference's fixed eye (0, 0, -2.5) (:47-58): lanes that miss the atmosphere keep
+// o == 0 exactly (hit_o = 0, t = 0), every other lane has rd.x, rd.y either exactly 0 (the centre ray, which stops on the terrain
+// at |o| >= 1) or >= 1e-6 in magnitude (pixel centres), and o.x = (t0 + t) * rd.x has no cancellation: |o|^2 >= 1e-12 >> 2^-96 = 1.3e-29.
+// The SKIP kernels run only for tame frames (finite, bounded u_time); a NaN resolution gives NaN, which sqrt_n_ passes through.
+#ifndef PL_SQRT_N
+#define PL_SQRT_N 1
+#endif
+template <bool SKIP>
+__device__ __forceinline__ float pl_length(v3 v) { return (SKIP && PL_SQRT_N) ? sqrt_n_(dot(v, v)) : length(v); }
 #define PL_EXP(x) ((SKIP && PL_EXP4K) ? exp_reg4k_((x), kExp2Tab4096) : exp_(x))
 // clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
 // SKIP = false (sbx_set_variant 1) evaluates everything: the reference form, kept for the parity sweeps
@@ -202,7 +214,7 @@ __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lan
         n1 = SMOOTHSTEP_K(.6f, 1.f, h1);
     }
     const float n = n0 + n1;
-    return V2(length(pos) - 1.f - n * PL_MAX_HEIGHT, div_by(n, 1.0 / (double)PL_MAX_HEIGHT));
+    return V2(pl_length<SKIP>(pos) - 1.f - n * PL_MAX_HEIGHT, div_by(n, 1.0 / (double)PL_MAX_HEIGHT));
 }
 
 __device__ __forceinline__ v3 setup_lights(v3 L, v3 normal) {                          // :217-236
@@ -319,7 +331,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
                     if (SKIP && !wave_any(cm && !(d2 > 1.5885f || d2 < 1.166f))) { tc += t_step; continue; }
                 }
                 const v3 cp = mul(F.rot_cloud, o - V3(0, 0, 0));
-                const float ch = div_by(length(cp) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
+                const float ch = div_by(pl_length<SKIP>(cp) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
                 if (cm) { cloud.pos = cp; cloud.height = ch; }
                 tc += t_step;
                 clouds_map<SKIP>(S, cloud, t_step, cm, lane);
@@ -387,7 +399,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
                 for (int i = 0; i < 5; ++i) {
                     const v3 o = sh.origin + ts * local_up;
                     sh.pos = mul(F.rot_cloud, o - V3(0, 0, 0));
-                    sh.height = div_by(length(sh.pos) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
+                    sh.height = div_by(pl_length<SKIP>(sh.pos) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
                     ts += t_step;
                     clouds_map<SKIP>(S, sh, t_step, hitl, lane);
                 }
