@@ -1050,7 +1050,10 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
         else hipLaunchKernelGGL((k_clouds<true, false, 0>), grid, block, 0, s, F, M, out, ct);
     } else {
         const YRow* ct = nullptr;
-        if (reg && zl) hipLaunchKernelGGL((k_clouds<false, true, 1>), grid, block, 0, s, F, M, out, ct);
+        const bool sm = F.exp_small && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
+        if (reg && zl && sm) hipLaunchKernelGGL((k_clouds<false, true, 1, true>), grid, block, 0, s, F, M, out, ct);
+        else if (reg && sm) hipLaunchKernelGGL((k_clouds<false, true, 0, true>), grid, block, 0, s, F, M, out, ct);
+        else if (reg && zl) hipLaunchKernelGGL((k_clouds<false, true, 1>), grid, block, 0, s, F, M, out, ct);
         else if (reg) hipLaunchKernelGGL((k_clouds<false, true, 0>), grid, block, 0, s, F, M, out, ct);
         else if (zl) hipLaunchKernelGGL((k_clouds<false, false, 1>), grid, block, 0, s, F, M, out, ct);
         else hipLaunchKernelGGL((k_clouds<false, false, 0>), grid, block, 0, s, F, M, out, ct);
