@@ -31,8 +31,10 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 
 // exp_ of this kernel reads the 2^(j/32) table from LDS.  For the density terms exp(-height / H) — 288 of the 336 exp of an
 // in-dome pixel — the binary32 range guard is left out when the uniforms are finite (FIN, decided on the host): a sample lies
-// inside the atmosphere shell, so -height / H is in [-50.1, 0.001], far inside the guard's [-104, 89], and a NaN passes
-// through the guard unchanged.  exp(-tau) keeps its guard: grazing sun rays reach optical depths beyond 104 (measured: a ring
+// inside the atmosphere sphere, so -height / H is >= -60e3 / 1200 = -50.1; a light sample below the ground returns before its exp
+// (:65), but a VIEW ray that dips below the horizon marches through the planet (no ground test, :119-122) with heights down to
+// -6.36e6, i.e. arguments up to +5300, where exp_ (guard at 89) and the guard-less forms alike overflow to +inf.  The guard-less
+// forms are shown equal to exp_ on every argument in [-80, 2^18]; a NaN passes through the guard unchanged.  exp(-tau) keeps its guard: grazing sun rays reach optical depths beyond 104 (measured: a ring
 // of 9 % of the pixels turns NaN / inf without it).
 #ifndef ATM_EXP_REG
 #define ATM_EXP_REG 1      // the density terms through exp_reg_ (sbx_math.h) when the uniforms are finite

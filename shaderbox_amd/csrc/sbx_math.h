@@ -364,7 +364,8 @@ __device__ __forceinline__ float exp_reg64_(float x, const Tab& tab) {
 // The same with a 4096-entry table (sbx_exp4k_table.h, 32 KB, read from global memory through the vector L1): x = (k/4096) ln2 + r,
 // |r| <= ln2/8192, and the degree-3 Taylor polynomial (truncation r^4/24 <= 2.1e-18): TWO binary64 fma less than exp_reg64_ and no
 // coefficient to move into a register pair.  A kernel-internal form like exp_reg64_, admitted on the same ground: equal to exp_ on
-// EVERY binary32 argument with |x| <= 80 (2.2e9 values; host: tests/test_exp_small.py against the oracle's m_exp; GPU:
+// EVERY binary32 argument in [-80, 2^18] (2.3e9 values; beyond 88.7 all three overflow to +inf; host: tests/test_exp_small.py against
+// the oracle's m_exp; GPU:
 // tests/test_gpu_round3.py::test_exp_reg64_equals_exp_on_its_whole_domain).  (2048 entries: ONE argument of the 2.2e9 differs.)
 template <class Tab>
 __device__ __forceinline__ float exp_reg4k_(float x, const Tab& tab) {

@@ -341,14 +341,17 @@ def test_clouds_exp_small_domain_edges(renderer, oracle):
 
 def test_exp_reg64_equals_exp_on_its_whole_domain(renderer):
     """exp_reg64_ (sbx_math.h: 64-entry table, degree-5 polynomial — one binary64 fma less than the spec's form; with and
-    without the three-address asm) and exp_reg4k_ (4096-entry table, degree 3: k_atmosphere's density terms) against exp_ of the math spec on EVERY binary32 argument with |x| < 80 — what the REG kernels
-    of APP_CLOUDS (|sigma * dt| <= 80, density in [0, 1)) and APP_ATMOSPHERE's density terms ([-50.1, .001]) can produce."""
+    without the three-address asm) and exp_reg4k_ (4096-entry table, degree 3) against exp_ of the math spec on EVERY binary32
+    argument in [-80, 2^18]: the REG kernels of APP_CLOUDS / CLOUDS_TEX and APP_PLANET's cloud samples produce |x| <= 80;
+    APP_ATMOSPHERE's density terms exp(-height / H) reach -50.1 at the top of the atmosphere and, for view rays that dip below
+    the horizon (negative heights down to -6.36e6 m, src/app_atmosphere.h:119-122: no ground test on the view ray), +5300 —
+    where both forms overflow to +inf like exp_."""
     import torch
-    lim = np.array([80.0], dtype=np.float32).view(np.uint32)[0]
     chunk = 1 << 26
-    for sign in (0, 0x80000000):
-        for start in range(0, int(lim) + 1, chunk):
-            stop = min(start + chunk, int(lim) + 1)
+    for sign, top in ((0x80000000, 80.0), (0, 262144.0)):
+        lim = int(np.array([top], dtype=np.float32).view(np.uint32)[0])
+        for start in range(0, lim + 1, chunk):
+            stop = min(start + chunk, lim + 1)
             bits = (torch.arange(start, stop, dtype=torch.int64, device="cuda") | sign).to(torch.int32)
             x = bits.view(torch.float32)
             b = renderer.math("exp", x)
