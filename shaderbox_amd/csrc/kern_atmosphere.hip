@@ -34,8 +34,9 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 // inside the atmosphere sphere, so -height / H is >= -60e3 / 1200 = -50.1; a light sample below the ground returns before its exp
 // (:65), but a VIEW ray that dips below the horizon marches through the planet (no ground test, :119-122) with heights down to
 // -6.36e6, i.e. arguments up to +5300, where exp_ (guard at 89) and the guard-less forms alike overflow to +inf.  The guard-less
-// forms are shown equal to exp_ on every argument in [-80, 2^18]; a NaN passes through the guard unchanged.  exp(-tau) keeps its guard: grazing sun rays reach optical depths beyond 104 (measured: a ring
-// of 9 % of the pixels turns NaN / inf without it).
+// forms are shown equal to exp_ on every argument in [-80, 2^18]; a NaN passes through the guard unchanged.  exp(-tau): grazing sun
+// rays reach optical depths beyond 104 (a ring of 9 % of the pixels turns NaN / inf without the guard), so the guard-less form is
+// used only where a wave-wide test shows tau <= 80 for every lane (ATM_TAU4K: 4.02 -> 3.94 ms).
 #ifndef ATM_EXP_REG
 #define ATM_EXP_REG 1      // the density terms through exp_reg_ (sbx_math.h) when the uniforms are finite
 #endif
@@ -49,6 +50,9 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
                            // 32 KB, and a workgroup's LDS is held until its last wave ends; per-CU persistent workgroups that copy once
                            // and walk through the tiles: the tile loop makes the compiler hoist the kernel's constants into registers,
                            // 95 VGPRs / 5 waves or 84 B of scratch at 64, 4.66 ms.  profiles/r03_log.md)
+#ifndef ATM_TAU4K
+#define ATM_TAU4K 1         // exp(-tau) through exp_reg4k_ where a wave's optical depths allow it
+#endif
 #ifndef ATM_TX
 #define ATM_TX 1           // waves per workgroup (1: 4.03 ms, 4: 4.06)
 #endif
@@ -121,7 +125,14 @@ __global__ void __launch_bounds__(64 * ATM_TX) k_atmosphere(FrameAtmosphere F, R
             float lR = 0.f, lM = 0.f;
             if (sun_light<FIN>(s, F.sun_dir, lR, lM, etab, etab64)) {
                 const v3 tau = betaR * (odR + lR) + betaM * 1.1f * (odM + lM);
-                const v3 att = V3(ATM_EXP(-tau.x), ATM_EXP(-tau.y), ATM_EXP(-tau.z));
+                // exp(-tau): the guard-less form where every lane that got here has all three tau <= 80 (tau >= 0: sums of
+                // non-negative terms; a NaN fails the test), exp_'s guarded form for the wave otherwise (grazing sun rays)
+                v3 att;
+                if (FIN && ATM_EXP_REG && ATM_EXP4K && ATM_TAU4K &&
+                    __builtin_amdgcn_ballot_w64(!(fmax_(fmax_(tau.x, tau.y), tau.z) <= 80.f)) == 0ull)
+                    att = V3(exp_reg4k_(-tau.x, kExp2Tab4096), exp_reg4k_(-tau.y, kExp2Tab4096), exp_reg4k_(-tau.z, kExp2Tab4096));
+                else
+                    att = V3(ATM_EXP(-tau.x), ATM_EXP(-tau.y), ATM_EXP(-tau.z));
                 sumR = sumR + hr * att;
                 sumM = sumM + hm * att;
             }
