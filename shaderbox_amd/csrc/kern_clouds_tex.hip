@@ -43,6 +43,9 @@
 #ifndef TEX_YTAB
 #define TEX_YTAB 1         // the y terms of the main march (and of the z-only light march) from a per-workgroup table in LDS
 #endif
+#ifndef TEX_EXP_SMALL
+#define TEX_EXP_SMALL 1    // exp_small_ where every active lane's argument lies in its domain [-0.205, 0] (tested per call)
+#endif
 #ifndef TEX_XB
 #define TEX_XB 1          // 0: never exp_reg4k_ (A/B timing)
 #endif
@@ -199,6 +202,13 @@ __device__ __forceinline__ float tex3d_z(const NoiseTex& T, float pz, TexCell& c
     return mix_(c.p0, c.p1, uz - lz);
 }
 
+// The kernel's exp: exp_small_ (10 instructions) when all active lanes' arguments lie in [-0.205, 0] — most samples: the argument
+// is -density * sigma * dt with densities well below the bound the host can prove — else exp_reg4k_ (xb) or exp_ itself.  All three
+// are equal to exp_ on their domains, so the choice changes no bit.  A NaN fails the test.
+__device__ __forceinline__ float tex_exp(float x, int xb) {
+    if (TEX_EXP_SMALL && __builtin_amdgcn_ballot_w64(!(x >= EXP_SMALL_MIN && x <= 0.f)) == 0ull) return exp_small_(x);
+    return xb ? exp_reg4k_(x, kExp2Tab4096) : exp_(x);
+}
 __device__ __forceinline__ float remap_(float v, float omin, float omax, float nmin, float nmax) {   // util.h:127-138
     return nmin + (((v - omin) / (omax - omin)) * (nmax - nmin));
 }
@@ -231,7 +241,7 @@ __device__ __forceinline__ float hg_phase_tex(float mu, float g) {   // volumetr
 //      every density so that |density * sigma * dt| <= 80: the exps are exp_reg4k_ of sbx_math.h (no range guard, 4096-entry table,
 //      degree 3: 15 instructions against exp_'s 21), equal to exp_ on that whole range.
 struct TexArgs { NoiseTex T1, T2; double rsteps, rlsteps; int xb; };
-#define TEX_EXP(x) (A.xb ? exp_reg4k_((x), kExp2Tab4096) : exp_(x))
+#define TEX_EXP(x) tex_exp((x), A.xb)
 constexpr int TEX_LH_N = 64;     // light steps whose `j / lsteps` comes from the workgroup's LDS table (more: computed per sample)
 template <bool POW2, bool ZL, bool REG, bool YT>      // ZL (decided on the host): POW2 and the light step has no x and no y component
 __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out, TexArgs A) {
