@@ -75,8 +75,9 @@
 
 namespace sbx {
 
-// The REG kernels' exp is exp_reg_ of sbx_math.h (|x| <= 80 shown on the host per launch): no range guard, three-address
-// v_fma_f64, power-of-two scaling after the rounding to binary32.  CL_EXP_ASM = 0 falls back to exp_tab_<false>.
+// The REG kernels' exp (|sigma * dt| <= 80 shown on the host per launch) is one of the guard-less forms of sbx_math.h that are equal
+// to exp_ on their whole domain: exp_small_ in the SM instantiations (every argument in [-0.205, -0], launch_clouds),
+// exp_reg4k_ in the others.  The CL_EXP* switches below keep the older forms (exp_reg64_, exp_reg_, exp_tab_<false>) for A/B timing.
 #ifndef CL_EXP64
 #define CL_EXP64 1         // REG kernels: the 64-entry / degree-5 form of exp_reg_ (one binary64 fma less; exhaustively equal on |x| <= 80)
 #endif
