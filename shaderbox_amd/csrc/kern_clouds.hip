@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(64) k_clouds_ytab(FrameClouds F, YRow* __restr
 }
 
 // NFL: the noise factor is the literal .001 (the y-table kernels, which never run SKY_SPHERE frames); else F.nf
-template <bool NFL>
+template <bool NFL, bool B40 = false>          // B40: lattice indices shown below 2^40 on the host (sbx_noise.h hash1_b)
 __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, bool active, WaveCache& S, int lane) {
     v3 p = (pos_in * (NFL ? .001f : F.nf)) * 2.03f;      // :66,72
     float fx[4], fy[4], fz[4];
@@ -296,7 +296,7 @@ __device__ __forceinline__ float coop_density(const FrameClouds& F, v3 pos_in, b
         for (int k = 0; k < 4; ++k) {
             H8 h;
             if (wave_any(active && ne[k])) {
-                h = hc_slow(S, k, nbits[k], slot[k], active, lane);
+                h = hc_slow<B40>(S, k, nbits[k], slot[k], active, lane);
             } else {
                 h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
                 h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
@@ -320,7 +320,7 @@ __device__ __forceinline__ void hc_blend_xy(float4 lo, float4 hi, float fx, floa
 }
 
 // Octaves [K0, K1) of a main sample's fBm: lattice terms, tag checks, ONE wave-uniform all-hit test, reads, blends.
-template <int K0, int K1>
+template <int K0, int K1, bool B40>
 __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (&rgy)[4], const float (&rpy)[4], float& qx, float& qz,
                                             float& t, float& H, bool active, unsigned long long active_mask, WaveCache& S,
                                             int lane, float (&fx)[4], float (&nxy)[4], float (&mab)[4], float (&mcd)[4],
@@ -363,7 +363,7 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
         for (int k = K0; k < K1; ++k) {
             H8 h;
             if (wave_any(active && ne[k])) {
-                h = hc_slow(S, k, nbits[k], slot[k], active, lane);
+                h = hc_slow<B40>(S, k, nbits[k], slot[k], active, lane);
             } else {
                 h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][0]);
                 h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot[k]][4]);
@@ -401,7 +401,7 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
 // = 2e-4 per end point (s3: 4e-4): the 1e-3 in the gaps covers both ends, the 1 % in c the rounding of t and D.  Positions
 // are eye + proj * 150 + wind_dir * u_time * 1000 + t * proj with |proj.x|, |proj.z| <= 20 (dir.y >= .05) — unbounded in
 // u_time and wind_dir, both caller-set: at |wind_off| = 2e7 (ulp 2) the bound fails numerically, hence the check.
-template <bool LIP>
+template <bool LIP, bool B40>
 __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
                                                   unsigned long long active_mask, WaveCache& S, int lane,
                                                   float (&fx)[4], float (&nxy)[4], float (&mab)[4], float (&mcd)[4],
@@ -413,7 +413,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
     float t = 0.f, H = .5f;
     float lip_inv = 0.f;
     if (LIP) lip_inv = *lip_slot;                        // 1 / c of this lane, kept in LDS (read early, used after the first stage)
-    row_octaves<0, 2>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
+    row_octaves<0, 2, B40>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
     // (t + .1876 < cov written as t < cov - .1876 with the right side a frame constant: one instruction; the 1e-4 of slack over
     //  .1875 covers the half ulp by which the two forms can differ, and a skipped sample is exactly 0 either way)
     if (!wave_any_mask(active_mask & wave_mask(!(t < F.thr1)))) {                        // NaN compares false: goes on
@@ -435,7 +435,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 #ifdef SBX_CL_STATS
     if (lane == 0) S.stat[4] += 1.f;
 #endif
-    row_octaves<2, 3>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
+    row_octaves<2, 3, B40>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
     if (!wave_any_mask(active_mask & wave_mask(!(t < F.thr2)))) {
 #if CL_LIPSKIP2
         if (LIP) {
@@ -459,7 +459,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
 #ifdef SBX_CL_STATS
     if (lane == 0) S.stat[5] += 1.f;
 #endif
-    row_octaves<3, 4>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
+    row_octaves<3, 4, B40>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
     return t * smoothstep_rd(F.cov, F.cov_rd, t);        // :83-84
 }
 
@@ -583,7 +583,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
                 curz[k] = pzv[k];
                 H8 h;
                 if (wave_any(lit && ne)) {
-                    h = hc_slow(S, k, nbits, slot, lit, lane);
+                    h = hc_slow<SM>(S, k, nbits, slot, lit, lane);
                 } else {
                     h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot][0]);
                     h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
@@ -672,7 +672,7 @@ __device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 
                 const bool ne = (S.tag[k][slot] != nbits);
                 H8 h;
                 if (wave_any(lit && ne)) {
-                    h = hc_slow(S, k, nbits, slot, lit, lane);
+                    h = hc_slow<SM>(S, k, nbits, slot, lit, lane);
                 } else {
                     h.lo = *reinterpret_cast<const float4*>(&S.h[k][slot][0]);
                     h.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
@@ -881,8 +881,8 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
                 float mfx[4] = {0.f, 0.f, 0.f, 0.f}, mnxy[4] = {0.f, 0.f, 0.f, 0.f};
                 float mab[4] = {0.f, 0.f, 0.f, 0.f}, mcd[4] = {0.f, 0.f, 0.f, 0.f};
                 float mpz[4] = {u2f(0x7fc00001u), u2f(0x7fc00001u), u2f(0x7fc00001u), u2f(0x7fc00001u)};
-                float density = YTAB ? coop_density_row<LIP>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, mab, mcd, mpz, lip_slot, skip)
-                                           : coop_density<false>(F, pos, alive, S, lane);
+                float density = YTAB ? coop_density_row<LIP, SM>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, mab, mcd, mpz, lip_slot, skip)
+                                           : coop_density<false, SM>(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
                 if (wave_any_mask(lit_mask)) {
@@ -912,7 +912,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
 #endif
                     } else {
                         for (int j = 0; j < F.lsteps; ++j) {
-                            const float d = coop_density<YTAB>(F, lp, lit, S, lane);
+                            const float d = coop_density<YTAB, SM>(F, lp, lit, S, lane);
                             ltrans *= REG ? CL_EXP_REG(-d * vsigma * vdt) : CL_EXP(-d * F.sigma * F.dt);
                             lp = lp + lstep;
                         }
@@ -1011,6 +1011,20 @@ static bool clouds_lip_domain(const FrameClouds& F) {
     return std::isfinite(F.wind_off.x) && std::isfinite(F.wind_off.y) && std::isfinite(F.wind_off.z) && far <= 131072.0;   // NaN compares false
 }
 
+// sin_b40_'s domain (the SM kernels' hash passes): every lattice index n = px + 157 py + 113 pz (+ up to 271) the frame can hash is
+// below 2^39 in magnitude.  A sample's coordinates are bounded by |eye| + |wind_off| + the main march's reach (|dir / dir.y| <= 20
+// above the horizon cut; SKY_SPHERE: the atmosphere sphere and a unit direction) + the light march's (lsteps + 1) |L dt|; the finest
+// octave scales them by nf * 2.03 * 2.64^3.
+static bool clouds_index_domain(const FrameClouds& F) {
+    auto m3 = [](v3 v) { return std::fmax(std::fabs((double)v.x), std::fmax(std::fabs((double)v.y), std::fabs((double)v.z))); };
+    const double reach = 21.0 * 150.0 + 22.0 * std::fabs((double)F.dt) * (double)F.steps;
+    const double light = ((double)F.lsteps + 1.0) * m3(F.sun_dir) * std::fabs((double)F.dt);
+    const double sky = F.sky ? std::fabs((double)F.atm_r) + std::fabs((double)F.atm_y) : 0.0;
+    const double P = m3(F.cam.eye) + m3(F.wind_off) + reach + light + sky;
+    const double n = 271.0 * (P * std::fabs((double)F.nf) * 2.03 * 18.4 + 2.0);
+    return std::isfinite(n) && n <= 549755813888.0;                  // 2^39; NaN compares false
+}
+
 void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows,
                    bool build_table) {
     FrameClouds F = F_in;
@@ -1039,7 +1053,8 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
         YRow* tab = reinterpret_cast<YRow*>(ytab);
         if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
         const YRow* ct = tab;
-        const bool sm = F.exp_small && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
+        // SM kernels: exp_small_'s domain AND lattice indices below 2^40 for sin_b40_
+        const bool sm = F.exp_small && clouds_index_domain(F) && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
         if (reg && zl && sm) hipLaunchKernelGGL((k_clouds<true, true, 1, true>), grid, block, pad, s, F, M, out, ct);
         else if (reg && zl) hipLaunchKernelGGL((k_clouds<true, true, 1>), grid, block, pad, s, F, M, out, ct);
         else if (reg && yz && sm && CL_YZ_SM) hipLaunchKernelGGL((k_clouds<true, true, 2, true>), grid, block, 0, s, F, M, out, ct);
@@ -1051,7 +1066,7 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
         else hipLaunchKernelGGL((k_clouds<true, false, 0>), grid, block, 0, s, F, M, out, ct);
     } else {
         const YRow* ct = nullptr;
-        const bool sm = F.exp_small && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
+        const bool sm = F.exp_small && clouds_index_domain(F) && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
         if (reg && zl && sm) hipLaunchKernelGGL((k_clouds<false, true, 1, true>), grid, block, 0, s, F, M, out, ct);
         else if (reg && sm) hipLaunchKernelGGL((k_clouds<false, true, 0, true>), grid, block, 0, s, F, M, out, ct);
         else if (reg && zl) hipLaunchKernelGGL((k_clouds<false, true, 1>), grid, block, 0, s, F, M, out, ct);

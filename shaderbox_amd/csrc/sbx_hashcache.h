@@ -53,6 +53,7 @@ struct alignas(16) WaveCache {
 
 // miss path, one octave: the lanes in `need` lack their cell.  Leaders (one per distinct slot) are
 // elected with ballot/readlane, up to 8 cells per pass; lane (r, c) evaluates corner c of pending cell r.
+template <bool B40 = false>
 __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, int slot, bool need, int lane) {
     const int corner = lane & 7;
     const float off = (corner & 1 ? 1.0f : 0.0f) + (corner & 2 ? 157.0f : 0.0f) + (corner & 4 ? 113.0f : 0.0f);
@@ -75,7 +76,7 @@ __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, i
             const int r = lane >> 3;
             const unsigned n0 = S.ins_tag[r];
             const int s0 = (int)S.ins_slot[r];
-            S.h[k][s0][corner] = hash1(u2f(n0) + off);
+            S.h[k][s0][corner] = hash1_b<B40>(u2f(n0) + off);
             if (corner == 0) S.tag[k][s0] = n0;
         }
         __builtin_amdgcn_wave_barrier();
@@ -92,6 +93,8 @@ struct H8 { float4 lo, hi; };
 #ifndef SBX_HC_SLOW_INLINE
 #define SBX_HC_SLOW_INLINE __forceinline__
 #endif
+// B40: the caller has shown |n| <= 2^40 for every lattice index it can produce (hash1_b)
+template <bool B40 = false>
 __device__ SBX_HC_SLOW_INLINE H8 hc_slow(WaveCache& S, int k, unsigned nbits, int slot, bool active, int lane) {
     H8 r;
     r.lo = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -107,7 +110,7 @@ __device__ SBX_HC_SLOW_INLINE H8 hc_slow(WaveCache& S, int k, unsigned nbits, in
             need = false;
         }
         if (!wave_any(need)) break;
-        hc_insert(S, k, nbits, slot, need, lane);
+        hc_insert<B40>(S, k, nbits, slot, need, lane);
     }
     return r;
 }
@@ -174,7 +177,7 @@ __device__ __forceinline__ void coop_noise_n(WaveCache& S, const v3 (&p)[N], con
         for (int i = 0; i < N; ++i) {
             H8 h;
             if (wave_any(active && ne[i])) {
-                h = hc_slow(S, tab[i], nbits[i], slot[i], active, lane);
+                h = hc_slow<XI>(S, tab[i], nbits[i], slot[i], active, lane);       // XI: indices below 2^24
             } else {
                 h.lo = *reinterpret_cast<const float4*>(&S.h[tab[i]][slot[i]][0]);
                 h.hi = *reinterpret_cast<const float4*>(&S.h[tab[i]][slot[i]][4]);

@@ -167,6 +167,37 @@ SBX_HD double d_cos(double x) {
     return u2d(d2u(d_sin_poly(r)) ^ flip);
 }
 SBX_HD float sin_(float x) { return (float)d_sin((double)x); }
+// sin with a degree-15 minimax polynomial (Remez on [0, pi/2], relative error 2^-58; tools/gen_math_coeffs.py --sin15) in place of
+// the spec's Taylor polynomial to r^21: the same argument reduction, three binary64 fma less.  A kernel-internal form like the exp
+// forms below, admitted on the same ground: EQUAL to sin_ on every binary32 argument with |x| < 2^44.6 — all 2.9e9 of them were run
+// (the first difference is at x = 0x1.95f654p+44, where the two-term reduction has long stopped delivering an r in [-pi/2, pi/2]);
+// callers use it for |x| <= 2^40 (host: tests/test_exp_small.py against the oracle's m_sin; GPU: tests/test_gpu_round3.py).
+// cos_ does NOT have this property (it differs at x = 0x1.8f219cp+5) and keeps the spec's polynomial.
+constexpr float SIN_B40_MAX = 0x1p+40f;
+#define SBX_SIN15_COEFS -0x1.a09498de90541p-41, 0x1.60f3b0ed85645p-33, -0x1.ae63ac7b0bc8cp-26, 0x1.71de3921ccf1fp-19, \
+                         -0x1.a01a019dfb495p-13, 0x1.111111110f8bcp-7, -0x1.5555555555543p-3       /* r^15 ... r^3 */
+#if defined(__HIP_DEVICE_COMPILE__)
+__constant__ const double kSin15Coef[7] = {SBX_SIN15_COEFS};
+#else
+constexpr double kSin15Coef[7] = {SBX_SIN15_COEFS};
+#endif
+SBX_HD float sin_b40_(float x) {
+    const double xd = (double)x;
+    double kd = __builtin_fma(xd, D_INV_PI, D_MAGIC);
+    const uint64_t flip = d2u(kd) << 63;
+    kd = kd - D_MAGIC;
+    double r = __builtin_fma(kd, -D_PI, xd);
+    r = __builtin_fma(kd, -D_PI_LO, r);
+    const double s = r * r;
+    double p = kSin15Coef[0];                         // (read like kSinCoef: scalar loads at the use, no literals held in registers)
+    p = __builtin_fma(p, s, kSin15Coef[1]);
+    p = __builtin_fma(p, s, kSin15Coef[2]);
+    p = __builtin_fma(p, s, kSin15Coef[3]);
+    p = __builtin_fma(p, s, kSin15Coef[4]);
+    p = __builtin_fma(p, s, kSin15Coef[5]);
+    p = __builtin_fma(p, s, kSin15Coef[6]);
+    return (float)u2d(d2u(__builtin_fma(r * s, p, r)) ^ flip);
+}
 SBX_HD float cos_(float x) { return (float)d_cos((double)x); }
 SBX_HD float tan_(float x) { return (float)(d_sin((double)x) / d_cos((double)x)); }
 

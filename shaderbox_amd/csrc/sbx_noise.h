@@ -6,7 +6,23 @@
 namespace sbx {
 
 // hash(n) = fract(sin(n) * 753.5453123)                                   noise_iq.h:5-9
+#ifdef SBX_ABLATE_SIN     // timing experiment only (wrong pixels): what the sin of the lattice hash costs a kernel
+__device__ __forceinline__ float hash1(float n) { return fract_((n * .318f) * 753.5453123f); }
+#else
 __device__ __forceinline__ float hash1(float n) { return fract_(sin_(n) * 753.5453123f); }
+#endif
+// hash1 for callers that have shown |n| <= 2^40 (B40; the lattice index of a bounded position): sin_b40_ of sbx_math.h, equal to
+// sin_ on that whole range, three binary64 fma cheaper.  (Both forms behind a wave-wide test of n cost the hash pass' callers
+// 40-60 B of scratch: the choice is a template parameter decided from the host's domain checks instead.)
+template <bool B40>
+__device__ __forceinline__ float hash1_b(float n) {
+#if defined(SBX_ABLATE_SIN) || defined(SBX_NO_SIN_B40)
+    return hash1(n);
+#else
+    return B40 ? fract_(sin_b40_(n) * 753.5453123f) : hash1(n);
+#endif
+}
+
 
 // trilinear value noise over the 8 lattice corners                        noise_iq.h:11-29
 // (1 - f) is written once per axis instead of once per mix(): same value, same bits.

@@ -107,3 +107,63 @@ def test_exp_reg4k_equals_the_spec_exp_for_all_arguments_up_to_80(tmp_path):
     subprocess.run(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-msse4.1", "-o", str(exe), str(src)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "mismatches 0" in r.stdout and "checked 2334130178" in r.stdout, r.stdout
+
+
+SRC_SIN = r"""
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <thread>
+#include <vector>
+#include <atomic>
+#include "%(root)s/oracle/sbx_math_ref.h"
+using namespace sbxref;
+static const double C[7] = {%(coefs)s};
+static inline float sin15(float xf) {
+    const double x = (double)xf;
+    double kd = fma(x, SBX_D_INV_PI, SBX_D_MAGIC);
+    const uint64_t flip = d2u(kd) << 63;
+    kd = kd - SBX_D_MAGIC;
+    double r = fma(kd, -SBX_D_PI, x);
+    r = fma(kd, -SBX_D_PI_LO, r);
+    const double s = r * r;
+    double p = C[0];
+    for (int i = 1; i < 7; ++i) p = fma(p, s, C[i]);
+    return (float)u2d(d2u(fma(r * s, p, r)) ^ flip);
+}
+int main() {
+    const uint32_t lim = f2u(%(lim)s);
+    std::atomic<long> bad{0};
+    std::vector<std::thread> th;
+    const int T = 8;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
+        long b = 0;
+        for (uint64_t i = t; i <= lim; i += T)
+            for (uint32_t sign = 0; sign < 2; ++sign) {
+                const float x = u2f((uint32_t)i | (sign << 31));
+                if (f2u(sin15(x)) != f2u(m_sin(x))) ++b;
+            }
+        bad += b;
+    });
+    for (auto& t : th) t.join();
+    printf("checked %%lu mismatches %%ld\n", 2ul * ((unsigned long)lim + 1), bad.load());
+    return bad.load() != 0;
+}
+"""
+
+
+def test_sin_b40_equals_the_spec_sin_up_to_2_pow_40(tmp_path):
+    """sin_b40_ (sbx_math.h: the spec's argument reduction, a degree-15 minimax polynomial instead of the Taylor polynomial to r^21 —
+    the hash passes' sin) restated in C with the coefficients read from sbx_math.h, against the oracle's m_sin on EVERY binary32
+    argument with |x| <= 2^40 (2.8e9 values, 8 threads)."""
+    text = open(os.path.join(ROOT, "shaderbox_amd", "csrc", "sbx_math.h")).read()
+    coefs = re.search(r"#define SBX_SIN15_COEFS (.*?)/\*", text, re.S).group(1).replace("\\\n", " ")
+    assert len(re.findall(r"0x", coefs)) == 7
+    lim = re.search(r"SIN_B40_MAX = (0x1p\+40f)", text).group(1)
+    src = tmp_path / "exhsin.cpp"
+    src.write_text(SRC_SIN % dict(root=ROOT, coefs=coefs, lim=lim))
+    exe = tmp_path / "exhsin"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-msse4.1", "-pthread", "-o", str(exe), str(src)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout and "checked 2801795074" in r.stdout, r.stdout

@@ -298,6 +298,23 @@ def test_clouds_tex_texel_ranges(renderer, oracle):
     oracle.set_noise_volumes(baked1.cpu().numpy(), baked2.cpu().numpy())
 
 
+def test_sin_b40_equals_sin_up_to_2_pow_40(renderer):
+    """sin_b40_ (sbx_math.h: degree-15 minimax polynomial on the spec's argument reduction — the hash passes of k_clouds' SM
+    kernels and k_planet's tame-frame kernels, whose lattice indices the host bounds below 2^40) against sin_ of the math spec on
+    EVERY binary32 argument with |x| <= 2^40."""
+    import torch
+    lim = int(np.array([2.0 ** 40], dtype=np.float32).view(np.uint32)[0])
+    chunk = 1 << 26
+    for sign in (0, 0x80000000):
+        for start in range(0, lim + 1, chunk):
+            stop = min(start + chunk, lim + 1)
+            bits = (torch.arange(start, stop, dtype=torch.int64, device="cuda") | sign).to(torch.int32)
+            x = bits.view(torch.float32)
+            bad = renderer.math("sin_b40", x).view(torch.int32) != renderer.math("sin", x).view(torch.int32)
+            assert not bool(bad.any()), "first mismatch at bits 0x%08x" % int(bits[bad][0].item() & 0xffffffff)
+    assert bool(torch.isnan(renderer.math("sin_b40", torch.tensor([float("nan")], device="cuda"))).all())
+
+
 def test_exp_small_equals_exp_on_its_whole_domain(renderer):
     """exp_small_ (sbx_math.h: degree-8 minimax polynomial, no argument reduction, no table; with and without the three-address
     asm) against exp_ of the math spec on EVERY binary32 argument in [-0.205, -0] and at +0 — what k_clouds' REG kernels can

@@ -266,3 +266,48 @@ def exp_small(X="0.205", N=8):
 
 if __name__ == "__main__" and "--exp-small" in __import__("sys").argv:
     exp_small()
+
+
+def sin15(N=7):
+    """Coefficients of sin_b40_ (sbx_math.h): sin r ~ r + c3 r^3 + ... + c15 r^15 minimising the RELATIVE error on (0, pi/2 + 1e-6]
+    (Remez exchange on a fine grid, 70 digits); printed from r^15 down to r^3."""
+    mp.mp.dps = 70
+    a, b = mp.mpf("1e-3"), mp.pi / 2 + mp.mpf("1e-6")
+    m = N + 1
+
+    def err(c, r):
+        return (r + sum(c[k] * r ** (2 * k + 3) for k in range(N)) - mp.sin(r)) / mp.sin(r)
+    ref = [a + (b - a) * (1 - mp.cos(mp.pi * (i + 0.5) / m)) / 2 for i in range(m)]
+    for _ in range(40):
+        A, rhs = mp.matrix(m, m), mp.matrix(m, 1)
+        for i, r in enumerate(ref):
+            for k in range(N):
+                A[i, k] = r ** (2 * k + 3)
+            A[i, N] = -((-1) ** i) * mp.sin(r)
+            rhs[i] = mp.sin(r) - r
+        sol = mp.lu_solve(A, rhs)
+        c, E = [sol[k] for k in range(N)], sol[N]
+        G = 6000
+        xs = [a + (b - a) * mp.mpf(i) / G for i in range(G + 1)]
+        es = [err(c, x) for x in xs]
+        ext = []
+        for i in range(G + 1):
+            if es[i] != 0 and (i == 0 or abs(es[i]) >= abs(es[i - 1])) and (i == G or abs(es[i]) >= abs(es[i + 1])):
+                if ext and (ext[-1][1] > 0) == (es[i] > 0):
+                    if abs(es[i]) > abs(ext[-1][1]):
+                        ext[-1] = (xs[i], es[i])
+                else:
+                    ext.append((xs[i], es[i]))
+        while len(ext) > m:
+            ext.pop(0 if abs(ext[0][1]) < abs(ext[-1][1]) else -1)
+        if len(ext) < m:          # the error curve has flattened to the grid's resolution: the current solution stands
+            break
+        ref = [x for x, _ in ext]
+        if max(abs(v) for _, v in ext) / min(abs(v) for _, v in ext) < mp.mpf("1.001"):
+            break
+    print("// sin r = r + c3 r^3 + ... + c%d r^%d on (0, pi/2]: levelled relative error 2^%s" % (2 * N + 1, 2 * N + 1, mp.nstr(mp.log(abs(E), 2), 5)))
+    print("    " + ", ".join(float.hex(float(ck)) for ck in reversed(c)))
+
+
+if __name__ == "__main__" and "--sin15" in __import__("sys").argv:
+    sin15()
