@@ -53,6 +53,9 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #ifndef ATM_TAU4K
 #define ATM_TAU4K 1         // exp(-tau) through exp_reg4k_ where a wave's optical depths allow it
 #endif
+#ifndef ATM_DIV3
+#define ATM_DIV3 1         // FIN kernels: -height / H through div3_ (sbx_math.h; the divisors and their reciprocals held in VGPRs) instead of
+#endif                     // div_by's binary64 multiply: |height| is 0 or in [.5, 6.4e6] (a multiple of ulp(6.4e6)), the quotient only feeds exp
 #ifndef ATM_TX
 #define ATM_TX 1           // waves per workgroup (1: 4.03 ms, 4: 4.06)
 #endif
@@ -68,8 +71,11 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #define ATM_EXP(x) exp_tab_<true>((x), etab)
 
 // (march_pos + 0.5 * march_step below is written fma(.5, march_step, march_pos): the half is exact, so it is one rounding either way)
+struct AtmDiv { float hr, rhr, hm, rhm; };            // H_R, RN(1 / H_R), H_M, RN(1 / H_M)
+#define ATM_DIV_HR(h) ((FIN && ATM_DIV3) ? div3_((h), K.hr, K.rhr) : div_by((h), ATM_HR_RD))
+#define ATM_DIV_HM(h) ((FIN && ATM_DIV3) ? div3_((h), K.hm, K.rhm) : div_by((h), ATM_HM_RD))
 template <bool FIN>
-__device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, const double (&etab)[32], const double* etab64) {   // :50-76
+__device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, const double (&etab)[32], const double* etab64, const AtmDiv& K) {   // :50-76
     float t1;
     isect_atmosphere(ro, rd, t1);
     float march_pos = 0.f;
@@ -78,8 +84,8 @@ __device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, 
         const v3 s = ro + rd * __builtin_fmaf(0.5f, march_step, march_pos);
         const float height = sqrt_n_(dot(s, s)) - ATM_EARTH_R;   // length(s), |s| ~ 6.4e6
         if (height < 0.f) return false;
-        odR += ATM_EXP_H(div_by(-height, ATM_HR_RD)) * march_step;
-        odM += ATM_EXP_H(div_by(-height, ATM_HM_RD)) * march_step;
+        odR += ATM_EXP_H(ATM_DIV_HR(-height)) * march_step;
+        odM += ATM_EXP_H(ATM_DIV_HM(-height)) * march_step;
         march_pos += march_step;
     }
     return true;
@@ -106,6 +112,8 @@ __global__ void __launch_bounds__(64 * ATM_TX) k_atmosphere(FrameAtmosphere F, R
 
     v3 col = V3(0.f, 0.f, 0.f);
     float t1;
+    AtmDiv K{ATM_HR, 1.0f / ATM_HR, ATM_HM, 1.0f / ATM_HM};
+    if (FIN && ATM_DIV3) asm volatile("" : "+v"(K.hr), "+v"(K.rhr), "+v"(K.hm), "+v"(K.rhm));      // VGPR operands: full rate
     if (isect_atmosphere(ro, rd, t1)) {                             // get_incident_light :78-160
         const v3 betaR = V3(5.5e-6f, 13.0e-6f, 22.4e-6f), betaM = V3(21e-6f, 21e-6f, 21e-6f);   // :29-30
         const float march_step = t1 / 16.f;
@@ -118,12 +126,12 @@ __global__ void __launch_bounds__(64 * ATM_TX) k_atmosphere(FrameAtmosphere F, R
         for (int i = 0; i < 16; ++i) {
             const v3 s = ro + rd * __builtin_fmaf(0.5f, march_step, march_pos);
             const float height = sqrt_n_(dot(s, s)) - ATM_EARTH_R;   // length(s)
-            const float hr = ATM_EXP_H(div_by(-height, ATM_HR_RD)) * march_step;
-            const float hm = ATM_EXP_H(div_by(-height, ATM_HM_RD)) * march_step;
+            const float hr = ATM_EXP_H(ATM_DIV_HR(-height)) * march_step;
+            const float hm = ATM_EXP_H(ATM_DIV_HM(-height)) * march_step;
             odR += hr;
             odM += hm;
             float lR = 0.f, lM = 0.f;
-            if (sun_light<FIN>(s, F.sun_dir, lR, lM, etab, etab64)) {
+            if (sun_light<FIN>(s, F.sun_dir, lR, lM, etab, etab64, K)) {
                 const v3 tau = betaR * (odR + lR) + betaM * 1.1f * (odM + lM);
                 // exp(-tau): the guard-less form where every lane that got here has all three tau <= 80 (tau >= 0: sums of
                 // non-negative terms; a NaN fails the test), exp_'s guarded form for the wave otherwise (grazing sun rays)

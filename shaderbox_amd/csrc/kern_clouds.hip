@@ -91,6 +91,9 @@ namespace sbx {
 #ifndef CL_YZ_SM
 #define CL_YZ_SM 1        // exp_small_ in the y-z light march's kernel as well
 #endif
+#ifndef CL_DIV3
+#define CL_DIV3 1          // SM kernels: the coverage smoothstep's division through div3_ (sbx_math.h)
+#endif
 #ifndef CL_EXP4K
 #define CL_EXP4K 1         // the REG kernels outside exp_small_'s domain: exp_reg4k_ (4096-entry table through the vector L1, degree 3)
 #endif                     // instead of exp_reg64_ (64 entries in LDS, degree 5)
@@ -401,11 +404,11 @@ __device__ __forceinline__ void row_octaves(const float (&rfy)[4], const float (
 // = 2e-4 per end point (s3: 4e-4): the 1e-3 in the gaps covers both ends, the 1 % in c the rounding of t and D.  Positions
 // are eye + proj * 150 + wind_dir * u_time * 1000 + t * proj with |proj.x|, |proj.z| <= 20 (dir.y >= .05) — unbounded in
 // u_time and wind_dir, both caller-set: at |wind_off| = 2e7 (ulp 2) the bound fails numerically, hence the check.
-template <bool LIP, bool B40>
+template <bool LIP, bool B40, bool D3>          // D3: the coverage smoothstep through div3_ (vcd, vcr = F.cov_d, F.cov_r in VGPRs)
 __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_in, const YRow& row, bool active,
                                                   unsigned long long active_mask, WaveCache& S, int lane,
                                                   float (&fx)[4], float (&nxy)[4], float (&mab)[4], float (&mcd)[4],
-                                                  float (&mpz)[4], const float* lip_slot, int& skip) {
+                                                  float (&mpz)[4], const float* lip_slot, int& skip, float vcd, float vcr) {
     float qx = (pos_in.x * .001f) * 2.03f, qz = (pos_in.z * .001f) * 2.03f;
     const float rfy[4] = {row.fy.x, row.fy.y, row.fy.z, row.fy.w};
     const float rgy[4] = {row.gy.x, row.gy.y, row.gy.z, row.gy.w};
@@ -460,7 +463,7 @@ __device__ __forceinline__ float coop_density_row(const FrameClouds& F, v3 pos_i
     if (lane == 0) S.stat[5] += 1.f;
 #endif
     row_octaves<3, 4, B40>(rfy, rgy, rpy, qx, qz, t, H, active, active_mask, S, lane, fx, nxy, mab, mcd, mpz);
-    return t * smoothstep_rd(F.cov, F.cov_rd, t);        // :83-84
+    return D3 ? t * smoothstep_d3(F.cov, vcd, vcr, t) : t * smoothstep_rd(F.cov, F.cov_rd, t);        // :83-84
 }
 
 // illuminate_volume's march (:106-113) when the light step L*dt has no x and no y component — the
@@ -485,7 +488,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
                                                WaveCache& S, int lane, const YRow& row, const float (&mfx)[4],
                                                const float (&mnxy)[4], const float (&mab)[4], const float (&mcd)[4],
                                                const float (&mpz)[4], const double* etab, float vsigma, float vdt,
-                                               float vcov) {
+                                               float vcov, float vcd, float vcr) {       // vcd, vcr: F.cov_d, F.cov_r in VGPRs (SM)
     float fx[4], fy[4], gy[4], nxy[4], ab[4], cd[4], curz[4];
     if (YTAB) {
         // lp.x = pos.x + 0 and lp.y = pos.y + 0: the x terms are the main sample's own (same operations on
@@ -608,7 +611,8 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
             H *= .5f;
         }
         if (REG) {
-            const float d = x_smoothstep_rd_med3(vcov, F.cov_rd, t);
+            // SM: the coverage smoothstep's division through div3_ (three full-rate instructions; launch_clouds checks its domain)
+            const float d = (SM && CL_DIV3) ? x_smoothstep_d3_med3(vcov, vcd, vcr, t) : x_smoothstep_rd_med3(vcov, F.cov_rd, t);
             ltrans *= CL_EXP_REG(-d * vsigma * vdt);
         } else {
             const float d = t * smoothstep_rd(F.cov, F.cov_rd, t);
@@ -632,7 +636,7 @@ __device__ __forceinline__ float light_march_z(const FrameClouds& F, v3 lp, v3 l
 template <bool REG, bool SM>
 __device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 lstep, bool lit, unsigned long long lit_mask,
                                                 WaveCache& S, int lane, const float (&mfx)[4], const double* etab,
-                                                float vsigma, float vdt, float vcov) {
+                                                float vsigma, float vdt, float vcov, float vcd, float vcr) {
     float xa[4], xb[4], xc[4], xd[4], cy[4], cz[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { cy[k] = cz[k] = u2f(0x7fc00001u); xa[k] = xb[k] = xc[k] = xd[k] = 0.f; }
@@ -698,7 +702,8 @@ __device__ __forceinline__ float light_march_yz(const FrameClouds& F, v3 lp, v3 
             H *= .5f;
         }
         if (REG) {
-            const float d = x_smoothstep_rd_med3(vcov, F.cov_rd, t);
+            // SM: the coverage smoothstep's division through div3_ (three full-rate instructions; launch_clouds checks its domain)
+            const float d = (SM && CL_DIV3) ? x_smoothstep_d3_med3(vcov, vcd, vcr, t) : x_smoothstep_rd_med3(vcov, F.cov_rd, t);
             ltrans *= CL_EXP_REG(-d * vsigma * vdt);
         } else {
             const float d = t * smoothstep_rd(F.cov, F.cov_rd, t);
@@ -856,8 +861,11 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
             const float* lip_slot = &lip_inv_ok;
 #endif
             int skip = 0;
-            float vsigma = F.sigma, vdt = F.dt, vcov = F.cov;
+            float vsigma = F.sigma, vdt = F.dt, vcov = F.cov, vcd = F.cov_d, vcr = F.cov_r;
             asm volatile("" : "+v"(vsigma), "+v"(vdt), "+v"(vcov));
+            // (not in the general light march's kernels: two more live registers there mean 12 B of scratch, 4.82 -> 4.86 ms)
+            constexpr bool D3 = SM && CL_DIV3 && LM != 0;
+            if (D3) asm volatile("" : "+v"(vcd), "+v"(vcr));
             float t = 0.f;
             unsigned long long alive_mask = wave_mask(alive);
             for (int i = 0; i < F.steps; ++i) {
@@ -881,7 +889,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
                 float mfx[4] = {0.f, 0.f, 0.f, 0.f}, mnxy[4] = {0.f, 0.f, 0.f, 0.f};
                 float mab[4] = {0.f, 0.f, 0.f, 0.f}, mcd[4] = {0.f, 0.f, 0.f, 0.f};
                 float mpz[4] = {u2f(0x7fc00001u), u2f(0x7fc00001u), u2f(0x7fc00001u), u2f(0x7fc00001u)};
-                float density = YTAB ? coop_density_row<LIP, SM>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, mab, mcd, mpz, lip_slot, skip)
+                float density = YTAB ? coop_density_row<LIP, SM, D3>(F, pos, row, alive, alive_mask, S, lane, mfx, mnxy, mab, mcd, mpz, lip_slot, skip, vcd, vcr)
                                            : coop_density<false, SM>(F, pos, alive, S, lane);
                 const bool lit = alive && !(density < .005f);     // integrate_volume :132
                 const unsigned long long lit_mask = alive_mask & wave_mask(!(density < .005f));
@@ -902,8 +910,8 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
                         asm volatile("" ::: "memory");     // the reloads below cannot be forwarded from these stores: the values
                                                            // are dead across the light march
 #endif
-                        if (LM == 1) ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov);
-                        else ltrans = light_march_yz<REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, mfx, etab, vsigma, vdt, vcov);
+                        if (LM == 1) ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov, vcd, vcr);
+                        else ltrans = light_march_yz<REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, mfx, etab, vsigma, vdt, vcov, vcd, vcr);
 #if CL_PARK
                         asm volatile("" ::: "memory");
                         origin.x = pk[0 * 64]; origin.z = pk[1 * 64]; projection.x = pk[2 * 64]; projection.z = pk[3 * 64];
@@ -1015,6 +1023,13 @@ static bool clouds_lip_domain(const FrameClouds& F) {
 // below 2^39 in magnitude.  A sample's coordinates are bounded by |eye| + |wind_off| + the main march's reach (|dir / dir.y| <= 20
 // above the horizon cut; SKY_SPHERE: the atmosphere sphere and a unit direction) + the light march's (lsteps + 1) |L dt|; the finest
 // octave scales them by nf * 2.03 * 2.64^3.
+// div3_'s domain for the coverage smoothstep (x - cov) / (cov_hi - cov) of the SM kernels: x is an fBm sum in [0, .9375] or NaN, so
+// with 2^-20 <= |cov| <= 2^20 a non-zero x - cov is at least 2^-45 in magnitude (and at most 2^21); the divisor within 2^+-60.
+static bool clouds_div3_domain(const FrameClouds& F) {
+    const double c = std::fabs((double)F.cov), d = std::fabs((double)F.cov_d);
+    return std::isfinite(F.cov) && std::isfinite(F.cov_d) && std::isfinite(F.cov_r) && c >= 0x1p-20 && c <= 0x1p20 && d >= 0x1p-60 &&
+           d <= 0x1p60 && F.cov_d == F.cov_hi - F.cov && F.cov_r == 1.0f / F.cov_d;
+}
 static bool clouds_index_domain(const FrameClouds& F) {
     auto m3 = [](v3 v) { return std::fmax(std::fabs((double)v.x), std::fmax(std::fabs((double)v.y), std::fabs((double)v.z))); };
     const double reach = 21.0 * 150.0 + 22.0 * std::fabs((double)F.dt) * (double)F.steps;
@@ -1054,7 +1069,7 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
         if (build_table) hipLaunchKernelGGL(k_clouds_ytab, dim3((F.steps + 63) / 64), dim3(64), 0, s, F, tab);
         const YRow* ct = tab;
         // SM kernels: exp_small_'s domain AND lattice indices below 2^40 for sin_b40_
-        const bool sm = F.exp_small && clouds_index_domain(F) && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
+        const bool sm = F.exp_small && clouds_index_domain(F) && (!CL_DIV3 || clouds_div3_domain(F)) && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
         if (reg && zl && sm) hipLaunchKernelGGL((k_clouds<true, true, 1, true>), grid, block, pad, s, F, M, out, ct);
         else if (reg && zl) hipLaunchKernelGGL((k_clouds<true, true, 1>), grid, block, pad, s, F, M, out, ct);
         else if (reg && yz && sm && CL_YZ_SM) hipLaunchKernelGGL((k_clouds<true, true, 2, true>), grid, block, 0, s, F, M, out, ct);
@@ -1066,7 +1081,7 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
         else hipLaunchKernelGGL((k_clouds<true, false, 0>), grid, block, 0, s, F, M, out, ct);
     } else {
         const YRow* ct = nullptr;
-        const bool sm = F.exp_small && clouds_index_domain(F) && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
+        const bool sm = F.exp_small && clouds_index_domain(F) && (!CL_DIV3 || clouds_div3_domain(F)) && CL_EXP_SMALL && CL_EXP_ASM && CL_EXP64;
         if (reg && zl && sm) hipLaunchKernelGGL((k_clouds<false, true, 1, true>), grid, block, 0, s, F, M, out, ct);
         else if (reg && sm) hipLaunchKernelGGL((k_clouds<false, true, 0, true>), grid, block, 0, s, F, M, out, ct);
         else if (reg && zl) hipLaunchKernelGGL((k_clouds<false, true, 1>), grid, block, 0, s, F, M, out, ct);

@@ -34,8 +34,18 @@ constexpr float PL_MAX_RAY_DIST = PL_MAX_HEIGHT * 4.f;  // :21
 struct Vol { v3 origin, pos; float height, transmittance, radiance, alpha; };   // volumetric.h:47-68 (radiance r=g=b)
 __device__ __forceinline__ Vol make_vol(v3 o) { return Vol{o, o, 0.f, 1.f, 0.f, 0.f}; }
 
-// smoothstep with literal edges: the division by (e1 - e0) is an exact multiply by its binary64 reciprocal
-#define SMOOTHSTEP_K(e0, e1, x) smoothstep_rd((e0), 1.0 / (double)((e1) - (e0)), (x))
+// smoothstep with literal edges: the division by (e1 - e0) is an exact multiply by its binary64 reciprocal — or, in the SKIP kernels,
+// div3_ of sbx_math.h: three full-rate binary32 instructions with the literal divisor and its reciprocal, equal to the IEEE quotient
+// for every pair of significands.  Its domain (finite dividend, zero or within 2^+-100; the sign of a zero quotient unused) holds on
+// the tame frames those kernels run for: the dividends are differences of numbers of order 1 (zero or >= 2^-26), exp of a height in
+// [-2.5, 2], a smoothstep value (zero or >= 2^-60) or |p| - 1 (zero — always +0 — or >= 2^-24); a NaN gives NaN either way.
+#ifndef PL_DIV3
+#define PL_DIV3 1
+#endif
+#define PL_DIVK(a, dlit) ((SKIP && PL_DIV3) ? div3_((a), (dlit), 1.0f / (dlit)) : div_by((a), 1.0 / (double)(dlit)))
+#define SMOOTHSTEP_K(e0, e1, x) ((SKIP && PL_DIV3) ? smoothstep_d3((e0), (e1) - (e0), 1.0f / ((e1) - (e0)), (x)) \
+                                                   : smoothstep_rd((e0), 1.0 / (double)((e1) - (e0)), (x)))
+template <bool SKIP>
 __device__ __forceinline__ float band(float t) {                     // band(.2, .35, .65, t)  util.h:103-112
     return SMOOTHSTEP_K(.2f, .35f, t) * (1.f - SMOOTHSTEP_K(.35f, .65f, t));
 }
@@ -160,7 +170,7 @@ __device__ __forceinline__ bool clouds_density(WaveCache& S, v3 pos, float heigh
     // T_i = exp(-0) = 1, and the three updates below are `*= 1`, `+= 0`, `+= 0 * (1 - alpha)`: nothing changes.
     // When that holds for every committing lane of the wave the noise is not evaluated at all (most steps of the
     // 75-step march and 2-3 of the 5 shadow steps).  A NaN height compares unequal and takes the full path.
-    const float bd = band(height);
+    const float bd = band<SKIP>(height);
     if (SKIP && !wave_any(on && bd != 0.f)) return false;
     // fbm of |2 noise - 1| in [0, 1], gains .5 .25 .125 .0625: evaluated in stages {0,1}, {2}, {3}; once the part so far
     // plus the largest possible rest is below the coverage edge for every committing lane, smoothstep(cov, ..) is
@@ -190,7 +200,7 @@ __device__ __forceinline__ void clouds_map(WaveCache& S, Vol& c, float t_step, b
     if (!clouds_density<SKIP>(S, c.pos, c.height, t_step, on, lane, dens, T_i)) return;
     if (on) {
         c.transmittance *= T_i;
-        c.radiance += dens * div_by(PL_EXP(c.height), 1.0 / (double).055f) * c.transmittance * t_step;
+        c.radiance += dens * PL_DIVK(PL_EXP(c.height), .055f) * c.transmittance * t_step;
         c.alpha += (1.f - T_i) * (1.f - c.alpha);
     }
 }
@@ -214,7 +224,7 @@ __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lan
         n1 = SMOOTHSTEP_K(.6f, 1.f, h1);
     }
     const float n = n0 + n1;
-    return V2(pl_length<SKIP>(pos) - 1.f - n * PL_MAX_HEIGHT, div_by(n, 1.0 / (double)PL_MAX_HEIGHT));
+    return V2(pl_length<SKIP>(pos) - 1.f - n * PL_MAX_HEIGHT, PL_DIVK(n, PL_MAX_HEIGHT));
 }
 
 __device__ __forceinline__ v3 setup_lights(v3 L, v3 normal) {                          // :217-236
@@ -331,7 +341,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
                     if (SKIP && !wave_any(cm && !(d2 > 1.5885f || d2 < 1.166f))) { tc += t_step; continue; }
                 }
                 const v3 cp = mul(F.rot_cloud, o - V3(0, 0, 0));
-                const float ch = div_by(pl_length<SKIP>(cp) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
+                const float ch = PL_DIVK(pl_length<SKIP>(cp) - 1.f, PL_MAX_HEIGHT);
                 if (cm) { cloud.pos = cp; cloud.height = ch; }
                 tc += t_step;
                 clouds_map<SKIP>(S, cloud, t_step, cm, lane);
@@ -399,7 +409,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
                 for (int i = 0; i < 5; ++i) {
                     const v3 o = sh.origin + ts * local_up;
                     sh.pos = mul(F.rot_cloud, o - V3(0, 0, 0));
-                    sh.height = div_by(pl_length<SKIP>(sh.pos) - 1.f, 1.0 / (double)PL_MAX_HEIGHT);
+                    sh.height = PL_DIVK(pl_length<SKIP>(sh.pos) - 1.f, PL_MAX_HEIGHT);
                     ts += t_step;
                     clouds_map<SKIP>(S, sh, t_step, hitl, lane);
                 }

@@ -88,6 +88,7 @@ struct FrameClouds {
     float dt;             // cld_thick / float(cld_march_steps)         app_clouds.h:98,180
     float cov, cov_hi;    // 1 - cld_coverage, cov + .0135              app_clouds.h:83-84
     double cov_rd;        // recip64(cov_hi - cov): the smoothstep division becomes an exact multiply
+    float cov_d, cov_r;   // cov_hi - cov and RN(1 / that): the same division through div3_ (sbx_math.h) in k_clouds' SM kernels
     float thr1, thr2;     // cov - .1876, cov - .06255: the staged main sample's two cut-offs (launch_clouds)
     int lip_ok;           // 1: the march positions are small enough for k_clouds' Lipschitz sample skip (set per launch by
                           //    launch_clouds / clouds_lip_domain; 0 disables the skip, nothing else)

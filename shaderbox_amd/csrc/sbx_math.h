@@ -68,7 +68,31 @@ SBX_HD float smoothstep_rd(float e0, double rd, float x) {
     float t = clamp_(div_by(x - e0, rd), 0.0f, 1.0f);
     return (t * t) * tm2_(t);
 }
+// Division by a KNOWN divisor in three binary32 instructions: with r = RN(1 / d) computed once,
+//     q0 = RN(a * r);   e = fma(-q0, d, a)  (the exact remainder);   q = fma(e, r, q0)
+// is EQUAL to the IEEE quotient RN(a / d) for every pair of binary32 significands — all 2^47 pairs were run on the GPU
+// (tools/div3_exhaustive.hip, profiles/r03_div3_exhaustive.txt: 0 divisors of 8 388 608 have a failing dividend; division is
+// scale-free away from overflow and underflow).  6.75 issue cycles on gfx950 against 12.6 for div_by's cvt + binary64 multiply + cvt
+// (and ~40 for the IEEE expansion).  Valid where nothing over- or underflows on the way and the sign of a zero quotient is not used:
+// callers show a finite with 2^-100 <= |a| <= 2^100 or a == 0 (a zero dividend of either sign gives +0), and 2^-60 <= |d| <= 2^60.
+// A NaN dividend gives NaN.
+struct Div3 { float d, r; };
+SBX_HD Div3 make_div3(float d) { return Div3{d, 1.0f / d}; }
+SBX_HD float div3_(float a, float d, float r) {
+    const float q0 = a * r;
+    const float e = __builtin_fmaf(-q0, d, a);
+    return __builtin_fmaf(e, r, q0);
+}
+// smoothstep(e0, e0 + d, x) through div3_ (the clamp makes the sign of a zero quotient irrelevant: t * t is +0 either way)
+SBX_HD float smoothstep_d3(float e0, float d, float r, float x) {
+    const float t = clamp_(div3_(x - e0, d, r), 0.0f, 1.0f);
+    return (t * t) * tm2_(t);
+}
 #if defined(__HIPCC__)
+__device__ __forceinline__ float x_smoothstep_d3_med3(float e0, float d, float r, float x) {      // x_smoothstep_rd_med3 with div3_
+    const float t = __builtin_amdgcn_fmed3f(div3_(x - e0, d, r), 0.0f, 1.0f);
+    return x * ((t * t) * tm2_(t));
+}
 // x * smoothstep(e0, e1, x) with the clamp done by ONE v_med3_f32 (half the issue cost of two compare/select pairs).
 // v_med3_f32(t, 0, 1) differs from clamp_(t, 0, 1) in two cases only, and neither survives the operations around it:
 //   t = -0 : clamp_ gives -0, med3 may give +0 — the next operation is t * t = +0 either way;

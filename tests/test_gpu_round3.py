@@ -298,6 +298,34 @@ def test_clouds_tex_texel_ranges(renderer, oracle):
     oracle.set_noise_volumes(baked1.cpu().numpy(), baked2.cpu().numpy())
 
 
+def test_div3_equals_ieee_division(renderer):
+    """div3_ (sbx_math.h: q0 = a * RN(1 / d), q = fma(fma(-q0, d, a), RN(1 / d), q0)) against the IEEE quotient.  The complete run —
+    every pair of significands, 2^47 quotients, 63 s on an MI355X — is tools/div3_exhaustive.hip (profiles/r03_div3_exhaustive.txt:
+    no divisor has a failing dividend); here: 4 096 random divisors and the kernels' own (.65, .4, .15, .3, .0135, .055, 7994,
+    1200) against ALL 2^24 dividend significands of two binades, plus random pairs across the exponent range the callers use."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(11)
+    sig = (torch.arange(0, 1 << 24, dtype=torch.int64, device="cuda") + 0x3f800000).to(torch.int32).view(torch.float32)   # [1, 4)
+    ds = torch.cat([torch.tensor([1 - .35, 1 - .6, .35 - .2, .65 - .35, (.465 + .0135) - .465, .055, .4, 7994.0, 1200.0],
+                                 dtype=torch.float32, device="cuda"),
+                    (torch.randint(0, 1 << 23, (4096,), generator=g, device="cuda", dtype=torch.int64) + 0x3f800000)
+                    .to(torch.int32).view(torch.float32)])
+    for d in ds.tolist():
+        b = torch.full_like(sig, d)
+        bad = renderer.math("div3", sig, b).view(torch.int32) != renderer.math("div", sig, b).view(torch.int32)
+        assert not bool(bad.any()), (d, float(sig[bad][0]))
+    n = 1 << 26
+    a = torch.randint(0, 1 << 23, (n,), generator=g, device="cuda", dtype=torch.int64) | (torch.randint(127 - 90, 127 + 90, (n,), generator=g, device="cuda", dtype=torch.int64) << 23)
+    b = torch.randint(0, 1 << 23, (n,), generator=g, device="cuda", dtype=torch.int64) | (torch.randint(127 - 30, 127 + 30, (n,), generator=g, device="cuda", dtype=torch.int64) << 23)
+    a = (a | (torch.randint(0, 2, (n,), generator=g, device="cuda", dtype=torch.int64) << 31)).to(torch.int32).view(torch.float32)
+    b = b.to(torch.int32).view(torch.float32)
+    bad = renderer.math("div3", a, b).view(torch.int32) != renderer.math("div", a, b).view(torch.int32)
+    assert not bool(bad.any())
+    z = torch.zeros(4, device="cuda")
+    assert bool((renderer.math("div3", z, torch.full_like(z, .4)) == 0).all())
+    assert bool(torch.isnan(renderer.math("div3", torch.tensor([float("nan")], device="cuda"), torch.tensor([.4], device="cuda"))).all())
+
+
 def test_sin_b40_equals_sin_up_to_2_pow_40(renderer):
     """sin_b40_ (sbx_math.h: degree-15 minimax polynomial on the spec's argument reduction — the hash passes of k_clouds' SM
     kernels and k_planet's tame-frame kernels, whose lattice indices the host bounds below 2^40) against sin_ of the math spec on
