@@ -56,6 +56,11 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #ifndef ATM_DIV3
 #define ATM_DIV3 1         // FIN kernels: -height / H through div3_ (sbx_math.h; the divisors and their reciprocals held in VGPRs) instead of
 #endif                     // div_by's binary64 multiply: |height| is 0 or in [.5, 6.4e6] (a multiple of ulp(6.4e6)), the quotient only feeds exp
+#ifndef ATM_SQRT_RS
+#define ATM_SQRT_RS 1      // FIN kernels: length(s) of a march position through sqrt_rs_ (sbx_math.h: five instructions, exact for finite
+#endif                     // x >= 2^-102): |s|^2 is ~4e13 on the ray from (0, R + 1, 0), never 0 or inf.  (isect_atmosphere keeps sqrt_n_:
+                           // its argument can be exactly 0.)
+#define ATM_LEN(x) ((FIN && ATM_SQRT_RS) ? sqrt_rs_(x) : sqrt_n_(x))
 #ifndef ATM_TX
 #define ATM_TX 1           // waves per workgroup (1: 4.03 ms, 4: 4.06)
 #endif
@@ -82,7 +87,7 @@ __device__ __forceinline__ bool sun_light(v3 ro, v3 rd, float& odR, float& odM, 
     const float march_step = t1 / 8.f;
     for (int i = 0; i < 8; ++i) {
         const v3 s = ro + rd * __builtin_fmaf(0.5f, march_step, march_pos);
-        const float height = sqrt_n_(dot(s, s)) - ATM_EARTH_R;   // length(s), |s| ~ 6.4e6
+        const float height = ATM_LEN(dot(s, s)) - ATM_EARTH_R;   // length(s), |s| ~ 6.4e6
         if (height < 0.f) return false;
         odR += ATM_EXP_H(ATM_DIV_HR(-height)) * march_step;
         odM += ATM_EXP_H(ATM_DIV_HM(-height)) * march_step;
@@ -125,7 +130,7 @@ __global__ void __launch_bounds__(64 * ATM_TX) k_atmosphere(FrameAtmosphere F, R
         v3 sumR = V3(0, 0, 0), sumM = V3(0, 0, 0);
         for (int i = 0; i < 16; ++i) {
             const v3 s = ro + rd * __builtin_fmaf(0.5f, march_step, march_pos);
-            const float height = sqrt_n_(dot(s, s)) - ATM_EARTH_R;   // length(s)
+            const float height = ATM_LEN(dot(s, s)) - ATM_EARTH_R;   // length(s)
             const float hr = ATM_EXP_H(ATM_DIV_HR(-height)) * march_step;
             const float hm = ATM_EXP_H(ATM_DIV_HM(-height)) * march_step;
             odR += hr;

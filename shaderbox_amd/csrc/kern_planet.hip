@@ -153,11 +153,18 @@ __device__ __forceinline__ float coop_fbm(WaveCache& S, v3 q, float lacunarity, 
 // o == 0 exactly (hit_o = 0, t = 0), every other lane has rd.x, rd.y either exactly 0 (the centre ray, which stops on the terrain
 // at |o| >= 1) or >= 1e-6 in magnitude (pixel centres), and o.x = (t0 + t) * rd.x has no cancellation: |o|^2 >= 1e-12 >> 2^-96 = 1.3e-29.
 // The SKIP kernels run only for tame frames (finite, bounded u_time); a NaN resolution gives NaN, which sqrt_n_ passes through.
+#ifndef PL_SQRT_RS
+#define PL_SQRT_RS 1
+#endif
 #ifndef PL_SQRT_N
 #define PL_SQRT_N 1
 #endif
 template <bool SKIP>
-__device__ __forceinline__ float pl_length(v3 v) { return (SKIP && PL_SQRT_N) ? sqrt_n_(dot(v, v)) : length(v); }
+__device__ __forceinline__ float pl_length(v3 v) {
+    // (PL_SQRT_RS: sqrt_rs_, five instructions, exact for finite x >= 2^-102 — the lanes whose |o|^2 is exactly 0 are the ones that
+    //  missed the atmosphere: they never commit a result, and what they compute here, a NaN, decides nothing)
+    return (SKIP && PL_SQRT_RS) ? sqrt_rs_(dot(v, v)) : (SKIP && PL_SQRT_N) ? sqrt_n_(dot(v, v)) : length(v);
+}
 #define PL_EXP(x) ((SKIP && PL_EXP4K) ? exp_reg4k_((x), kExp2Tab4096) : exp_(x))
 // clouds_map :102-119 + integrate_volume :79-100; `on` = lanes that commit
 // SKIP = false (sbx_set_variant 1) evaluates everything: the reference form, kept for the parity sweeps

@@ -749,15 +749,15 @@ int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms) {
 int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, float* out, size_t n, void* stream) {
     if (!ctx) return SBX_ERR_ARG;
     if (!fn || !a || !out) return fail(ctx, SBX_ERR_ARG, "NULL argument");
-    static const char* names[] = {"sin", "cos", "tan", "exp", "pow", "acos", "atan2", "hash", "div", "div_rd", "exp_h13", "pow_h", "sqrt_n", "sqrt_ieee", "exp_reg", "exp_reg_plain", "exp_reg64", "exp_reg64_plain", "exp_small", "exp_small_plain", "exp_reg4k", "sin_b40", "div3"};
+    static const char* names[] = {"sin", "cos", "tan", "exp", "pow", "acos", "atan2", "hash", "div", "div_rd", "exp_h13", "pow_h", "sqrt_n", "sqrt_ieee", "exp_reg", "exp_reg_plain", "exp_reg64", "exp_reg64_plain", "exp_small", "exp_small_plain", "exp_reg4k", "sin_b40", "div3", "sqrt_rs"};
     int id = -1;
-    for (int i = 0; i < 23; ++i) if (std::strcmp(fn, names[i]) == 0) id = i;
+    for (int i = 0; i < 24; ++i) if (std::strcmp(fn, names[i]) == 0) id = i;
     if (id < 0) return fail(ctx, SBX_ERR_ARG, "unknown math function");
     if ((id == 4 || id == 6 || id == 8 || id == 9 || id == 11 || id == 22) && !b) return fail(ctx, SBX_ERR_ARG, "binary function needs b");
     if (n == 0) return SBX_OK;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
-    if (id == 21 || id == 22) { if (launch_math_eval(id, a, b, out, n, (hipStream_t)stream) != 0) return fail(ctx, SBX_ERR_ARG, "math function not in the kernel"); }
+    if (id >= 21) { if (launch_math_eval(id, a, b, out, n, (hipStream_t)stream) != 0) return fail(ctx, SBX_ERR_ARG, "math function not in the kernel"); }
     else if (id == 20) launch_exp4k_eval(a, out, n, (hipStream_t)stream);                 // k_atmosphere's 4096-entry form
     else if (id >= 14) launch_cl_exp_eval(a, out, n, (hipStream_t)stream, id - 14);   // exp_reg_ of sbx_math.h (|x| <= 80): k_clouds' / k_atmosphere's form
     else if (launch_math_eval(id, a, b, out, n, (hipStream_t)stream) != 0) return fail(ctx, SBX_ERR_ARG, "math function not in the kernel");

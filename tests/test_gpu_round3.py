@@ -298,6 +298,22 @@ def test_clouds_tex_texel_ranges(renderer, oracle):
     oracle.set_noise_volumes(baked1.cpu().numpy(), baked2.cpu().numpy())
 
 
+def test_sqrt_rs_is_ieee_sqrt_from_2_pow_minus_100(renderer):
+    """sqrt_rs_ (sbx_math.h: v_rsq_f32 and one corrected step, five instructions) against the compiler's IEEE square root on EVERY
+    finite binary32 argument >= 2^-100 (the complete run over all positive arguments, with the counts per exponent below 2^-102, is
+    tools/sqrt_rsq_exhaustive.hip / profiles/r03_sqrt_rsq_exhaustive.txt); negative arguments and NaN give NaN in both."""
+    import torch
+    lo = int(np.array([2.0 ** -100], dtype=np.float32).view(np.uint32)[0])
+    chunk = 1 << 26
+    for start in range(lo, 0x7f800000, chunk):
+        stop = min(start + chunk, 0x7f800000)
+        x = torch.arange(start, stop, dtype=torch.int64, device="cuda").to(torch.int32).view(torch.float32)
+        bad = renderer.math("sqrt_rs", x).view(torch.int32) != renderer.math("sqrt_ieee", x).view(torch.int32)
+        assert not bool(bad.any()), "first mismatch at %r" % float(x[bad][0])
+    odd = torch.tensor([-1.0, -1e-30, float("nan")], device="cuda")
+    assert bool(torch.isnan(renderer.math("sqrt_rs", odd)).all()) and bool(torch.isnan(renderer.math("sqrt_ieee", odd)).all())
+
+
 def test_div3_equals_ieee_division(renderer):
     """div3_ (sbx_math.h: q0 = a * RN(1 / d), q = fma(fma(-q0, d, a), RN(1 / d), q0)) against the IEEE quotient.  The complete run —
     every pair of significands, 2^47 quotients, 63 s on an MI355X — is tools/div3_exhaustive.hip (profiles/r03_div3_exhaustive.txt:
