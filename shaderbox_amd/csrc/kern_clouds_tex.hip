@@ -46,6 +46,9 @@
 #ifndef TEX_EXP_SMALL
 #define TEX_EXP_SMALL 1    // exp_small_ where every active lane's argument lies in its domain [-0.205, 0] (tested per call)
 #endif
+#ifndef TEX_DIVN
+#define TEX_DIVN 1        // 0: remap's division always through the IEEE expansion (A/B timing)
+#endif
 #ifndef TEX_XB
 #define TEX_XB 1          // 0: never exp_reg4k_ (A/B timing)
 #endif
@@ -240,8 +243,15 @@ __device__ __forceinline__ float hg_phase_tex(float mu, float g) {   // volumetr
 // xb (decided on the host, clouds_tex_exp_bound): REG, and the texel values of both volumes (scanned when they were bound) bound
 //      every density so that |density * sigma * dt| <= 80: the exps are exp_reg4k_ of sbx_math.h (no range guard, 4096-entry table,
 //      degree 3: 15 instructions against exp_'s 21), equal to exp_ on that whole range.
-struct TexArgs { NoiseTex T1, T2; double rsteps, rlsteps; int xb; };
+// dv (clouds_tex_bounds): xb, and the texel ranges keep remap's divisor 1 - .7 ww within [1e-3, 2^40] and its dividend below 2^40, with
+//      the coverage edge in [2^-20, 2^20]: the division is divn_ of sbx_math.h (six instructions, equal to the IEEE quotient for all
+//      significand pairs).  A dividend so small that its quotient is below 2^-89 — both forms then differ from the IEEE quotient at
+//      most in such a value — is far under the coverage edge: the density is quotient * smoothstep(..) = quotient * 0, a zero of the
+//      quotient's sign either way (and remap's `0 +` turns a zero quotient into +0 in both).
+struct TexArgs { NoiseTex T1, T2; double rsteps, rlsteps; int xb, dv; };
 #define TEX_EXP(x) tex_exp((x), A.xb)
+// remap(v, o, 1, 0, 1) = 0 + ((v - o) / (1 - o)) * (1 - 0)     util.h:127-138 (the multiply by 1 and the sum with 0 kept: -0 -> +0)
+#define TEX_REMAP(v, o) ((TEX_DIVN && A.dv) ? 0.f + (divn_((v) - (o), 1.f - (o)) * (1.f - 0.f)) : remap_((v), (o), 1.f, 0.f, 1.f))
 constexpr int TEX_LH_N = 64;     // light steps whose `j / lsteps` comes from the workgroup's LDS table (more: computed per sample)
 template <bool POW2, bool ZL, bool REG, bool YT>      // ZL (decided on the host): POW2 and the light step has no x and no y component
 __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(FrameClouds F, RowMap M, float* __restrict__ out, TexArgs A) {
@@ -325,7 +335,7 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
                 float shape = tex3d_seed_y(T1, qx, qz, rf.y, ri.x, ri.y, c1, fs1, m1);
                 const float w = tex3d_seed_y(T2, qx, qz, rf.z, ri.z, ri.w, c2, fs2, m2);
                 const float ww = mix_(w, 1.f - w, height);
-                shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
+                shape = TEX_REMAP(shape, ww * .7f);
                 density = REG ? x_smoothstep_rd_med3(vcov, F.cov_rd, shape) : shape * smoothstep_rd(F.cov, F.cov_rd, shape);
             } else {
                 height = div_by((float)i, rsteps);                                  // :183  i / steps
@@ -337,7 +347,7 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
                         float shape = tex3d_seed(T1, q, c1, fs1, m1);                            // tex_density with the cells kept
                         const float w = tex3d_seed(T2, q, c2, fs2, m2);
                         const float ww = mix_(w, 1.f - w, height);
-                        shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
+                        shape = TEX_REMAP(shape, ww * .7f);
                         density = shape * smoothstep_rd(F.cov, F.cov_rd, shape);
                     } else {
                         density = tex_density<POW2>(F, T1, T2, pos, height);
@@ -359,7 +369,7 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
                         const float lh = lh_lds ? lh_tab[j] : div_by((float)j, rlsteps);   // :108  j / lsteps
                         const float w = tex3d_z(T2, qz, c2, fs2, m2);
                         const float ww = mix_(w, 1.f - w, lh);
-                        shape = remap_(shape, ww * .7f, 1.f, 0.f, 1.f);
+                        shape = TEX_REMAP(shape, ww * .7f);
                         const float d = REG ? x_smoothstep_rd_med3(vcov, F.cov_rd, shape) : shape * smoothstep_rd(F.cov, F.cov_rd, shape);
                         if (REG && TEX_SKIP && d == 0.f) continue;                  // exp(-+0) = 1
                         ltrans *= TEX_EXP(-d * vsig * vdt);
@@ -442,13 +452,15 @@ static bool clouds_tex_regular(const FrameClouds& F) {
 // combination (binary32 weights in [0, 1]) and stays within the texels' range up to rounding; ww = mix(w, 1 - w, h) with h in [0, 1]
 // lies between min(lo2, 1 - hi2) and max(hi2, 1 - lo2); remap = (shape - .7 ww) / (1 - .7 ww); density = remap * smoothstep in [0, 1].
 // Returns < 0 when there is no bound (unknown or non-finite ranges, or 1 - .7 ww can come near 0).
-static double clouds_tex_density_bound(const float* b) {      // b = {lo1, hi1, lo2, hi2}
+static double clouds_tex_density_bound(const float* b, bool* dv_ok) {      // b = {lo1, hi1, lo2, hi2}
+    if (dv_ok) *dv_ok = false;
     for (int i = 0; i < 4; ++i) if (!std::isfinite(b[i])) return -1.0;
     const double wlo = std::min((double)b[2], 1.0 - b[3]), whi = std::max((double)b[3], 1.0 - b[2]);
     const double olo = std::min(.7 * wlo, .7 * whi) - 1e-5, ohi = std::max(.7 * wlo, .7 * whi) + 1e-5;
     const double bmin = 1.0 - ohi;
     if (!(bmin >= 1e-3)) return -1.0;
     const double amax = std::max(std::fabs(b[0] - ohi), std::fabs(b[1] - olo)) + 1e-5;
+    if (dv_ok) *dv_ok = amax <= 0x1p40 && (1.0 - olo) <= 0x1p40;       // divn_'s exponent ranges (bmin >= 1e-3 already)
     return amax / bmin * 1.001;
 }
 void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStream_t s, const float* shape_r, int shape_size,
@@ -471,9 +483,11 @@ void launch_clouds_tex(const FrameClouds& F, const RowMap& M, float* out, hipStr
         yt = far * .001f < lim;                                  // NaN compares false
     }
     // exp_reg4k_'s domain: |density * sigma * dt| <= 80 (bounds == nullptr: the volumes were bound without a scan)
-    const double dens_max = bounds ? clouds_tex_density_bound(bounds) : -1.0;
+    bool dv_ok = false;
+    const double dens_max = bounds ? clouds_tex_density_bound(bounds, &dv_ok) : -1.0;
     const int xb = (TEX_XB && reg && dens_max >= 0.0 && dens_max * std::fabs((double)F.sigma) * std::fabs((double)F.dt) * 1.001 <= 80.0) ? 1 : 0;
-    const TexArgs A{T1, T2, rs, rl, xb};
+    const int dv = (TEX_DIVN && xb && dv_ok && std::fabs(F.cov) >= 0x1p-20f && std::fabs(F.cov) <= 0x1p20f && F.cov > 0.f) ? 1 : 0;
+    const TexArgs A{T1, T2, rs, rl, xb, dv};
     const dim3 grid = grid_for<TEX_TW, TEX_TX>(M), block(64 * TEX_TX);
 #define SBX_TEX_LAUNCH(P, Z) do {                                                                                          \
         if (reg && yt) hipLaunchKernelGGL((k_clouds_tex<P, Z, true, true>), grid, block, 0, s, F, M, out, A);               \

@@ -83,6 +83,21 @@ SBX_HD float div3_(float a, float d, float r) {
     const float e = __builtin_fmaf(-q0, d, a);
     return __builtin_fmaf(e, r, q0);
 }
+// The same for a divisor that is NOT known in advance: v_rcp_f32 (1 ulp) made exact enough by one Newton step, then div3_'s three
+// instructions — six in all (~20 issue cycles against ~36 for the compiler's IEEE expansion with its two v_div_scale, v_div_fmas and
+// v_div_fixup).  EQUAL to the IEEE quotient for every pair of binary32 significands (tools/divv_exhaustive.hip, all 2^47 pairs on
+// the GPU, profiles/r03_divv_exhaustive.txt; WITHOUT the Newton step 47 024 failures are reported).  Same domain as div3_, and the
+// divisor must be finite and non-zero: callers show 2^-60 <= |b| <= 2^60 and a finite, zero or within 2^+-100.
+SBX_HD float divn_(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r0, 1.0f);
+    const float r = __builtin_fmaf(e, r0, r0);
+    return div3_(a, b, r);
+#else
+    return a / b;
+#endif
+}
 // smoothstep(e0, e0 + d, x) through div3_ (the clamp makes the sign of a zero quotient irrelevant: t * t is +0 either way)
 SBX_HD float smoothstep_d3(float e0, float d, float r, float x) {
     const float t = clamp_(div3_(x - e0, d, r), 0.0f, 1.0f);

@@ -337,6 +337,14 @@ def test_div3_equals_ieee_division(renderer):
     b = b.to(torch.int32).view(torch.float32)
     bad = renderer.math("div3", a, b).view(torch.int32) != renderer.math("div", a, b).view(torch.int32)
     assert not bool(bad.any())
+    bad = renderer.math("divn", a, b).view(torch.int32) != renderer.math("div", a, b).view(torch.int32)
+    assert not bool(bad.any())
+    # divn_ (variable divisor: v_rcp_f32 + a Newton step + the same three instructions; tools/divv_exhaustive.hip ran all 2^47 pairs):
+    # 1 024 random divisors against all 2^24 dividend significands
+    for d in ds[-1024:].tolist():
+        bb = torch.full_like(sig, d)
+        bad = renderer.math("divn", sig, bb).view(torch.int32) != renderer.math("div", sig, bb).view(torch.int32)
+        assert not bool(bad.any()), (d, float(sig[bad][0]))
     z = torch.zeros(4, device="cuda")
     assert bool((renderer.math("div3", z, torch.full_like(z, .4)) == 0).all())
     assert bool(torch.isnan(renderer.math("div3", torch.tensor([float("nan")], device="cuda"), torch.tensor([.4], device="cuda"))).all())
