@@ -7,7 +7,11 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include "sbx_device.h"
+#include "sbx_exp4k_table.h"
 
+#ifndef CB_FAST_MATH
+#define CB_FAST_MATH 1
+#endif
 namespace sbx {
 
 // XI ("exact integers", decided on the host per launch: every lattice coordinate of the frame is below 2^22 in magnitude): the
@@ -108,6 +112,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, R
         const v3 origin = F.cam.eye + projection * 100.f;
         float pos_x = origin.x, pos_z = origin.z;
         float T = 1.f, C = 0.f, alpha = 0.f;                               // C: the three channels are equal
+        float cd = (F.cov + .035f) - F.cov, cr = 1.0f / ((F.cov + .035f) - F.cov);        // div3_'s divisor and reciprocal, in VGPRs
+        asm volatile("" : "+v"(cd), "+v"(cr));
         for (int i = 0; i < CB_STEPS; ++i) {
             const CBRow& row = F.row[i];
             // density_func :577-589 : p = pos * .001 + wind ; fbm_clouds(p * 2.032, 2.6434, .5, .5)
@@ -120,9 +126,13 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, R
                 qx = qx * 2.6434f; qz = qz * 2.6434f;
                 H *= .5f;
             }
-            dens = dens * smoothstep_rd(F.cov, F.cov_rd, dens);
+            // XI frames (finite, bounded: launch_clouds_best): the smoothstep's division through div3_ and the exp through exp_reg4k_ of
+            // sbx_math.h, both equal to the forms of the other branch on their domains — dens is a sum of |simplex noise| <= 1 with gains
+            // .5 ... .03125, so dens - cov is zero or >= 2^-26 in magnitude and |dens * march_step| < 80 (checked on the host).
+            if (XI && CB_FAST_MATH) dens = dens * smoothstep_d3(F.cov, cd, cr, dens);
+            else dens = dens * smoothstep_rd(F.cov, F.cov_rd, dens);
             // integrate_volume :392-407
-            const float T_i = exp_((-1.f * dens) * F.march_step);
+            const float T_i = (XI && CB_FAST_MATH) ? exp_reg4k_((-1.f * dens) * F.march_step, kExp2Tab4096) : exp_((-1.f * dens) * F.march_step);
             T *= T_i;
             C += ((T * row.illum) * dens) * F.march_step;
             alpha += (1.f - T_i) * (1.f - alpha);
@@ -141,7 +151,8 @@ void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, h
     double far = (std::fabs((double)F.cam.eye.x) + std::fabs((double)F.cam.eye.y) + std::fabs((double)F.cam.eye.z) + 2100.0 +
                   21.0 * CB_STEPS * std::fabs((double)F.march_step)) * .001 + std::fabs((double)F.wind_z);
     for (int i = 0; i < CB_STEPS; ++i) far = std::fmax(far, std::fabs((double)F.row[i].qy[0]) / 2.032);
-    const bool xi = far * (2.032 * 48.83 * 2.0) < 4194304.0;       // NaN compares false
+    const bool xi = far * (2.032 * 48.83 * 2.0) < 4194304.0 &&       // NaN compares false
+                    std::fabs((double)F.march_step) <= 40.0 && F.cov >= 0x1p-20f && F.cov <= 0x1p20f;   // exp_reg4k_'s / div3_'s domains
     if (xi) hipLaunchKernelGGL(k_clouds_best<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
     else hipLaunchKernelGGL(k_clouds_best<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
