@@ -19,6 +19,11 @@
 #include "sbx_device.h"
 #include "sbx_noise.h"
 #include "sbx_hashcache.h"
+#include "sbx_exp4k_table.h"
+#include <cmath>
+#ifndef UE4_FAST_MATH
+#define UE4_FAST_MATH 1
+#endif
 
 namespace sbx {
 
@@ -27,6 +32,11 @@ namespace sbx {
 #ifndef UE4_MIN_WAVES
 #define UE4_MIN_WAVES 5
 #endif
+// FAST (decided on the host, launch_clouds_ue4): the coverage smoothstep's division through div3_ and the exp through exp_reg4k_ of
+// sbx_math.h — equal to smoothstep_rd / exp_ on their domains: dens is a sum of noise values in [0, 1] with gains < 1 (or NaN), so
+// dens - cov is zero or >= 2^-45 in magnitude for 2^-20 <= |cov| <= 2^20, and the exp argument is -absorbtion * clamp(dens, 0, 1) *
+// march_step with |absorbtion * march_step| <= 80.
+template <bool FAST>
 __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameCloudsUe4 F, RowMap M, float* __restrict__ out) {
     __shared__ WaveCache cache[WG_THREADS / 64];
     const int lane = threadIdx.x & 63;
@@ -41,6 +51,8 @@ __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameC
     v3 pos = V3(0, 0, 0) + dir * 100.f;
     float T = 1.f, C = 0.f, alpha = 0.f;
     const int tab[4] = {0, 1, 2, 3};
+    float cd = F.cov_d, cr = F.cov_r;
+    if (FAST) asm volatile("" : "+v"(cd), "+v"(cr));          // VGPR operands: full rate
     for (int i = 0; i < UE4_STEPS; ++i) {
         // density_func :164-179
         v3 p[4];
@@ -52,9 +64,9 @@ __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameC
         dens += 0.25584929f * nz[1];
         dens += 0.12527603f * nz[2];
         dens += 0.06255931f * nz[3];
-        dens *= smoothstep_rd(F.cov, F.cov_rd, dens);
+        dens *= FAST ? smoothstep_d3(F.cov, cd, cr, dens) : smoothstep_rd(F.cov, F.cov_rd, dens);
         dens = clamp_(dens, 0.f, 1.f);
-        const float T_i = exp_(-F.absorbtion * dens * F.march_step);
+        const float T_i = FAST ? exp_reg4k_(-F.absorbtion * dens * F.march_step, kExp2Tab4096) : exp_(-F.absorbtion * dens * F.march_step);
         T *= T_i;
         C += T * F.eh[i] * dens * F.march_step;                    // exp(h) / 1.75, h = i / steps: a frame constant
         alpha += (1.f - T_i) * (1.f - alpha);
@@ -70,7 +82,11 @@ __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameC
 }
 
 void launch_clouds_ue4(const FrameCloudsUe4& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_clouds_ue4, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    const double c = std::fabs((double)F.cov), d = std::fabs((double)F.cov_d);
+    const bool fast = UE4_FAST_MATH && std::isfinite(F.cov) && std::isfinite(F.cov_d) && std::isfinite(F.cov_r) && c >= 0x1p-20 && c <= 0x1p20 &&
+                      d >= 0x1p-60 && d <= 0x1p60 && std::fabs((double)F.absorbtion) * std::fabs((double)F.march_step) <= 80.0;   // NaN: false
+    if (fast) hipLaunchKernelGGL(k_clouds_ue4<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_clouds_ue4<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

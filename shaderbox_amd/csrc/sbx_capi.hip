@@ -326,6 +326,8 @@ static FrameCloudsUe4 build_clouds_ue4(const sbx_uniforms& U, const sbx_aux_clou
     F.absorbtion = A.absorbtion;
     F.cov = 1.f - A.coverage;                                           // :256
     F.cov_rd = recip64((F.cov + A.fuzziness) - F.cov);                  // :175
+    F.cov_d = (F.cov + A.fuzziness) - F.cov;
+    F.cov_r = 1.0f / F.cov_d;
     for (int i = 0; i < UE4_STEPS; ++i) F.eh[i] = exp_(float(i) / float(UE4_STEPS)) / 1.75f;   // :213,221
     return F;
 }

@@ -182,6 +182,7 @@ struct FrameCloudsUe4 {
     float absorbtion;
     float cov;                // 1 - coverage                                                 :256
     double cov_rd;            // recip64((cov + fuzziness) - cov)                             :175
+    float cov_d, cov_r;       // (cov + fuzziness) - cov and RN(1 / that): the same division through div3_ (sbx_math.h)
     float eh[UE4_STEPS];      // exp(h) / 1.75 with h = float(i) / float(steps)               :213,221
 };
 
