@@ -123,17 +123,18 @@ __global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restri
     case 10: r = exp_h13_(x); break;                // the former 13-term exp (equivalence test against the table form)
     case 12: r = sqrt_n_(x); break;                 // v_sqrt_f32 + fix-up (exact outside (0, 2^-96))
     case 13: r = sqrt_ieee_(x); break;              // the compiler's IEEE expansion
-    case 21: r = sin_b40_(x); break;
-    case 22: r = div3_(x, y, 1.0f / y); break;
-    case 23: r = sqrt_rs_(x); break;
-    case 24: r = divn_(x, y); break;                // v_rcp_f32 + a Newton step + div3_'s three instructions                // v_rsq_f32 + one corrected step (exact for x >= 2^-102, finite)      // division by a known divisor in three binary32 instructions (sbx_math.h)                // sin with the degree-15 polynomial (equal to sin_ for |x| < 2^44.6)
+    case 21: r = sin_b40_(x); break;                // sin with the degree-15 polynomial (equal to sin_ for |x| < 2^44.6)
+    case 22: r = div3_(x, y, 1.0f / y); break;      // division by a known divisor in three binary32 instructions
+    case 23: r = sqrt_rs_(x); break;                // v_rsq_f32 + one corrected step (exact for finite x >= 2^-102)
+    case 24: r = divn_(x, y); break;                // v_rcp_f32 + a Newton step + div3_'s three instructions
+    case 25: r = srgb_pow_(x); break;               // pow_(x, 1 / 2.2f) in its short form (equal on all 2^32 arguments)
     default: r = 0.f;
     }
     out[i] = r;
 }
 
 int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t n, hipStream_t s) {
-    if (fn < 0 || (fn > 13 && fn != 21 && fn != 22 && fn != 23 && fn != 24)) return -1;
+    if (fn < 0 || (fn > 13 && fn != 21 && fn != 22 && fn != 23 && fn != 24 && fn != 25)) return -1;
     hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, a, b, out, n);
     return 0;
 }

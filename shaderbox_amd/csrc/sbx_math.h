@@ -642,6 +642,56 @@ SBX_HD float pow_(float x, float y) {
     if (t > 136.0) t = 136.0;
     return (float)d_exp2_tab(t);
 }
+// pow_(x, 1 / 2.2f) — linear_to_srgb's exponent (src/util.h:72-77), three times per pixel in every kernel — in ~45 instructions
+// instead of pow_'s ~100 (its 19 binary64 constants arrive as literals: the compiler moves each into a register pair first).  The SAME
+// log2 (table, reduction and polynomial of d_log2_tab, the exponent / index / significand taken from the high word with 32-bit
+// operations, the coefficients as scalar operands of three-address v_fma_f64), t = y log2 x without the clamps (|t| < 70), and
+// d_exp2_tab's own 2^t, scaled after the rounding to binary32 (x^(1/2.2) of a binary32 x lies in [2^-68, 2^59]: normal).  The same
+// operations on the same operands, hence EQUAL to pow_(x, 1 / 2.2f); run on ALL 2^32 binary32 arguments all the same
+// (2^t through exp_reg4k_'s table and degree 3 instead: ONE argument of the 2^32 differs, 0x1.6e3b6ap+93 — not used) (tests/test_gpu_round3.py::test_srgb_pow_equals_pow_everywhere),
+// so it needs no domain: to_srgb (sbx_frame.h) uses it on the device.
+SBX_HD float srgb_pow_(float x) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return pow_(x, 1.f / 2.2f);
+#else
+    const double xd = (double)x;
+    const uint32_t hi = (uint32_t)(d2u(xd) >> 32);                      // high word: sign, exponent, 20 significand bits
+    const uint32_t tmp = hi - 0x3fe60000u;
+    const int i = (int)((tmp >> 13) & 127u);
+    const int k = (int)tmp >> 20;
+    const double z = u2d((d2u(xd) & 0xffffffffull) | ((uint64_t)(hi - (tmp & 0xfff00000u)) << 32));
+    const double r = __builtin_fma(z, kLog2Tab[i][0], -1.0);
+    double p;
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %0, %2, %4\n\t"
+        "v_fma_f64 %0, %0, %2, %5\n\t"
+        "v_fma_f64 %0, %0, %2, %6\n\t"
+        "v_fma_f64 %0, %0, %2, %7\n\t"
+        "v_fma_f64 %0, %0, %2, %8\n\t"
+        "v_fma_f64 %0, %0, %2, %9"
+        : "=&v"(p) : "v"(-0x1.71547652b82fep-3), "v"(r), "s"(0x1.a61762a7aded9p-3), "s"(-0x1.ec709dc3a03fdp-3), "s"(0x1.2776c50ef9bfep-2),
+                     "s"(-0x1.71547652b82fep-2), "s"(0x1.ec709dc3a03fdp-2), "s"(-0x1.71547652b82fep-1), "s"(0x1.71547652b82fep+0));
+    const double lg = __builtin_fma(r, p, (double)k + kLog2Tab[i][1]);
+    const double t = (double)(1.f / 2.2f) * lg;
+    double kd = __builtin_fma(t, 32.0, D_MAGIC);                          // d_exp2_tab's own steps
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - D_MAGIC;
+    const double u = __builtin_fma(kd, -0.03125, t) * D_LN2;
+    double q;
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %0, %2, %4\n\t"
+        "v_fma_f64 %0, %0, %2, %5"
+        : "=&v"(q) : "v"(0x1.6c16c16c16c17p-10), "v"(u), "s"(0x1.1111111111111p-7), "s"(0x1.5555555555555p-5), "s"(0x1.5555555555555p-3));
+    q = __builtin_fma(q, u, 0.5);
+    q = __builtin_fma(q, u, 1.0);
+    q = __builtin_fma(q, u, 1.0);
+    const float y = __builtin_ldexpf((float)(q * kExp2Tab[ki & 31]), ki >> 5);
+    // pow_'s special cases for y > 0: NaN or negative -> the quiet NaN; +-0 -> +0; +inf -> +inf
+    float res = (x == 0.0f) ? 0.0f : y;
+    res = (x == u2f(0x7f800000u)) ? x : res;
+    return (x < 0.0f || x != x) ? u2f(0x7fc00000u) : res;
+#endif
+}
 SBX_HD double d_atan_pos(double z) {
     bool inv = z > 1.0;
     if (inv) z = 1.0 / z;

@@ -298,6 +298,22 @@ def test_clouds_tex_texel_ranges(renderer, oracle):
     oracle.set_noise_volumes(baked1.cpu().numpy(), baked2.cpu().numpy())
 
 
+def test_srgb_pow_equals_pow_everywhere(renderer):
+    """srgb_pow_ (sbx_math.h: pow_'s own log2 and 2^t with the coefficients as scalar operands, 32-bit index arithmetic, no clamps —
+    to_srgb's form on the device) against pow_(x, 1 / 2.2f) of the math spec on ALL 2^32 binary32 arguments,
+    NaN == NaN."""
+    import torch
+    y = np.float32(1.0) / np.float32(2.2)
+    chunk = 1 << 26
+    for start in range(0, 1 << 32, chunk):
+        bits = torch.arange(start, start + chunk, dtype=torch.int64, device="cuda").to(torch.int32)
+        x = bits.view(torch.float32)
+        a = renderer.math("srgb_pow", x)
+        b = renderer.math("pow", x, torch.full_like(x, float(y)))
+        bad = (a.view(torch.int32) != b.view(torch.int32)) & ~(torch.isnan(a) & torch.isnan(b))
+        assert not bool(bad.any()), "first mismatch at bits 0x%08x" % int(bits[bad][0].item() & 0xffffffff)
+
+
 def test_sqrt_rs_is_ieee_sqrt_from_2_pow_minus_100(renderer):
     """sqrt_rs_ (sbx_math.h: v_rsq_f32 and one corrected step, five instructions) against the compiler's IEEE square root on EVERY
     finite binary32 argument >= 2^-100 (the complete run over all positive arguments, with the counts per exponent below 2^-102, is
