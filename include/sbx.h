@@ -210,7 +210,7 @@ int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms);
 int sbx_set_variant(sbx_ctx* ctx, int variant);
 
 /* Device evaluation of the math spec, elementwise over device arrays (for parity tests):
- * fn in {"sin","cos","tan","exp","pow","acos","atan2","hash","div","div_rd","exp_h13","pow_h","sqrt_n","sqrt_ieee","exp_reg","exp_reg_plain","exp_reg64","exp_reg64_plain","exp_small","exp_small_plain","exp_reg4k","sin_b40","div3","sqrt_rs","divn","srgb_pow"}; b may be NULL
+ * fn in {"sin","cos","tan","exp","pow","acos","atan2","hash","div","div_rd","exp_h13","pow_h","sqrt_n","sqrt_ieee","exp_reg","exp_reg_plain","exp_reg64","exp_reg64_plain","exp_small","exp_small_plain","exp_reg4k","sin_b40","div3","sqrt_rs","divn","srgb_pow","pow_spec"}; b may be NULL
  * for unary fns ("exp_reg*": kernel-internal forms of exp — 32-entry table / degree 6 and 64-entry / degree 5, each with and without
  * the three-address asm — used by the regular-frame k_clouds and by k_atmosphere's density terms, equal to
  * "exp" for |x| <= 80; "exp_reg4k": the 4096-entry / degree-3 form of k_atmosphere's density terms, equal to "exp" for |x| <= 80;
@@ -219,6 +219,7 @@ int sbx_set_variant(sbx_ctx* ctx, int variant);
  * every argument lies in [-0.205, -0], equal to "exp" on that whole interval and at +0).
  * "div3" = a/b as q0 = a * RN(1/b), q = fma(fma(-q0, b, a), RN(1/b), q0): equal to "div" away from overflow and underflow;
  * "divn" = a/b through v_rcp_f32, one Newton step and div3's three instructions (equal to "div" away from overflow / underflow);
+ * "pow_spec" = pow exactly as stated in the oracle ("pow" is the device's shorter instruction sequence for the same operations);
  * "srgb_pow" = pow(x, 1/2.2f) in the short form to_srgb uses on the device (equal to "pow" with b = 1/2.2f on all 2^32 arguments);
  * "sqrt_rs" = v_rsq_f32 and one corrected step: equal to "sqrt_ieee" for finite x >= 2^-102;
  * "div" = IEEE a/b, "div_rd" = the same quotient through the binary64 reciprocal of b (must be identical). */

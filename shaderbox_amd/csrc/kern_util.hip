@@ -127,14 +127,16 @@ __global__ void __launch_bounds__(256) k_math_eval(int fn, const float* __restri
     case 22: r = div3_(x, y, 1.0f / y); break;      // division by a known divisor in three binary32 instructions
     case 23: r = sqrt_rs_(x); break;                // v_rsq_f32 + one corrected step (exact for finite x >= 2^-102)
     case 24: r = divn_(x, y); break;                // v_rcp_f32 + a Newton step + div3_'s three instructions
-    case 25: r = srgb_pow_(x); break;               // pow_(x, 1 / 2.2f) in its short form (equal on all 2^32 arguments)
+    case 25: r = srgb_pow_(x); break;
+    case 26: r = pow_spec_(x, y); break;            // pow as stated (pow_ is its lean device form)
+               // pow_(x, 1 / 2.2f) in its short form (equal on all 2^32 arguments)
     default: r = 0.f;
     }
     out[i] = r;
 }
 
 int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t n, hipStream_t s) {
-    if (fn < 0 || (fn > 13 && fn != 21 && fn != 22 && fn != 23 && fn != 24 && fn != 25)) return -1;
+    if (fn < 0 || (fn > 13 && fn != 21 && fn != 22 && fn != 23 && fn != 24 && fn != 25 && fn != 26)) return -1;
     hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, a, b, out, n);
     return 0;
 }

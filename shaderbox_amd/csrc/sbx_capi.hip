@@ -751,11 +751,11 @@ int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms) {
 int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, float* out, size_t n, void* stream) {
     if (!ctx) return SBX_ERR_ARG;
     if (!fn || !a || !out) return fail(ctx, SBX_ERR_ARG, "NULL argument");
-    static const char* names[] = {"sin", "cos", "tan", "exp", "pow", "acos", "atan2", "hash", "div", "div_rd", "exp_h13", "pow_h", "sqrt_n", "sqrt_ieee", "exp_reg", "exp_reg_plain", "exp_reg64", "exp_reg64_plain", "exp_small", "exp_small_plain", "exp_reg4k", "sin_b40", "div3", "sqrt_rs", "divn", "srgb_pow"};
+    static const char* names[] = {"sin", "cos", "tan", "exp", "pow", "acos", "atan2", "hash", "div", "div_rd", "exp_h13", "pow_h", "sqrt_n", "sqrt_ieee", "exp_reg", "exp_reg_plain", "exp_reg64", "exp_reg64_plain", "exp_small", "exp_small_plain", "exp_reg4k", "sin_b40", "div3", "sqrt_rs", "divn", "srgb_pow", "pow_spec"};
     int id = -1;
-    for (int i = 0; i < 26; ++i) if (std::strcmp(fn, names[i]) == 0) id = i;
+    for (int i = 0; i < 27; ++i) if (std::strcmp(fn, names[i]) == 0) id = i;
     if (id < 0) return fail(ctx, SBX_ERR_ARG, "unknown math function");
-    if ((id == 4 || id == 6 || id == 8 || id == 9 || id == 11 || id == 22 || id == 24) && !b) return fail(ctx, SBX_ERR_ARG, "binary function needs b");
+    if ((id == 4 || id == 6 || id == 8 || id == 9 || id == 11 || id == 22 || id == 24 || id == 26) && !b) return fail(ctx, SBX_ERR_ARG, "binary function needs b");
     if (n == 0) return SBX_OK;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);

@@ -631,7 +631,8 @@ SBX_HD double d_exp2_tab(double t) {
     const double y = p * kExp2Tab[ki & 31];
     return u2d(d2u(y) + ((uint64_t)(int64_t)(ki >> 5) << 52));
 }
-SBX_HD float pow_(float x, float y) {
+// the statement of pow (oracle/sbx_math_ref.h m_pow): what the host runs, and the device's test hook "pow_spec"
+SBX_HD float pow_spec_(float x, float y) {
     if (y == 0.0f) return 1.0f;
     if (x != x || y != y) return u2f(0x7fc00000u);
     if (x < 0.0f) return u2f(0x7fc00000u);
@@ -641,6 +642,59 @@ SBX_HD float pow_(float x, float y) {
     if (t < -160.0) t = -160.0;
     if (t > 136.0) t = 136.0;
     return (float)d_exp2_tab(t);
+}
+// pow on the device: the SAME operations on the same operands as pow_spec_ in about half the instructions — the polynomial
+// coefficients as scalar operands of three-address v_fma_f64 (as literals the compiler moves each of the 19 constants into a register
+// pair: 29 v_mov_b32 + 13 two-address v_fmac_f64), exponent / table index / significand from the high word with 32-bit operations, the
+// final scaling as a 32-bit add to the high word.  Equal to pow_spec_ by
+// construction; tests/test_gpu_round3.py::test_pow_equals_its_statement runs all 2^32 x for every exponent the kernels use.
+SBX_HD float pow_(float x, float y) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return pow_spec_(x, y);
+#else
+    const double xd = (double)x;
+    const uint32_t hi = (uint32_t)(d2u(xd) >> 32);
+    const uint32_t tmp = hi - 0x3fe60000u;
+    const int i = (int)((tmp >> 13) & 127u);
+    const int k = (int)tmp >> 20;
+    const double z = u2d((d2u(xd) & 0xffffffffull) | ((uint64_t)(hi - (tmp & 0xfff00000u)) << 32));
+    const double r = __builtin_fma(z, kLog2Tab[i][0], -1.0);
+    double p;
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %0, %2, %4\n\t"
+        "v_fma_f64 %0, %0, %2, %5\n\t"
+        "v_fma_f64 %0, %0, %2, %6\n\t"
+        "v_fma_f64 %0, %0, %2, %7\n\t"
+        "v_fma_f64 %0, %0, %2, %8\n\t"
+        "v_fma_f64 %0, %0, %2, %9"
+        : "=&v"(p) : "v"(-0x1.71547652b82fep-3), "v"(r), "s"(0x1.a61762a7aded9p-3), "s"(-0x1.ec709dc3a03fdp-3), "s"(0x1.2776c50ef9bfep-2),
+                     "s"(-0x1.71547652b82fep-2), "s"(0x1.ec709dc3a03fdp-2), "s"(-0x1.71547652b82fep-1), "s"(0x1.71547652b82fep+0));
+    const double lg = __builtin_fma(r, p, (double)k + kLog2Tab[i][1]);
+    double t = (double)y * lg;
+    t = (t < -160.0) ? -160.0 : t;                                        // (a NaN t — x = 1, y = inf — stays NaN, as in pow_spec_)
+    t = (t > 136.0) ? 136.0 : t;
+    double kd = __builtin_fma(t, 32.0, D_MAGIC);
+    const int32_t ki = (int32_t)(uint32_t)(d2u(kd) & 0xffffffffull);
+    kd = kd - D_MAGIC;
+    const double u = __builtin_fma(kd, -0.03125, t) * D_LN2;
+    double q;
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %0, %2, %4\n\t"
+        "v_fma_f64 %0, %0, %2, %5"
+        : "=&v"(q) : "v"(0x1.6c16c16c16c17p-10), "v"(u), "s"(0x1.1111111111111p-7), "s"(0x1.5555555555555p-5), "s"(0x1.5555555555555p-3));
+    q = __builtin_fma(q, u, 0.5);
+    q = __builtin_fma(q, u, 1.0);
+    q = __builtin_fma(q, u, 1.0);
+    const double yv = q * kExp2Tab[ki & 31];
+    const uint64_t yb = d2u(yv);
+    const float v = (float)u2d((yb & 0xffffffffull) | ((uint64_t)((uint32_t)(yb >> 32) + ((uint32_t)(ki >> 5) << 20)) << 32));
+    // the special cases, in pow_spec_'s order of precedence
+    float res = v;
+    res = (x == u2f(0x7f800000u)) ? ((y > 0.0f) ? x : 0.0f) : res;
+    res = (x == 0.0f) ? ((y > 0.0f) ? 0.0f : u2f(0x7f800000u)) : res;
+    res = (x < 0.0f || x != x || y != y) ? u2f(0x7fc00000u) : res;
+    return (y == 0.0f) ? 1.0f : res;
+#endif
 }
 // pow_(x, 1 / 2.2f) — linear_to_srgb's exponent (src/util.h:72-77), three times per pixel in every kernel — in ~45 instructions
 // instead of pow_'s ~100 (its 19 binary64 constants arrive as literals: the compiler moves each into a register pair first).  The SAME

@@ -298,6 +298,29 @@ def test_clouds_tex_texel_ranges(renderer, oracle):
     oracle.set_noise_volumes(baked1.cpu().numpy(), baked2.cpu().numpy())
 
 
+def test_pow_equals_its_statement(renderer):
+    """pow_ on the device (pow_spec_'s operations with scalar-operand coefficients and 32-bit index arithmetic) against pow_spec_:
+    all 2^32 x for every exponent the kernels use, and 2^27 random (x, y) pairs including the special cases."""
+    import torch
+    chunk = 1 << 26
+    for y in (float(np.float32(1.0) / np.float32(2.2)), 1500.0, 10.0, 1.5, 30.0):
+        for start in range(0, 1 << 32, chunk):
+            x = torch.arange(start, start + chunk, dtype=torch.int64, device="cuda").to(torch.int32).view(torch.float32)
+            yy = torch.full_like(x, y)
+            a, b = renderer.math("pow", x, yy), renderer.math("pow_spec", x, yy)
+            bad = (a.view(torch.int32) != b.view(torch.int32)) & ~(torch.isnan(a) & torch.isnan(b))
+            assert not bool(bad.any()), (y, float(x[bad][0]))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = 1 << 27
+    x = torch.randint(0, 1 << 32, (n,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32).view(torch.float32)
+    y = torch.randint(0, 1 << 32, (n,), generator=g, device="cuda", dtype=torch.int64).to(torch.int32).view(torch.float32)
+    sp = torch.tensor([0.0, -0.0, 1.0, -1.0, float("inf"), -float("inf"), float("nan"), 2.0, .5], device="cuda")
+    x = torch.cat([x, sp.repeat_interleave(len(sp))]); y = torch.cat([y, sp.repeat(len(sp))])
+    a, b = renderer.math("pow", x, y), renderer.math("pow_spec", x, y)
+    bad = (a.view(torch.int32) != b.view(torch.int32)) & ~(torch.isnan(a) & torch.isnan(b))
+    assert not bool(bad.any()), (float(x[bad][0]), float(y[bad][0]))
+
+
 def test_srgb_pow_equals_pow_everywhere(renderer):
     """srgb_pow_ (sbx_math.h: pow_'s own log2 and 2^t with the coefficients as scalar operands, 32-bit index arithmetic, no clamps —
     to_srgb's form on the device) against pow_(x, 1 / 2.2f) of the math spec on ALL 2^32 binary32 arguments,
