@@ -30,8 +30,13 @@ SBX_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 SBX_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 
 // ---- GLSL built-ins (GLSL spec formulas) -------------------------------
+#if defined(SBX_ABLATE_MINMAX) && defined(__HIP_DEVICE_COMPILE__)     // timing experiment only: v_min_f32 / v_max_f32 (differ for NaN and for zeros of opposite sign)
+SBX_HD float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+SBX_HD float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
 SBX_HD float fmin_(float a, float b) { return (b < a) ? b : a; }
 SBX_HD float fmax_(float a, float b) { return (a < b) ? b : a; }
+#endif
 SBX_HD float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 SBX_HD float abs_(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 SBX_HD float floor_(float x) { return __builtin_floorf(x); }
