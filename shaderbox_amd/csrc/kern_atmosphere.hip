@@ -58,8 +58,11 @@ __device__ __forceinline__ bool isect_atmosphere(v3 ro, v3 rd, float& t1) {
 #endif                     // div_by's binary64 multiply: |height| is 0 or in [.5, 6.4e6] (a multiple of ulp(6.4e6)), the quotient only feeds exp
 #ifndef ATM_SQRT_RS
 #define ATM_SQRT_RS 1      // FIN kernels: length(s) of a march position through sqrt_rs_ (sbx_math.h: five instructions, exact for finite
-#endif                     // x >= 2^-102): |s|^2 is ~4e13 on the ray from (0, R + 1, 0), never 0 or inf.  (isect_atmosphere keeps sqrt_n_:
-                           // its argument can be exactly 0.)
+#endif                     // x >= 2^-102): |s|^2 is ~4e13 along rays that stay above the ground; a view ray below the horizon passes through
+                           // the planet, but a position's components are multiples of their own ulp, so |s|^2 is either >= 2^-40 or exactly 0,
+                           // and exactly 0 needs all three components to cancel at once: rd.x = rd.z = 0 only for theta = 0, the ray straight
+                           // UP (acos never returns pi exactly), and a light sample under the ground ends its march before it could reach the
+                           // centre.  (isect_atmosphere keeps sqrt_n_: its argument can be exactly 0.)
 #define ATM_LEN(x) ((FIN && ATM_SQRT_RS) ? sqrt_rs_(x) : sqrt_n_(x))
 #ifndef ATM_TX
 #define ATM_TX 1           // waves per workgroup (1: 4.03 ms, 4: 4.06)
