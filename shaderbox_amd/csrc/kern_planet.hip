@@ -43,7 +43,11 @@ __device__ __forceinline__ Vol make_vol(v3 o) { return Vol{o, o, 0.f, 1.f, 0.f, 
 #define PL_DIV3 1
 #endif
 #define PL_DIVK(a, dlit) ((SKIP && PL_DIV3) ? div3_((a), (dlit), 1.0f / (dlit)) : div_by((a), 1.0 / (double)(dlit)))
-#define SMOOTHSTEP_K(e0, e1, x) ((SKIP && PL_DIV3) ? smoothstep_d3((e0), (e1) - (e0), 1.0f / ((e1) - (e0)), (x)) \
+#ifndef PL_MED3
+#define PL_MED3 1           // the clamp of those smoothsteps as one v_med3_f32: their arguments (fBm sums of hashes, heights of finite positions)
+#endif                      // are never NaN on the tame frames of the SKIP kernels (finite u_time, u_res checked by the C API, fixed camera)
+#define SMOOTHSTEP_K(e0, e1, x) ((SKIP && PL_DIV3 && PL_MED3) ? smoothstep_d3_med3((e0), (e1) - (e0), 1.0f / ((e1) - (e0)), (x)) \
+                                 : (SKIP && PL_DIV3) ? smoothstep_d3((e0), (e1) - (e0), 1.0f / ((e1) - (e0)), (x)) \
                                                    : smoothstep_rd((e0), 1.0 / (double)((e1) - (e0)), (x)))
 template <bool SKIP>
 __device__ __forceinline__ float band(float t) {                     // band(.2, .35, .65, t)  util.h:103-112

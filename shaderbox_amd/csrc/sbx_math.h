@@ -109,6 +109,12 @@ SBX_HD float smoothstep_d3(float e0, float d, float r, float x) {
     return (t * t) * tm2_(t);
 }
 #if defined(__HIPCC__)
+// smoothstep_d3 with the clamp as ONE v_med3_f32: equal for every FINITE x (a -0 quotient squares to +0 either way); a NaN x gives 0
+// here and NaN there, so only for callers whose x cannot be a NaN
+__device__ __forceinline__ float smoothstep_d3_med3(float e0, float d, float r, float x) {
+    const float t = __builtin_amdgcn_fmed3f(div3_(x - e0, d, r), 0.0f, 1.0f);
+    return (t * t) * tm2_(t);
+}
 __device__ __forceinline__ float x_smoothstep_d3_med3(float e0, float d, float r, float x) {      // x_smoothstep_rd_med3 with div3_
     const float t = __builtin_amdgcn_fmed3f(div3_(x - e0, d, r), 0.0f, 1.0f);
     return x * ((t * t) * tm2_(t));
