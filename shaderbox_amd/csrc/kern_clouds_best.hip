@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, R
             // XI frames (finite, bounded: launch_clouds_best): the smoothstep's division through div3_ and the exp through exp_reg4k_ of
             // sbx_math.h, both equal to the forms of the other branch on their domains — dens is a sum of |simplex noise| <= 1 with gains
             // .5 ... .03125, so dens - cov is zero or >= 2^-26 in magnitude and |dens * march_step| < 80 (checked on the host).
-            if (XI && CB_FAST_MATH) dens = dens * smoothstep_d3(F.cov, cd, cr, dens);
+            if (XI && CB_FAST_MATH) dens = x_smoothstep_d3_med3(F.cov, cd, cr, dens);      // (dens * smoothstep: a NaN dens stays NaN)
             else dens = dens * smoothstep_rd(F.cov, F.cov_rd, dens);
             // integrate_volume :392-407
             const float T_i = (XI && CB_FAST_MATH) ? exp_reg4k_((-1.f * dens) * F.march_step, kExp2Tab4096) : exp_((-1.f * dens) * F.march_step);

@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameC
         dens += 0.25584929f * nz[1];
         dens += 0.12527603f * nz[2];
         dens += 0.06255931f * nz[3];
-        dens *= FAST ? smoothstep_d3(F.cov, cd, cr, dens) : smoothstep_rd(F.cov, F.cov_rd, dens);
+        if (FAST) dens = x_smoothstep_d3_med3(F.cov, cd, cr, dens);      // dens * smoothstep(..): one v_med3 for the clamp, a NaN dens stays NaN
+        else dens *= smoothstep_rd(F.cov, F.cov_rd, dens);
         dens = clamp_(dens, 0.f, 1.f);
         const float T_i = FAST ? exp_reg4k_(-F.absorbtion * dens * F.march_step, kExp2Tab4096) : exp_(-F.absorbtion * dens * F.march_step);
         T *= T_i;
