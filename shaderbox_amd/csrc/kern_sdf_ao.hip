@@ -13,34 +13,41 @@
 
 namespace sbx {
 
+// HW (the CULL kernels, which run for tame frames only: finite u_time, u_res checked by the C API, hence finite points): the SDF's min /
+// max as v_min_f32 / v_max_f32 (sbx_sdf.h hmin_ / hmax_).  Besides the primitives' own, the unions below are safe: every operand is a
+// primitive's value (never -0) except `-c` in op_sub, which is the SECOND operand of a max whose first, a box distance, is never -0.
+#ifndef AO_HW_MINMAX
+#define AO_HW_MINMAX 1
+#endif
+template <bool HW>
 __device__ __forceinline__ D2 ao_sdf_pipe(const FrameSdfAo& F, v3 pos) {                          // :54-113
     const v3 size = V3(1.3f, 1.f, 1.25f);                                                          // :52
     v3 p = pos - V3(0, size.y, 0);
-    const float b = sd_box(p, size);
+    const float b = sd_box<HW>(p, size);
     p = p - V3(.7f, .5f, 0);
     p = mul(p, F.rx_m90);
-    const float c = sd_y_cylinder(p, size.y + .55f, 2.f * size.z + .1f);
-    const D2 pipe = {fmax_(b, -c), 2.f};                                                           // op_sub, mat_pipe
+    const float c = sd_y_cylinder<HW>(p, size.y + .55f, 2.f * size.z + .1f);
+    const D2 pipe = {hmax_<HW>(b, -c), 2.f};                                                           // op_sub, mat_pipe
 
     p = pos - V3(0, size.y, 0);
     p = p - V3(-size.x + .525f, size.y, 0);
     p = mul(p, F.rx_m90);
-    const D2 coping = {sd_y_cylinder(p, .025f, 2.f * size.z), 5.f};                                // mat_coping
+    const D2 coping = {sd_y_cylinder<HW>(p, .025f, 2.f * size.z), 5.f};                                // mat_coping
 
     p = pos - V3(0, size.y * 2.f, 0);
-    const float rail = sd_box(p + V3(size.x, -.25f, 0), V3(.025f, .05f, size.z));
+    const float rail = sd_box<HW>(p + V3(size.x, -.25f, 0), V3(.025f, .05f, size.z));
     const v3 B = V3(.025f, .125f, .025f);
     const float H = -.125f;
-    const float bar_1 = sd_box(p + V3(size.x, H, 0), B);
-    const float bar_2 = sd_box(p + V3(size.x, H, size.z / 2.f), B);
-    const float bar_3 = sd_box(p + V3(size.x, H, size.z), B);
-    const float bar_4 = sd_box(p + V3(size.x, H, -size.z / 2.f), B);
-    const float bar_5 = sd_box(p + V3(size.x, H, -size.z), B);
-    const float b_a = fmin_(bar_1, bar_2);
-    const float b_b = fmin_(b_a, bar_3);
-    const float b_c = fmin_(bar_4, bar_5);
-    const float bars = fmin_(b_b, b_c);
-    const D2 railing = {fmin_(rail, bars), 4.f};                                                   // mat_deck
+    const float bar_1 = sd_box<HW>(p + V3(size.x, H, 0), B);
+    const float bar_2 = sd_box<HW>(p + V3(size.x, H, size.z / 2.f), B);
+    const float bar_3 = sd_box<HW>(p + V3(size.x, H, size.z), B);
+    const float bar_4 = sd_box<HW>(p + V3(size.x, H, -size.z / 2.f), B);
+    const float bar_5 = sd_box<HW>(p + V3(size.x, H, -size.z), B);
+    const float b_a = hmin_<HW>(bar_1, bar_2);
+    const float b_b = hmin_<HW>(b_a, bar_3);
+    const float b_c = hmin_<HW>(bar_4, bar_5);
+    const float bars = hmin_<HW>(b_b, b_c);
+    const D2 railing = {hmin_<HW>(rail, bars), 4.f};                                                   // mat_deck
     const D2 deck = op_add2(railing, coping);
     return op_add2(pipe, deck);
 }
@@ -61,21 +68,22 @@ __device__ __forceinline__ bool ao_pipe_far(v3 s, float dmin) {
 
 template <bool CULL>   // false (sbx_set_variant 1): both ramps evaluated everywhere, the reference form
 __device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos) {                                // :115-150
+    constexpr bool HW = CULL && AO_HW_MINMAX;
     const v3 size = V3(1.3f, 1.f, 1.25f);
     const float B = .15f;
     v3 p = pos - V3(0, B, 0);
-    const D2 bottom = {sd_box(p, V3(2.25f * size.x, B, size.z)), 3.f};                             // mat_bottom
-    const D2 ref = {sd_box(pos, V3(.025f, 15, .025f)), 0.f};                                       // mat_debug
+    const D2 bottom = {sd_box<HW>(p, V3(2.25f * size.x, B, size.z)), 3.f};                             // mat_bottom
+    const D2 ref = {sd_box<HW>(pos, V3(.025f, 15, .025f)), 0.f};                                       // mat_debug
     const D2 ground = {dot(V3(0, 1, 0), pos) + 0.f, 1.f};                                          // sd_plane, mat_ground
-    const float dmin = fmin_(fmin_(ground.d, ref.d), bottom.d);
+    const float dmin = hmin_<HW>(hmin_<HW>(ground.d, ref.d), bottom.d);       // (ground.d ends in `+ 0.f`: never -0)
     const float inf = u2f(0x7f800000u);
     const v3 s1 = p + V3(1.25f * size.x, 0, 0);
     D2 pipe1 = {inf, 2.f};
-    if (!(CULL && ao_pipe_far(s1, dmin))) pipe1 = ao_sdf_pipe(F, s1);
+    if (!(CULL && ao_pipe_far(s1, dmin))) pipe1 = ao_sdf_pipe<HW>(F, s1);
     p = p - V3(1.25f * size.x, 0, 0);
     p = mul(p, F.ry_180);
     D2 pipe2 = {inf, 2.f};
-    if (!(CULL && ao_pipe_far(p, dmin))) pipe2 = ao_sdf_pipe(F, p);
+    if (!(CULL && ao_pipe_far(p, dmin))) pipe2 = ao_sdf_pipe<HW>(F, p);
     const D2 pipe = op_add2(pipe1, pipe2);
     const D2 g = op_add2(ground, ref);
     const D2 b = op_add2(pipe, bottom);

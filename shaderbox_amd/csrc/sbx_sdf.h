@@ -12,11 +12,20 @@ __device__ __forceinline__ float op_blend(float a, float b, float k) {          
     float h = clamp_(0.5f + 0.5f * (b - a) / k, 0.0f, 1.0f);
     return mix_(b, a, h) - k * h * (1.0f - h);
 }
+// HW = true: v_max_f32 / v_min_f32 instead of the spec's compare-and-select (sbx_math.h fmin_ / fmax_: two half-rate instructions and
+// a VCC hazard each).  The hardware forms return the same value unless the FIRST operand is a NaN or the operands are zeros of
+// opposite sign ((+0, -0) for min, (-0, +0) for max).  Callers pass HW only where neither can happen: a finite point p (no NaN: these
+// primitives only add, subtract, multiply and take the root of a sum of squares), and every zero in them is +0 — a difference x - y
+// of equal numbers is +0, |p| - b is never -0, the literal zeros are +0.
+template <bool HW> __device__ __forceinline__ float hmax_(float a, float b) { return HW ? __builtin_fmaxf(a, b) : fmax_(a, b); }
+template <bool HW> __device__ __forceinline__ float hmin_(float a, float b) { return HW ? __builtin_fminf(a, b) : fmin_(a, b); }
+template <bool HW = false>
 __device__ __forceinline__ float sd_box(v3 p, v3 b) {                                          // sdf.h:67-73
-    return fmax_(abs_(p.x) - b.x, fmax_(abs_(p.y) - b.y, abs_(p.z) - b.z));
+    return hmax_<HW>(abs_(p.x) - b.x, hmax_<HW>(abs_(p.y) - b.y, abs_(p.z) - b.z));
 }
+template <bool HW = false>
 __device__ __forceinline__ float sd_y_cylinder(v3 p, float r, float h) {                        // sdf.h:85-93
-    return fmax_(length(V2(p.x, p.z)) - r, abs_(p.y) - h / 2.f);
+    return hmax_<HW>(length(V2(p.x, p.z)) - r, abs_(p.y) - h / 2.f);
 }
 __device__ __forceinline__ float det2(v2 a, v2 b) { return a.x * b.y - b.x * a.y; }             // sdf.h:114-119
 
