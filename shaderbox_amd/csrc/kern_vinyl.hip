@@ -27,25 +27,36 @@ namespace sbx {
 #define FV(x) (F.x)
 #endif
 
+// HW (the CULL kernel: tame frames, fixed camera, hence finite points): the unions' min / max as v_min_f32 / v_max_f32 (sbx_sdf.h
+// hmin_ / hmax_).  They differ from the spec's compare-and-select only when the FIRST operand is a NaN — the one member that can be a
+// NaN, the Bezier link (0 / 0 at isolated points), enters its min as the SECOND operand — or for zeros of opposite sign in the
+// order (+0, -0) for min, (-0, +0) for max: primitive values are never -0 (a length, a difference of equal numbers, |p| - b), a -0
+// arises only from `max(x, -y)` with y == +0, and the places where such a value meets a +0 are first operands of a min (equal
+// either way) or dmin2, which is only compared with 0 and added to a margin.
+#ifndef VIN_HW_MINMAX
+#define VIN_HW_MINMAX 1
+#endif
+template <bool HW>
 __device__ __forceinline__ float vinyl_logo(const FrameVinyl& F, v3 pos, float thick) {       // :68-85
     const v3 b = V3(.25f, thick, 1.2f), d = V3(.7f, 0, 0);
     v3 p = mul(pos, FV(ry30));
-    const float v1 = sd_box(p - d, b);
+    const float v1 = sd_box<HW>(p - d, b);
     p = mul(pos, FV(rym30));
-    const float v2 = sd_box(p + d, b);
-    const float x = sd_box(pos, V3(1.5f, thick, 1.35f));
-    return fmax_(fmin_(v1, v2), x);                              // op_intersect(op_add(v1, v2), x)
+    const float v2 = sd_box<HW>(p + d, b);
+    const float x = sd_box<HW>(pos, V3(1.5f, thick, 1.35f));
+    return hmax_<HW>(hmin_<HW>(v1, v2), x);                              // op_intersect(op_add(v1, v2), x)
 }
+template <bool HW>
 __device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {                       // :87-125
     const float thick = .1f;
-    const D2 lead_in = {sd_y_cylinder(p, 6.f, thick - .05f), 2.f};
-    const D2 groove = {sd_y_cylinder(p, 5.9f, thick), 1.f};
-    const D2 dead_wax = {sd_y_cylinder(p, 3.f, thick), 2.f};
-    const D2 label = {sd_y_cylinder(p, 2.f, thick), 3.f};
-    const D2 logo = {vinyl_logo(F, p, thick - .0175f), 4.f};
-    const float spc = sd_y_cylinder(p, .10f, .6f);
+    const D2 lead_in = {sd_y_cylinder<HW>(p, 6.f, thick - .05f), 2.f};
+    const D2 groove = {sd_y_cylinder<HW>(p, 5.9f, thick), 1.f};
+    const D2 dead_wax = {sd_y_cylinder<HW>(p, 3.f, thick), 2.f};
+    const D2 label = {sd_y_cylinder<HW>(p, 2.f, thick), 3.f};
+    const D2 logo = {vinyl_logo<HW>(F, p, thick - .0175f), 4.f};
+    const float spc = sd_y_cylinder<HW>(p, .10f, .6f);
     const float sps = length(p - V3(0, .3f, 0)) - .10f;
-    const D2 spindle = {fmin_(spc, sps), 5.f};
+    const D2 spindle = {hmin_<HW>(spc, sps), 5.f};
     const D2 d0 = op_add2(groove, lead_in);
     const D2 d1 = op_add2(d0, dead_wax);
     const D2 d2 = op_add2(label, logo);
@@ -53,8 +64,8 @@ __device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {        
     const D2 d4 = op_add2(d3, spindle);
     const float defect1 = length(p + V3(6.05f, 0, 0)) - .1f;
     const float defect2 = length(p + V3(-6.05f, 0, 0)) - .1f;
-    const float defect = fmin_(defect1, defect2);
-    return D2{fmax_(d4.d, -defect), d4.m};                       // op_sub
+    const float defect = hmin_<HW>(defect1, defect2);
+    return D2{hmax_<HW>(d4.d, -defect), d4.m};                       // op_sub
 }
 // Exact culling (as in kern_egg.hip): `dmin` is the distance the platter already gives at pos; a group of the tonearm
 // whose lower bound exceeds the running minimum cannot be returned by the union and enters it as +inf.
@@ -68,20 +79,21 @@ __device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {        
 //    every member is >= .577 (|p - a3| - 1.3) - so with K = 1.74 (dmin + 1e-3) + 1.35, |p - a3| > K puts them all above dmin.
 template <bool CULL>   // false (sbx_set_variant 1): no culling, the reference form
 __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float dmin) {        // :127-255
+    constexpr bool HW = CULL && VIN_HW_MINMAX;
     const float inf = u2f(0x7f800000u);
     const v3 base_p = V3(-7, 0, -5);
     D2 base = {inf, 5.f};
     {
         const v3 q = pos - base_p;
-        const float lb = fmax_(abs_(q.x) - 3.01f, fmax_(abs_(q.y) - 1.26f, abs_(q.z) - 3.01f));
+        const float lb = hmax_<HW>(abs_(q.x) - 3.01f, hmax_<HW>(abs_(q.y) - 1.26f, abs_(q.z) - 3.01f));
         if (!(CULL && dmin >= 0.f && lb > dmin * 1.001f + 2e-3f)) {
-            const float platter = sd_y_cylinder(pos, 6.25f, 1.f);
-            const float base_0 = sd_y_cylinder(pos - base_p, 3.f, .25f);
-            const float base_1 = fmax_(base_0, -platter);
-            const float base_2 = sd_y_cylinder(pos - base_p, 1.25f, 1.f);
-            const float base_12 = fmin_(base_1, base_2);
+            const float platter = sd_y_cylinder<HW>(pos, 6.25f, 1.f);
+            const float base_0 = sd_y_cylinder<HW>(pos - base_p, 3.f, .25f);
+            const float base_1 = hmax_<HW>(base_0, -platter);
+            const float base_2 = sd_y_cylinder<HW>(pos - base_p, 1.25f, 1.f);
+            const float base_12 = hmin_<HW>(base_1, base_2);
             const D2 base_a = {base_12, 5.f};
-            const D2 base_b = {sd_y_cylinder(pos - base_p, 0.5f, 2.5f), 5.f};
+            const D2 base_b = {sd_y_cylinder<HW>(pos - base_p, 0.5f, 2.5f), 5.f};
             base = op_add2(base_a, base_b);
         }
     }
@@ -91,12 +103,12 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
     const float arm1 = sd_capsule_f(p, FV(arm1.a), FV(arm1.ab), FV(arm1.rd), R);
     const float arm2 = sd_capsule_f(p, FV(arm2.a), FV(arm2.ab), FV(arm2.rd), R);
     const float arm3 = sd_capsule_f(p, FV(arm3.a), FV(arm3.ab), FV(arm3.rd), R);
-    const float arm_link1 = fmin_(arm1, arm2);
-    const float arm_link2 = fmin_(arm_link1, arm3);
-    const float dmin2 = fmin_(fmin_(dmin, base.d), arm_link2);
+    const float arm_link1 = hmin_<HW>(arm1, arm2);
+    const float arm_link2 = hmin_<HW>(arm_link1, arm3);
+    const float dmin2 = hmin_<HW>(hmin_<HW>(dmin, base.d), arm_link2);
     const BezierFrame abz = FV(armb);
     const float armb = (CULL && bezier_far(abz, p, R, dmin2)) ? inf : sd_bezier_x(abz, p, R);
-    const D2 arm = {fmin_(arm_link2, armb), 5.f};
+    const D2 arm = {hmin_<HW>(arm_link2, armb), 5.f};
     {
         const v3 q = p - FV(a3);
         const float K = (dmin2 + 1e-3f) * 1.74f + 1.35f;
@@ -108,27 +120,27 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
 
     const v3 clr_p = p - FV(a3);
     const float clr_r = R * 1.5f;
-    const float collar = sd_cylinder0(FV(collar), clr_p, clr_r);
+    const float collar = sd_cylinder0<HW>(FV(collar), clr_p, clr_r);
     const float fl_w = .045f, fl_h = .020f;
     const float fl_len1 = clr_r * 1.f;
     const float fl_len2 = fl_len1 * 1.2f;
     const v3 fl_p = mul(clr_p - FV(fl_sub1) - FV(fl_sub2), FV(fl_rot));
-    const float fl1 = sd_box(fl_p, V3(fl_w, fl_h, fl_len1));
-    const float fl2 = sd_box(mul(fl_p - V3(0, 0, fl_len1), FV(fl_rot2)) - V3(0, 0, fl_len2), V3(fl_w, fl_h, fl_len2));
-    const float finger_lift = fmin_(fl1, fl2);
-    const D2 headshell = {fmin_(collar, finger_lift), 5.f};
+    const float fl1 = sd_box<HW>(fl_p, V3(fl_w, fl_h, fl_len1));
+    const float fl2 = sd_box<HW>(mul(fl_p - V3(0, 0, fl_len1), FV(fl_rot2)) - V3(0, 0, fl_len2), V3(fl_w, fl_h, fl_len2));
+    const float finger_lift = hmin_<HW>(fl1, fl2);
+    const D2 headshell = {hmin_<HW>(collar, finger_lift), 5.f};
 
     const float ctg_w = .05f, ctg_h = .05f, ctg_len1 = .3f, ctg_len2 = .5f;
     const v3 ctg_p = mul(clr_p, FV(arm_xform));
-    const float ctg1 = sd_box(ctg_p, V3(ctg_len1, ctg_h, ctg_w));
+    const float ctg1 = sd_box<HW>(ctg_p, V3(ctg_len1, ctg_h, ctg_w));
     const v3 ctg2_p = mul(ctg_p - V3(ctg_len1, 0, 0), FV(ctg_rot)) - V3(ctg_len2 - 0.03f, -.01f, 0);
-    const float ctg2 = sd_box(ctg2_p, V3(ctg_len2, ctg_h, ctg_w));
-    const float cut = sd_box(mul(mul(ctg2_p, FV(cut_rx10)) - V3(0, .05f, .175f), FV(cut_rym5)),
+    const float ctg2 = sd_box<HW>(ctg2_p, V3(ctg_len2, ctg_h, ctg_w));
+    const float cut = sd_box<HW>(mul(mul(ctg2_p, FV(cut_rx10)) - V3(0, .05f, .175f), FV(cut_rym5)),
                              V3(ctg_len2 * 2.f, ctg_h * 3.f, ctg_w * 3.2f));
-    const float cut2 = sd_box(mul(ctg2_p - V3(.3f, .2f, 0), FV(cut2_rz10)), V3(.4f, .2f, .3f));
-    const float ctg12 = fmin_(ctg1, ctg2);
-    const float ctg12c = fmax_(ctg12, -cut);
-    const D2 cartridge = {fmax_(ctg12c, -cut2), 5.f};
+    const float cut2 = sd_box<HW>(mul(ctg2_p - V3(.3f, .2f, 0), FV(cut2_rz10)), V3(.4f, .2f, .3f));
+    const float ctg12 = hmin_<HW>(ctg1, ctg2);
+    const float ctg12c = hmax_<HW>(ctg12, -cut);
+    const D2 cartridge = {hmax_<HW>(ctg12c, -cut2), 5.f};
 
     const D2 tone1 = op_add2(base, arm);
     const D2 tone2 = op_add2(headshell, cartridge);
@@ -136,7 +148,7 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
 }
 template <bool CULL>
 __device__ __forceinline__ D2 vinyl_sdf(const FrameVinyl& F, v3 pos) {                         // :257-265
-    const D2 plat = vinyl_platter(F, mul(pos, FV(platter_rot)));
+    const D2 plat = vinyl_platter<(CULL && VIN_HW_MINMAX)>(F, mul(pos, FV(platter_rot)));
     const D2 arm = vinyl_tonearm<CULL>(F, pos, plat.d);
     return op_add2(plat, arm);
 }

@@ -62,11 +62,12 @@ __device__ __forceinline__ bool bezier_far(const BezierFrame& B, v3 p, float thi
     return dmin >= 0.f && dot(q, q) > K * K;
 }
 // sd_cylinder(P, 0, P1, R), point-dependent part (frame = cyl_frame(0, P1))                    sdf.h:95-109
+template <bool HW = false>      // (HW: dist = a length is never -0 and the negated planes are second operands)
 __device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) {
     const float dist = length(cross(C.dir, P - V3(0.f, 0.f, 0.f)));
     const float plane_1 = dot(C.dir, P) + C.len1;
     const float plane_2 = dot(-C.dir, P) + (-C.len0);
-    return fmax_(fmax_(dist, -plane_1), -plane_2) - R;           // op_sub(op_sub(dist, p1), p2) - R
+    return hmax_<HW>(hmax_<HW>(dist, -plane_1), -plane_2) - R;   // op_sub(op_sub(dist, p1), p2) - R
 }
 // sd_capsule(p, a, b, r) with ab = b - a and rd = recip64(dot(ab, ab)) from the frame         sdf.h:162-171
 __device__ __forceinline__ float sd_capsule_f(v3 p, v3 a, v3 ab, double rd, float r) {
