@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Serial launches (one stream, HIP events, median) of the kernels of the BASELINE.json GPU configs only:
+C2 EGG 1920x1080, C3 RAYTRACER 3840x2160, C4 CLOUDS 3840x2160, C5 ATMOSPHERE and PLANET 7680x4320.
+The process tools/profile_baseline.sh runs under rocprofv3 (kernel trace + one counter group per pass)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+import shaderbox_amd
+
+R = shaderbox_amd.Renderer(0)
+R.set_timing(True)
+CASES = [("clouds", 3840, 2160), ("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320)]
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for _ in range(20):                      # clocks up before the first case
+    R.render("clouds", 3840, 2160, 0.37)
+torch.cuda.synchronize()
+for app, w, h in CASES:
+    buf = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    R.render(app, w, h, 0.37, out=buf); torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        R.render(app, w, h, 0.37, out=buf); ms.append(R.last_kernel_ms())
+    ms.sort()
+    print("%-10s %5dx%-5d %8.3f ms  %9.1f Mpix/s" % (app, w, h, ms[len(ms) // 2], w * h / ms[len(ms) // 2] / 1e3))
+    del buf
