@@ -72,7 +72,8 @@ typedef enum sbx_status {
     SBX_ERR_ARG = -1,          /* NULL pointer, bad row range, bad resolution ... */
     SBX_ERR_UNSUPPORTED = -2,  /* app not on the accelerated path */
     SBX_ERR_HIP = -3,          /* a HIP runtime call failed; see sbx_last_error() */
-    SBX_ERR_NO_DEVICE = -4     /* no gfx950 device visible: the library never falls back to a CPU */
+    SBX_ERR_NO_DEVICE = -4,    /* no gfx950 device visible: the library never falls back to a CPU */
+    SBX_ERR_FAULT = -5         /* a kernel reported an internal invariant violation on this device (sticky; sbx_fault_status) */
 } sbx_status;
 
 /* cbuffer b0 (src/uniform_buffer.h:25-30): u_res@c0.xy, u_mouse@c0.zw, u_time@c1.x.
@@ -136,12 +137,26 @@ int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* 
 
 /* The reference's own per-pixel entry, for hosts that keep their pixel loop:
  *     void mainImage(out vec4 fragColor, in vec2 fragCoord)            src/main.h:6-9
- * (what the absent VML/SDL harness calls per pixel, src/Makefile:21).  The first call for a given
- * (app, uniforms, aux) renders the whole frame on the GPU with one launch and copies it to the host;
- * later calls read their pixel.  fragCoord is a pixel centre (x + .5, y + .5), y = 0 at the bottom
- * row; coordinates outside the frame are clamped to it.  One caller per context. */
+ * (what the absent VML/SDL harness calls per pixel, src/Makefile:21).  mainImage is a function of fragCoord — it divides it
+ * by u_res (main.h:40) and never snaps or clamps it — and so is this call:
+ *   - fragCoord = the centre (x + .5, y + .5) of a pixel of the frame (y = 0 at the bottom row) and u_res whole numbers: the
+ *     first call for a given (app, uniforms, aux) renders the whole frame on the GPU with one launch and brings it to pinned
+ *     host memory with one asynchronous copy; later calls read their pixel from it;
+ *   - ANY other fragCoord (off-centre: a supersampling host; outside the frame; a fractional u_res): evaluated exactly at that
+ *     coordinate by a one-point launch (sbx_main_image_batch with n = 1) — never another pixel's sample.
+ * Safe to call from several host threads on one context (serialised inside); hosts with many samples per frame should use
+ * sbx_main_image_batch or sbx_render_points. */
 int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
                    const float fragCoord[2], float fragColor[4]);
+/* mainImage at n arbitrary fragCoords in ONE launch: the per-pixel entry in the shape a GPU can serve (n samples of a
+ * supersampling / jittering / foveated host).  Nothing is cached and nothing is assumed about the coordinates; u_res may be any
+ * positive finite numbers.  sbx_main_image_batch: host arrays (fragCoords n x 2 floats in, fragColors n x 4 floats out),
+ * staged through pinned memory, returns when the colours are there.  sbx_render_points: device arrays (frag n x 2, rgba n x 4,
+ * 16-byte aligned), asynchronous on `stream`. */
+int sbx_main_image_batch(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, size_t n,
+                         const float* fragCoords, float* fragColors);
+int sbx_render_points(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, size_t n,
+                      const float* frag, float* rgba, void* stream);
 
 /* Render the cyclic row-blocks owned by one rank of an N-way split: blocks of
  * `block_rows` rows, rank r owns blocks r, r+N, r+2N, ...  The rank's rows are written densely,
@@ -190,6 +205,39 @@ int sbx_render_split_rgb(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
                          int nranks, int root_rounds, int rounds, int r0, int r1, float* rgb, void* stream);
 int sbx_assemble_peers(sbx_ctx* ctx, int width, int height, int block_rows, int nranks, int root_rounds, int rounds,
                        int channels, const float* peers, float* frame, void* stream);
+
+/* ---- The span exchange: only the EXPENSIVE part of a row-block is sharded -----------------------------------------------
+ * (The reference has no multi-device path; this is the build's answer to SURVEY.md 8e at the sizes where the one exchange step
+ * is link-bound: at 7680x4320 a peer's 3-channel slab is 49.8 MB, 0.65 ms on one xGMI link at its 76.8 GB/s peak, against 0.47 ms
+ * of APP_ATMOSPHERE rendering per rank.)  Several apps leave mainImage through an early exit over a large part of the frame:
+ * APP_CLOUDS below the horizon (src/app_clouds.h:212), APP_ATMOSPHERE outside the dome and where the view ray dives under the
+ * ground (src/app_atmosphere.h:196-207, 65-67), APP_PLANET where the ray misses the atmosphere shell (src/app_planet.h:315-321).
+ * sbx_span_table gives, for every row-block g of the split, the interval [x0, x1) of columns (multiples of 64) OUTSIDE of which
+ * the host expects only such cheap pixels — a hint computed with the kernels' own tests at tile corners, widened by a tile:
+ *   - a peer renders and sends only the spans of its blocks, packed block after block, 3 floats per pixel (sbx_render_span_peer);
+ *   - the frame's owner renders its own blocks AND everything outside the other blocks' spans, in place, with ONE launch over the
+ *     frame (sbx_render_span_root), receives the packed slabs (still exactly one exchange step) and scatters them, writing alpha
+ *     (sbx_assemble_spans).
+ * Whoever renders a pixel runs the app's full kernel on its global coordinates: the table moves work and bytes, never a bit of
+ * the image.  Apps without a model get whole rows (the exchange then equals the direct one).
+ *
+ * sbx_span_table (host only; no context, no GPU): table = 4 int32 per row-block {x0, x1, offset of the block's span in its
+ * owner's packed slab (pixels), owner rank} or NULL; rank_pixels = nranks int64 (pixels of every rank's packed slab; rank 0's
+ * counts its own spans, which never travel) or NULL; max_width = the widest span among the peers' blocks or NULL.  Returns the
+ * number of row-blocks or a negative sbx_status.  The table depends on (app, u_res, u_mouse, split) only.
+ * sbx_render_span_peer: slab rows [r0, r1) (whole blocks; r1 clipped) of peer `rank` (1 .. nranks-1); `rgb` is the START of the
+ * rank's packed slab (3 * rank_pixels[rank] floats): the table's offsets are absolute in it, so a host can render and send the
+ * slab in pieces.  sbx_assemble_spans: `peers` holds the slab of rank r at (r - 1) * stride_pixels * 3 floats.
+ * The context keeps the device copies of the last few tables; a frame whose table is not on the device yet cannot be recorded
+ * into a stream capture (render it once before). */
+int sbx_span_table(int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks, int root_rounds, int rounds,
+                   int32_t* table, int64_t* rank_pixels, int32_t* max_width);
+int sbx_render_span_peer(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank, int nranks,
+                         int root_rounds, int rounds, int r0, int r1, float* rgb, void* stream);
+int sbx_render_span_root(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks,
+                         int root_rounds, int rounds, float* frame, void* stream);
+int sbx_assemble_spans(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks,
+                       int root_rounds, int rounds, const float* peers, int64_t stride_pixels, float* frame, void* stream);
 
 /* The write into hlsltoy's DXGI_FORMAT_R8G8B8A8_UNORM back buffer (util/hlsltoy/src/hlsltoy.cpp:79,192): float RGBA
  * rows -> 8-bit RGBA by the Direct3D float -> UNORM rule (NaN -> 0, clamp to [0, 1], * 255 + .5, truncate).
@@ -289,6 +337,16 @@ const char* sbx_multi_last_error(sbx_multi* m);
  * grouped ncclSend / ncclRecv pair from the rank to itself on two streams, compare.  0 = ok; *step (may be NULL) names the
  * failing step: 1 load, 2 communicator, 3 buffers, 4 group call, 5 data. */
 int sbx_multi_rccl_selftest(int device, int* step);
+
+/* Internal-invariant faults.  The cooperative hash cache of APP_CLOUDS / APP_PLANET serves lattice-cell misses in a loop that
+ * needs at most 64 rounds and is bounded at 4096; reaching the bound would mean wrong pixels.  Instead of passing silently the
+ * wave sets a sticky word in pinned host memory (one per device): from then on every render call on a context of that device
+ * returns SBX_ERR_FAULT — checked on entry, without synchronising — and sbx_last_error says why, until sbx_clear_fault (which
+ * waits for the device first).  sbx_fault_status = the check on its own (e.g. after synchronising a frame);
+ * sbx_debug_raise_fault launches one wave through the fault path (tests). */
+int sbx_fault_status(sbx_ctx* ctx);
+int sbx_clear_fault(sbx_ctx* ctx);
+int sbx_debug_raise_fault(sbx_ctx* ctx, void* stream);
 
 const char* sbx_last_error(sbx_ctx* ctx);
 const char* sbx_version(void);

@@ -26,7 +26,7 @@ APPS = {"APP_PLANET": APP_PLANET, "APP_CLOUDS": APP_CLOUDS, "APP_VINYL": APP_VIN
         "APP_CLOUDS_SKY": APP_CLOUDS_SKY,      # APP_CLOUDS + SKY_SPHERE (src/app_clouds.h:8,14-19,154-162)
         "APP_VINYL_GPU": APP_VINYL_GPU}        # APP_VINYL with the 180 march steps of its GLSL / HLSL builds (src/app_vinyl.h:411-416)
 
-SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE, SBX_ERR_FAULT = 0, -1, -2, -3, -4, -5
 
 
 class SbxError(RuntimeError):
@@ -102,6 +102,8 @@ def load_library(path=None):
     lib.sbx_pack_unorm8.argtypes = [vp, ci, ci, fp, vp, ci, vp]
     lib.sbx_main_image.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ctypes.POINTER(ctypes.c_float * 2),
                                    ctypes.POINTER(ctypes.c_float * 4)]
+    lib.sbx_main_image_batch.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ctypes.c_size_t, fp, fp]
+    lib.sbx_render_points.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ctypes.c_size_t, fp, fp, vp]
     lib.sbx_render_rank_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, fp, vp]
     lib.sbx_rank_rows.argtypes = [ci, ci, ci, ci]
     lib.sbx_rank_rows_max.argtypes = [ci, ci, ci]
@@ -112,6 +114,13 @@ def load_library(path=None):
     lib.sbx_assemble_split.argtypes = [vp, ci, ci, ci, ci, ci, ci, fp, fp, vp]
     lib.sbx_render_split_rgb.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, ci, ci, fp, vp]
     lib.sbx_assemble_peers.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, fp, fp, vp]
+    lib.sbx_span_table.argtypes = [ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, vp, vp, vp]
+    lib.sbx_render_span_peer.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, ci, ci, fp, vp]
+    lib.sbx_render_span_root.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, fp, vp]
+    lib.sbx_assemble_spans.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, fp, ctypes.c_int64, fp, vp]
+    lib.sbx_fault_status.argtypes = [vp]
+    lib.sbx_clear_fault.argtypes = [vp]
+    lib.sbx_debug_raise_fault.argtypes = [vp, vp]
     lib.sbx_set_timing.argtypes = [vp, ci]
     lib.sbx_set_variant.argtypes = [vp, ci]
     lib.sbx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -154,6 +163,34 @@ def sdf_ao_defaults(lib=None):
     a = AuxSdfAo()
     lib.sbx_aux_sdf_ao_defaults(ctypes.byref(a))
     return a
+
+
+def uniforms(width, height, time, mouse=(0.0, 0.0)):
+    u = Uniforms()
+    u.u_res[0], u.u_res[1] = float(width), float(height)
+    u.u_mouse[0], u.u_mouse[1] = float(mouse[0]), float(mouse[1])
+    u.u_time = float(time)
+    return u
+
+
+def span_table(app, width, height, time, block_rows, nranks, root_rounds=1, rounds=1, mouse=(0.0, 0.0), aux=None, lib=None):
+    """sbx_span_table (host only, no GPU needed): (table, rank_pixels, max_width) of the span exchange — table int32
+    [nblocks, 4] = {x0, x1, offset in the owner's packed slab (pixels), owner} per global row-block; rank_pixels[r] = pixels of
+    rank r's packed slab; max_width = the widest span among the peers' blocks."""
+    import numpy as np
+    lib = lib or load_library()
+    u = uniforms(width, height, time, mouse)
+    nb = shard.num_blocks(int(height), int(block_rows))
+    table = np.zeros((nb, 4), dtype=np.int32)
+    pix = np.zeros(int(nranks), dtype=np.int64)
+    mw = ctypes.c_int32(0)
+    auxp = ctypes.cast(ctypes.byref(aux), ctypes.c_void_p) if aux is not None else None
+    rc = lib.sbx_span_table(app_id(app), ctypes.byref(u), auxp, int(block_rows), int(nranks), int(root_rounds), int(rounds),
+                            table.ctypes.data_as(ctypes.c_void_p), pix.ctypes.data_as(ctypes.c_void_p),
+                            ctypes.cast(ctypes.byref(mw), ctypes.c_void_p))
+    if rc < 0:
+        raise SbxError(rc, "sbx_span_table: bad arguments")
+    return table, pix, int(mw.value)
 
 
 class Renderer:
@@ -248,10 +285,34 @@ class Renderer:
                                              ctypes.c_void_p(out.data_ptr()), 1 if flip_y else 0, self._stream()))
         return out
 
+    def render_points(self, app, width, height, time, frag, mouse=(0.0, 0.0), aux=None, out=None):
+        """mainImage at arbitrary fragCoords: `frag` is a float32 device tensor [n, 2]; returns [n, 4] (device).  u_res =
+        (width, height) need not be whole numbers here.  Asynchronous on the current stream."""
+        u = self.uniforms(width, height, time, mouse)
+        frag = frag.to(self.tdev, self.torch.float32).contiguous().view(-1, 2)
+        n = int(frag.shape[0])
+        if out is None:
+            out = self.torch.empty((n, 4), dtype=self.torch.float32, device=self.tdev)
+        assert out.is_cuda and out.dtype == self.torch.float32 and out.is_contiguous() and out.numel() >= 4 * n
+        self._check(self.lib.sbx_render_points(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), n,
+                                               ctypes.c_void_p(frag.data_ptr()), ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def main_image_batch(self, app, width, height, time, frag_coords, mouse=(0.0, 0.0), aux=None):
+        """sbx_main_image_batch: host arrays in, host arrays out — numpy float32 [n, 2] -> [n, 4]; synchronous."""
+        import numpy as np
+        u = self.uniforms(width, height, time, mouse)
+        fc = np.ascontiguousarray(frag_coords, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((fc.shape[0], 4), dtype=np.float32)
+        self._check(self.lib.sbx_main_image_batch(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), fc.shape[0],
+                                                  fc.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def main_image(self, app, width, height, time, frag_coord, mouse=(0.0, 0.0), aux=None):
         """void mainImage(out vec4 fragColor, in vec2 fragCoord) (src/main.h:6-9) for hosts that loop over the
-        pixels themselves: returns the RGBA tuple of the pixel whose centre is frag_coord.  The first call for a
-        frame renders all of it on the GPU; later calls read from the host copy."""
+        pixels themselves: returns the RGBA tuple of mainImage at frag_coord.  For the centre of a pixel of the frame the
+        first call renders the whole frame on the GPU and later calls read from the host copy; any other coordinate
+        (off-centre, outside the frame) is evaluated exactly, by a one-point launch."""
         u = self.uniforms(width, height, time, mouse)
         fc = (ctypes.c_float * 2)(float(frag_coord[0]), float(frag_coord[1]))
         out = (ctypes.c_float * 4)()
@@ -285,6 +346,44 @@ class Renderer:
                                                        self._stream()))
         return frame
 
+    # -- the span exchange: only the expensive part of each row-block is sharded (include/sbx.h) ------------------
+    def span_table(self, app, width, height, time, block_rows, nranks, root_rounds=1, rounds=1, mouse=(0.0, 0.0), aux=None):
+        return span_table(app, width, height, time, block_rows, nranks, root_rounds, rounds, mouse, aux, lib=self.lib)
+
+    def render_span_peer(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0), aux=None,
+                         root_rounds=1, rounds=1):
+        """Slab rows [r0, r1) (whole blocks) of peer `rank`, spans only, packed 3 floats per pixel into `slab` (a flat float32
+        device buffer of >= 3 * rank_pixels[rank] floats: the table's offsets are absolute within it)."""
+        u = self.uniforms(width, height, time, mouse)
+        assert slab.is_cuda and slab.dtype == self.torch.float32 and slab.is_contiguous()
+        self._check(self.lib.sbx_render_span_peer(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, rank, nranks,
+                                                  root_rounds, rounds, int(r0), int(r1), ctypes.c_void_p(slab.data_ptr()),
+                                                  self._stream()))
+        return slab
+
+    def render_span_root(self, app, width, height, time, block_rows, nranks, frame, mouse=(0.0, 0.0), aux=None, root_rounds=1,
+                         rounds=1):
+        """The owner's launch of the span exchange, in place over the whole `frame` [H, W, 4]: rank 0's row-blocks in full and
+        every other block outside its span."""
+        u = self.uniforms(width, height, time, mouse)
+        assert frame.is_cuda and frame.dtype == self.torch.float32 and frame.is_contiguous()
+        assert tuple(frame.shape) == (int(height), int(width), 4)
+        self._check(self.lib.sbx_render_span_root(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, nranks,
+                                                  root_rounds, rounds, ctypes.c_void_p(frame.data_ptr()), self._stream()))
+        return frame
+
+    def assemble_spans(self, app, width, height, time, block_rows, nranks, peers, stride_pixels, frame, mouse=(0.0, 0.0), aux=None,
+                       root_rounds=1, rounds=1):
+        """Scatter the peers' packed span slabs (`peers`: flat float32, slab of rank r at (r - 1) * stride_pixels * 3) into
+        `frame`, alpha = 1; everything else in the frame is left as sbx_render_span_root wrote it."""
+        u = self.uniforms(width, height, time, mouse)
+        assert peers.is_cuda and peers.dtype == self.torch.float32 and peers.is_contiguous()
+        assert peers.numel() >= (int(nranks) - 1) * int(stride_pixels) * 3
+        self._check(self.lib.sbx_assemble_spans(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, nranks,
+                                                root_rounds, rounds, ctypes.c_void_p(peers.data_ptr()), int(stride_pixels),
+                                                ctypes.c_void_p(frame.data_ptr()), self._stream()))
+        return frame
+
     def assemble_peers(self, peers, width, height, block_rows, nranks, frame, root_rounds=1, rounds=1):
         """Root side of the direct exchange: scatter the slabs of ranks 1 .. nranks-1 (`peers` [nranks-1, rows_max, W, 3|4])
         to their rows of `frame` [H, W, 4] (alpha = 1 for 3-channel slabs); rank 0's rows are left as rendered in place."""
@@ -314,6 +413,13 @@ class Renderer:
                                                 ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
                                                 self._stream()))
         return frame
+
+    def fault_status(self):
+        """0, or SBX_ERR_FAULT once a kernel on this device has reported an invariant violation (sticky until clear_fault)"""
+        return int(self.lib.sbx_fault_status(self.ctx))
+
+    def clear_fault(self):
+        self._check(self.lib.sbx_clear_fault(self.ctx))
 
     def set_variant(self, variant):
         """0 = default kernels, 1 = per-lane cross-check kernels (bit-identical by specification)."""

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(64 * ATM_TX) k_atmosphere(FrameAtmosphere F, R
     if (ATM_TX > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     const Pixel px = pixel_of_thread<8, ATM_TX>(M);
     if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
 
     // sky dome mapping :195-207
     const float z2 = pc.x * pc.x + pc.y * pc.y;

@@ -143,7 +143,7 @@ __device__ __forceinline__ float clouds_illuminate(const FrameClouds& F, v3 orig
 __global__ void __launch_bounds__(WG_THREADS) k_clouds_perlane(FrameClouds F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread<32>(M);
     if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 dir = primary_dir(F.cam, pc);
 
     // render_sky_color :36-46
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
         // and the sky colour are recomputed in the epilogue from the pixel coordinates — same operations,
         // same bits — which keeps the register budget of the march at 4 waves per SIMD without spills.
         const Pixel px = pixel_of_thread<CL_TW, CL_TX, CL_TOP_FIRST>(M);
-        const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+        const v2 pc = point_cam(F.cam, px.fx, px.fy);
         const v3 dir = primary_dir(F.cam, pc);
         const float cutoff = dot(dir, V3(0, 1, 0));
         marches = px.valid && !(cutoff < 0.05f);                  // :212
@@ -977,7 +977,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
     const Pixel px = pixel_of_thread<CL_TW, CL_TX, CL_TOP_FIRST>(ME);
 #endif
     if (!px.valid) return;
-    const v2 pc = point_cam(FE.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(FE.cam, px.fx, px.fy);
     const v3 dir = primary_dir(FE.cam, pc);
     const v3 sky = clouds_sky(FE, dir);
     v3 col = sky;
@@ -1090,5 +1090,10 @@ void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStre
         else hipLaunchKernelGGL((k_clouds<false, false, 0>), grid, block, 0, s, F, M, out, ct);
     }
 }
+
+hipError_t bind_fault_clouds(unsigned* word) { return hc_bind_fault_word(word); }
+// test hook (sbx_debug_raise_fault): one wave takes the path a failed miss loop takes
+__global__ void k_raise_fault(unsigned code) { hc_fault(code); }
+void launch_raise_fault(unsigned code, hipStream_t s) { hipLaunchKernelGGL(k_raise_fault, dim3(1), dim3(64), 0, s, code); }
 
 }  // namespace sbx

@@ -93,7 +93,7 @@ template <bool XI>
 __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 dir = primary_dir(F.cam, pc);
 
     // render_sky_color :564-575

@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(64 * TEX_TX, TEX_MIN_WAVES) k_clouds_tex(Frame
     const bool lh_lds = TEX_LH && F.lsteps <= TEX_LH_N;
     const Pixel px = pixel_of_thread<TEX_TW, TEX_TX>(M);
     if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 dir = primary_dir(F.cam, pc);
 
     float sun_amount = fmax_(dot(dir, F.sun_dir), 0.f);        // render_sky_color :36-46

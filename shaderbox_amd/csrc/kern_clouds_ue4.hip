@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameC
     WaveCache& S = cache[threadIdx.x >> 6];
     hc_init(S, lane);
     const Pixel px = pixel_of_thread(M);
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 dir = primary_dir(F.cam, pc);                        // cam_dir
 
     // render_clouds :181-231
@@ -89,5 +89,7 @@ void launch_clouds_ue4(const FrameCloudsUe4& F, const RowMap& M, float* out, hip
     if (fast) hipLaunchKernelGGL(k_clouds_ue4<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
     else hipLaunchKernelGGL(k_clouds_ue4<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
+
+hipError_t bind_fault_clouds_ue4(unsigned* word) { return hc_bind_fault_word(word); }
 
 }  // namespace sbx

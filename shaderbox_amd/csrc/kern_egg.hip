@@ -112,7 +112,7 @@ template <bool CULL>
 __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread<EGG_TW, EGG_TX>(M);
     if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
 
     float depth = -1e8f;                                    // :188, fresh per pixel

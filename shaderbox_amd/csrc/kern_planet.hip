@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
     WaveCache& S = cache[threadIdx.x >> 6];
     hc_init(S, lane);
     const Pixel px = pixel_of_thread<PL_TW>(M);
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
 
     // intersect_sphere(eye, atmosphere = {0, 1 + max_height}) on no_hit      intersect.h:7-33
@@ -444,5 +444,7 @@ void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_
     if (variant == 1) hipLaunchKernelGGL(k_planet<false>, grid_for<PL_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
     else hipLaunchKernelGGL(k_planet<true>, grid_for<PL_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
+
+hipError_t bind_fault_planet(unsigned* word) { return hc_bind_fault_word(word); }
 
 }  // namespace sbx

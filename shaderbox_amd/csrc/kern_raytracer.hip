@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowM
 #endif
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 eye = F.cam.eye;
     v3 ro = eye, rd = primary_dir(F.cam, pc);
 

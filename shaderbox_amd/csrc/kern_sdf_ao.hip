@@ -94,7 +94,7 @@ template <bool CULL>
 __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo F, RowMap M, float* __restrict__ out) {
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, (float)px.x + .5f, (float)px.y + .5f);
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
 
     v3 rgb = V3(.1f, .1f, .7f);                                   // background :9-12

@@ -77,6 +77,30 @@ void launch_assemble_peers(int width, int height, int block_rows, int nranks, in
                            peers, reinterpret_cast<float4*>(frame));
 }
 
+// The span exchange (RowMap.span): a peer's slab holds, block after block, only the span [x0, x1) of each of its row-blocks,
+// 3 floats per pixel; slab r - 1 starts at peers + (r - 1) * stride_pixels * 3.  One thread per frame pixel; pixels of rank 0's
+// blocks and pixels outside their block's span were rendered in place by the owner (sbx_render_span_root) and are left alone.
+__global__ void __launch_bounds__(256) k_assemble_spans(int width, int height, int block_rows, const int4* __restrict__ span,
+                                                         const float* __restrict__ peers, size_t stride_pixels,
+                                                         float4* __restrict__ frame) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)width * height;
+    if (i >= total) return;
+    const int y = (int)(i / width), x = (int)(i - (size_t)y * width);
+    const int g = y / block_rows;
+    const int4 T = span[g];
+    if (T.w == 0 || x < T.x || x >= T.y) return;
+    const size_t src = (size_t)(T.w - 1) * stride_pixels + (size_t)T.z + (size_t)(y - g * block_rows) * (size_t)(T.y - T.x) + (size_t)(x - T.x);
+    const float* p = peers + src * 3;
+    frame[i] = make_float4(p[0], p[1], p[2], 1.0f);                // alpha: the constant of main.h:52
+}
+void launch_assemble_spans(int width, int height, int block_rows, const int4* span, const float* peers, size_t stride_pixels,
+                           float* frame, hipStream_t s) {
+    const size_t total = (size_t)width * height;
+    hipLaunchKernelGGL(k_assemble_spans, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, width, height, block_rows, span,
+                       peers, stride_pixels, reinterpret_cast<float4*>(frame));
+}
+
 // float RGBA -> R8G8B8A8_UNORM, the back-buffer write of hlsltoy (util/hlsltoy/src/hlsltoy.cpp:79,192), by the
 // Direct3D float -> UNORM rule: NaN -> 0, clamp to [0, 1], scale by 255, add .5, truncate.  One pixel per thread:
 // a 16-byte load and a 4-byte store, both coalesced.  flip != 0 writes the top row first (D3D / PPM order).

@@ -7,9 +7,11 @@
 // a gfx950 device sbx_create fails with SBX_ERR_NO_DEVICE.
 #include "../../include/sbx.h"
 #include "sbx_device.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,14 +57,43 @@ struct sbx_ctx {
     // sbx_main_image: the frame of the last (app, uniforms, aux) seen, on the device and on the host
     float* mi_dev = nullptr;
     size_t mi_floats = 0;
-    std::vector<float> mi_host;
+    float* mi_host = nullptr;        // pinned (hipHostMalloc): the frame comes back with one asynchronous copy
     bool mi_valid = false;
+    // sbx_main_image_batch / off-centre sbx_main_image: staging of a point list (device: 2 + 4 floats per point; host: pinned)
+    float* pt_dev = nullptr;
+    float* pt_host = nullptr;
+    size_t pt_cap = 0;
+    std::mutex mi_lock;              // sbx_main_image / sbx_main_image_batch may be called from several host threads
+    // span tables of the multi-GPU span exchange (sbx_render_span_*): a few device copies, most recently used first
+    struct SpanSlot { std::vector<int> key; std::vector<int> table; int4* dev = nullptr; int max_w = 0; size_t cap = 0; };
+    SpanSlot span_slots[4];
+    unsigned span_next = 0;
     int mi_app = -1;
     sbx_uniforms mi_uni{};
     unsigned char mi_aux[sizeof(sbx_aux_clouds)] = {0};
     int mi_aux_bytes = -1;
     std::string err;
 };
+
+// The sticky fault word of each device (sbx_hashcache.h g_hc_fault): pinned host memory the kernels can write and the host can
+// read without synchronising; process-wide, shared by the contexts of a device, never freed.
+static unsigned* g_fault_word[64] = {nullptr};
+static std::mutex g_fault_lock;
+static int bind_fault_word(int device) {
+    std::lock_guard<std::mutex> g(g_fault_lock);
+    if (device < 0 || device >= 64) return SBX_ERR_ARG;
+    if (!g_fault_word[device]) {
+        unsigned* w = nullptr;
+        if (hipHostMalloc((void**)&w, 64, hipHostMallocMapped) != hipSuccess) return SBX_ERR_HIP;
+        *w = 0u;
+        g_fault_word[device] = w;
+    }
+    unsigned* dev = nullptr;
+    if (hipHostGetDevicePointer((void**)&dev, g_fault_word[device], 0) != hipSuccess) return SBX_ERR_HIP;
+    if (bind_fault_clouds(dev) != hipSuccess || bind_fault_clouds_ue4(dev) != hipSuccess || bind_fault_planet(dev) != hipSuccess)
+        return SBX_ERR_HIP;
+    return SBX_OK;
+}
 
 static int fail(sbx_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
     if (ctx) {
@@ -376,7 +407,9 @@ int sbx_create(int device, sbx_ctx** out) {
     sbx_ctx* ctx = new sbx_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
-        hipMalloc((void**)&ctx->ytab, (size_t)(CLOUDS_YTAB_RING + CLOUDS_YTAB_CAPTURE) * CLOUDS_YTAB_BYTES) != hipSuccess) {
+        hipMalloc((void**)&ctx->ytab, (size_t)(CLOUDS_YTAB_RING + CLOUDS_YTAB_CAPTURE) * CLOUDS_YTAB_BYTES) != hipSuccess ||
+        bind_fault_word(device) != SBX_OK) {
+        if (ctx->ytab) (void)hipFree(ctx->ytab);
         delete ctx;
         return SBX_ERR_HIP;
     }
@@ -389,6 +422,10 @@ void sbx_destroy(sbx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->ytab) (void)hipFree(ctx->ytab);
     if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
+    if (ctx->mi_host) (void)hipHostFree(ctx->mi_host);
+    if (ctx->pt_dev) (void)hipFree(ctx->pt_dev);
+    if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
+    for (auto& sl : ctx->span_slots) if (sl.dev) (void)hipFree(sl.dev);
     if (ctx->noise_tex) (void)hipFree(ctx->noise_tex);
     if (ctx->noise_tex2) (void)hipFree(ctx->noise_tex2);
     if (ctx->tex_scan) (void)hipFree(ctx->tex_scan);
@@ -464,6 +501,13 @@ static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, fl
     return SBX_OK;
 }
 
+static const char* kFaultText = "an earlier launch on this device hit the bound of the hash cache's miss loop (sbx_hashcache.h): its "
+                                "pixels are invalid; re-render after sbx_clear_fault";
+static bool device_fault(const sbx_ctx* ctx) {
+    const unsigned* w = (ctx->device >= 0 && ctx->device < 64) ? g_fault_word[ctx->device] : nullptr;
+    return w && *(volatile const unsigned*)w != 0u;
+}
+
 // Domain of the margin-based culls of EGG / SDF_AO / VINYL (bounding spheres and boxes around members placed by rotations) and
 // of PLANET's |o|^2 band test (a rotation preserves the norm): their proofs take the frame's rotations to BE rotations.  The
 // spec's sin / cos reduce their argument with a two-term pi, which is accurate while |angle| < 2^30 or so; the fastest angle
@@ -480,6 +524,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     if (M.nrows == 0) return SBX_OK;
+    if (device_fault(ctx)) return fail(ctx, SBX_ERR_FAULT, kFaultText);
     // argument checks come before anything is enqueued or recorded
     if (app < SBX_APP_PLANET || app > SBX_APP_VINYL_GPU) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
     sbx_aux_clouds AC;
@@ -511,7 +556,9 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
     case SBX_APP_CLOUDS_SKY: launch_clouds(build_clouds(*uni, AC, true), M, rgba, s, ctx->variant, nullptr, 0, false); break;
     case SBX_APP_CLOUDS_TEX: launch_clouds_tex(build_clouds(*uni, AC), M, rgba, s, ctx->noise_tex, ctx->noise_tex_size, ctx->noise_tex2, ctx->noise_tex2_size,
-                                                    ctx->tex_bounds_valid ? ctx->tex_bounds : nullptr); break;
+                                                    // a captured launch is replayed later, possibly over volumes re-bound in place with
+                                                    // other texel ranges: no bounds baked into a graph (the plain exp_ / IEEE divide)
+                                                    (ctx->tex_bounds_valid && !capturing) ? ctx->tex_bounds : nullptr); break;
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, cull_variant); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
@@ -561,10 +608,85 @@ int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* 
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
 }
 
+// mainImage at `n` arbitrary fragCoords (device arrays): one launch laid out as a pseudo-frame (RowMap.frag)
+static const int POINTS_ROW = 256;         // a multiple of every kernel's workgroup width in pixels
+int sbx_render_points(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, size_t n, const float* frag,
+                      float* rgba, void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (!uni) return fail(ctx, SBX_ERR_ARG, "NULL uniforms");
+    if (n == 0) return SBX_OK;
+    if (!frag || !rgba) return fail(ctx, SBX_ERR_ARG, "NULL point list or output");
+    if (n > (size_t)0x7fffffff - POINTS_ROW) return fail(ctx, SBX_ERR_ARG, "too many points");
+    // u_res is what fragCoord is divided by (main.h:40) and what the aspect ratio comes from (:33): any positive finite
+    // numbers do; only the frame-granular entry points need a whole number of pixels
+    if (!(uni->u_res[0] > 0.f) || !(uni->u_res[1] > 0.f) || std::isinf(uni->u_res[0]) || std::isinf(uni->u_res[1]))
+        return fail(ctx, SBX_ERR_ARG, "u_res must be positive and finite");
+    if (((uintptr_t)rgba & 15u) != 0) return fail(ctx, SBX_ERR_ARG, "output must be 16-byte aligned");
+    const int rows = (int)((n + POINTS_ROW - 1) / POINTS_ROW);
+    RowMap M{POINTS_ROW, rows, 0, rows, 1, 0, rows, 0, 1, 1, 0, 0, frag, (int)n};
+    return render_mapped(ctx, app, uni, aux, M, rgba, stream);
+}
+
+static int stage_points(sbx_ctx* ctx, size_t n) {
+    if (n <= ctx->pt_cap) return SBX_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    if (ctx->pt_dev) (void)hipFree(ctx->pt_dev);
+    if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
+    ctx->pt_dev = nullptr; ctx->pt_host = nullptr; ctx->pt_cap = 0;
+    const size_t cap = n < 1024 ? 1024 : n;
+    if ((e = hipMalloc((void**)&ctx->pt_dev, cap * 6 * sizeof(float))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
+    if ((e = hipHostMalloc((void**)&ctx->pt_host, cap * 6 * sizeof(float), hipHostMallocDefault)) != hipSuccess)
+        return fail(ctx, SBX_ERR_HIP, "hipHostMalloc", e);
+    ctx->pt_cap = cap;
+    return SBX_OK;
+}
+static int main_image_points(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, size_t n, const float* frag,
+                             float* colors) {
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    int rc = stage_points(ctx, n);
+    if (rc != SBX_OK) return rc;
+    // layout of both staging buffers: the n colours (16-byte aligned) first, then the n coordinates
+    float* hcol = ctx->pt_host; float* hfrag = ctx->pt_host + 4 * ctx->pt_cap;
+    float* dcol = ctx->pt_dev;  float* dfrag = ctx->pt_dev + 4 * ctx->pt_cap;
+    std::memcpy(hfrag, frag, n * 2 * sizeof(float));
+    if ((e = hipMemcpyAsync(dfrag, hfrag, n * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr)) != hipSuccess)
+        return fail(ctx, SBX_ERR_HIP, "hipMemcpyAsync", e);
+    rc = sbx_render_points(ctx, app, uni, aux, n, dfrag, dcol, nullptr);
+    if (rc != SBX_OK) return rc;
+    if ((e = hipMemcpyAsync(hcol, dcol, n * 4 * sizeof(float), hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
+        (e = hipStreamSynchronize(nullptr)) != hipSuccess)
+        return fail(ctx, SBX_ERR_HIP, "point list copy", e);
+    std::memcpy(colors, hcol, n * 4 * sizeof(float));
+    return SBX_OK;
+}
+int sbx_main_image_batch(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, size_t n, const float* fragCoords,
+                         float* fragColors) {
+    if (!ctx) return SBX_ERR_ARG;
+    std::lock_guard<std::mutex> g(ctx->mi_lock);
+    if (!uni) return fail(ctx, SBX_ERR_ARG, "NULL uniforms");
+    if (n == 0) return SBX_OK;
+    if (!fragCoords || !fragColors) return fail(ctx, SBX_ERR_ARG, "NULL argument");
+    return main_image_points(ctx, app, uni, aux, n, fragCoords, fragColors);
+}
+
 int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, const float fragCoord[2],
                    float fragColor[4]) {
     if (!ctx) return SBX_ERR_ARG;
+    std::lock_guard<std::mutex> g(ctx->mi_lock);
     if (!uni || !fragCoord || !fragColor) return fail(ctx, SBX_ERR_ARG, "NULL argument");
+    // Is fragCoord the centre of a pixel of the frame?  Then the pixel comes from the frame cached for (app, uniforms, aux).
+    // ANY other coordinate — off-centre (a supersampling host), outside the frame, NaN, or a frame whose u_res is not a whole
+    // number of pixels — is evaluated exactly where it is, by a one-point launch: mainImage is a function of fragCoord
+    // (src/main.h:40), it never snaps or clamps.
+    const float W_f = uni->u_res[0], H_f = uni->u_res[1];
+    const int W = (int)W_f, H = (int)H_f;
+    const float fx = fragCoord[0], fy = fragCoord[1];
+    const bool whole = W > 0 && H > 0 && (float)W == W_f && (float)H == H_f && W <= 65536 && H <= 65536;
+    const float cx = std::floor(fx), cy = std::floor(fy);
+    const bool centre = whole && fx == cx + .5f && fy == cy + .5f && cx >= 0.f && cy >= 0.f && cx < W_f && cy < H_f;
+    if (!centre) return main_image_points(ctx, app, uni, aux, 1, fragCoord, fragColor);
     const int aux_bytes = !aux ? 0 : ((app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX || app == SBX_APP_CLOUDS_SKY) ? (int)sizeof(sbx_aux_clouds)
                                       : (app == SBX_APP_SDF_AO ? (int)sizeof(sbx_aux_sdf_ao)
                                       : (app == SBX_APP_CLOUDS_UE4 ? (int)sizeof(sbx_aux_clouds_ue4) : 0)));
@@ -572,31 +694,31 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
                      ctx->mi_aux_bytes == aux_bytes && (aux_bytes == 0 || std::memcmp(ctx->mi_aux, aux, aux_bytes) == 0);
     if (!hit) {
         ctx->mi_valid = false;
-        const int W = (int)uni->u_res[0], H = (int)uni->u_res[1];
-        if (W <= 0 || H <= 0) return fail(ctx, SBX_ERR_ARG, "bad resolution");
         const size_t n = (size_t)W * (size_t)H * 4;
         hipError_t e = hipSetDevice(ctx->device);
         if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
         if (n != ctx->mi_floats) {
             if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
-            ctx->mi_dev = nullptr; ctx->mi_floats = 0;
+            if (ctx->mi_host) (void)hipHostFree(ctx->mi_host);
+            ctx->mi_dev = nullptr; ctx->mi_host = nullptr; ctx->mi_floats = 0;
             if ((e = hipMalloc((void**)&ctx->mi_dev, n * sizeof(float))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
+            if ((e = hipHostMalloc((void**)&ctx->mi_host, n * sizeof(float), hipHostMallocDefault)) != hipSuccess) {
+                (void)hipFree(ctx->mi_dev); ctx->mi_dev = nullptr;
+                return fail(ctx, SBX_ERR_HIP, "hipHostMalloc", e);
+            }
             ctx->mi_floats = n;
-            ctx->mi_host.assign(n, 0.f);
         }
         const int rc = sbx_render_rows(ctx, app, uni, aux, 0, H, ctx->mi_dev, nullptr);
         if (rc != SBX_OK) return rc;
-        if ((e = hipMemcpy(ctx->mi_host.data(), ctx->mi_dev, n * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess)
-            return fail(ctx, SBX_ERR_HIP, "hipMemcpy", e);
+        // pinned destination: one DMA transfer at the link's rate behind the kernel, then one wait
+        if ((e = hipMemcpyAsync(ctx->mi_host, ctx->mi_dev, n * sizeof(float), hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
+            (e = hipStreamSynchronize(nullptr)) != hipSuccess)
+            return fail(ctx, SBX_ERR_HIP, "frame copy", e);
         ctx->mi_app = app; ctx->mi_uni = *uni; ctx->mi_aux_bytes = aux_bytes;
         if (aux_bytes) std::memcpy(ctx->mi_aux, aux, aux_bytes);
         ctx->mi_valid = true;
     }
-    const int W = (int)uni->u_res[0], H = (int)uni->u_res[1];
-    int x = (int)std::floor(fragCoord[0]), y = (int)std::floor(fragCoord[1]);      // centre (x+.5, y+.5) -> (x, y)
-    x = x < 0 ? 0 : (x >= W ? W - 1 : x);
-    y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-    const float* p = &ctx->mi_host[((size_t)y * W + x) * 4];
+    const float* p = &ctx->mi_host[((size_t)(int)cy * W + (int)cx) * 4];
     fragColor[0] = p[0]; fragColor[1] = p[1]; fragColor[2] = p[2]; fragColor[3] = p[3];
     return SBX_OK;
 }
@@ -636,6 +758,243 @@ int sbx_rank_rows(int height, int block_rows, int rank, int nranks) {
 }
 int sbx_rank_rows_max(int height, int block_rows, int nranks) {
     return sbx_split_rows_max(height, block_rows, nranks, 1, 1);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Spans: which part of a row-block is worth sending to another GPU (include/sbx.h "span exchange")
+// ---------------------------------------------------------------------------------------------
+// Several apps leave mainImage through an early exit for a large part of the frame: APP_CLOUDS below the horizon
+// (src/app_clouds.h:212), APP_ATMOSPHERE outside the dome (acos of an argument below -1 is a NaN direction, the atmosphere test
+// fails, src/app_atmosphere.h:196-207,85-88), APP_PLANET where the view ray misses the atmosphere shell (src/app_planet.h:315-321).
+// Such pixels cost a few hundred instructions; shipping them costs 12 bytes each on the one xGMI link between their renderer
+// and the frame's owner, which at 7680x4320 is the slower of the two by far.  So the split deals out only the SPAN of each
+// row-block that the host expects to be expensive, and the owner renders the rest of every block itself, in place.
+// The predicate below is a HINT: it repeats the kernels' own early-exit tests with the same math spec on the host, at tile
+// corners only, and widens the result by a tile — whoever renders a pixel runs the full kernel on it, so a wrong hint costs
+// balance, never a pixel.
+namespace {
+constexpr int SPAN_ALIGN = 64;        // spans start and end on multiples of this many pixels (every kernel's workgroup width divides it)
+
+struct SpanProbe {
+    int app;
+    Camera cam;
+    bool model;                       // false: no early-exit model for this app, every block's span is the whole row
+};
+static SpanProbe span_probe(int app, const sbx_uniforms& U, const void* aux) {
+    SpanProbe P;
+    P.app = app;
+    P.model = true;
+    switch (app) {
+    case SBX_APP_CLOUDS: case SBX_APP_CLOUDS_TEX: case SBX_APP_CLOUDS_SKY: {
+        sbx_aux_clouds A;
+        if (aux) A = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&A);
+        P.cam = build_clouds(U, A).cam;
+        break;
+    }
+    case SBX_APP_ATMOSPHERE: P.cam = build_atmosphere(U).cam; break;
+    case SBX_APP_PLANET: P.cam = build_planet(U).cam; break;
+    default: P.model = false; P.cam = Camera{}; break;
+    }
+    return P;
+}
+// may mainImage at fragCoord (fx, fy) get past the app's early exit?
+static bool span_heavy(const SpanProbe& P, float fx, float fy) {
+    const v2 pc = point_cam(P.cam, fx, fy);
+    switch (P.app) {
+    case SBX_APP_CLOUDS: case SBX_APP_CLOUDS_TEX: case SBX_APP_CLOUDS_SKY: {
+        const v3 dir = primary_dir(P.cam, pc);
+        return !(dir.y < 0.05f);                                   // app_clouds.h:212
+    }
+    case SBX_APP_ATMOSPHERE: {
+        // app_atmosphere.h:195-207: acos(1 - z2) is a NaN beyond z2 = 2 and the atmosphere test then fails (:85-88): free pixels.
+        // Below the horizon (1 < z2 <= 2) the view ray dives into the planet from 1 m above the ground; once all 16 view samples
+        // (:119-123) lie under the ground every get_sun_light returns at its first sample (:65-67) and the pixel costs about a
+        // sixth of a sky pixel.  "Heavy" = some view sample is above the ground.
+        const float z2 = pc.x * pc.x + pc.y * pc.y;
+        if (z2 > 2.0f) return false;
+        const float phi = atan2_(pc.y, pc.x), theta = acos_(1.0f - z2);
+        const v3 rd = V3(sin_(theta) * cos_(phi), cos_(theta), sin_(theta) * sin_(phi));
+        const float Re = 6360e3f, Ra = 6420e3f;
+        const v3 ro = V3(0, Re + 1.f, 0);
+        const float tca = dot(V3(0, 0, 0) - ro, rd);
+        const float d2 = dot(ro, ro) - tca * tca;
+        if (!(d2 < Ra * Ra)) return false;
+        const float t1 = tca + sqrt_(Ra * Ra - d2);
+        const float step = t1 / 16.f;
+        for (int i = 0; i < 16; ++i) {
+            const v3 sp = ro + rd * (((float)i + .5f) * step);
+            if (!(length(sp) - Re < 0.f)) return true;
+        }
+        return false;
+    }
+    case SBX_APP_PLANET: {                                         // intersect_sphere(eye, {0, 1 + max_height}), kern_planet.hip
+        const v3 ro = P.cam.eye, rd = primary_dir(P.cam, pc);
+        const float radius = 1.f + .4f;                            // planet.radius + max_height   app_planet.h:16-20,311-312
+        const v3 rc = V3(0, 0, 0) - ro;
+        const float tca = dot(rc, rd);
+        if (tca < 0.f) return false;
+        const float d2 = dot(rc, rc) - tca * tca;
+        return !(d2 > radius * radius * 1.01f);
+    }
+    default: return true;
+    }
+}
+}  // namespace
+
+extern "C" int sbx_span_table(int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks, int root_rounds,
+                              int rounds, int32_t* table, int64_t* rank_pixels, int32_t* max_width) {
+    if (!uni) return SBX_ERR_ARG;
+    const int W = (int)uni->u_res[0], H = (int)uni->u_res[1];
+    if (W <= 0 || H <= 0 || (float)W != uni->u_res[0] || (float)H != uni->u_res[1] || W > 65536 || H > 65536) return SBX_ERR_ARG;
+    if (!split_ok(H, block_rows, nranks, root_rounds, rounds)) return SBX_ERR_ARG;
+    if (app < SBX_APP_PLANET || app > SBX_APP_VINYL_GPU) return SBX_ERR_UNSUPPORTED;
+    const int nblocks = (H + block_rows - 1) / block_rows;
+    const int ntiles = (W + SPAN_ALIGN - 1) / SPAN_ALIGN;
+    const SpanProbe P = span_probe(app, *uni, aux);
+    std::vector<int> x0(nblocks, 0), x1(nblocks, W);
+    if (P.model) {
+        // the heavy part of a row-block is taken to be ONE interval of tiles (a disc, a horizon): scan inwards from both ends
+        for (int g = 0; g < nblocks; ++g) {
+            const int ya = g * block_rows, yb = std::min(H, ya + block_rows) - 1;
+            auto tile_heavy = [&](int k) {
+                const int xa = k * SPAN_ALIGN, xb = std::min(W, xa + SPAN_ALIGN) - 1;
+                const int xs[3] = {xa, (xa + xb) / 2, xb}, ys[3] = {ya, (ya + yb) / 2, yb};
+                for (int j = 0; j < 3; ++j)
+                    for (int i = 0; i < 3; ++i)
+                        if (span_heavy(P, (float)xs[i] + .5f, (float)ys[j] + .5f)) return true;
+                return false;
+            };
+            int lo = 0, hi = ntiles - 1;
+            while (lo <= hi && !tile_heavy(lo)) ++lo;
+            while (hi > lo && !tile_heavy(hi)) --hi;
+            if (lo > hi) { x0[g] = 0; x1[g] = 0; continue; }
+            lo = std::max(0, lo - 1); hi = std::min(ntiles - 1, hi + 1);          // one tile of slack either side
+            x0[g] = lo * SPAN_ALIGN;
+            x1[g] = std::min(W, (hi + 1) * SPAN_ALIGN);
+        }
+    }
+    // owner and slab offset of every block: the ranks' local blocks in slab order (sbx_split_rank_rows' enumeration)
+    std::vector<int> owner(nblocks, 0), off(nblocks, 0);
+    std::vector<long long> pix(nranks, 0);
+    const int V = split_cycle_blocks(nranks, root_rounds, rounds);
+    int maxw = 0;
+    for (int rank = 0; rank < nranks; ++rank) {
+        const int cnt = rank == 0 ? root_rounds : rounds;
+        for (int cycle = 0; cycle * V < nblocks; ++cycle)
+            for (int round = 0; round < cnt; ++round) {
+                const int v = round < root_rounds ? round * nranks + rank
+                                                  : root_rounds * nranks + (round - root_rounds) * (nranks - 1) + (rank - 1);
+                const int g = cycle * V + v;
+                if (g >= nblocks) continue;
+                const int rows = std::min(H, (g + 1) * block_rows) - g * block_rows;
+                owner[g] = rank;
+                if (pix[rank] + (long long)rows * W > 0x7fffffffLL) return SBX_ERR_ARG;      // offsets are 32-bit pixel counts
+                off[g] = (int)pix[rank];
+                pix[rank] += (long long)rows * (x1[g] - x0[g]);
+                if (rank > 0) maxw = std::max(maxw, x1[g] - x0[g]);
+            }
+    }
+    if (table)
+        for (int g = 0; g < nblocks; ++g) { table[4 * g] = x0[g]; table[4 * g + 1] = x1[g]; table[4 * g + 2] = off[g]; table[4 * g + 3] = owner[g]; }
+    if (rank_pixels) for (int r = 0; r < nranks; ++r) rank_pixels[r] = pix[r];
+    if (max_width) *max_width = maxw;
+    return nblocks;
+}
+
+// the device copy of the span table of (app, uniforms, aux, split): looked up among the context's few slots, else built and
+// uploaded.  An upload overwrites the least recently filled slot; launches that may still read that slot are waited for
+// (hipDeviceSynchronize: a table changes when the frame's geometry does, not per frame).
+static int span_table_device(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks,
+                             int root_rounds, int rounds, hipStream_t s, const int4** dev, int* max_w, const std::vector<int>** host) {
+    // the table depends on the camera (u_res, u_mouse) and the split, not on u_time or the rest of the aux block
+    std::vector<int> key = {app, block_rows, nranks, root_rounds, rounds};
+    int bits[4];
+    std::memcpy(bits, uni->u_res, 8); std::memcpy(bits + 2, uni->u_mouse, 8);
+    key.insert(key.end(), bits, bits + 4);
+    for (auto& sl : ctx->span_slots)
+        if (sl.dev && sl.key == key) { *dev = sl.dev; *max_w = sl.max_w; if (host) *host = &sl.table; return SBX_OK; }
+    if (stream_is_capturing(s)) return fail(ctx, SBX_ERR_ARG, "the span table of this frame is not on the device yet: render it once outside the stream capture");
+    const int H = (int)uni->u_res[1];
+    if (!split_ok(H, block_rows, nranks, root_rounds, rounds)) return fail(ctx, SBX_ERR_ARG, "bad rank split");
+    const int nblocks = (H + block_rows - 1) / block_rows;
+    sbx_ctx::SpanSlot& sl = ctx->span_slots[ctx->span_next++ % 4];
+    sl.key.clear();
+    sl.table.assign((size_t)nblocks * 4, 0);
+    int mw = 0;
+    const int rc = sbx_span_table(app, uni, aux, block_rows, nranks, root_rounds, rounds, sl.table.data(), nullptr, &mw);
+    if (rc < 0) return fail(ctx, rc, "bad span table arguments");
+    hipError_t e;
+    if (sl.dev) (void)hipDeviceSynchronize();                      // earlier launches may still read the slot's old table
+    if (sl.cap < (size_t)nblocks) {
+        if (sl.dev) (void)hipFree(sl.dev);
+        sl.dev = nullptr; sl.cap = 0;
+        if ((e = hipMalloc((void**)&sl.dev, (size_t)nblocks * sizeof(int4))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
+        sl.cap = (size_t)nblocks;
+    }
+    if ((e = hipMemcpy(sl.dev, sl.table.data(), (size_t)nblocks * sizeof(int4), hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(ctx, SBX_ERR_HIP, "span table upload", e);
+    sl.max_w = mw;
+    sl.key = key;
+    *dev = sl.dev; *max_w = mw; if (host) *host = &sl.table;
+    return SBX_OK;
+}
+
+extern "C" int sbx_render_span_peer(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                                    int nranks, int root_rounds, int rounds, int r0, int r1, float* rgb, void* stream) {
+    int W, H;
+    int rc = check_common(ctx, uni, rgb, W, H);
+    if (rc != SBX_OK) return rc;
+    if (rank < 1 || rank >= nranks) return fail(ctx, SBX_ERR_ARG, "span slabs are rendered by ranks 1 .. nranks-1");
+    const int rows = sbx_split_rank_rows(H, block_rows, rank, nranks, root_rounds, rounds);
+    if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
+    if (r0 < 0 || r1 < r0 || (r0 % block_rows) != 0) return fail(ctx, SBX_ERR_ARG, "bad slab row range (whole blocks)");
+    if (r1 > rows) r1 = rows;
+    if (r0 >= r1) return SBX_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    const int4* dev = nullptr; int mw = 0;
+    rc = span_table_device(ctx, app, uni, aux, block_rows, nranks, root_rounds, rounds, (hipStream_t)stream, &dev, &mw, nullptr);
+    if (rc != SBX_OK) return rc;
+    if (mw <= 0) return SBX_OK;                                    // every span of the peers is empty: nothing to render or send
+    // `rgb` is the start of the rank's packed slab: the table's offsets are absolute within it
+    RowMap M{mw, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0, 1, nullptr, 0, dev, 1};
+    return render_mapped(ctx, app, uni, aux, M, rgb, stream);
+}
+extern "C" int sbx_render_span_root(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks,
+                                    int root_rounds, int rounds, float* frame, void* stream) {
+    int W, H;
+    int rc = check_common(ctx, uni, frame, W, H);
+    if (rc != SBX_OK) return rc;
+    if (!split_ok(H, block_rows, nranks, root_rounds, rounds)) return fail(ctx, SBX_ERR_ARG, "bad rank split");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    const int4* dev = nullptr; int mw = 0;
+    rc = span_table_device(ctx, app, uni, aux, block_rows, nranks, root_rounds, rounds, (hipStream_t)stream, &dev, &mw, nullptr);
+    if (rc != SBX_OK) return rc;
+    // one launch over the whole frame, in place: rank 0's blocks in full, everybody else's outside their spans
+    RowMap M{W, H, 0, H, 1, 0, H, 0, 1, 1, 1, 0, nullptr, 0, dev, 2};
+    M.block_rows = block_rows;                                     // (row_to_y of a contiguous map: y = r for any block size)
+    return render_mapped(ctx, app, uni, aux, M, frame, stream);
+}
+extern "C" int sbx_assemble_spans(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks,
+                                  int root_rounds, int rounds, const float* peers, int64_t stride_pixels, float* frame, void* stream) {
+    int W, H;
+    int rc = check_common(ctx, uni, frame, W, H);
+    if (rc != SBX_OK) return rc;
+    if (!split_ok(H, block_rows, nranks, root_rounds, rounds) || stride_pixels < 0) return fail(ctx, SBX_ERR_ARG, "bad assemble arguments");
+    if (nranks == 1) return SBX_OK;
+    if (!peers) return fail(ctx, SBX_ERR_ARG, "NULL peers");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    const int4* dev = nullptr; int mw = 0;
+    rc = span_table_device(ctx, app, uni, aux, block_rows, nranks, root_rounds, rounds, (hipStream_t)stream, &dev, &mw, nullptr);
+    if (rc != SBX_OK) return rc;
+    if (mw <= 0) return SBX_OK;
+    launch_assemble_spans(W, H, block_rows, dev, peers, (size_t)stride_pixels, frame, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "assemble launch", e);
+    return SBX_OK;
 }
 
 static int render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank, int nranks,
@@ -803,6 +1162,7 @@ int sbx_set_noise_volumes(sbx_ctx* ctx, int shape_size, const float* shape_rgba,
     if (!ctx) return SBX_ERR_ARG;
     if (!shape_rgba || !detail_rgba || shape_size <= 0 || detail_size <= 0 || shape_size > 1024 || detail_size > 1024)
         return fail(ctx, SBX_ERR_ARG, "bad noise volume arguments");
+    ctx->tex_bounds_valid = false;                                 // whatever happens below, the old volumes' bounds are gone
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     const size_t n1 = (size_t)shape_size * shape_size * shape_size, n2 = (size_t)detail_size * detail_size * detail_size;
@@ -856,7 +1216,32 @@ int sbx_tex3d_eval(sbx_ctx* ctx, int size, const float* rgba, const float* xyz, 
     return SBX_OK;
 }
 
-const char* sbx_last_error(sbx_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+int sbx_fault_status(sbx_ctx* ctx) {
+    if (!ctx) return SBX_ERR_ARG;
+    return device_fault(ctx) ? fail(ctx, SBX_ERR_FAULT, kFaultText) : SBX_OK;
+}
+int sbx_clear_fault(sbx_ctx* ctx) {
+    if (!ctx) return SBX_ERR_ARG;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipDeviceSynchronize", e);   // no launch may still set it
+    if (ctx->device >= 0 && ctx->device < 64 && g_fault_word[ctx->device]) *(volatile unsigned*)g_fault_word[ctx->device] = 0u;
+    return SBX_OK;
+}
+int sbx_debug_raise_fault(sbx_ctx* ctx, void* stream) {
+    if (!ctx) return SBX_ERR_ARG;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    launch_raise_fault(1u, (hipStream_t)stream);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "fault kernel launch", e);
+    return SBX_OK;
+}
+
+const char* sbx_last_error(sbx_ctx* ctx) {
+    if (!ctx) return "no context";
+    if (device_fault(ctx) && ctx->err.find("hash cache") == std::string::npos) { ctx->err += ctx->err.empty() ? "" : "; "; ctx->err += kFaultText; }
+    return ctx->err.c_str();
+}
 const char* sbx_version(void) { return "libsbx 0.1 (gfx950, ABI 1)"; }
 
 }  // extern "C"

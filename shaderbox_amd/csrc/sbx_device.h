@@ -19,7 +19,13 @@ namespace sbx {
 #endif
 constexpr int WG_TILES_X = SBX_WG_WAVES, WG_THREADS = 64 * SBX_WG_WAVES;
 
-struct Pixel { int x, y; size_t idx; bool valid; };
+#ifndef SBX_PIXEL_POINTS
+#define SBX_PIXEL_POINTS 1     // A/B switches (tools/ab_build.py): the point-list and span forms of pixel_of compiled in
+#endif
+#ifndef SBX_PIXEL_SPANS
+#define SBX_PIXEL_SPANS 1
+#endif
+struct Pixel { int x, y; size_t idx; bool valid; float fx, fy; };   // (fx, fy) = fragCoord: the pixel centre, or a listed point
 
 // TOP_FIRST: workgroups are dispatched in increasing blockIdx (x fastest, then y); with TOP_FIRST the first ones take
 // the TOP rows of the launch.  For APP_CLOUDS the bottom rows never march (src/app_clouds.h:212), so the launch then ends
@@ -38,8 +44,34 @@ __device__ __forceinline__ Pixel pixel_of(const RowMap& M, int tid, int bx, int 
     const int by = TOP_FIRST ? (grid_y - 1 - by_in) : by_in;
     const int r = by * TH + (lane / TW);
     p.valid = (p.x < M.width) && (r < M.nrows);
+    if (SBX_PIXEL_POINTS && M.frag) {                        // wave-uniform (a kernel argument): point list, see RowMap
+        p.idx = (size_t)r * M.width + p.x;
+        p.valid = p.valid && p.idx < (size_t)M.npoints;
+        p.y = r;
+        p.fx = p.valid ? M.frag[2 * p.idx] : .5f;
+        p.fy = p.valid ? M.frag[2 * p.idx + 1] : .5f;
+        return p;
+    }
     p.y = row_to_y(M, r);
+    if (SBX_PIXEL_SPANS && M.span_mode) {                    // wave-uniform: the span forms of the multi-GPU split, see RowMap
+        const int yc = p.y < M.height ? p.y : M.height - 1;  // (rows past the frame are invalid anyway; keep the read in range)
+        const int g = yc / M.block_rows;
+        const int4 T = M.span[g];
+        if (M.span_mode == 1) {
+            p.x += T.x;
+            p.valid = p.valid && p.x < T.y;
+            p.idx = (size_t)T.z + (size_t)(yc - g * M.block_rows) * (size_t)(T.y - T.x) + (size_t)(p.x - T.x);
+        } else {
+            p.valid = p.valid && (T.w == 0 || p.x < T.x || p.x >= T.y);
+            p.idx = (size_t)p.y * M.width + p.x;
+        }
+        p.fx = (float)p.x + .5f;
+        p.fy = (float)p.y + .5f;
+        return p;
+    }
     p.idx = (size_t)(M.in_place ? p.y : r) * M.width + p.x;
+    p.fx = (float)p.x + .5f;                                 // fragCoord of pixel (x, y) is its centre
+    p.fy = (float)p.y + .5f;
     return p;
 }
 template <int TW = 8, int TX = WG_TILES_X, bool TOP_FIRST = false>
@@ -87,6 +119,12 @@ void launch_assemble(int width, int height, int block_rows, int nranks, int root
                      const float* gathered, float* frame, hipStream_t s);
 void launch_assemble_peers(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
                            int channels, const float* peers, float* frame, hipStream_t s);
+hipError_t bind_fault_clouds(unsigned* word);
+hipError_t bind_fault_clouds_ue4(unsigned* word);
+hipError_t bind_fault_planet(unsigned* word);
+void launch_raise_fault(unsigned code, hipStream_t s);
+void launch_assemble_spans(int width, int height, int block_rows, const int4* span, const float* peers, size_t stride_pixels,
+                           float* frame, hipStream_t s);
 void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);
 void launch_worley_volume(int size, float* out, hipStream_t s);

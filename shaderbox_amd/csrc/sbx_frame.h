@@ -8,6 +8,7 @@
 // arguments are wave-uniform and live in SGPRs, which is the "per-tile camera/uniform
 // constants" staging the design calls for without spending LDS or VGPRs on them.
 #pragma once
+#include <hip/hip_runtime.h>
 #include "sbx_vec.h"
 
 namespace sbx {
@@ -27,6 +28,25 @@ struct RowMap {
     int in_place;   // 0: rows are written densely (slab row r); 1: at their global row y of a full-size frame
     int rgb;        // 1: the output holds 3 floats per pixel (a peer's slab on its way to the root: alpha is the constant 1 of
                     //    main.h:52 and need not cross xGMI); 0: float4 pixels
+    // POINT LIST (sbx_render_points / sbx_main_image): frag != NULL makes the launch evaluate mainImage at `npoints` arbitrary
+    // fragCoords read from device memory (x, y interleaved) instead of at the pixel centres of a row range: the launch is laid
+    // out as a pseudo-frame of `width` columns whose "pixel" (x, r) is point r * width + x; results are written densely, 4
+    // (or 3) floats per point.  u_res stays the real frame's: fragCoord / u_res is what mainImage computes (main.h:40).
+    const float* frag;
+    int npoints;
+    // SPANS (sbx_render_span_peer / sbx_render_span_root; the multi-GPU exchange that ships only the expensive part of a
+    // row-block): span[g] = {x0, x1, off, owner} for every GLOBAL row-block g of the frame — pixels x0 <= x < x1 of the block
+    // are the part that is sharded ("heavy": the host expects real work there), the rest leaves mainImage through an early
+    // exit and is rendered by the frame's owner itself; `off` = where the block's span starts in its owner's packed slab
+    // (in pixels), `owner` = the rank the split deals the block to.
+    //   span_mode 1 (a peer): the launch covers the rank's local rows x the widest span; a pixel is rendered iff it lies in
+    //                 its block's span and lands at slab pixel off + row_in_block * (x1 - x0) + (x - x0);
+    //   span_mode 2 (the owner of the frame, in place over the WHOLE frame): a pixel is rendered iff its block is rank 0's
+    //                 or it lies OUTSIDE its block's span.
+    // Either way every pixel is computed by the same kernel from its global coordinates: the spans decide who renders a
+    // pixel, never what it looks like.
+    const int4* span;
+    int span_mode;
 };
 // blocks in one cycle, and the position of (round, rank) in it
 SBX_HD int split_cycle_blocks(int nranks, int root_rounds, int rounds) {

@@ -90,6 +90,17 @@ __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, i
 // the latch with the caller's pre-loop read and turned the loop into a per-lane (divergent) one — the
 // hash pass then ran with its worker lanes masked off and the loop never finished.
 struct H8 { float4 lo, hi; };
+// The miss loop of hc_slow needs at most 64 rounds (one cell per slot per round, 64 lanes); its bound exists because a compiler
+// that re-nests the loop on per-lane terms (the hazard described above) would otherwise hang the GPU.  Reaching the bound means
+// some lane's hashes were never delivered: the pixels of that launch are WRONG.  That must not pass silently: the wave sets the
+// device's sticky fault word — one word of pinned host memory per device, bound to this translation unit's pointer by
+// sbx_create — and every later call on a context of that device fails with SBX_ERR_FAULT until sbx_clear_fault.
+static __device__ unsigned* g_hc_fault = nullptr;
+__device__ __noinline__ void hc_fault(unsigned code) {
+    unsigned* p = g_hc_fault;
+    if (p) __hip_atomic_fetch_or(p, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+inline hipError_t hc_bind_fault_word(unsigned* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_hc_fault), &p, sizeof(p)); }
 #ifndef SBX_HC_SLOW_INLINE
 #define SBX_HC_SLOW_INLINE __forceinline__
 #endif
@@ -103,7 +114,8 @@ __device__ SBX_HC_SLOW_INLINE H8 hc_slow(WaveCache& S, int k, unsigned nbits, in
 #ifdef SBX_CL_STATS
     if (lane == 0) S.stat[0] += 1.f;
 #endif
-    for (int round = 0; round < 4096; ++round) {          // bounded on principle; needs <= 64 rounds
+    int round = 0;
+    for (; round < 4096; ++round) {                       // bounded on principle; needs <= 64 rounds
         if (need && S.tag[k][slot] == nbits) {
             r.lo = *reinterpret_cast<const float4*>(&S.h[k][slot][0]);
             r.hi = *reinterpret_cast<const float4*>(&S.h[k][slot][4]);
@@ -112,6 +124,10 @@ __device__ SBX_HC_SLOW_INLINE H8 hc_slow(WaveCache& S, int k, unsigned nbits, in
         if (!wave_any(need)) break;
         hc_insert<B40>(S, k, nbits, slot, need, lane);
     }
+#ifndef SBX_HC_FAULT
+#define SBX_HC_FAULT 1
+#endif
+    if (SBX_HC_FAULT && round >= 4096) hc_fault(1u);                      // (wave-uniform) never observed; see g_hc_fault
     return r;
 }
 

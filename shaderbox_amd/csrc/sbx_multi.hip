@@ -108,8 +108,15 @@ struct sbx_multi {
     int exchange = SBX_MULTI_EXCHANGE_SLABS;
     unsigned calls = 0;
     hipEvent_t start[kInFlight] = {};
+    bool recv_recorded[kInFlight] = {false, false};       // root.recv_done[k] has been recorded at least once
     std::string err;
 };
+
+// every device of the world idle: before buffers that launches of EITHER in-flight frame may still touch are freed (hipFree
+// waits for the current device only; a peer's copy into the root's landing area runs on the peer's stream)
+static void sync_all_ranks(sbx_multi* m) {
+    for (Rank& r : m->ranks) { (void)hipSetDevice(r.device); (void)hipDeviceSynchronize(); }
+}
 
 static int mfail(sbx_multi* m, int code, const std::string& what, hipError_t e = hipSuccess) {
     if (m) {
@@ -346,6 +353,8 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
     if (n > 1 && slabs) {                                           // the root's landing area: (n - 1) slabs of rows_max rows
         const size_t need = (size_t)(n - 1) * rows_max * slab_row;
         if (need > root.stage_floats) {
+            sync_all_ranks(m);                                      // the other in-flight frame may still be landing in stage[1 - k]
+            (void)hipSetDevice(root.device);
             for (int q = 0; q < kInFlight; ++q) {
                 if (root.stage[q]) (void)hipFree(root.stage[q]);
                 root.stage[q] = nullptr;
@@ -359,14 +368,21 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
         Rank& r = m->ranks[i];
         if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
         if ((e = hipStreamWaitEvent(r.render[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+        // slot k's landing area (and, in copy mode, the rows the peers write into the frame) is free again only when the root has
+        // scattered the frame that used it last: order that explicitly instead of through the caller's stream, which may differ
+        // from frame to frame
+        if (m->recv_recorded[k] && (e = hipStreamWaitEvent(r.render[k], root.recv_done[k], 0)) != hipSuccess)
+            return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
         int rc;
         if (i == 0) {
             rc = sbx_render_split_in_place(r.ctx, app, uni, aux, br, 0, n, m0, mr, frame, r.render[k]);
         } else {
             const size_t need = (size_t)rows_max * row_floats;       // sized for either exchange
             if (need > r.slab_floats) {
+                sync_all_ranks(m);                                    // a transfer out of slab[1 - k] may still be running (RCCL: on the root's side too)
+                (void)hipSetDevice(r.device);
                 for (int q = 0; q < kInFlight; ++q) {
-                    if (r.slab[q]) (void)hipFree(r.slab[q]);          // hipFree waits for the device: nothing reads the old slab
+                    if (r.slab[q]) (void)hipFree(r.slab[q]);
                     r.slab[q] = nullptr;
                     if ((e = hipMalloc((void**)&r.slab[q], need * sizeof(float))) != hipSuccess) { r.slab_floats = 0; return mfail(m, SBX_ERR_HIP, "hipMalloc slab", e); }
                 }
@@ -382,27 +398,36 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
         if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
         if ((e = hipStreamWaitEvent(root.recv[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
         if (m->use_rccl) {
+            // every call inside the group is checked; the first failure is remembered with its call and rank, the group is
+            // closed all the same (an open group would swallow every later RCCL call of the process), and the failure is what
+            // the caller gets, with ncclGetErrorString's text
+            std::string where = "ncclGroupStart";
             nccl_result_t nr = g_rccl.GroupStart();
+            auto check = [&](nccl_result_t rc, const char* call, int rank) {
+                if (nr == 0 && rc != 0) { nr = rc; where = std::string(call) + " (rank " + std::to_string(rank) + ")"; }
+                return nr == 0;
+            };
             for (int i = 1; i < n && nr == 0; ++i) {
                 Rank& r = m->ranks[i];
                 const int rows = sbx_split_rank_rows(H, br, i, n, m0, mr);
                 if (slabs) {                                        // one send / one receive per peer: the whole slab
                     if (rows <= 0) continue;
                     const size_t floats = (size_t)rows * slab_row;
-                    nr = g_rccl.Send(r.slab[k], floats, kNcclFloat, 0, r.comm, r.render[k]);
-                    if (nr == 0) nr = g_rccl.Recv(root.stage[k] + (size_t)(i - 1) * rows_max * slab_row, floats, kNcclFloat, i, root.comm, root.recv[k]);
+                    if (check(g_rccl.Send(r.slab[k], floats, kNcclFloat, 0, r.comm, r.render[k]), "ncclSend", i))
+                        check(g_rccl.Recv(root.stage[k] + (size_t)(i - 1) * rows_max * slab_row, floats, kNcclFloat, i, root.comm, root.recv[k]), "ncclRecv", i);
                     continue;
                 }
                 for (int lr = 0, lb = 0; lr < rows && nr == 0; lr += br, ++lb) {       // one pair per row-block, into the final rows
                     const int y = global_block(lb, i, n, m0, mr) * br;
                     const int cnt = (y + br <= H) ? br : (H - y);
                     const size_t floats = (size_t)cnt * row_floats;
-                    nr = g_rccl.Send(r.slab[k] + (size_t)lr * row_floats, floats, kNcclFloat, 0, r.comm, r.render[k]);
-                    if (nr == 0) nr = g_rccl.Recv(frame + (size_t)y * row_floats, floats, kNcclFloat, i, root.comm, root.recv[k]);
+                    if (check(g_rccl.Send(r.slab[k] + (size_t)lr * row_floats, floats, kNcclFloat, 0, r.comm, r.render[k]), "ncclSend", i))
+                        check(g_rccl.Recv(frame + (size_t)y * row_floats, floats, kNcclFloat, i, root.comm, root.recv[k]), "ncclRecv", i);
                 }
             }
             const nccl_result_t ne = g_rccl.GroupEnd();
-            if (nr != 0 || ne != 0) return mfail(m, SBX_ERR_HIP, std::string("RCCL send/recv: ") + g_rccl.GetErrorString(nr != 0 ? nr : ne));
+            if (nr != 0) return mfail(m, SBX_ERR_HIP, "RCCL " + where + ": " + g_rccl.GetErrorString(nr));
+            if (ne != 0) return mfail(m, SBX_ERR_HIP, std::string("RCCL ncclGroupEnd: ") + g_rccl.GetErrorString(ne));
         } else {
             for (int i = 1; i < n; ++i) {
                 Rank& r = m->ranks[i];
@@ -442,6 +467,7 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
             if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(root.ctx));
         }
         if ((e = hipEventRecord(root.recv_done[k], root.recv[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
+        m->recv_recorded[k] = true;
     }
     // ---- the caller's stream continues when every part of the frame is in place ---------------------------------
     for (int i = 0; i < n; ++i) {

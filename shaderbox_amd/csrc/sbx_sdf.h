@@ -17,8 +17,12 @@ __device__ __forceinline__ float op_blend(float a, float b, float k) {          
 // opposite sign ((+0, -0) for min, (-0, +0) for max).  Callers pass HW only where neither can happen: a finite point p (no NaN: these
 // primitives only add, subtract, multiply and take the root of a sum of squares), and every zero in them is +0 — a difference x - y
 // of equal numbers is +0, |p| - b is never -0, the literal zeros are +0.
-template <bool HW> __device__ __forceinline__ float hmax_(float a, float b) { return HW ? __builtin_fmaxf(a, b) : fmax_(a, b); }
-template <bool HW> __device__ __forceinline__ float hmin_(float a, float b) { return HW ? __builtin_fminf(a, b) : fmin_(a, b); }
+// The instructions are PINNED with inline asm: LLVM's minnum / maxnum leave the sign of a zero result and the NaN case to the
+// target, so a constant fold or a compiler upgrade could pick the other zero; v_min_f32 / v_max_f32 are what the proof is about.
+__device__ __forceinline__ float v_max_f32_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float v_min_f32_(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <bool HW> __device__ __forceinline__ float hmax_(float a, float b) { return HW ? v_max_f32_(a, b) : fmax_(a, b); }
+template <bool HW> __device__ __forceinline__ float hmin_(float a, float b) { return HW ? v_min_f32_(a, b) : fmin_(a, b); }
 template <bool HW = false>
 __device__ __forceinline__ float sd_box(v3 p, v3 b) {                                          // sdf.h:67-73
     return hmax_<HW>(abs_(p.x) - b.x, hmax_<HW>(abs_(p.y) - b.y, abs_(p.z) - b.z));

@@ -22,6 +22,14 @@ Two forms of that one exchange (`exchange=`):
 * "gather": `dist.gather` of equal RGBA slabs (the root's included) + `assemble` of all of them — round 1's form, kept for
   comparison and as the fallback of backends without grouped point-to-point.
 
+* "spans": the direct exchange with only the EXPENSIVE part of every row-block sharded.  The library's span table
+  (`sbx_span_table`, include/sbx.h) gives, per row-block, the interval of columns in which mainImage is expected to get past
+  its early exit (APP_CLOUDS above the horizon, APP_ATMOSPHERE where some view sample is above the ground, APP_PLANET where the
+  ray meets the atmosphere shell); a peer renders and sends only those intervals, packed; the root renders its own blocks AND
+  everything outside the peers' intervals in one in-place launch over the frame (cheap pixels by construction of the table,
+  and the same kernel, so the table can only cost balance, never a pixel), then scatters the packed slabs.  Still exactly one
+  exchange step.  At 7680x4320 a peer's 49.8 MB become 29.7 MB (ATMOSPHERE, PLANET); at 4K APP_CLOUDS 12.4 -> 9.2 MB.
+
 `renderer` is duck-typed (render_rank_rows / render_rank_in_place / assemble / assemble_peers / empty):
 shaderbox_amd.Renderer on GPUs; the CPU tests drive the same code over gloo with an oracle-backed stand-in.
 """
@@ -33,8 +41,10 @@ class FramePlan:
 
     def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS, groups=1, root_rounds=1,
                  rounds=1, exchange="direct", channels=3):
-        if exchange not in ("direct", "gather"):
-            raise ValueError("exchange must be 'direct' or 'gather'")
+        if exchange not in ("direct", "gather", "spans"):
+            raise ValueError("exchange must be 'direct', 'gather' or 'spans'")
+        if exchange == "spans":
+            channels = 3
         if exchange == "gather":
             channels = 4
         if channels not in (3, 4):
@@ -59,6 +69,10 @@ class FramePlan:
                 self.gathered = renderer.empty((self.world, self.rows_max, self.width, 4))
                 self.glists = [[self.gathered[i, a:b] for i in range(self.world)] for a, b in self.ranges]
                 self.frame = renderer.empty((self.height, self.width, 4))
+        elif exchange == "spans":
+            if self.rank == 0:
+                self.frame = renderer.empty((self.height, self.width, 4))
+            self._span_key = None        # buffers and descriptors depend on the app's span table: built at the first render
         elif self.rank == 0:
             self.frame = renderer.empty((self.height, self.width, 4))
             if self.world > 1:
@@ -67,12 +81,83 @@ class FramePlan:
             self.slab = renderer.empty((self.rows_max, self.width, self.channels), zero=True)
         # the point-to-point descriptors of the direct exchange, built once (they only name fixed buffers and peers)
         self.p2p = []
-        if exchange == "direct" and self.world > 1:
+        if exchange == "direct" and self.world > 1:          # ("spans": built with the layout, _span_layout)
             for a, b in self.ranges:
                 if self.rank == 0:
                     self.p2p.append([dist.P2POp(dist.irecv, self.peers[i - 1, a:b], i) for i in range(1, self.world)])
                 else:
                     self.p2p.append([dist.P2POp(dist.isend, self.slab[a:b], 0)])
+
+    # -- the span exchange ------------------------------------------------------------------------------------
+    def _span_layout(self, app, time, mouse, aux):
+        """(Re)build buffers and point-to-point descriptors for the span table of (app, mouse): the table depends on the camera
+        and the split only, so an animation keeps one layout."""
+        key = (str(app), float(mouse[0]), float(mouse[1]))
+        if self._span_key == key:
+            return
+        table, pix, _ = self.r.span_table(app, self.width, self.height, time, self.block_rows, self.world,
+                                          self.root_rounds, self.rounds, mouse=mouse, aux=aux)
+        self.span_pixels = [int(p) for p in pix]
+        # every peer's slab starts at a multiple of `stride` pixels in the root's landing area
+        self.span_stride = (max(self.span_pixels[1:] + [0]) + 63) // 64 * 64
+        br = self.block_rows
+
+        def pixel_range(rank, a, b):             # packed-pixel interval of slab rows [a, b) of `rank`
+            blocks = shard._rank_blocks(self.height, br, rank, self.world, self.root_rounds, self.rounds)
+            lo, hi = a // br, b // br
+
+            def at(i):
+                return int(table[blocks[i]][2]) if i < len(blocks) else self.span_pixels[rank]
+            return at(min(lo, len(blocks))), at(min(hi, len(blocks)))
+        d = self.dist
+        self.p2p = []
+        if self.rank == 0:
+            self.peers = self.r.empty((max(self.world - 1, 1) * max(self.span_stride, 1) * 3,), zero=True)
+            for a, b in self.ranges:
+                ops = []
+                for i in range(1, self.world):
+                    lo, hi = pixel_range(i, a, b)
+                    if hi > lo:
+                        base = (i - 1) * self.span_stride
+                        ops.append(d.P2POp(d.irecv, self.peers[(base + lo) * 3:(base + hi) * 3], i))
+                self.p2p.append(ops)
+        else:
+            self.slab = self.r.empty((max(self.span_pixels[self.rank], 1) * 3,), zero=True)
+            for a, b in self.ranges:
+                lo, hi = pixel_range(self.rank, a, b)
+                self.p2p.append([d.P2POp(d.isend, self.slab[lo * 3:hi * 3], 0)] if hi > lo else [])
+        self._span_key = key
+
+    def _render_spans(self, app, time, mouse, aux, mark):
+        self._span_layout(app, time, mouse, aux)
+        d = self.dist
+        works = []
+        if self.rank == 0:
+            for ops in self.p2p:
+                if ops:
+                    works += d.batch_isend_irecv(ops)
+            self.r.render_span_root(app, self.width, self.height, time, self.block_rows, self.world, self.frame, mouse=mouse,
+                                    aux=aux, root_rounds=self.root_rounds, rounds=self.rounds)
+            mark("render")
+            for w in works:
+                w.wait()
+            mark("exchange")
+            if self.world > 1:
+                self.r.assemble_spans(app, self.width, self.height, time, self.block_rows, self.world, self.peers,
+                                      self.span_stride, self.frame, mouse=mouse, aux=aux, root_rounds=self.root_rounds,
+                                      rounds=self.rounds)
+            mark("assemble")
+            return self.frame
+        for g, (a, b) in enumerate(self.ranges):
+            self.r.render_span_peer(app, self.width, self.height, time, self.block_rows, self.rank, self.world, a, b, self.slab,
+                                    mouse=mouse, aux=aux, root_rounds=self.root_rounds, rounds=self.rounds)
+            if self.p2p[g]:
+                works += d.batch_isend_irecv(self.p2p[g])
+        mark("render")
+        for w in works:
+            w.wait()
+        mark("exchange")
+        return None
 
     def render(self, app, time, mouse=(0.0, 0.0), aux=None, mark=None):
         """All ranks call this; rank 0 returns the assembled [H, W, 4] frame, the others None.  `mark(name)`, if given, is
@@ -81,6 +166,8 @@ class FramePlan:
         mark = mark or (lambda name: None)
         if self.exchange == "gather":
             return self._render_gather(app, time, mouse, aux, mark)
+        if self.exchange == "spans":
+            return self._render_spans(app, time, mouse, aux, mark)
         d = self.dist
         works = []
         if self.rank == 0:
@@ -130,3 +217,67 @@ class FramePlan:
             mark("assemble")
             return frame
         return None
+
+
+class LoopbackWorld:
+    """An N-rank world inside ONE process on ONE device: what tests and tools use to run the real FramePlan schedule of every
+    rank — the real kernels, buffers, span tables and assembly — where only one GPU exists.  `rank(i)` is a stand-in for
+    torch.distributed as FramePlan uses it (get_rank / get_world_size / P2POp / isend / irecv / batch_isend_irecv): a send
+    stashes its tensor view, the matching receive copies from the stash on the current stream.  Per frame the callers must run
+    the peers' `render` before the root's (the root posts its receives first).  An emulation: it measures nothing about xGMI."""
+
+    class _Work:
+        def wait(self):
+            return True
+
+    class _Op:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Rank:
+        isend, irecv = "isend", "irecv"
+
+        def __init__(self, world, rank):
+            self._w, self._rank = world, rank
+            self.P2POp = LoopbackWorld._Op
+
+        def get_world_size(self):
+            return self._w.n
+
+        def get_rank(self):
+            return self._rank
+
+        def batch_isend_irecv(self, ops):
+            for op in ops:
+                if op.op == self.isend:
+                    self._w.box.setdefault((self._rank, op.peer), []).append(op.tensor)
+                else:
+                    q = self._w.box.get((op.peer, self._rank))
+                    if not q:
+                        raise RuntimeError("LoopbackWorld: rank %d receives from %d before it sent (run the peers first)"
+                                           % (self._rank, op.peer))
+                    src = q.pop(0)
+                    if src.numel() != op.tensor.numel():
+                        raise RuntimeError("LoopbackWorld: send of %d floats meets a receive of %d" % (src.numel(), op.tensor.numel()))
+                    op.tensor.copy_(src.reshape(op.tensor.shape))
+                    self._w.bytes_moved += src.numel() * src.element_size()
+            return [LoopbackWorld._Work()]
+
+    def __init__(self, n):
+        self.n = int(n)
+        self.box = {}
+        self.bytes_moved = 0
+
+    def rank(self, i):
+        return LoopbackWorld._Rank(self, int(i))
+
+    def plans(self, renderer, width, height, **kw):
+        """one FramePlan per rank, all on `renderer`'s device"""
+        return [FramePlan(renderer, self.rank(i), width, height, **kw) for i in range(self.n)]
+
+    @staticmethod
+    def render(plans, app, time, **kw):
+        """one frame through all ranks in the order the emulation needs: peers, then the root; returns the root's frame"""
+        for p in plans[1:]:
+            p.render(app, time, **kw)
+        return plans[0].render(app, time, **kw)

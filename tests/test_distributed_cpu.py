@@ -52,6 +52,55 @@ class OracleRenderer:
                     frame[y, :, 3] = 1.0
         return frame
 
+    # -- the span exchange: mirrors of sbx_render_span_peer / sbx_render_span_root / k_assemble_spans over the REAL span table
+    #    (sbx_span_table is host code of libsbx: no GPU needed) ------------------------------------------------
+    def span_table(self, app, width, height, time, block_rows, nranks, root_rounds=1, rounds=1, mouse=(0.0, 0.0), aux=None):
+        import shaderbox_amd
+        return shaderbox_amd.span_table(app, width, height, time, block_rows, nranks, root_rounds, rounds, mouse, aux)
+
+    def render_span_peer(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0), aux=None,
+                         root_rounds=1, rounds=1):
+        from oracle.oracle import APP_IDS
+        from shaderbox_amd import shard
+        table, _, _ = self.span_table(app, width, height, time, block_rows, nranks, root_rounds, rounds, mouse, aux)
+        rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)[r0:r1]
+        rows = [y for y in rows if table[y // block_rows][1] > table[y // block_rows][0]]
+        if rows:
+            img = torch.from_numpy(self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2))
+            for k, y in enumerate(rows):
+                x0, x1, off, owner = (int(v) for v in table[y // block_rows])
+                assert owner == rank
+                at = off + (y % block_rows) * (x1 - x0)
+                slab[at * 3:(at + x1 - x0) * 3] = img[k, x0:x1, :3].reshape(-1)
+        return slab
+
+    def render_span_root(self, app, width, height, time, block_rows, nranks, frame, mouse=(0.0, 0.0), aux=None, root_rounds=1,
+                         rounds=1):
+        from oracle.oracle import APP_IDS
+        table, _, _ = self.span_table(app, width, height, time, block_rows, nranks, root_rounds, rounds, mouse, aux)
+        rows = [y for y in range(height) if table[y // block_rows][3] == 0 or
+                table[y // block_rows][1] - table[y // block_rows][0] < width]
+        img = torch.from_numpy(self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2))
+        for k, y in enumerate(rows):
+            x0, x1, off, owner = (int(v) for v in table[y // block_rows])
+            if owner == 0:
+                frame[y] = img[k]
+            else:
+                frame[y, :x0] = img[k, :x0]
+                frame[y, x1:] = img[k, x1:]
+        return frame
+
+    def assemble_spans(self, app, width, height, time, block_rows, nranks, peers, stride_pixels, frame, mouse=(0.0, 0.0), aux=None,
+                       root_rounds=1, rounds=1):
+        table, _, _ = self.span_table(app, width, height, time, block_rows, nranks, root_rounds, rounds, mouse, aux)
+        for y in range(height):
+            x0, x1, off, owner = (int(v) for v in table[y // block_rows])
+            if owner > 0 and x1 > x0:
+                at = (owner - 1) * stride_pixels + off + (y % block_rows) * (x1 - x0)
+                frame[y, x0:x1, :3] = peers[at * 3:(at + x1 - x0) * 3].reshape(x1 - x0, 3)
+                frame[y, x0:x1, 3] = 1.0
+        return frame
+
     def assemble(self, gathered, width, height, block_rows, nranks, out=None, root_rounds=1, rounds=1):
         from shaderbox_amd import shard          # mirror of k_assemble (kern_util.hip)
         for y, (r, local) in enumerate(shard.slab_source(height, block_rows, nranks, root_rounds, rounds)):
@@ -113,3 +162,49 @@ def test_gather_with_root_relief(tmp_path, oracle, world, app, w, h, br, groups,
     got = np.load(path)
     ref = oracle.render(APP_IDS[app], w, h, 0.37)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,app,w,h,br,groups,relief", [(2, "clouds", 96, 54, 8, 1, (1, 1)),      # empty spans below the horizon
+                                                             (3, "clouds", 128, 72, 4, 3, (1, 2)),
+                                                             (2, "atmosphere", 448, 252, 8, 2, (1, 1)),  # partial spans: the dome
+                                                             (3, "planet", 448, 96, 8, 1, (2, 3)),
+                                                             (2, "egg", 64, 45, 8, 2, (1, 1))])         # no span model: whole rows
+def test_span_exchange_assembles_the_single_process_frame(tmp_path, oracle, world, app, w, h, br, groups, relief):
+    """exchange='spans': only the expensive interval of every row-block is dealt out and sent; the root renders the rest of
+    every block itself; the frame is the single-process frame bit for bit whatever the span table says"""
+    import shaderbox_amd
+    from oracle.oracle import APP_IDS
+    table, pix, maxw = shaderbox_amd.span_table(app, w, h, 0.37, br, world, relief[0], relief[1])
+    if app in ("atmosphere", "planet"):
+        part = [int(t[1] - t[0]) for t in table if t[3] > 0]
+        assert maxw > 0 and any(0 < v < w for v in part), "the case is meant to have partial spans"
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, groups, path, relief, "spans"), nprocs=world, join=True)
+    got = np.load(path)
+    ref = oracle.render(APP_IDS[app], w, h, 0.37)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_span_table_is_a_consistent_layout():
+    """offsets tile every rank's packed slab exactly; spans are aligned intervals; owners follow the split"""
+    import shaderbox_amd
+    from shaderbox_amd import shard
+    for app, w, h, br, n, m0, m in [("atmosphere", 7680, 4320, 8, 8, 1, 1), ("planet", 7680, 4320, 8, 8, 3, 4),
+                                    ("clouds", 3840, 2160, 8, 8, 1, 2), ("clouds", 1000, 333, 5, 3, 1, 1), ("egg", 100, 50, 8, 2, 1, 1)]:
+        table, pix, maxw = shaderbox_amd.span_table(app, w, h, 0.37, br, n, m0, m)
+        src = shard.slab_source(h, br, n, m0, m)
+        for r in range(n):
+            at = 0
+            for g in shard._rank_blocks(h, br, r, n, m0, m):
+                x0, x1, off, owner = (int(v) for v in table[g])
+                rows = min(h, (g + 1) * br) - g * br
+                assert owner == r == src[g * br][0] and off == at and 0 <= x0 <= x1 <= w
+                assert x0 % 64 == 0 and (x1 % 64 == 0 or x1 == w)
+                at += rows * (x1 - x0)
+            assert at == pix[r]
+        assert maxw == max([int(t[1] - t[0]) for t in table if t[3] > 0] + [0])
+    # the tables that matter at the BASELINE sizes: what fraction of the peers' pixels still crosses xGMI
+    for app, w, h, lo, hi in [("atmosphere", 7680, 4320, .55, .65), ("planet", 7680, 4320, .55, .65), ("clouds", 3840, 2160, .70, .78)]:
+        table, pix, _ = shaderbox_amd.span_table(app, w, h, 0.37, 8, 8)
+        full = sum(shard.rank_rows(h, 8, r, 8) * w for r in range(1, 8))
+        assert lo < sum(int(p) for p in pix[1:]) / full < hi, (app, sum(pix[1:]) / full)

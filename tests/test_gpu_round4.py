@@ -1,0 +1,272 @@
+"""GPU tests added in round 4: the per-pixel boundary at arbitrary fragCoords (VERDICT r3 "Next" #3), the 8-GPU form of config 5
+(#1), the hardened error paths (#7)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALL_APPS = ["planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best", "clouds_ue4", "clouds_sky",
+            "vinyl_gpu"]
+
+
+def compare(gpu, ref):
+    both_nan = np.isnan(gpu) & np.isnan(ref)
+    d = np.where(both_nan, 0.0, np.abs(gpu.astype(np.float64) - ref.astype(np.float64)))
+    d = np.nan_to_num(d, nan=np.inf)
+    bits = (gpu.view(np.uint32) != ref.view(np.uint32)) & ~both_nan
+    return float(d.max()), int(bits.any(axis=-1).sum())
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    import shaderbox_amd
+    r = shaderbox_amd.Renderer(0)
+    yield r
+    r.close()
+
+
+def oracle_points(oracle, app, w, h, t, pts, mouse=(0.0, 0.0)):
+    from oracle.oracle import APP_IDS
+    return np.stack([oracle.main_image(APP_IDS[app], w, h, t, float(x), float(y), mouse=mouse) for x, y in pts])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mainImage(fragColor, fragCoord) at arbitrary coordinates (src/main.h:6-53: fragCoord is divided by u_res, never snapped)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("app", ALL_APPS)
+def test_main_image_off_centre_and_outside_the_frame(renderer, oracle, app):
+    """sbx_main_image must evaluate the coordinate it is given: off-centre samples (a supersampling host), coordinates outside
+    the frame and on its edges.  Round 3 returned floor(fragCoord)'s pixel, clamped to the frame, with rc 0."""
+    w, h, t = 96, 54, 0.37
+    pts = [(10.25, 20.75), (47.5, 30.5), (47.9990234375, 30.0009765625), (0.0, 0.0), (96.0, 54.0), (-3.5, 10.5), (50.5, -7.25),
+           (120.5, 70.5), (95.5, 53.5), (0.5, 0.5), (31.125, 0.875)]
+    got = np.array([renderer.main_image(app, w, h, t, p) for p in pts], dtype=np.float32)
+    ref = oracle_points(oracle, app, w, h, t, pts)
+    assert compare(got, ref) == (0.0, 0)
+    # the two pixel centres above came from the cached frame, the others from one-point launches: both must agree with a
+    # frame render
+    frame = renderer.render(app, w, h, t).cpu().numpy()
+    assert compare(got[8], frame[53, 95]) == (0.0, 0) and compare(got[9], frame[0, 0]) == (0.0, 0)
+
+
+@pytest.mark.parametrize("app", ALL_APPS)
+def test_render_points_random_against_oracle(renderer, oracle, app):
+    """sbx_render_points / sbx_main_image_batch: n arbitrary fragCoords in one launch, bit-identical to the oracle's mainImage at
+    those coordinates; the lanes of a wave are then NOT neighbouring pixels (hash cache, wave-wide exits and culls must not care)"""
+    import torch
+    rng = np.random.default_rng(7 + len(app))
+    w, h, t = 640, 360, 0.37
+    n = 700                                           # not a multiple of the pseudo-frame's row length
+    pts = np.stack([rng.uniform(-40, w + 40, n), rng.uniform(-30, h + 30, n)], axis=1).astype(np.float32)
+    pts[:64] = np.stack([rng.uniform(300, 302, 64), rng.uniform(200, 201, 64)], axis=1)      # a wave inside one pixel pair
+    got_dev = renderer.render_points(app, w, h, t, torch.from_numpy(pts)).cpu().numpy()
+    got_host = renderer.main_image_batch(app, w, h, t, pts)
+    ref = oracle_points(oracle, app, w, h, t, pts)
+    assert compare(got_dev, ref) == (0.0, 0)
+    assert compare(got_host, ref) == (0.0, 0)
+
+
+def test_render_points_pixel_centres_equal_the_frame(renderer):
+    """the point list at every pixel centre of a frame, in a scrambled order, is that frame (both paths share the kernels)"""
+    import torch
+    w, h, t = 200, 120, 1.25
+    for app in ("clouds", "egg", "atmosphere", "planet", "raytracer", "sdf_ao"):
+        frame = renderer.render(app, w, h, t).cpu().numpy().reshape(-1, 4)
+        ys, xs = np.divmod(np.arange(w * h), w)
+        perm = np.random.default_rng(3).permutation(w * h)
+        pts = np.stack([xs[perm] + .5, ys[perm] + .5], axis=1).astype(np.float32)
+        got = renderer.render_points(app, w, h, t, torch.from_numpy(pts)).cpu().numpy()
+        assert compare(got, frame[perm]) == (0.0, 0), app
+
+
+def test_points_with_fractional_resolution_and_bad_arguments(renderer, oracle):
+    import shaderbox_amd
+    import torch
+    pts = np.array([[10.5, 3.25], [100.0, 50.0]], dtype=np.float32)
+    got = renderer.render_points("egg", 191.5, 107.25, 0.37, torch.from_numpy(pts)).cpu().numpy()
+    ref = oracle_points(oracle, "egg", 191.5, 107.25, 0.37, pts)
+    assert compare(got, ref) == (0.0, 0)
+    with pytest.raises(shaderbox_amd.SbxError):
+        renderer.render_points("egg", 0.0, 100.0, 0.37, torch.from_numpy(pts))
+    with pytest.raises(shaderbox_amd.SbxError):
+        renderer.render_points(99, 100.0, 100.0, 0.37, torch.from_numpy(pts))
+    assert renderer.render_points("egg", 100.0, 100.0, 0.37, torch.zeros((0, 2))).shape == (0, 4)
+    # NaN coordinates are data, as in the reference: whatever mainImage makes of them
+    nanpt = np.array([[np.nan, 5.5]], dtype=np.float32)
+    got = renderer.main_image_batch("clouds", 64, 36, 0.37, nanpt)
+    ref = oracle_points(oracle, "clouds", 64, 36, 0.37, nanpt)
+    assert compare(got, ref) == (0.0, 0)
+
+
+def test_main_image_from_several_threads(renderer, oracle):
+    """§8b: the per-pixel entry may be called from many host threads (the reference's globals are thread_local, src/def.h:7-8)"""
+    import threading
+    w, h, t = 64, 36, 0.37
+    res = {}
+
+    def work(k):
+        out = []
+        for i in range(40):
+            x, y = (k * 7 + i * 3) % w + (.5 if i % 2 else .3), (k * 5 + i) % h + .5
+            out.append(((x, y), renderer.main_image("egg", w, h, t, (x, y))))
+        res[k] = out
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    pts = [p for k in sorted(res) for p, _ in res[k]]
+    got = np.array([c for k in sorted(res) for _, c in res[k]], dtype=np.float32)
+    assert compare(got, oracle_points(oracle, "egg", w, h, t, pts)) == (0.0, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the 8-GPU form of the BASELINE configs on one GPU: every rank's real schedule (FramePlan) through a loopback world
+# ---------------------------------------------------------------------------------------------------------
+def loop_frame(renderer, app, w, h, t, n, exchange, groups=1, relief=(1, 1), br=8, frames=1):
+    import torch
+    from shaderbox_amd.distributed import LoopbackWorld
+    world = LoopbackWorld(n)
+    plans = world.plans(renderer, w, h, block_rows=br, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=exchange)
+    out = None
+    for _ in range(frames):
+        plans[0].frame.fill_(-7.0)                    # every pixel must be written again
+        out = LoopbackWorld.render(plans, app, t)
+    torch.cuda.synchronize()
+    return out, world
+
+
+@pytest.mark.parametrize("app", ["atmosphere", "planet"])
+def test_config5_eight_ranks_at_7680x4320_equal_one_launch(renderer, app):
+    """BASELINE config 5 as it runs on 8 GPUs — cyclic 8-row blocks, root in place, ONE exchange — with all 8 ranks' FramePlans on
+    this one GPU: the direct exchange (whole 3-channel slabs) and the span exchange (only the expensive interval of every block
+    crosses; the root renders the rest), plain and with root relief and pipelined groups.  Same bits as one launch."""
+    import torch
+    w, h, t = 7680, 4320, 0.37
+    full = renderer.render(app, w, h, t)
+    for exchange, groups, relief in [("direct", 1, (1, 1)), ("spans", 1, (1, 1)), ("spans", 3, (3, 4))]:
+        got, world = loop_frame(renderer, app, w, h, t, 8, exchange, groups, relief)
+        assert torch.equal(got.view(torch.int32), full.view(torch.int32)), (app, exchange, groups, relief)
+        mb = world.bytes_moved / 1e6
+        print("%s 7680x4320, 8 ranks, %s, groups %d, relief %s: %.1f MB cross the links per frame" % (app, exchange, groups, relief, mb))
+        if exchange == "spans":
+            assert mb < 0.66 * 7 * 49.8                # 7 x 49.8 MB with whole slabs
+        del got, world
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_span_exchange_small_frames(renderer, n):
+    """ragged sizes, every app with a span model plus one without, frames repeated into the same buffers"""
+    import torch
+    for app, w, h, t, br, groups, relief in [("clouds", 1000, 333, .37, 8, 2, (1, 1)), ("atmosphere", 1111, 500, 1.5, 8, 1, (1, 2)),
+                                             ("planet", 900, 400, .37, 4, 3, (1, 1)), ("egg", 203, 95, .37, 8, 1, (1, 1)),
+                                             ("clouds_sky", 640, 360, .37, 8, 1, (1, 1))]:
+        full = renderer.render(app, w, h, t)
+        got, _ = loop_frame(renderer, app, w, h, t, n, "spans", groups, relief, br, frames=2)
+        assert torch.equal(got.view(torch.int32), full.view(torch.int32)), (app, n)
+
+
+def test_span_exchange_follows_the_camera(renderer):
+    """the span table depends on the camera: APP_CLOUDS with the mouse turned (another layout key), same plans reused"""
+    import torch
+    from shaderbox_amd.distributed import LoopbackWorld
+    world = LoopbackWorld(4)
+    plans = world.plans(renderer, 1280, 720, exchange="spans")
+    for mouse in [(0.0, 0.0), (2.0, 0.0), (0.0, 0.0)]:
+        got = LoopbackWorld.render(plans, "clouds", .37, mouse=mouse)
+        full = renderer.render("clouds", 1280, 720, .37, mouse=mouse)
+        assert torch.equal(got.view(torch.int32), full.view(torch.int32)), mouse
+
+
+# ---------------------------------------------------------------------------------------------------------
+# hardening (VERDICT r3 "Next" #7)
+# ---------------------------------------------------------------------------------------------------------
+def test_hash_cache_fault_is_sticky_and_loud(renderer):
+    """hc_slow's round bound (sbx_hashcache.h) used to return zeros silently.  Now the wave sets the device's sticky fault word;
+    every later render on that device fails with SBX_ERR_FAULT, sbx_last_error says why, sbx_clear_fault re-arms."""
+    import torch
+    import shaderbox_amd
+    assert renderer.fault_status() == 0
+    ref = renderer.render("clouds", 96, 54, .37)
+    assert renderer.lib.sbx_debug_raise_fault(renderer.ctx, None) == 0      # one wave through the path a failed miss loop takes
+    torch.cuda.synchronize()
+    assert renderer.fault_status() == shaderbox_amd.SBX_ERR_FAULT
+    with pytest.raises(shaderbox_amd.SbxError) as e:
+        renderer.render("clouds", 96, 54, .37)
+    assert e.value.code == shaderbox_amd.SBX_ERR_FAULT and "hash cache" in str(e.value)
+    other = shaderbox_amd.Renderer(0)                                     # the word belongs to the device, not to a context
+    with pytest.raises(shaderbox_amd.SbxError):
+        other.render("egg", 32, 32, .37)
+    assert b"hash cache" in other.lib.sbx_last_error(other.ctx)
+    other.clear_fault()
+    other.close()
+    assert renderer.fault_status() == 0
+    again = renderer.render("clouds", 96, 54, .37)
+    assert torch.equal(again.view(torch.int32), ref.view(torch.int32))
+
+
+def test_multi_create_device_lists(renderer):
+    """sbx_multi_create with repeated-then-distinct device lists: ranks that share a device and ranks that do not in one world
+    (copies instead of RCCL); a list naming a device the box does not have fails cleanly with the reason."""
+    import torch
+    import shaderbox_amd
+    ndev = torch.cuda.device_count()
+    if ndev >= 2:
+        for devs in ([0, 0, 1], [0, 1, 1, 0]):
+            m = shaderbox_amd.MultiRenderer(devs)
+            assert not m.uses_rccl
+            got = m.render("clouds", 200, 117, .37)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), renderer.render("clouds", 200, 117, .37).view(torch.int32))
+            m.close()
+    else:
+        with pytest.raises(shaderbox_amd.SbxError) as e:
+            shaderbox_amd.MultiRenderer([0, 0, 1])
+        assert "device id out of range" in str(e.value)
+        m = shaderbox_amd.MultiRenderer([0, 0, 0, 0])
+        assert not m.uses_rccl and m.lib.sbx_multi_ranks(m.m) == 4
+        m.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ADVICE r3
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("app", ["vinyl", "vinyl_gpu", "sdf_ao", "egg"])
+def test_hardware_min_max_kernels_equal_plain_over_a_time_sweep(renderer, app):
+    """the SDF kernels' v_min_f32 / v_max_f32 (pinned with inline asm, sbx_sdf.h hmin_ / hmax_) against the compare-and-select
+    spec form (variant 1: plain kernels) over a random u_time sweep, bit for bit — the zero-sign and NaN argument of the proof is
+    about operand ORDER, so it is checked where it could break: many poses"""
+    rng = np.random.default_rng(11)
+    ts = np.concatenate([rng.uniform(0, 20, 24), rng.uniform(-500, 5000, 8), [0.0, 1e5, 3.3e7]])
+    for t in ts:
+        renderer.set_variant(0)
+        a = renderer.render(app, 240, 135, float(t)).cpu().numpy()
+        renderer.set_variant(1)
+        b = renderer.render(app, 240, 135, float(t)).cpu().numpy()
+        renderer.set_variant(0)
+        assert compare(a, b) == (0.0, 0), (app, float(t))
+
+
+def test_atmosphere_below_the_horizon_against_oracle(renderer, oracle):
+    """k_atmosphere's length() is sqrt_rs_ (exact for finite x >= 2^-102, NaN at 0): the rays that could bring |s|^2 near 0 are the
+    ones that dive through the planet (1 < z2 <= 2, src/app_atmosphere.h:195-207), up to the straight-down direction on the circle
+    z2 = 2.  Points all over that band, its two edges and odd resolutions (centre pixels exactly on the axes) against the oracle."""
+    import torch
+    rng = np.random.default_rng(5)
+    w, h = 1920.0, 1080.0
+    n = 6000
+    z2 = np.concatenate([rng.uniform(0.98, 2.002, n - 2000), rng.uniform(1.9995, 2.0005, 1000), rng.uniform(0.9995, 1.0005, 1000)])
+    phi = rng.uniform(-np.pi, np.pi, n)
+    phi[:64] = np.repeat([0.0, np.pi / 2, -np.pi / 2, np.pi], 16)
+    pcx, pcy = np.sqrt(z2) * np.cos(phi), np.sqrt(z2) * np.sin(phi)
+    keep = np.abs(pcy) <= 1.02
+    fx = (pcx[keep] / (w / h) + 1.0) * .5 * w
+    fy = (pcy[keep] + 1.0) * .5 * h
+    pts = np.stack([fx, fy], axis=1).astype(np.float32)
+    for t in (0.37, 3.0):
+        got = renderer.render_points("atmosphere", w, h, t, torch.from_numpy(pts)).cpu().numpy()
+        ref = oracle_points(oracle, "atmosphere", w, h, t, pts)
+        assert compare(got, ref) == (0.0, 0), t
+    for ww, hh in [(333, 187), (101, 101), (255, 143)]:
+        from oracle.oracle import APP_ATMOSPHERE
+        got = renderer.render("atmosphere", ww, hh, 0.37).cpu().numpy()
+        assert compare(got, oracle.render(APP_ATMOSPHERE, ww, hh, 0.37)) == (0.0, 0), (ww, hh)
