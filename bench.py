@@ -84,7 +84,7 @@ VALU_ISSUE_CYCLES = 2.0             # wave64 VALU instruction on a SIMD-32 (MI35
 NOMINAL_CLOCK_HZ = 2.4e9
 LANES_PER_SIMD_CYCLE = 32           # a SIMD-32 retires half a wave64 instruction per cycle
 PEAK_LANEOPS_NOMINAL_T = N_SIMD * LANES_PER_SIMD_CYCLE * NOMINAL_CLOCK_HZ / 1e12     # 78.6 T lane-ops/s
-PMC_ROUND = "r03"                   # committed per-launch counters: profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json
+PMC_ROUND = "r04"                   # committed per-launch counters: profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json
 # the other BASELINE.json configs that fit one GPU: (app, W, H) — C2, C3, C5 (both apps)
 OTHER_CONFIGS = [("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320)]
 KERNEL_OF = {"clouds": "k_clouds", "egg": "k_egg", "raytracer": "k_raytracer", "atmosphere": "k_atmosphere",
@@ -157,11 +157,14 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--time", type=float, default=0.37)
     ap.add_argument("--block-rows", type=int, default=8)
-    ap.add_argument("--gather-groups", type=int, default=1,
-                    help="N>1: issue the gather in this many pipelined pieces (1 = one plain gather)")
-    ap.add_argument("--exchange", choices=["direct", "gather"], default="direct",
-                    help="N>1 (engine dist): 'direct' = the root renders in place and receives the peers' slabs by ONE grouped "
-                         "send/recv (distributed.py); 'gather' = dist.gather of equal RGBA slabs + assembly of all of them (round 1)")
+    ap.add_argument("--gather-groups", default="auto",
+                    help="N>1: issue the one exchange in this many pipelined pieces ('auto': one per ~12 MB of a peer's payload, "
+                         "so a 4K slab goes out whole and an 8K one in 3 pieces; 1 = one plain exchange)")
+    ap.add_argument("--exchange", choices=["spans", "direct", "gather"], default="spans",
+                    help="N>1 (engine dist): 'spans' = only the expensive interval of every row-block is dealt to the peers and "
+                         "sent, the root renders the rest in place (distributed.py; config 5's 49.8 MB per peer become 29.7 MB); "
+                         "'direct' = the root renders its blocks in place and receives the peers' whole slabs by ONE grouped "
+                         "send/recv; 'gather' = dist.gather of equal RGBA slabs + assembly of all of them (round 1)")
     ap.add_argument("--channels", type=int, choices=[3, 4], default=3,
                     help="N>1, exchange direct: floats per pixel that cross xGMI (3: alpha, the constant 1 of main.h:52, is written "
                          "by the root's assembly)")
@@ -233,151 +236,262 @@ def main():
 
     ns = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(ns)] if ns > 1 else [torch.cuda.current_stream(dev)]
-    relief = (1, 1)
-    if not use_dist:
-        frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
-
-        def step(i=0):
-            with torch.cuda.stream(streams[i % ns]):
-                R.render(app, W, H, t, out=frames[i % ns])
-    else:
-        from shaderbox_amd.distributed import FramePlan
-        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, args.exchange,
-                               args.channels)
-        plans = [FramePlan(R, dist, W, H, br, groups=args.gather_groups, root_rounds=relief[0], rounds=relief[1],
-                           exchange=args.exchange, channels=args.channels) for _ in range(ns)]
-        slab = torch.empty((plans[0].rows_max, W, 4), dtype=torch.float32, device=dev)   # for the un-overlapped kernel timing
-
-        def step(i=0):
-            with torch.cuda.stream(streams[i % ns]):
-                plans[i % ns].render(app, t)      # render_rank + the single RCCL gather + assemble on rank 0
-
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # One-time initialisation, outside warm-up and timing (context creation is excluded): the first launch
-    # of a kernel loads the code object and builds APP_CLOUDS' y table; the first RCCL transfer sets up the peer links.
     for st in streams:                                  # a HIP stream's hardware queue is created on its first submission
         with torch.cuda.stream(st):
             R.render(app, 64, 36, t)
-    if not use_dist:
-        for f in frames:
-            f.zero_()                                   # first touch of the framebuffers (page mapping) is not rendering
-    else:
-        for p in plans:
-            for buf in (p.slab, p.gathered, p.peers, p.frame):
-                if buf is not None:
-                    buf.zero_()
-    if dist is not None:
+    if dist is not None:                                # the first RCCL transfer sets up the peer links
         tiny = torch.zeros(4, device=dev)
         dist.gather(tiny, [torch.zeros(4, device=dev) for _ in range(world)] if rank == 0 else None, dst=0)
-    sync()
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+
+    status = 0
+    if use_dist:
+        res = dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, rank, args.steps, args.warmup)
+        out = None
+        if rank == 0:
+            out = dist_line(res, args, app, W, H, t, world)
+            if res["mismatching_pixels"]:
+                status = 3
+            if not args.no_cpu_baseline:
+                base, rows, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
+                out["cpu_baseline"] = base
+                par = parity(res["frame"][rows].cpu().numpy(), ref, len(rows))
+                out["parity"]["oracle"] = par
+                if not (par["max_abs_diff"] <= 1e-4):
+                    status = 3
+        res.pop("frame", None)
+        res.pop("plans", None)
+        torch.cuda.empty_cache()
+        # BASELINE config 5 on the same ranks: APP_ATMOSPHERE and APP_PLANET 7680x4320 through the same FramePlan schedule
+        if not args.no_other_configs and app == "clouds":
+            others = []
+            for oa, ow, oh in DIST_OTHER_CONFIGS:
+                r2 = dist_frame_bench(R, dist, torch, dev, streams, args, oa, ow, oh, t, world, rank, min(args.steps, 10),
+                                      min(args.warmup, 2))
+                if rank == 0:
+                    o2 = dist_line(r2, args, oa, ow, oh, t, world)
+                    others.append({k: o2[k] for k in ("value", "unit", "ms_per_step", "steps", "value_serial", "serial", "steady_state",
+                                                      "roofline", "phases", "parity", "exchange")} |
+                                  {"workload": o2["config"]["workload"], "parallelism": o2["config"]["parallelism"],
+                                   "kernel": KERNEL_OF.get(oa)})
+                    if r2["mismatching_pixels"]:
+                        status = 3
+                r2.clear()
+                torch.cuda.empty_cache()
+            if rank == 0:
+                out["other_configs"] = others
+        if rank == 0:
+            claim_stdout()(json.dumps(out))
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(status)
+
+    # ---- N = 1: the frame is one kernel launch ---------------------------------------------------------------
+    frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
+
+    def step(i=0):
+        with torch.cuda.stream(streams[i % ns]):
+            R.render(app, W, H, t, out=frames[i % ns])
+    for f in frames:
+        f.zero_()                                       # first touch of the framebuffers (page mapping) is not rendering
+    torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i)
-    sync()
+    torch.cuda.synchronize(dev)
     step_done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]     # completion of every timed frame
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
         step_done[i].record(streams[i % ns])
-    sync()
+    torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region, one launch at a time,
     # so that the event queries do not perturb it and the launches do not overlap)
     kernel_ms = []
     for _ in range(min(max(args.steps, 3), 10)):
-        if not use_dist:
-            R.render(app, W, H, t, out=frames[0])
-        else:
-            R.render_rank(app, W, H, t, br, rank, world, out=slab, root_rounds=relief[0], rounds=relief[1])
+        R.render(app, W, H, t, out=frames[0])
         kernel_ms.append(R.last_kernel_ms())
-    sync()
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        km = torch.tensor([sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device=dev)
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kmean = float(km.item())
-    else:
-        kmean = sum(kernel_ms) / len(kernel_ms)
-
-    # N > 1: what each rank's frame consists of, timed with events on serial frames (outside the timed region)
-    phases = steady = None
-    if use_dist:
-        phases = dist_phases(plans[0], torch, dist, dev, app, t, world, rank)
-    status = 0
-    if rank == 0:
-        pixels = W * H
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = pixels / (ms_per_step * 1e-3) / 1e6
-        launch_pixels = pixels if not use_dist else max(shard.rank_rows(H, br, r, world, relief[0], relief[1]) for r in range(world)) * W
-        pmc = None
-        if world == 1 and not use_dist and args.pmc != "off":
-            pmc = pmc_counters(args, app, W, H, t)
-        elif args.pmc != "off":
-            pmc = pmc_committed(app, W, H)                      # N > 1: per-pixel instruction count of the committed profile
-        roofline, roofline_hbm = rooflines(app, launch_pixels, W * H, kmean, min(kernel_ms), pmc)
-        if roofline is not None and use_dist:
-            roofline["rank"] = "slowest (max over ranks of the un-overlapped launch duration; %d pixels)" % launch_pixels
-        steady = steady_state(step_done, ns, pixels)
-        out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(value, 3),
-               "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)"
-                                      % (app.upper(), W, H, t),
-                          "frames_in_flight": ns,
-                          "parallelism": "1 GPU, one launch per frame" if world == 1 else
-                                         "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + %s "
-                                         "(in %d pipelined pieces) + assemble" % (br, world, relief[0], relief[1], 
-                                         "1 RCCL gather of RGBA slabs" if args.exchange == "gather" else
-                                         "1 grouped RCCL send/recv of the peers' %d-channel slabs to the root (root in place)" % args.channels,
-                                         args.gather_groups)},
-               "serial": {"value": round(launch_pixels / (kmean * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
-                          "what": "one un-overlapped launch (HIP events), %d pixels" % launch_pixels},
-               "steady_state": steady,
-               "roofline": roofline, "roofline_hbm": roofline_hbm}
-        if use_dist:
-            out["phases"] = phases
-            # the assembled frame of the multi-GPU path against a one-launch render of the same frame: same bits
-            whole = R.render(app, W, H, t)
-            a, b = plans[(args.steps - 1) % ns].frame.view(torch.int32), whole.view(torch.int32)
-            bad = int((a != b).any(dim=-1).sum().item())
-            out["parity"] = {"against": "one-launch render of the same frame on rank 0", "rows": H,
-                             "mismatching_pixels": bad}
-            if bad:
-                status = 3
-            if not args.no_cpu_baseline:
-                base, rows, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
-                out["cpu_baseline"] = base
-                par = parity(plans[(args.steps - 1) % ns].frame[rows].cpu().numpy(), ref, len(rows))
-                out["parity"]["oracle"] = par
-                if not (par["max_abs_diff"] <= 1e-4):
-                    status = 3
-        elif not args.no_cpu_baseline:
-            base, rows, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
-            out["cpu_baseline"] = base
-            # parity of the TIMED frame: the oracle rows just rendered against the same rows of the GPU frame
-            gpu = frames[(args.steps - 1) % ns][rows].cpu().numpy()
-            out["parity"] = parity(gpu, ref, len(rows))
-            if not (out["parity"]["max_abs_diff"] <= 1e-4):
-                status = 3
-            speed = cpu_baseline_speed(app, W, H, t, rows)
-            if speed is not None:
-                out["cpu_baseline_speed"] = speed
-        if world == 1 and not use_dist and not args.no_other_configs and app == "clouds":
-            out["other_configs"] = other_configs(R, torch, dev, streams, t, check_rows=0 if args.no_cpu_baseline else 16,
-                                                 pmc_mode=args.pmc)
-            if any(c["parity"] and not (c["parity"]["max_abs_diff"] <= 1e-4) for c in out["other_configs"]):
-                status = 3
-        claim_stdout()(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    torch.cuda.synchronize(dev)
+    kmean = sum(kernel_ms) / len(kernel_ms)
+    pixels = W * H
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = pixels / (ms_per_step * 1e-3) / 1e6
+    pmc = pmc_counters(args, app, W, H, t) if args.pmc != "off" else None
+    roofline, roofline_hbm = rooflines(app, pixels, pixels, kmean, min(kernel_ms), pmc)
+    serial = round(pixels / (kmean * 1e-3) / 1e6, 3)
+    out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(value, 3),
+           "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)" % (app.upper(), W, H, t),
+                      "frames_in_flight": ns, "parallelism": "1 GPU, one launch per frame"},
+           # `value` has frames_in_flight launches overlapping (the timed region's wall clock); `value_serial` is SURVEY.md 8d's
+           # form: one un-overlapped launch, HIP events.  Compare like with like across N: value with value, serial with serial.
+           "value_serial": serial,
+           "serial": {"value": serial, "unit": "Mpixels/s", "what": "one un-overlapped launch (HIP events), %d pixels" % pixels},
+           "steady_state": steady_state(step_done, ns, pixels),
+           "roofline": roofline, "roofline_hbm": roofline_hbm}
+    if not args.no_cpu_baseline:
+        base, rows, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
+        out["cpu_baseline"] = base
+        # parity of the TIMED frame: the oracle rows just rendered against the same rows of the GPU frame
+        gpu = frames[(args.steps - 1) % ns][rows].cpu().numpy()
+        out["parity"] = parity(gpu, ref, len(rows))
+        if not (out["parity"]["max_abs_diff"] <= 1e-4):
+            status = 3
+        speed = cpu_baseline_speed(app, W, H, t, rows)
+        if speed is not None:
+            out["cpu_baseline_speed"] = speed
+    if not args.no_other_configs and app == "clouds":
+        out["other_configs"] = other_configs(R, torch, dev, streams, t, check_rows=0 if args.no_cpu_baseline else 16,
+                                             pmc_mode=args.pmc)
+        if any(c["parity"] and not (c["parity"]["max_abs_diff"] <= 1e-4) for c in out["other_configs"]):
+            status = 3
+    claim_stdout()(json.dumps(out))
     sys.exit(status)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N > 1: one (app, size) through FramePlan on the ranks this process group has
+# ---------------------------------------------------------------------------------------------------------
+DIST_OTHER_CONFIGS = [("atmosphere", 7680, 4320), ("planet", 7680, 4320)]      # BASELINE config 5, both apps as written
+
+
+def auto_groups(spec, payload_bytes_per_peer):
+    """pieces the one exchange is issued in: 'auto' = one per ~12 MB of a peer's payload (a 4K CLOUDS slab goes out whole, an 8K
+    slab in 3-4 pieces that leave while the rest renders), at most 8"""
+    if spec not in ("auto", "0", 0):
+        return max(1, int(spec))
+    return max(1, min(8, int(-(-payload_bytes_per_peer // 12e6))))
+
+
+def rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, exchange):
+    """pixels the launch(es) of `rank` render per frame"""
+    from shaderbox_amd import shard
+    if exchange != "spans" or world == 1:
+        return shard.rank_rows(H, br, rank, world, relief[0], relief[1]) * W
+    table, pix, _ = R.span_table(app, W, H, t, br, world, relief[0], relief[1])
+    if rank > 0:
+        return int(pix[rank])
+    own = shard.rank_rows(H, br, 0, world, relief[0], relief[1]) * W
+    outside = sum((min(H, (g + 1) * br) - g * br) * (W - int(x1 - x0)) for g, (x0, x1, _, owner) in enumerate(table) if owner > 0)
+    return own + outside
+
+
+def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, rank, steps, warmup):
+    """relief calibration, plans, first touch, warm-up, the timed K frames (barrier + synchronize on both sides, MAX over ranks),
+    every rank's un-overlapped launch, the phases of serial frames, the assembled frame against one launch.  Collective: every
+    rank calls it; the returned dict is complete on rank 0."""
+    from shaderbox_amd import shard
+    from shaderbox_amd.distributed import FramePlan
+    ns = len(streams)
+    br = args.block_rows
+    relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, args.exchange, args.channels)
+    payload = 0
+    if world > 1:
+        if args.exchange == "spans":
+            payload = 12 * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
+        else:
+            payload = (12 if (args.exchange == "direct" and args.channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
+    groups = auto_groups(args.gather_groups, payload)
+    plans = [FramePlan(R, dist, W, H, br, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=args.exchange,
+                       channels=args.channels) for _ in range(ns)]
+
+    def step(i=0):
+        with torch.cuda.stream(streams[i % ns]):
+            plans[i % ns].render(app, t)              # the rank's launch(es) + the ONE exchange + assembly on rank 0
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    for i in range(ns):                                 # builds the span layout, touches every buffer (page mapping)
+        step(i)
+    sync()
+    for i in range(warmup):
+        step(i)
+    sync()
+    step_done = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+        step_done[i].record(streams[i % ns])
+    sync()
+    elapsed = time.perf_counter() - t0
+    # every rank's own launch, un-overlapped
+    km = []
+    frame0 = plans[0].frame
+    scratch = None
+    for _ in range(min(max(steps, 3), 8)):
+        if args.exchange == "spans":
+            if rank == 0:
+                R.render_span_root(app, W, H, t, br, world, frame0, root_rounds=relief[0], rounds=relief[1])
+            else:
+                R.render_span_peer(app, W, H, t, br, rank, world, 0, 1 << 30, plans[0].slab, root_rounds=relief[0], rounds=relief[1])
+        else:
+            if scratch is None:
+                scratch = torch.empty((plans[0].rows_max, W, 4), dtype=torch.float32, device=dev)
+            R.render_rank(app, W, H, t, br, rank, world, out=scratch, root_rounds=relief[0], rounds=relief[1])
+        km.append(R.last_kernel_ms())
+    del scratch
+    sync()
+    mine = torch.tensor([elapsed, sum(km) / len(km), min(km), float(rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, args.exchange))],
+                        dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    phases = dist_phases(plans[0], torch, dist, dev, app, t, world, rank)
+    res = {"relief": relief, "groups": groups, "payload_bytes_per_peer": payload, "ns": ns, "steps": steps, "warmup": warmup}
+    if rank == 0:
+        per = [[float(x) for x in v] for v in allr]
+        slow = max(range(world), key=lambda r: per[r][1])
+        res.update({"elapsed": max(p[0] for p in per), "kmean": per[slow][1], "kmin": per[slow][2], "launch_pixels": int(per[slow][3]),
+                    "slowest_rank": slow, "per_rank_launch_ms": [round(p[1], 4) for p in per],
+                    "steady": steady_state(step_done, ns, W * H), "phases": phases})
+        # the assembled frame of the multi-GPU path against a one-launch render of the same frame: same bits
+        whole = R.render(app, W, H, t)
+        frame = plans[(steps - 1) % ns].frame
+        res["mismatching_pixels"] = int((frame.view(torch.int32) != whole.view(torch.int32)).any(dim=-1).sum().item())
+        res["frame"] = frame
+        del whole
+    res["plans"] = plans
+    return res
+
+
+def dist_line(res, args, app, W, H, t, world):
+    """rank 0: the JSON object of one N > 1 measurement"""
+    pixels = W * H
+    relief, ns = res["relief"], res["ns"]
+    ms_per_step = res["elapsed"] * 1e3 / res["steps"]
+    pmc = pmc_committed(app, W, H) if args.pmc != "off" else None
+    roofline, roofline_hbm = rooflines(app, res["launch_pixels"], pixels, res["kmean"], res["kmin"], pmc)
+    if roofline is not None:
+        roofline["rank"] = "slowest (rank %d of the un-overlapped launches %s ms; %d pixels)" % (res["slowest_rank"], res["per_rank_launch_ms"],
+                                                                                              res["launch_pixels"])
+    ph = res["phases"]
+    serial_ms = max((p["render_ms"] + p["exchange_wait_ms"] + p["assemble_ms"]) for p in ph["per_rank"]) if ph else None
+    exch = {"direct": "1 grouped RCCL send/recv of the peers' %d-channel slabs to the root (root in place)" % args.channels,
+            "gather": "1 RCCL gather of RGBA slabs",
+            "spans": "1 grouped RCCL send/recv of the peers' packed 3-channel SPANS (the root renders its blocks and everything "
+                     "outside the spans in place)"}[args.exchange]
+    return {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(pixels / (ms_per_step * 1e-3) / 1e6, 3),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": res["steps"], "warmup": res["warmup"],
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)" % (app.upper(), W, H, t),
+                       "frames_in_flight": ns,
+                       "parallelism": "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + %s (in %d pipelined "
+                                      "pieces) + assemble" % (args.block_rows, world, relief[0], relief[1], exch, res["groups"])},
+            "exchange": {"kind": args.exchange, "bytes_per_peer": res["payload_bytes_per_peer"], "pieces": res["groups"],
+                         "link_ms_at_76p8_GBps": round(res["payload_bytes_per_peer"] / 76.8e9 * 1e3, 4),
+                         "what": "the largest peer payload of one frame; one xGMI link per peer, 76.8 GB/s per direction at its peak"},
+            "value_serial": round(pixels / (serial_ms * 1e-3) / 1e6, 3) if serial_ms else None,
+            "serial": {"value": round(res["launch_pixels"] / (res["kmean"] * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
+                       "what": "the slowest rank's un-overlapped launch (HIP events), %d pixels; value_serial = the frame's pixels / "
+                               "one serial frame of the whole pipeline (render + exchange wait + assemble on the root, `phases`)"
+                               % res["launch_pixels"]},
+            "steady_state": res["steady"], "roofline": roofline, "roofline_hbm": roofline_hbm, "phases": ph,
+            "parity": {"against": "one-launch render of the same frame on rank 0", "rows": H,
+                       "mismatching_pixels": res["mismatching_pixels"]}}
 
 
 def bench_lib(args):
@@ -609,23 +723,25 @@ def run_pmc_pass(counters, app, W, H, t, outdir, timeout=100):
 
 
 def pmc_committed(app, W, H):
-    """the committed per-launch counters of this app (profiles/<round>_pmc_<app>_<W>x<H>.json): the file of this very frame
-    size if there is one, else any size's (the instruction count PER PIXEL is resolution independent to < 1 %, SURVEY.md 8d);
-    'frame_pixels' says which frame the counters belong to.  None if there is none."""
+    """the committed per-launch counters of this app from THIS round's profile of the shipped kernels
+    (profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json): the file of this very frame size if there is one, else another size's (the
+    instruction count PER PIXEL is resolution independent to < 1 %; `frame_pixels` says which frame the counters
+    belong to and `other_size` flags it).  No fallback to an earlier round's files: counters of kernels that have since changed
+    would overstate or understate the executed work.  None if there is none."""
     import glob
     import re
-    for rnd in (PMC_ROUND, "r02"):
-        exact = os.path.join(ROOT, "profiles", "%s_pmc_%s_%dx%d.json" % (rnd, app, W, H))
-        paths = [exact] if os.path.exists(exact) else sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_pmc_%s_*x*.json" % (rnd, app))))
-        for path in paths:
-            m = re.search(r"_(\d+)x(\d+)\.json$", path)
-            if not m:
-                continue
-            got = json.load(open(path))
-            got["source"] = "committed: profiles/" + os.path.basename(path)
-            got["committed"] = True
-            got["frame_pixels"] = int(m.group(1)) * int(m.group(2))
-            return got
+    exact = os.path.join(ROOT, "profiles", "%s_pmc_%s_%dx%d.json" % (PMC_ROUND, app, W, H))
+    paths = [exact] if os.path.exists(exact) else sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_pmc_%s_*x*.json" % (PMC_ROUND, app))))
+    for path in paths:
+        m = re.search(r"_(\d+)x(\d+)\.json$", path)
+        if not m:
+            continue
+        got = {k: v for k, v in json.load(open(path)).items() if isinstance(v, (int, float))}
+        got["source"] = "committed: profiles/" + os.path.basename(path) + ("" if path == exact else " (another frame size: per-pixel counts)")
+        got["committed"] = True
+        got["other_size"] = path != exact
+        got["frame_pixels"] = int(m.group(1)) * int(m.group(2))
+        return got
     return None
 
 
@@ -744,7 +860,8 @@ def dist_phases(plan, torch, dist, dev, app, t, world, rank, reps=5):
 
 
 def relief_candidates(max_rounds=8):
-    """(root_rounds, rounds) from the plain split down to a root that renders half a share, coarsest cycle first"""
+    """(root_rounds, rounds) from the plain split down to a root that renders NO block of its own (0/1: with the span exchange
+    the root also renders everything outside the peers' spans, which at 7680x4320 is most of a share), coarsest cycle first"""
     seen, out = set(), []
     for m in range(1, max_rounds + 1):
         for m0 in range(m, 0, -1):
@@ -752,7 +869,8 @@ def relief_candidates(max_rounds=8):
             if f >= .5 and f not in seen:
                 seen.add(f)
                 out.append((m0, m))
-    return sorted(out, key=lambda c: -c[0] / c[1])
+    out = sorted(out, key=lambda c: -c[0] / c[1])
+    return out + [(1, 3), (1, 4), (1, 6), (0, 1)]
 
 
 def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, exchange="direct", channels=3):
@@ -770,7 +888,7 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
         return (m0, m)
     pick = torch.zeros(2, dtype=torch.int64, device=dev)
     if rank == 0:
-        ch = channels if exchange == "direct" else 4
+        ch = channels if exchange == "direct" else (3 if exchange == "spans" else 4)
         st = streams                                    # the loop's own streams (no extra hardware queues)
         nb = max(2, len(st))
         frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(nb)]
@@ -787,38 +905,67 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
 
         best = None
         for m0, m in relief_candidates():
-            rmax = shard.rank_rows_max(H, br, world, m0, m)
-            src = torch.zeros((world - 1, rmax, W, ch), dtype=torch.float32, device=dev)
-            land = [torch.zeros((world, rmax, W, ch), dtype=torch.float32, device=dev) for _ in range(nb)]
-            slabs = [torch.empty((rmax, W, ch), dtype=torch.float32, device=dev) for _ in range(nb)]
-
-            def root_frame(i):
-                with torch.cuda.stream(st[i % len(st)]):
-                    g, f = land[i % nb], frames[i % nb]
-                    if exchange == "direct":
-                        R.render_rank_in_place(app, W, H, t, br, 0, world, f, root_rounds=m0, rounds=m)
-                        g[1:].copy_(src)
-                        R.assemble_peers(g[1:], W, H, br, world, f, root_rounds=m0, rounds=m)
-                    else:
-                        R.render_rank_rows(app, W, H, t, br, 0, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
-                        g[0].copy_(slabs[i % nb])
-                        g[1:].copy_(src)
-                        R.assemble(g, W, H, br, world, out=f, root_rounds=m0, rounds=m)
-
-            def peer_frame(r):
-                def fn(i):
-                    with torch.cuda.stream(st[i % len(st)]):
-                        R.render_rank_rows(app, W, H, t, br, r, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
-                return fn
-            cost = max(per_frame(root_frame), max(per_frame(peer_frame(r)) for r in sorted({1, world - 1})))
+            cost = max(emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0, m, exchange, ch, per_frame)
+                       for r in sorted({0, 1, world - 1}))
             if best is None or cost < best[0] * .995:        # a later (more relieved) split must win by a margin
                 best = (cost, (m0, m))
-            del src, land, slabs
         pick[0], pick[1] = best[1]
         del frames
         torch.cuda.empty_cache()
     dist.broadcast(pick, src=0)
     return (int(pick[0].item()), int(pick[1].item()))
+
+
+def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0, m, exchange, ch, per_frame):
+    """ms per frame of rank `r`'s part of a `world`-rank frame, ALL of it on this one device with the launches in flight on the
+    streams `st`: a peer = its launch; the root = its launch + the landing of the peers' payloads in its HBM (a device copy of
+    that many bytes standing in for what RCCL's receive kernels write) + the assembly kernel.  Used by the relief calibration on
+    rank 0 and by tools/strip_scaling.py; it knows nothing about the links."""
+    from shaderbox_amd import shard
+    nb = len(frames)
+    if exchange == "spans":
+        _, pix, _ = R.span_table(app, W, H, t, br, world, m0, m)
+        stride = (int(max(pix[1:])) + 63) // 64 * 64
+        if r > 0:
+            slabs = [torch.empty((max(int(pix[r]), 1) * 3,), dtype=torch.float32, device=dev) for _ in range(nb)]
+
+            def peer(i):
+                with torch.cuda.stream(st[i % len(st)]):
+                    R.render_span_peer(app, W, H, t, br, r, world, 0, 1 << 30, slabs[i % nb], root_rounds=m0, rounds=m)
+            return per_frame(peer)
+        total = sum(int(p) for p in pix[1:])
+        src = torch.zeros((max(total, 1) * 3,), dtype=torch.float32, device=dev)
+        land = [torch.zeros(((world - 1) * max(stride, 1) * 3,), dtype=torch.float32, device=dev) for _ in range(nb)]
+
+        def root(i):
+            with torch.cuda.stream(st[i % len(st)]):
+                R.render_span_root(app, W, H, t, br, world, frames[i % nb], root_rounds=m0, rounds=m)
+                land[i % nb][:src.numel()].copy_(src)
+                R.assemble_spans(app, W, H, t, br, world, land[i % nb], stride, frames[i % nb], root_rounds=m0, rounds=m)
+        return per_frame(root)
+    rmax = shard.rank_rows_max(H, br, world, m0, m)
+    slabs = [torch.empty((rmax, W, ch), dtype=torch.float32, device=dev) for _ in range(nb)]
+    if r > 0:
+        def peer(i):
+            with torch.cuda.stream(st[i % len(st)]):
+                R.render_rank_rows(app, W, H, t, br, r, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
+        return per_frame(peer)
+    src = torch.zeros((world - 1, rmax, W, ch), dtype=torch.float32, device=dev)
+    land = [torch.zeros((world, rmax, W, ch), dtype=torch.float32, device=dev) for _ in range(nb)]
+
+    def root(i):
+        with torch.cuda.stream(st[i % len(st)]):
+            g, f = land[i % nb], frames[i % nb]
+            if exchange == "direct":
+                R.render_rank_in_place(app, W, H, t, br, 0, world, f, root_rounds=m0, rounds=m)
+                g[1:].copy_(src)
+                R.assemble_peers(g[1:], W, H, br, world, f, root_rounds=m0, rounds=m)
+            else:
+                R.render_rank_rows(app, W, H, t, br, 0, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
+                g[0].copy_(slabs[i % nb])
+                g[1:].copy_(src)
+                R.assemble(g, W, H, br, world, out=f, root_rounds=m0, rounds=m)
+    return per_frame(root)
 
 
 def cpu_rows(H, stride, cores, rows_per_s=None, target_s=12.0):

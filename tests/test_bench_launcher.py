@@ -50,7 +50,8 @@ def test_bench_line_contract_and_parity():
     r, line = run_bench("--steps", "10", "--warmup", "1", "--width", "640", "--height", "360", "--pmc", "off", "--cpu-row-stride", "8")
     assert r.returncode == 0, r.stderr[-2000:]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_speed", "parity", "serial", "other_configs"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_speed", "parity", "serial", "value_serial",
+              "other_configs"):
         assert k in line, k
     assert line["parity"]["mismatching_pixels"] == 0 and line["parity"]["max_abs_diff"] == 0.0 and line["parity"]["rows"] == 45
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["value"] > 0
@@ -59,7 +60,7 @@ def test_bench_line_contract_and_parity():
     assert rf["useful_work_ratio"]["value"] > 0 and rf["useful_work_ratio"]["ops_per_pixel"] == 60248.0
     assert rf["frac"] is None or 0 < rf["frac"] <= 1.0            # --pmc off: no counters, or the committed file's (<= 1 either way)
     assert line["cpu_baseline"]["one_thread"]["value"] > 0 and "affinity" in line["cpu_baseline"] and "cgroup_cpu_max" in line["cpu_baseline"]
-    assert line["steady_state"]["value"] > 0
+    assert line["steady_state"]["value"] > 0 and line["value_serial"] == line["serial"]["value"] > 0
     assert [c["kernel"] for c in line["other_configs"]] == ["k_egg", "k_raytracer", "k_atmosphere", "k_planet"]
     assert all(c["value"] > 0 and c["kernel_ms"] > 0 for c in line["other_configs"])
     assert all(c["parity"]["rows"] == 16 and c["parity"]["mismatching_pixels"] == 0 for c in line["other_configs"])
@@ -78,6 +79,14 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
     assert line["roofline"]["bound"] == "valu" and (line["roofline"]["frac"] is None or line["roofline"]["frac"] <= 1.0)
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     assert line["parity"]["oracle"]["mismatching_pixels"] == 0
+    # the default exchange is the span exchange; BASELINE config 5 runs through the same schedule (VERDICT r3 "Next" #1a)
+    assert line["exchange"]["kind"] == "spans" and line["value_serial"] > 0
+    oc = line["other_configs"]
+    assert [c["kernel"] for c in oc] == ["k_atmosphere", "k_planet"] and all("7680x4320" in c["workload"] for c in oc)
+    assert all(c["parity"]["mismatching_pixels"] == 0 and c["value"] > 0 and c["phases"]["per_rank"][0]["render_ms"] > 0 for c in oc)
+    r3, line3 = run_bench("--force-dist", "--exchange", "direct", "--steps", "4", "--warmup", "1", "--width", "640", "--height", "360",
+                          "--no-cpu-baseline", "--no-other-configs")
+    assert r3.returncode == 0 and line3["exchange"]["kind"] == "direct" and line3["parity"]["mismatching_pixels"] == 0
 
 
 @pytest.mark.gpu

@@ -270,3 +270,28 @@ def test_atmosphere_below_the_horizon_against_oracle(renderer, oracle):
         from oracle.oracle import APP_ATMOSPHERE
         got = renderer.render("atmosphere", ww, hh, 0.37).cpu().numpy()
         assert compare(got, oracle.render(APP_ATMOSPHERE, ww, hh, 0.37)) == (0.0, 0), (ww, hh)
+
+
+def test_bench_relief_calibration_for_the_span_exchange(renderer):
+    """bench.py choose_relief('auto') on rank 0 with a stand-in world of 8 and the span exchange: the root's emulated frame (its
+    launch over the whole frame + landing of the packed spans + scatter) against the peers', for APP_ATMOSPHERE and APP_CLOUDS"""
+    import importlib.util
+    import os
+    import torch
+    from shaderbox_amd import shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class FakeDist:
+        @staticmethod
+        def broadcast(t, src=0):
+            return None
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for app, w, h in (("atmosphere", 1920, 1080), ("clouds", 960, 540)):
+        m0, m = bench.choose_relief("auto", renderer, FakeDist, torch, dev, app, w, h, .37, 8, 8, 0, streams, "spans", 3)
+        assert (m0, m) in bench.relief_candidates() and 0 <= m0 <= m
+        assert sum(shard.rank_rows(h, 8, r, 8, m0, m) for r in range(8)) == h
+    assert bench.auto_groups("auto", 9.2e6) == 1 and bench.auto_groups("auto", 29.7e6) == 3 and bench.auto_groups("2", 1e9) == 2
