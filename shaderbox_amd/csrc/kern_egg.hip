@@ -7,6 +7,9 @@
 // axes) is a frame constant evaluated once on the host (FrameEgg); only the point-dependent part
 // runs per march step.  `depth` (a _mutable global, :188) is a per-thread register that starts
 // at -max_dist for every pixel = GLSL per-invocation semantics.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include "sbx_device.h"
 #include "sbx_sdf.h"
 
@@ -108,9 +111,55 @@ __device__ __forceinline__ float egg_shadowmarch(const FrameEgg& F, v3 ro, v3 rd
     return umbra;
 }
 
+// HOT-FIRST DISPATCH.  Workgroups start in increasing (blockIdx.y, blockIdx.x).  The census of a 1920x1080 launch
+// (tools/egg_census.py, profiles/r04_egg_census.txt) shows the chip full for the first 95 us and then 125 us of tail with fewer than
+// 500 of 7168 wave slots in use: the ~350 waves on the SILHOUETTE of the egg and its legs, whose grazing rays run all 80 trace steps
+// next to the surface (no member of the union can be culled there), take 100-175 us each and start around t = 50 us because the
+// rows are dealt bottom to top.  With `hot` = the tiles under the projected bounding sphere of everything but the ground
+// (launch_egg), the first hot.w * hot.h workgroups take those tiles and the others take the rest of the frame in row order: the
+// long waves start at t = 0 and the cheap ones fill in behind them.  Which tile a workgroup renders changes nothing about a pixel.
+#ifndef EGG_HOT_FIRST
+#define EGG_HOT_FIRST 1
+#endif
+#ifndef EGG_PRIO_STEP
+#define EGG_PRIO_STEP 0    // a wave still tracing after this many steps raises its issue priority (s_setprio): 0 = never.  Measured
+                           // with steps 8 ... 45 and priorities 2 and 3: no difference at all (0.237-0.243 ms either way)
+#endif
+#ifndef EGG_PRIO
+#define EGG_PRIO 2
+#endif
+#ifndef EGG_LDS_PAD
+#define EGG_LDS_PAD 0      // bytes of dynamic LDS per (single-wave) workgroup, allocated only to CAP the waves per SIMD (see launch_egg)
+#endif
+struct HotRect { int x0, y0, w, h; };       // in workgroup tiles; w = 0: plain order
+__device__ __forceinline__ void hot_first_tile(const HotRect& R, int gx, int& bx, int& by) {
+    const int b = by * gx + bx, nr = R.w * R.h;
+    if (b < nr) { by = R.y0 + b / R.w; bx = R.x0 + (b - (b / R.w) * R.w); return; }
+    int c = b - nr;
+    const int below = R.y0 * gx;
+    if (c < below) { by = c / gx; bx = c - by * gx; return; }
+    c -= below;
+    const int side = gx - R.w, mid = R.h * side;
+    if (c < mid) {
+        const int q = c / side, k = c - q * side;
+        by = R.y0 + q;
+        bx = k < R.x0 ? k : k + R.w;
+        return;
+    }
+    c -= mid;
+    by = R.y0 + R.h + c / gx;
+    bx = c - (c / gx) * gx;
+}
+
 template <bool CULL>
-__global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float* __restrict__ out) {
-    const Pixel px = pixel_of_thread<EGG_TW, EGG_TX>(M);
+__global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float* __restrict__ out, HotRect hot) {
+#ifdef SBX_EGG_STATS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();      // census build (tools/egg_census.py): 100 MHz counter
+    int st_trace = 0, st_shadow = 0;
+#endif
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (EGG_HOT_FIRST && hot.w > 0) hot_first_tile(hot, (int)gridDim.x, bx, by);          // wave-uniform
+    const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
@@ -128,12 +177,19 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     int mat = 0;
     v3 hp = V3(0, 0, 0);
     for (int i = 0; i < 80; ++i) {                          // render_scene :190-231
+        if (EGG_PRIO_STEP > 0 && i == EGG_PRIO_STEP) __builtin_amdgcn_s_setprio(EGG_PRIO);   // a long wave: ahead of the short ones on its SIMD
         const v3 p = ro + rd * t;
         const D2 d = egg_sdf<CULL>(F, p);
         if (t > 15.f) break;
         if (d.d < 0.001f) { hit = true; mat = (int)d.m; hp = p; break; }
         t += d.d;
+#ifdef SBX_EGG_STATS
+        ++st_trace;
+#endif
     }
+#ifdef SBX_EGG_STATS
+    if (hit && mat == 3) st_shadow = 1;
+#endif
     if (hit) {
         if (mat == 1 || mat == 2) depth = fmax_(depth, hp.z);
         float s = 1.f;
@@ -151,12 +207,70 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);
     const float depth_factor = 1.f - step_(1.f, depth);
     color = abs3(mix3(color, V3(.6f, .6f, .6f), bar_factor * depth_factor));
+#ifdef SBX_EGG_STATS
+    {   // lane 0 of the wave: start / end time, the wave's longest trace, lanes that ran a shadow march, the wave's place
+        int mx = st_trace;
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        const int nsh = __popcll(__builtin_amdgcn_ballot_w64(st_shadow != 0));
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        float4 o4;
+        o4.x = __uint_as_float((unsigned)(st_t0 & 0xffffffffu));
+        o4.y = __uint_as_float((unsigned)(st_t1 - st_t0));
+        o4.z = __uint_as_float((unsigned)mx | ((unsigned)nsh << 8) | ((xcc & 0xfu) << 16) | ((hwid & 0xffffu) << 20));
+        o4.w = __uint_as_float(hwid);
+        reinterpret_cast<float4*>(out)[px.idx] = o4;
+        return;
+    }
+#endif
     store_rgba(M, out, px.idx, to_srgb(color));
 }
 
+// The tiles under the projection of the sphere (F.oc, F.orad) around everything but the ground (sdf()'s p space: P = rot_y^T (p +
+// (0, .5, 3.5))), for a launch that covers whole rows of the frame from row M.y0 (a contiguous strip; other maps: plain order).
+// A hint about cost: off by any amount it only changes the order in which the same workgroups run.
+static HotRect egg_hot_rect(const FrameEgg& F, const RowMap& M, dim3 grid) {
+    HotRect none{0, 0, 0, 0};
+    if (!EGG_HOT_FIRST || M.nranks != 1 || M.frag || M.span_mode || M.r0 != 0) return none;
+    const v3 c = mul(transpose(F.rot_y), F.oc + V3(0, 0.5f, 3.5f));
+    const v3 v = c - F.cam.eye;
+    const float depth = dot(v, F.cam.fwd), r = F.orad;
+    if (!(depth > r * 1.05f)) return none;                               // the camera is inside or beside the sphere
+    // extent of x = X / Z over the sphere: the planes through the eye that contain the camera's up axis and touch the sphere — in
+    // the (right, fwd) plane the sphere is a circle of radius r at (vx, depth), the tangents from the origin are at phi +- asin(r / d)
+    const float vx = dot(v, F.cam.right), vy = dot(v, F.cam.up);
+    auto extent = [&](float side, float& lo, float& hi) {
+        const float d = sqrt_(side * side + depth * depth);
+        const float phi = std::atan2(side, depth), al = std::asin(std::min(1.f, r / d));
+        const float a = std::max(phi - al, -1.5f), b = std::min(phi + al, 1.5f);
+        lo = std::tan(a); hi = std::tan(b);
+    };
+    float pxa, pxb, pya, pyb;
+    extent(vx, pxa, pxb);
+    extent(vy, pya, pyb);
+    // point_cam = ((2 ndc - 1) * aspect * fov, (2 ndc - 1) * fov)  ->  pixel = ndc * res
+    const float sx = F.cam.aspect_x * F.cam.fov, sy = F.cam.fov;
+    auto pix = [](float pc, float scale, float res) { return (pc / scale + 1.f) * .5f * res; };
+    const float xa = pix(pxa, sx, F.cam.res_x), xb = pix(pxb, sx, F.cam.res_x);
+    const float ya = pix(pya, sy, F.cam.res_y) - (float)M.y0, yb = pix(pyb, sy, F.cam.res_y) - (float)M.y0;
+    if (!(xa == xa && xb == xb && ya == ya && yb == yb)) return none;
+    constexpr int TWP = EGG_TW * EGG_TX, THP = 64 / EGG_TW;
+    const int gx = (int)grid.x, gy = (int)grid.y;
+    const int x0 = std::max(0, std::min(gx, (int)std::floor(xa / TWP))), x1 = std::max(0, std::min(gx, (int)std::ceil(xb / TWP)));
+    const int y0 = std::max(0, std::min(gy, (int)std::floor(ya / THP))), y1 = std::max(0, std::min(gy, (int)std::ceil(yb / THP)));
+    if (x1 <= x0 || y1 <= y0) return none;
+    return HotRect{x0, y0, x1 - x0, y1 - y0};
+}
+
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant) {
-    if (variant == 1) hipLaunchKernelGGL(k_egg<false>, (grid_for<EGG_TW, EGG_TX>(M)), dim3(64 * EGG_TX), 0, s, F, M, out);
-    else hipLaunchKernelGGL(k_egg<true>, (grid_for<EGG_TW, EGG_TX>(M)), dim3(64 * EGG_TX), 0, s, F, M, out);
+    const dim3 grid = grid_for<EGG_TW, EGG_TX>(M);
+    const HotRect hot = egg_hot_rect(F, M, grid);
+    static const int pad = []() { const char* e = std::getenv("SBX_DEBUG_LDS_PAD"); return e ? std::atoi(e) : EGG_LDS_PAD; }();
+    if (variant == 1) hipLaunchKernelGGL(k_egg<false>, grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
+    else hipLaunchKernelGGL(k_egg<true>, grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
 }
 
 }  // namespace sbx
