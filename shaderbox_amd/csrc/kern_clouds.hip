@@ -36,9 +36,9 @@
 #ifndef CL_SEED
 #define CL_SEED 1
 #endif
-#ifndef CL_ABLATE_LIGHT
-#define CL_ABLATE_LIGHT 0   // timing experiment only: no light march (wrong pixels)
-#endif
+// (Every CL_* switch below is an A/B switch whose OTHER setting must still compile and render the same bits: `tools/ab_build.py
+//  --all-variants` builds each one, `tools/sweep_clouds_variants.py --all` runs the random-frame sweep against the per-lane kernel
+//  on them — profiles/r04_clouds_variants.txt: 22 variants, 0 differing frames.  Switches that changed pixels on purpose are gone.)
 #ifndef CL_NO_REG
 #define CL_NO_REG 0       // 1: never use the REG kernels (A/B timing)
 #endif
@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
                         asm volatile("" ::: "memory");     // the reloads below cannot be forwarded from these stores: the values
                                                            // are dead across the light march
 #endif
-                        if (LM == 1) ltrans = CL_ABLATE_LIGHT ? 1.f : light_march_z<YTAB, REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov, vcd, vcr);
+                        if (LM == 1) ltrans = light_march_z<YTAB, REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, row, mfx, mnxy, mab, mcd, mpz, etab, vsigma, vdt, vcov, vcd, vcr);
                         else ltrans = light_march_yz<REG, SM>(F, lp, lstep, lit, lit_mask, S, lane, mfx, etab, vsigma, vdt, vcov, vcd, vcr);
 #if CL_PARK
                         asm volatile("" ::: "memory");

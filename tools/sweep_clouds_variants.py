@@ -1,33 +1,65 @@
 #!/usr/bin/env python3
-"""One-off soak (run on the GPU box, PYTHONPATH=.): the shipped APP_CLOUDS kernel against the plain per-lane kernel
-(sbx_set_variant 1) on N random frames (time, mouse, aux).  tests/test_gpu_parity.py runs a short version."""
-import sys, torch, numpy as np
-sys.path.insert(0, ".")
-import shaderbox_amd
-R = shaderbox_amd.Renderer(0)
-rng = np.random.default_rng(123)
-bad = 0
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-for i in range(N):
-    aux = shaderbox_amd.clouds_defaults(R.lib)
-    t = float(rng.uniform(0, 50)) if i % 3 else float(rng.uniform(0, 3))
-    mouse = (float(rng.uniform(0, 6.3)), 0.0) if i % 2 else (0.0, 0.0)
-    aux.cld_coverage = float(rng.uniform(0.2, 0.9))
-    aux.cld_march_steps = int(rng.integers(10, 160))
-    aux.illum_march_steps = int(rng.integers(0, 9))
-    aux.cld_thick = float(rng.uniform(40, 300))
-    aux.sigma_scattering = float(rng.uniform(.02, .6))
-    if i % 5 == 0:
-        aux.wind_dir[0], aux.wind_dir[1], aux.wind_dir[2] = [float(x) for x in rng.uniform(-.3, .3, 3)]
-    if i % 7 == 0:
-        d = rng.standard_normal(3); d /= np.linalg.norm(d)
-        aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = [float(x) for x in d]
-    W, H = (640, 360) if i % 4 else (333, 187)
-    R.set_variant(0); a = R.render("clouds", W, H, t, mouse=mouse, aux=aux).clone()
-    R.set_variant(1); b = R.render("clouds", W, H, t, mouse=mouse, aux=aux)
-    same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
-    if not bool(same.all()):
-        bad += 1
-        print("MISMATCH", i, t, mouse, aux.cld_coverage, aux.cld_march_steps, int((~same).sum()))
-R.set_variant(0)
-print("frames", N, "mismatching", bad)
+"""Run on the GPU box: the random-frame sweep of tests/test_gpu_parity.py::test_clouds_random_sweep_default_equals_perlane — the
+default APP_CLOUDS kernel against the plain per-lane kernel (sbx_set_variant 1) on N random (time, mouse, aux) frames — for the
+shipped library and for every A/B library given (or, with --all, every build/ab/libsbx_v_*.so of `tools/ab_build.py
+--all-variants`).  One process per library (two libsbx in one process register kernels of the same name).
+
+    python tools/sweep_clouds_variants.py [--frames 120] [--all] [name ...]"""
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def one(path, N):
+    import numpy as np
+    import torch
+    import shaderbox_amd
+    if path != "base":
+        shaderbox_amd.LIB_PATH = path
+    R = shaderbox_amd.Renderer(0)
+    rng = np.random.default_rng(123)
+    bad = 0
+    for i in range(N):
+        aux = shaderbox_amd.clouds_defaults(R.lib)
+        t = float(rng.uniform(0, 50)) if i % 3 else float(rng.uniform(0, 3))
+        mouse = (float(rng.uniform(0, 6.3)), 0.0) if i % 2 else (0.0, 0.0)
+        aux.cld_coverage = float(rng.uniform(0.2, 0.9))
+        aux.cld_march_steps = int(rng.integers(10, 160))
+        aux.illum_march_steps = int(rng.integers(0, 9))
+        aux.cld_thick = float(rng.uniform(40, 300))
+        aux.sigma_scattering = float(rng.uniform(.02, .6))
+        if i % 5 == 0:
+            aux.wind_dir[0], aux.wind_dir[1], aux.wind_dir[2] = [float(x) for x in rng.uniform(-.3, .3, 3)]
+        if i % 7 == 0:
+            d = rng.standard_normal(3); d /= np.linalg.norm(d)
+            aux.sun_dir[0], aux.sun_dir[1], aux.sun_dir[2] = [float(x) for x in d]
+        if i % 11 == 0:
+            aux.sun_dir[0] = 0.0                      # a sun in the y-z plane: the y-z light march
+        W, H = (640, 360) if i % 4 else (333, 187)
+        R.set_variant(0); a = R.render("clouds", W, H, t, mouse=mouse, aux=aux).clone()
+        R.set_variant(1); b = R.render("clouds", W, H, t, mouse=mouse, aux=aux)
+        same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+        if not bool(same.all()):
+            bad += 1
+    R.set_variant(0)
+    print("%-44s frames %d, with a differing pixel: %d%s" % (os.path.basename(path), N, bad, "" if bad == 0 else "   <-- DIFFERENT"))
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    N = int(args[args.index("--frames") + 1]) if "--frames" in args else 120
+    if "--one" in args:
+        one(args[args.index("--one") + 1], N)
+        sys.exit(0)
+    names = [a for a in args if not a.startswith("--") and not a.isdigit()]
+    paths = ["base"] + [os.path.join(ROOT, "build", "ab", "libsbx_%s.so" % n) for n in names]
+    if "--all" in args:
+        paths += sorted(glob.glob(os.path.join(ROOT, "build", "ab", "libsbx_v_*.so")))
+    for p in paths:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", p, "--frames", str(N)], capture_output=True, text=True)
+        out = [l for l in r.stdout.splitlines() if "frames" in l]
+        print(out[-1] if out else "%-44s FAILED: %s" % (os.path.basename(p), r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "?"))
