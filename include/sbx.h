@@ -64,7 +64,14 @@ typedef enum sbx_app {
     SBX_APP_CLOUDS_SKY = 10,
     /* APP_VINYL with the march length of its GLSL / HLSL builds: 180 steps instead of the C++ build's 60
        (src/app_vinyl.h:411-416).  Everything else as SBX_APP_VINYL. */
-    SBX_APP_VINYL_GPU = 11
+    SBX_APP_VINYL_GPU = 11,
+    /* BASELINE config 5 read literally — "APP_ATMOSPHERE Rayleigh/Mie over APP_PLANET terrain".  The reference has no shader that
+       composites the two (SURVEY.md 8a note); this labelled extension is APP_PLANET (src/app_planet.h:303-367) with its
+       background() (:23-41, shown where the view ray misses the atmosphere shell :316-318 and behind the clouds :364-366)
+       replaced by APP_ATMOSPHERE's get_incident_light (src/app_atmosphere.h:78-160) for the ray from (0, earth_radius + 1, 0)
+       (:204-207) along the VIEW direction, lit by APP_ATMOSPHERE's sun (setup_scene :177-181, a function of u_time).
+       No reference-held answers: PARITY UNPINNED (bit-identical to the oracle's restatement of the same definition). */
+    SBX_APP_PLANET_ATMOSPHERE = 12
 } sbx_app;
 
 typedef enum sbx_status {

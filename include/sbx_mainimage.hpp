@@ -21,7 +21,9 @@
 
 #include "sbx.h"
 
-#if defined(APP_PLANET)
+#if defined(APP_PLANET_ATMOSPHERE)   /* config 5's composite (include/sbx.h): not an APP_* define of the reference */
+#define SBX_SELECTED_APP SBX_APP_PLANET_ATMOSPHERE
+#elif defined(APP_PLANET)
 #define SBX_SELECTED_APP SBX_APP_PLANET
 #elif defined(APP_CLOUDS)
 #define SBX_SELECTED_APP SBX_APP_CLOUDS

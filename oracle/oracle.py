@@ -11,10 +11,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST, APP_CLOUDS_TEX, APP_CLOUDS_UE4, APP_CLOUDS_SKY, APP_VINYL_GPU = range(12)
+APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST, APP_CLOUDS_TEX, APP_CLOUDS_UE4, APP_CLOUDS_SKY, APP_VINYL_GPU, APP_PLANET_ATMOSPHERE = range(13)
 APP_IDS = {"planet": APP_PLANET, "clouds": APP_CLOUDS, "egg": APP_EGG, "raytracer": APP_RAYTRACER,
            "atmosphere": APP_ATMOSPHERE, "sdf_ao": APP_SDF_AO, "vinyl": APP_VINYL, "clouds_best": APP_CLOUDS_BEST,
-           "clouds_tex": APP_CLOUDS_TEX, "clouds_ue4": APP_CLOUDS_UE4, "clouds_sky": APP_CLOUDS_SKY, "vinyl_gpu": APP_VINYL_GPU}
+           "clouds_tex": APP_CLOUDS_TEX, "clouds_ue4": APP_CLOUDS_UE4, "clouds_sky": APP_CLOUDS_SKY, "vinyl_gpu": APP_VINYL_GPU, "planet_atmosphere": APP_PLANET_ATMOSPHERE}
 
 
 def build(variant="", subdir=""):

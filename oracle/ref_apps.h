@@ -765,6 +765,10 @@ struct AppPlanet {
     static constexpr float TERR_EPS = .005f;                   /* :166 */
     enum { TERR_STEPS = 120 };                                 /* :165 */
     volume_sampler_t cloud;                                    /* :69 (_mutable, assigned before use) */
+    /* APP_PLANET_ATMOSPHERE (BASELINE config 5 read literally; SURVEY.md 8a note: "planet background() replaced by
+       get_incident_light"; NOT in the reference, parity unpinned): the sky of APP_ATMOSPHERE stands in for background() */
+    bool atm_sky = false;
+    AppAtmosphere sky;
 
     float fov() const { return m_tan(m_radians(30.f)); }       /* :368 */
     static sphere_t planet() { sphere_t s; s.origin = vec3(0, 0, 0); s.radius = 1.f; s.material = 0; return s; } /* :15-17 */
@@ -778,7 +782,16 @@ struct AppPlanet {
         sky += sun_color * m_clamp(m_pow(sun_amount, 10.0f) * .6f, 0.f, 1.f);
         return vabs(sky);
     }
-    void setup_scene() {}
+    void setup_scene() {
+        if (atm_sky) { sky.U = U; sky.sun_dir = vec3(0, 1, 0); sky.setup_scene(); }   /* app_atmosphere.h:177-181, fresh per pixel */
+    }
+    /* background() of the path: app_planet.h:23-41, or — composite — get_incident_light (app_atmosphere.h:78-160) for the ray
+       from 1 m above the ground (:204-207) along the view direction */
+    vec3 bg(const ray_t& eye) const {
+        if (!atm_sky) return background(eye);
+        ray_t r; r.origin = vec3(0, AppAtmosphere::earth_radius + 1.f, 0); r.direction = eye.direction;
+        return sky.get_incident_light(r);
+    }
     void setup_camera(vec3& eye, vec3& look_at) const {         /* :47-58 */
         eye = vec3(0, 0, -2.5f);
         look_at = vec3(0, 0, 2);
@@ -904,7 +917,7 @@ struct AppPlanet {
         atmosphere.radius += max_height;
         hit_t hit = no_hit();
         intersect_sphere(eye, atmosphere, hit);
-        if (hit.material_id < 0) return background(eye);
+        if (hit.material_id < 0) return bg(eye);
 
         float t = 0.f;
         vec2 df = vec2(1, max_height);
@@ -933,7 +946,7 @@ struct AppPlanet {
             shadow = m_mix(.7f, 1.f, m_step(cloud.alpha, 0.33f));
             return vabs(vmix(c_terr * shadow, c_cld, alpha));
         } else {
-            return vabs(vmix(background(eye), cloud.radiance, cloud.alpha));
+            return vabs(vmix(bg(eye), cloud.radiance, cloud.alpha));
         }
     }
 };

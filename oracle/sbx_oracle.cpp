@@ -30,7 +30,9 @@ enum { APP_PLANET = 0, APP_CLOUDS = 1, APP_VINYL = 2, APP_EGG = 3, APP_RAYTRACER
        APP_CLOUDS_TEX = 8  /* APP_CLOUDS compiled with USE_NOISE_TEX (src/app_clouds.h:9,51-56,69-81) */,
        APP_CLOUDS_UE4 = 9  /* ue4/volumetric_clouds/Shaders/app_clouds.usf under the build's host mapping (ref_apps.h) */,
        APP_CLOUDS_SKY = 10 /* APP_CLOUDS compiled with SKY_SPHERE (src/app_clouds.h:8,14-19,154-162) */,
-       APP_VINYL_GPU = 11  /* APP_VINYL with the march length of its non-C++ builds: 180 steps (src/app_vinyl.h:411-416) */ };
+       APP_VINYL_GPU = 11  /* APP_VINYL with the march length of its non-C++ builds: 180 steps (src/app_vinyl.h:411-416) */,
+       APP_PLANET_ATMOSPHERE = 12 /* the config-5 composite: APP_PLANET with background() = APP_ATMOSPHERE's get_incident_light
+                                     (ref_apps.h AppPlanet::bg; definition in include/sbx.h).  PARITY UNPINNED. */ };
 
 /* the two bound 3-D textures of the USE_NOISE_TEX build (t1, t2): set by sbxo_set_noise_volumes, owned by the caller */
 static noise_tex_t g_tex_noise, g_tex_noise_2;
@@ -78,6 +80,7 @@ static bool pixel(int app, const uniforms_t& U, const void* aux, float fx, float
     case APP_ATMOSPHERE: { AppAtmosphere a; a.U = U; c = main_image(a, fc); break; }
     case APP_SDF_AO: { AppSdfAo a; a.U = U; a.A = parse_sdf_ao_aux(aux); c = main_image(a, fc); break; }
     case APP_PLANET: { AppPlanet a; a.U = U; c = main_image(a, fc); break; }
+    case APP_PLANET_ATMOSPHERE: { AppPlanet a; a.U = U; a.atm_sky = true; c = main_image(a, fc); break; }
     case APP_VINYL: { AppVinyl a; a.U = U; c = main_image(a, fc); break; }
     case APP_VINYL_GPU: { AppVinyl a; a.U = U; a.march_steps = 180; c = main_image(a, fc); break; }
     case APP_CLOUDS_BEST: { AppCloudsBest a; a.U = U; c = main_image(a, fc); break; }

@@ -17,14 +17,15 @@ from . import shard  # noqa: F401  (pure-python row-block arithmetic, no GPU nee
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsbx.so")
 
-APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST, APP_CLOUDS_TEX, APP_CLOUDS_UE4, APP_CLOUDS_SKY, APP_VINYL_GPU = range(12)
+APP_PLANET, APP_CLOUDS, APP_VINYL, APP_EGG, APP_RAYTRACER, APP_ATMOSPHERE, APP_SDF_AO, APP_CLOUDS_BEST, APP_CLOUDS_TEX, APP_CLOUDS_UE4, APP_CLOUDS_SKY, APP_VINYL_GPU, APP_PLANET_ATMOSPHERE = range(13)
 APPS = {"APP_PLANET": APP_PLANET, "APP_CLOUDS": APP_CLOUDS, "APP_VINYL": APP_VINYL, "APP_EGG": APP_EGG,
         "APP_RAYTRACER": APP_RAYTRACER, "APP_ATMOSPHERE": APP_ATMOSPHERE, "APP_SDF_AO": APP_SDF_AO,
         "APP_CLOUDS_BEST": APP_CLOUDS_BEST,    # src/app_clouds_best.h (stand-alone shader, not an APP_* define)
         "APP_CLOUDS_TEX": APP_CLOUDS_TEX,      # APP_CLOUDS + USE_NOISE_TEX (src/app_clouds.h:9)
         "APP_CLOUDS_UE4": APP_CLOUDS_UE4,      # ue4/volumetric_clouds/Shaders/app_clouds.usf (host mapping: include/sbx.h)
         "APP_CLOUDS_SKY": APP_CLOUDS_SKY,      # APP_CLOUDS + SKY_SPHERE (src/app_clouds.h:8,14-19,154-162)
-        "APP_VINYL_GPU": APP_VINYL_GPU}        # APP_VINYL with the 180 march steps of its GLSL / HLSL builds (src/app_vinyl.h:411-416)
+        "APP_VINYL_GPU": APP_VINYL_GPU,
+        "APP_PLANET_ATMOSPHERE": APP_PLANET_ATMOSPHERE}   # config 5's composite: APP_PLANET with APP_ATMOSPHERE's sky as background (include/sbx.h)        # APP_VINYL with the 180 march steps of its GLSL / HLSL builds (src/app_vinyl.h:411-416)
 
 SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE, SBX_ERR_FAULT = 0, -1, -2, -3, -4, -5
 

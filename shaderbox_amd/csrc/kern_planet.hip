@@ -20,6 +20,7 @@
 #include "sbx_noise.h"
 #include "sbx_hashcache.h"
 #include "sbx_exp4k_table.h"
+#include "sbx_atmosphere.h"
 
 // All noise_iq evaluations go through the per-wave lattice-hash cache (sbx_hashcache.h): octave k of any fBm
 // uses table k & 3.  The cross-lane steps of the cache need wave-uniform control flow, so lanes never leave
@@ -277,8 +278,19 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
 //  against the 0.53 GB framebuffer; hit-shading parking 7.29 ms, 60 B, ~1.0 GB; parking the cloud march's ray and integrator
 //  as well: no spills there to remove, 7.66 ms; recomputing pixel and ray in the epilogue instead of keeping them: 7.54 ms)
 #define PL_PARK_N 10
-template <bool SKIP>
+// ATM: the config-5 composite SBX_APP_PLANET_ATMOSPHERE (include/sbx.h; SURVEY.md §8a note: "planet background() replaced by
+// get_incident_light"): wherever APP_PLANET shows its background() (app_planet.h:316-318, 364-366) the pixel shows APP_ATMOSPHERE's
+// sky instead — get_incident_light (app_atmosphere.h:78-160) for a ray from 1 m above the ground (:204-207) along the VIEW
+// direction, with APP_ATMOSPHERE's sun (setup_scene :177-181, FramePlanet.atm_sun).  The sky is evaluated in the plain statement of
+// the spec (atm_incident_light<false>): view directions are arbitrary here, the domains of k_atmosphere's shortcuts were argued for
+// its own camera.  No reference-held answers: parity unpinned.
+template <bool SKIP, bool ATM = false>
 __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
+    __shared__ double etab[ATM ? 32 : 1];
+    if (ATM) {
+        if (threadIdx.x < 32) etab[threadIdx.x & (ATM ? 31 : 0)] = kExp2Tab[threadIdx.x];
+        if (WG_THREADS > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    }
     __shared__ WaveCache cache[WG_THREADS / 64];
 #if PL_PARK
     __shared__ float park[WG_THREADS / 64][PL_PARK_N * 64];
@@ -435,12 +447,25 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
     const Pixel pxe = px;
     const v3 rde = rd;
     if (!pxe.valid) return;
-    if (cloud_sky) col = abs3(mix3(planet_background(rde), V3s(sky_r), sky_a));   // :364-366
-    if (!hit_atm) col = planet_background(rde);                  // :316-318
+    if (ATM) {
+        if (cloud_sky || !hit_atm) {
+            const v3 sky = atm_incident_light<false>(V3(0, ATM_EARTH_R + 1.f, 0), rde, F.atm_sun,
+                                                     reinterpret_cast<const double (&)[32]>(etab), nullptr);
+            col = hit_atm ? abs3(mix3(sky, V3s(sky_r), sky_a)) : sky;
+        }
+    } else {
+        if (cloud_sky) col = abs3(mix3(planet_background(rde), V3s(sky_r), sky_a));   // :364-366
+        if (!hit_atm) col = planet_background(rde);                  // :316-318
+    }
     store_rgba(M, out, pxe.idx, to_srgb(col));
 }
 
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant) {
+    if (F.atm_sky) {
+        if (variant == 1) hipLaunchKernelGGL((k_planet<false, true>), grid_for<PL_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
+        else hipLaunchKernelGGL((k_planet<true, true>), grid_for<PL_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
+        return;
+    }
     if (variant == 1) hipLaunchKernelGGL(k_planet<false>, grid_for<PL_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
     else hipLaunchKernelGGL(k_planet<true>, grid_for<PL_TW>(M), dim3(WG_THREADS), 0, s, F, M, out);
 }

@@ -43,6 +43,15 @@ struct sbx_ctx {
     hipEvent_t ytab_ready{};
     bool have_ytab_event = false;
     YtabSlot slots[CLOUDS_YTAB_RING];
+    // march lengths beyond the ring's rows (CLOUDS_YTAB_ROWS): ONE table grown on demand (48 B per step), rebuilt when its key
+    // changes after waiting for the device — such frames take tens of milliseconds, the wait is noise
+    char* ytab_big = nullptr;
+    int ytab_big_rows = 0;
+    bool ytab_big_valid = false;
+    float ytab_big_key[3] = {0, 0, 0};
+    int ytab_big_steps = 0;
+    hipEvent_t ytab_big_ready{};
+    bool have_ytab_big_event = false;
     std::vector<hipEvent_t> event_pool;
     // per-stream timing events (sbx_set_timing): a pair brackets the last launch on its stream
     std::vector<std::pair<hipStream_t, TimingPair>> timers;
@@ -307,8 +316,10 @@ static FrameVinyl build_vinyl(const sbx_uniforms& U, int steps) {
     return F;
 }
 
-static FramePlanet build_planet(const sbx_uniforms& U) {
+static FramePlanet build_planet(const sbx_uniforms& U, bool atm_sky = false) {
     FramePlanet F;
+    F.atm_sky = atm_sky ? 1 : 0;
+    F.atm_sun = build_atmosphere(U).sun_dir;
     F.cam = make_camera(U.u_res[0], U.u_res[1], tan_(radians_(30.f)), V3(0, 0, -2.5f), V3(0, 0, 2));   // app_planet.h:47-58,368
     const m3 rot_y = rotate_around_y(27.f);                            // :307
     F.rot = mul(rotate_around_x(U.u_time * -12.f), rot_y);             // :308
@@ -421,6 +432,8 @@ void sbx_destroy(sbx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->ytab) (void)hipFree(ctx->ytab);
+    if (ctx->ytab_big) (void)hipFree(ctx->ytab_big);
+    if (ctx->have_ytab_big_event) (void)hipEventDestroy(ctx->ytab_big_ready);
     if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
     if (ctx->mi_host) (void)hipHostFree(ctx->mi_host);
     if (ctx->pt_dev) (void)hipFree(ctx->pt_dev);
@@ -450,6 +463,38 @@ static bool stream_is_capturing(hipStream_t s) {
 //      still be reading that slot — and record, per stream, an event behind each consumer of the current slot.
 static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, float* rgba, hipStream_t s, bool capturing) {
     const bool uses_table = ctx->variant == 0 && F.steps > 0 && F.steps <= CLOUDS_YTAB_ROWS;
+    if (!uses_table && ctx->variant == 0 && F.steps > CLOUDS_YTAB_ROWS && F.steps <= CLOUDS_YTAB_BIG_MAX && !capturing) {
+        // (4) a march longer than the ring's tables: the context's one big table (round 3 fell back to the table-less kernels
+        //     here, ~2x slower per step)
+        const float key[3] = {F.cam.eye.y, F.wind_off.y, F.dt};
+        hipError_t e;
+        if (!ctx->have_ytab_big_event) {
+            if ((e = hipEventCreateWithFlags(&ctx->ytab_big_ready, hipEventDisableTiming)) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipEventCreate", e);
+            ctx->have_ytab_big_event = true;
+        }
+        const bool rebuild = !ctx->ytab_big_valid || ctx->ytab_big_steps != F.steps || std::memcmp(key, ctx->ytab_big_key, sizeof(key)) != 0;
+        if (rebuild) {
+            ctx->ytab_big_valid = false;
+            if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipDeviceSynchronize", e);   // readers of the old table
+            if (F.steps > ctx->ytab_big_rows) {
+                if (ctx->ytab_big) (void)hipFree(ctx->ytab_big);
+                ctx->ytab_big = nullptr; ctx->ytab_big_rows = 0;
+                const int rows = (F.steps + 4095) / 4096 * 4096;
+                if ((e = hipMalloc((void**)&ctx->ytab_big, (size_t)rows * 48)) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
+                ctx->ytab_big_rows = rows;
+            }
+        } else {
+            (void)hipStreamWaitEvent(s, ctx->ytab_big_ready, 0);
+        }
+        launch_clouds(F, M, rgba, s, 0, ctx->ytab_big, ctx->ytab_big_rows, rebuild);
+        if (rebuild) {
+            (void)hipEventRecord(ctx->ytab_big_ready, s);
+            std::memcpy(ctx->ytab_big_key, key, sizeof(key));
+            ctx->ytab_big_steps = F.steps;
+            ctx->ytab_big_valid = true;
+        }
+        return SBX_OK;
+    }
     if (!uses_table) {
         launch_clouds(F, M, rgba, s, ctx->variant, nullptr, 0, false);
         return SBX_OK;
@@ -526,7 +571,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     if (M.nrows == 0) return SBX_OK;
     if (device_fault(ctx)) return fail(ctx, SBX_ERR_FAULT, kFaultText);
     // argument checks come before anything is enqueued or recorded
-    if (app < SBX_APP_PLANET || app > SBX_APP_VINYL_GPU) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
+    if (app < SBX_APP_PLANET || app > SBX_APP_PLANET_ATMOSPHERE) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
     sbx_aux_clouds AC;
     if (app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX || app == SBX_APP_CLOUDS_SKY) {
         if (aux) AC = *(const sbx_aux_clouds*)aux; else sbx_aux_clouds_defaults(&AC);
@@ -569,6 +614,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         break;
     }
     case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s, cull_variant); break;
+    case SBX_APP_PLANET_ATMOSPHERE: launch_planet(build_planet(*uni, true), M, rgba, s, cull_variant); break;
     case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni, 60), M, rgba, s, cull_variant); break;
     case SBX_APP_VINYL_GPU: launch_vinyl(build_vinyl(*uni, 180), M, rgba, s, cull_variant); break;
     case SBX_APP_CLOUDS_BEST: launch_clouds_best(build_clouds_best(*uni), M, rgba, s); break;
@@ -848,7 +894,7 @@ extern "C" int sbx_span_table(int app, const sbx_uniforms* uni, const void* aux,
     const int W = (int)uni->u_res[0], H = (int)uni->u_res[1];
     if (W <= 0 || H <= 0 || (float)W != uni->u_res[0] || (float)H != uni->u_res[1] || W > 65536 || H > 65536) return SBX_ERR_ARG;
     if (!split_ok(H, block_rows, nranks, root_rounds, rounds)) return SBX_ERR_ARG;
-    if (app < SBX_APP_PLANET || app > SBX_APP_VINYL_GPU) return SBX_ERR_UNSUPPORTED;
+    if (app < SBX_APP_PLANET || app > SBX_APP_PLANET_ATMOSPHERE) return SBX_ERR_UNSUPPORTED;
     const int nblocks = (H + block_rows - 1) / block_rows;
     const int ntiles = (W + SPAN_ALIGN - 1) / SPAN_ALIGN;
     const SpanProbe P = span_probe(app, *uni, aux);

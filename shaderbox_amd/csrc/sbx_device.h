@@ -98,6 +98,7 @@ void launch_clouds(const FrameClouds& F, const RowMap& M, float* out, hipStream_
 constexpr int CLOUDS_YTAB_ROWS = 4096;      // march steps covered by the per-frame y table (192 KB per table; beyond it the
                                             // table-less kernels run: 1100 steps at 4K took 48 ms without a table)
 constexpr int CLOUDS_YTAB_BYTES = CLOUDS_YTAB_ROWS * 48;
+constexpr int CLOUDS_YTAB_BIG_MAX = 1 << 20;   // longest march served by the context's one on-demand table (48 MB); beyond it: the table-less kernels
 constexpr int CLOUDS_YTAB_RING = 8;         // eager tables: one per REBUILD (key change), round robin; reuse of a slot waits
                                             // for the launches that may still read it (sbx_capi.hip render_clouds)
 constexpr int CLOUDS_YTAB_CAPTURE = 8;      // tables used only by launches recorded into a stream capture

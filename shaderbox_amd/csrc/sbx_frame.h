@@ -182,6 +182,8 @@ struct FramePlanet {
     Camera cam;
     m3 rot, rot_cloud, rot_t;   // app_planet.h:307-309, transpose(rot) :356
     v3 L;                       // rot * normalize(1,1,0)   app_planet.h:289
+    int atm_sky;                // 1: SBX_APP_PLANET_ATMOSPHERE — background() is APP_ATMOSPHERE's get_incident_light (kern_planet.hip)
+    v3 atm_sun;                 // its sun: (0,1,0) * rotate_around_x(-|sin(t/2)|*90)   app_atmosphere.h:177-181
 };
 
 // ---- "clouds_best" (src/app_clouds_best.h, the stand-alone cloud shader) ------

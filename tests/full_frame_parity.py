@@ -14,7 +14,8 @@ from oracle.oracle import APP_IDS, Oracle
 
 CASES = [("egg", 1920, 1080), ("raytracer", 3840, 2160), ("clouds", 3840, 2160), ("atmosphere", 7680, 4320),
          ("planet", 7680, 4320), ("sdf_ao", 3840, 2160), ("vinyl", 3840, 2160), ("clouds_best", 3840, 2160),
-         ("clouds_ue4", 3840, 2160), ("clouds_sky", 3840, 2160), ("vinyl_gpu", 3840, 2160)]
+         ("clouds_ue4", 3840, 2160), ("clouds_sky", 3840, 2160), ("vinyl_gpu", 3840, 2160),
+         ("planet_atmosphere", 3840, 2160)]
 want = set(sys.argv[1:])
 R = shaderbox_amd.Renderer(0)
 O = Oracle()

@@ -28,7 +28,7 @@ def _same(a, b):
 
 def test_golden_set_is_complete():
     assert {c[1] for c in _cases()} == {"egg", "clouds", "raytracer", "atmosphere", "sdf_ao", "planet", "vinyl", "clouds_best",
-                                        "clouds_ue4", "clouds_tex", "clouds_sky", "vinyl_gpu"}
+                                        "clouds_ue4", "clouds_tex", "clouds_sky", "vinyl_gpu", "planet_atmosphere"}
 
 
 @pytest.mark.parametrize("path,app,w,h", list(_cases()))

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ALL_APPS = ["planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best", "clouds_ue4", "clouds_sky",
-            "vinyl_gpu"]
+            "vinyl_gpu", "planet_atmosphere"]
 
 
 def compare(gpu, ref):
@@ -295,3 +295,60 @@ def test_bench_relief_calibration_for_the_span_exchange(renderer):
         assert (m0, m) in bench.relief_candidates() and 0 <= m0 <= m
         assert sum(shard.rank_rows(h, 8, r, 8, m0, m) for r in range(8)) == h
     assert bench.auto_groups("auto", 9.2e6) == 1 and bench.auto_groups("auto", 29.7e6) == 3 and bench.auto_groups("2", 1e9) == 2
+
+
+def test_clouds_marches_longer_than_the_ring_tables(renderer, oracle):
+    """cld_march_steps beyond the 4096 rows of the y-table ring: the context's on-demand table (sbx_capi.hip render_clouds case 4)
+    instead of round 3's table-less fallback; same bits as the per-lane kernel and the oracle, across key changes and streams"""
+    import torch
+    import shaderbox_amd
+    from oracle.oracle import APP_CLOUDS
+    aux = shaderbox_amd.clouds_defaults()
+    w, h = 96, 54
+    s2 = torch.cuda.Stream()
+    for steps, t in [(4097, .37), (6000, .37), (6000, 1.5), (4100, .37), (100, .37), (9000, .37)]:
+        aux.cld_march_steps = steps
+        aux.cld_thick = 125.0 * steps / 100.0 if steps < 5000 else 300.0
+        renderer.set_variant(0)
+        a = renderer.render("clouds", w, h, t, aux=aux).cpu().numpy()
+        with torch.cuda.stream(s2):
+            a2 = renderer.render("clouds", w, h, t, aux=aux)
+        s2.synchronize()
+        renderer.set_variant(1)
+        b = renderer.render("clouds", w, h, t, aux=aux).cpu().numpy()
+        renderer.set_variant(0)
+        assert compare(a, b) == (0.0, 0), steps
+        assert compare(a2.cpu().numpy(), b) == (0.0, 0), steps
+    aux.cld_march_steps, aux.cld_thick = 4500, 200.0
+    got = renderer.render("clouds", 64, 36, .37, aux=aux).cpu().numpy()
+    assert compare(got, oracle.render(APP_CLOUDS, 64, 36, .37, aux=aux)) == (0.0, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE config 5 read literally: APP_PLANET with APP_ATMOSPHERE's sky as its background (labelled extension, parity unpinned)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,t", [(256, 144, .37), (333, 187, 0.0), (640, 360, 2.5), (96, 54, 40.0)])
+def test_planet_atmosphere_composite_matches_oracle(renderer, oracle, w, h, t):
+    """SBX_APP_PLANET_ATMOSPHERE (include/sbx.h): default and plain kernels == the oracle's restatement of the same definition,
+    NaN == NaN; where APP_PLANET shows terrain the two apps agree, elsewhere the sky is APP_ATMOSPHERE's"""
+    from oracle.oracle import APP_IDS
+    renderer.set_variant(0)
+    a = renderer.render("planet_atmosphere", w, h, t).cpu().numpy()
+    renderer.set_variant(1)
+    b = renderer.render("planet_atmosphere", w, h, t).cpu().numpy()
+    renderer.set_variant(0)
+    ref = oracle.render(APP_IDS["planet_atmosphere"], w, h, t)
+    assert compare(a, b) == (0.0, 0)
+    assert compare(a, ref) == (0.0, 0)
+    plain = renderer.render("planet", w, h, t).cpu().numpy()
+    same = ((a.view(np.uint32) == plain.view(np.uint32)) | (np.isnan(a) & np.isnan(plain))).all(-1)
+    assert 0.05 < same.mean() < 0.6                     # the terrain pixels; backgrounds differ
+
+
+def test_planet_atmosphere_through_the_multi_gpu_schedule(renderer):
+    import torch
+    w, h, t = 1280, 720, .37
+    full = renderer.render("planet_atmosphere", w, h, t)
+    for exchange in ("spans", "direct"):
+        got, _ = loop_frame(renderer, "planet_atmosphere", w, h, t, 8, exchange)
+        assert torch.equal(got.view(torch.int32), full.view(torch.int32)), exchange

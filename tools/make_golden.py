@@ -18,7 +18,8 @@ from oracle.oracle import APP_IDS, Oracle  # noqa: E402
 
 CASES = {"egg": (64, 64), "clouds": (96, 54), "raytracer": (64, 64), "atmosphere": (64, 36),
          "sdf_ao": (64, 36), "planet": (64, 36), "vinyl": (64, 36), "clouds_best": (96, 54),
-         "clouds_ue4": (96, 54), "clouds_tex": (96, 54), "clouds_sky": (96, 54), "vinyl_gpu": (64, 36)}
+         "clouds_ue4": (96, 54), "clouds_tex": (96, 54), "clouds_sky": (96, 54), "vinyl_gpu": (64, 36),
+         "planet_atmosphere": (64, 36)}
 TIMES = (0.0, 0.37, 2.5)
 
 

@@ -10,7 +10,7 @@ R.set_timing(True)
 CASES = [("clouds", 3840, 2160), ("egg", 1920, 1080), ("egg", 3840, 2160), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320),
          ("planet", 7680, 4320), ("sdf_ao", 3840, 2160), ("vinyl", 3840, 2160),
          ("clouds_best", 3840, 2160), ("clouds_tex", 3840, 2160), ("clouds_ue4", 3840, 2160), ("clouds_sky", 3840, 2160),
-         ("vinyl_gpu", 3840, 2160)]
+         ("vinyl_gpu", 3840, 2160), ("planet_atmosphere", 7680, 4320)]
 # APP_CLOUDS' USE_NOISE_TEX build samples two baked volumes: the 128^3 volume ddsvolgen bakes for the shape, a 64^3 one for the detail
 R.set_noise_volumes(R.worley_volume(128), R.worley_volume(64))
 for _ in range(30):                      # clocks up before the first case

@@ -43,7 +43,8 @@ CASES = [("default", None, .37, (0, 0)),
          ("thick 150", aux(cld_thick=150.), .37, (0, 0)),
          ("steps 200/12", aux(cld_march_steps=200, illum_march_steps=12), .37, (0, 0)),
          ("steps 50/3", aux(cld_march_steps=50, illum_march_steps=3), .37, (0, 0)),
-         ("steps 1100/6", aux(cld_march_steps=1100), .37, (0, 0)),        # more steps than the y table holds: the table-less kernels
+         ("steps 1100/6", aux(cld_march_steps=1100), .37, (0, 0)),
+         ("steps 5000/6 thick 6250", aux(cld_march_steps=5000, cld_thick=6250.), .37, (0, 0)),   # beyond the ring's 4096 rows: the on-demand table
          ("sigma 3", aux(sigma_scattering=3.), .37, (0, 0)),
          ("wind (1,0,.5)", aux(wind_dir=(1., 0., .5)), 7.0, (0, 0))]
 buf = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
