@@ -189,7 +189,7 @@ def main():
                     help="N>1: 'dist' = one process per GPU (torch.distributed / RCCL gather, the contract's launch shape); 'lib' = ONE "
                          "process drives the N GPUs through the library's own multi-GPU path (sbx_multi_*: RCCL send/recv per "
                          "row-block straight into the final rows, no assembly pass); with fewer GPUs than N the ranks share devices")
-    ap.add_argument("--lib-exchange", choices=["slabs", "blocks"], default="slabs",
+    ap.add_argument("--lib-exchange", choices=["slabs", "blocks", "spans"], default="slabs",
                     help="--engine lib: 'slabs' = one send/receive per peer of its whole 3-channel slab + one scatter kernel on the "
                          "root (default); 'blocks' = one send/receive pair per row-block straight into the final rows (round 2)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -309,11 +309,12 @@ def main():
     # per-launch kernel duration, HIP events on the launch stream (re-run outside the timed region, one launch at a time,
     # so that the event queries do not perturb it and the launches do not overlap)
     kernel_ms = []
-    for _ in range(min(max(args.steps, 3), 10)):
+    for _ in range(12):
         R.render(app, W, H, t, out=frames[0])
         kernel_ms.append(R.last_kernel_ms())
+    kernel_ms = kernel_ms[2:]                            # median of >= 10 launches after 2 warm-ups
     torch.cuda.synchronize(dev)
-    kmean = sum(kernel_ms) / len(kernel_ms)
+    kmean = sorted(kernel_ms)[len(kernel_ms) // 2]
     pixels = W * H
     ms_per_step = elapsed * 1e3 / args.steps
     value = pixels / (ms_per_step * 1e-3) / 1e6
@@ -564,8 +565,9 @@ def bench_lib(args):
                                      % (args.block_rows, n, devices,
                                         ("%s, %s" % ("RCCL send/recv" if M.uses_rccl else
                                                      "device copies (ranks share devices: emulation, not a scaling number)",
-                                                     "one per peer of its whole 3-channel slab + one scatter kernel" if args.lib_exchange == "slabs"
-                                                     else "one per row-block into the final rows")))},
+                                                     {"slabs": "one per peer of its whole 3-channel slab + one scatter kernel",
+                                                      "spans": "one per peer of its packed 3-channel spans + one scatter kernel, rank 0 renders the rest",
+                                                      "blocks": "one per row-block into the final rows"}[args.lib_exchange])))},
            "steady_state": steady, "roofline": roofline, "roofline_hbm": roofline_hbm,
            "parity": {"against": "one-launch render of the same frame", "rows": H, "mismatching_pixels": bad}}
     status = 3 if bad else 0
@@ -624,9 +626,10 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) * 1e3 / steps
     k = []
-    for _ in range(5):
+    for i in range(13):                       # median of >= 10 launches after 2 warm-ups (the first two are dropped)
         R.render(app, W, H, t, out=frames[0])
         k.append(R.last_kernel_ms())
+    k = k[2:]
     torch.cuda.synchronize(dev)
     par = None
     if check_rows:
@@ -636,7 +639,7 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
         ref = Oracle().render_rows(APP_IDS[app], W, H, t, rows)
         par = parity(frames[0][rows].cpu().numpy(), ref, len(rows))
     del frames
-    kmean = sum(k) / len(k)
+    kmean = sorted(k)[len(k) // 2]
     pmc = None
     if pmc_mode in ("auto", "live"):
         tmp = tempfile.mkdtemp(prefix="sbx_pmc_")

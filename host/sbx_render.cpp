@@ -1,7 +1,7 @@
 // host/sbx_render.cpp — C++ host over the C ABI: renders a frame or an animation on one or several MI355X and writes
 // every frame as binary PPM (sRGB 8-bit, top row first) and/or raw float32 RGBA (row 0 = bottom).
 //
-//   sbx_render --app clouds --res 3840x2160 [--time 0.37] [--frames N --dt S] [--mouse X,Y] [--gpus N]
+//   sbx_render --app clouds --res 3840x2160 [--time 0.37] [--frames N --dt S] [--mouse X,Y] [--gpus N [--exchange spans|slabs|blocks]]
 //              [--ppm out_%04d.ppm] [--f32 out_%04d.f32]
 //     APP_CLOUDS aux block (the ImGui panel of hlsltoy, util/hlsltoy/src/hlsltoy.cpp:466-483):
 //              [--wind x,y,z] [--sun x,y,z] [--sun-color r,g,b] [--sun-power P] [--sky-radius R] [--sky-height Y]
@@ -28,8 +28,8 @@
 
 static int app_from_name(const std::string& s) {
     const char* names[] = {"planet", "clouds", "vinyl", "egg", "raytracer", "atmosphere", "sdf_ao", "clouds_best", "clouds_tex", "clouds_ue4",
-                           "clouds_sky", "vinyl_gpu"};
-    const int n = 12;
+                           "clouds_sky", "vinyl_gpu", "planet_atmosphere"};
+    const int n = 13;
     std::string low;
     for (char c : s) low += (char)tolower(c);
     for (int i = 0; i < n; ++i)
@@ -84,7 +84,7 @@ static bool read_dds_volume(const std::string& path, int& size, std::vector<floa
 
 int main(int argc, char** argv) {
     std::string app = "clouds", ppm, f32, noise_tex;
-    int W = 1280, H = 720, frames = 1, gpus = 1;
+    int W = 1280, H = 720, frames = 1, gpus = 1, exchange = SBX_MULTI_EXCHANGE_SPANS;
     float t = 0.37f, dt = 1.f / 30.f, mx = 0, my = 0;
     sbx_aux_clouds ac;
     sbx_aux_sdf_ao as;
@@ -101,6 +101,11 @@ int main(int argc, char** argv) {
         else if (a == "--dt") dt = (float)atof(next());
         else if (a == "--frames") frames = atoi(next());
         else if (a == "--gpus") gpus = atoi(next());
+        else if (a == "--exchange") {
+            const std::string v = next();
+            exchange = v == "slabs" ? SBX_MULTI_EXCHANGE_SLABS : v == "blocks" ? SBX_MULTI_EXCHANGE_BLOCKS : v == "spans" ? SBX_MULTI_EXCHANGE_SPANS : -1;
+            if (exchange < 0) { fprintf(stderr, "--exchange slabs|blocks|spans\n"); return 2; }
+        }
         else if (a == "--mouse") { if (sscanf(next(), "%f,%f", &mx, &my) != 2) { fprintf(stderr, "--mouse X,Y\n"); return 2; } }
         else if (a == "--ppm") ppm = next();
         else if (a == "--f32") f32 = next();
@@ -141,7 +146,9 @@ int main(int argc, char** argv) {
         if (ndev < gpus) fprintf(stderr, "note: %d GPU(s) visible, running the %d-rank schedule with ranks sharing devices\n", ndev, gpus);
         rc = sbx_multi_create(gpus, devs.data(), &multi);
         if (rc != SBX_OK) { fprintf(stderr, "sbx_multi_create failed (%d): %s\n", rc, sbx_multi_create_error()); return 1; }
-        printf("%d ranks, transfers by %s\n", gpus, sbx_multi_uses_rccl(multi) ? "RCCL send/recv" : "device copies");
+        if ((rc = sbx_multi_set_exchange(multi, exchange)) != SBX_OK) { fprintf(stderr, "exchange: %s\n", sbx_multi_last_error(multi)); return 1; }
+        printf("%d ranks, transfers by %s, exchange %s\n", gpus, sbx_multi_uses_rccl(multi) ? "RCCL send/recv" : "device copies",
+               exchange == SBX_MULTI_EXCHANGE_SPANS ? "spans" : exchange == SBX_MULTI_EXCHANGE_BLOCKS ? "blocks" : "slabs");
     }
     (void)hipSetDevice(0);
     if (id == SBX_APP_CLOUDS_TEX) {

@@ -324,7 +324,8 @@ const char* sbx_multi_create_error(void);
 /* How the peers' rows reach rank 0: SLABS (default) = one send / receive per peer of its whole 3-channel slab + one scatter
  * kernel; BLOCKS = one send / receive pair per row-block straight into the final rows (no landing area, no scatter kernel,
  * but (N-1) x blocks point-to-point operations per frame in one group). */
-enum { SBX_MULTI_EXCHANGE_SLABS = 0, SBX_MULTI_EXCHANGE_BLOCKS = 1 };
+enum { SBX_MULTI_EXCHANGE_SLABS = 0, SBX_MULTI_EXCHANGE_BLOCKS = 1,
+       SBX_MULTI_EXCHANGE_SPANS = 2 /* the span exchange above: packed spans only, rank 0 renders the rest (sbx_render_span_*) */ };
 int sbx_multi_set_exchange(sbx_multi* m, int mode);
 void sbx_multi_destroy(sbx_multi* m);
 int sbx_multi_ranks(const sbx_multi* m);

@@ -531,8 +531,10 @@ class MultiRenderer:
 
     def set_exchange(self, mode):
         """'slabs' (default): one send / receive per peer of its whole 3-channel slab + one scatter kernel on rank 0;
-        'blocks': one send / receive pair per row-block straight into the final rows (the round-2 form)."""
-        self._check(self.lib.sbx_multi_set_exchange(self.m, {"slabs": 0, "blocks": 1}[mode] if isinstance(mode, str) else int(mode)))
+        'blocks': one send / receive pair per row-block straight into the final rows (the round-2 form);
+        'spans': the span exchange — only the expensive interval of every row-block is dealt to the peers and sent, rank 0
+        renders the rest in place (include/sbx.h)."""
+        self._check(self.lib.sbx_multi_set_exchange(self.m, {"slabs": 0, "blocks": 1, "spans": 2}[mode] if isinstance(mode, str) else int(mode)))
 
     def set_noise_volumes(self, shape_rgba, detail_rgba):
         self._check(self.lib.sbx_multi_set_noise_volumes(self.m, int(shape_rgba.shape[0]), ctypes.c_void_p(shape_rgba.data_ptr()),

@@ -276,7 +276,8 @@ int sbx_multi_set_split(sbx_multi* m, int block_rows, int root_rounds, int round
 
 int sbx_multi_set_exchange(sbx_multi* m, int mode) {
     if (!m) return SBX_ERR_ARG;
-    if (mode != SBX_MULTI_EXCHANGE_SLABS && mode != SBX_MULTI_EXCHANGE_BLOCKS) return mfail(m, SBX_ERR_ARG, "unknown exchange mode");
+    if (mode != SBX_MULTI_EXCHANGE_SLABS && mode != SBX_MULTI_EXCHANGE_BLOCKS && mode != SBX_MULTI_EXCHANGE_SPANS)
+        return mfail(m, SBX_ERR_ARG, "unknown exchange mode");
     m->exchange = mode;
     return SBX_OK;
 }
@@ -330,6 +331,111 @@ static int global_block(int lb, int rank, int nranks, int root_rounds, int round
     return cycle * (root_rounds * nranks + (rounds - root_rounds) * (nranks - 1)) + v;
 }
 
+// The span exchange (include/sbx.h "span exchange") inside the library: peers render and send only the spans of their blocks,
+// packed; rank 0 renders its blocks and everything outside the spans in one launch over the frame and scatters the packed slabs.
+static int render_spans(sbx_multi* m, int app, const sbx_uniforms* uni, const void* aux, float* frame, hipStream_t user, int k, int W, int H) {
+    const int n = (int)m->ranks.size();
+    const int br = m->block_rows, m0 = m->root_rounds, mr = m->rounds;
+    Rank& root = m->ranks[0];
+    hipError_t e;
+    std::vector<int64_t> pix(n, 0);
+    const int nb = sbx_span_table(app, uni, aux, br, n, m0, mr, nullptr, pix.data(), nullptr);
+    if (nb < 0) return mfail(m, nb, "bad span table arguments (app, u_res or split)");
+    int64_t stride = 0;
+    for (int i = 1; i < n; ++i) stride = pix[i] > stride ? pix[i] : stride;
+    stride = (stride + 63) / 64 * 64;
+    const size_t need_stage = (size_t)(n - 1) * (size_t)stride * 3;
+    if (need_stage > root.stage_floats) {
+        sync_all_ranks(m);
+        (void)hipSetDevice(root.device);
+        for (int q = 0; q < kInFlight; ++q) {
+            if (root.stage[q]) (void)hipFree(root.stage[q]);
+            root.stage[q] = nullptr;
+            if ((e = hipMalloc((void**)&root.stage[q], (need_stage ? need_stage : 1) * sizeof(float))) != hipSuccess) { root.stage_floats = 0; return mfail(m, SBX_ERR_HIP, "hipMalloc stage", e); }
+        }
+        root.stage_floats = need_stage;
+    }
+    for (int i = 0; i < n; ++i) {
+        Rank& r = m->ranks[i];
+        if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+        if ((e = hipStreamWaitEvent(r.render[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+        if (m->recv_recorded[k] && (e = hipStreamWaitEvent(r.render[k], root.recv_done[k], 0)) != hipSuccess)
+            return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+        int rc;
+        if (i == 0) {
+            rc = sbx_render_span_root(r.ctx, app, uni, aux, br, n, m0, mr, frame, r.render[k]);
+        } else {
+            const size_t need = (size_t)(pix[i] > 0 ? pix[i] : 1) * 3;
+            if (need > r.slab_floats) {
+                sync_all_ranks(m);
+                (void)hipSetDevice(r.device);
+                for (int q = 0; q < kInFlight; ++q) {
+                    if (r.slab[q]) (void)hipFree(r.slab[q]);
+                    r.slab[q] = nullptr;
+                    if ((e = hipMalloc((void**)&r.slab[q], need * sizeof(float))) != hipSuccess) { r.slab_floats = 0; return mfail(m, SBX_ERR_HIP, "hipMalloc slab", e); }
+                }
+                r.slab_floats = need;
+            }
+            rc = sbx_render_span_peer(r.ctx, app, uni, aux, br, i, n, m0, mr, 0, 0x7fffffff, r.slab[k], r.render[k]);
+        }
+        if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(r.ctx));
+    }
+    if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+    if ((e = hipStreamWaitEvent(root.recv[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+    if (m->use_rccl) {
+        std::string where = "ncclGroupStart";
+        nccl_result_t nr = g_rccl.GroupStart();
+        auto check = [&](nccl_result_t rc, const char* call, int rank) {
+            if (nr == 0 && rc != 0) { nr = rc; where = std::string(call) + " (rank " + std::to_string(rank) + ")"; }
+            return nr == 0;
+        };
+        for (int i = 1; i < n && nr == 0; ++i) {
+            if (pix[i] <= 0) continue;
+            Rank& r = m->ranks[i];
+            const size_t floats = (size_t)pix[i] * 3;
+            if (check(g_rccl.Send(r.slab[k], floats, kNcclFloat, 0, r.comm, r.render[k]), "ncclSend", i))
+                check(g_rccl.Recv(root.stage[k] + (size_t)(i - 1) * (size_t)stride * 3, floats, kNcclFloat, i, root.comm, root.recv[k]), "ncclRecv", i);
+        }
+        const nccl_result_t ne = g_rccl.GroupEnd();
+        if (nr != 0) return mfail(m, SBX_ERR_HIP, "RCCL " + where + ": " + g_rccl.GetErrorString(nr));
+        if (ne != 0) return mfail(m, SBX_ERR_HIP, std::string("RCCL ncclGroupEnd: ") + g_rccl.GetErrorString(ne));
+    } else {
+        for (int i = 1; i < n; ++i) {
+            Rank& r = m->ranks[i];
+            if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+            if (pix[i] > 0) {
+                float* dst = root.stage[k] + (size_t)(i - 1) * (size_t)stride * 3;
+                const size_t bytes = (size_t)pix[i] * 3 * sizeof(float);
+                if (r.device == root.device) e = hipMemcpyAsync(dst, r.slab[k], bytes, hipMemcpyDeviceToDevice, r.render[k]);
+                else e = hipMemcpyPeerAsync(dst, root.device, r.slab[k], r.device, bytes, r.render[k]);
+                if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "span slab copy", e);
+            }
+            if ((e = hipEventRecord(r.done[k], r.render[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
+        }
+        if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+        for (int i = 1; i < n; ++i)
+            if ((e = hipStreamWaitEvent(root.recv[k], m->ranks[i].done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+    }
+    // the scatter follows the receives only: it and rank 0's own launch over the frame write disjoint pixels (that launch leaves
+    // the peers' spans alone), so they may run side by side
+    {
+        const int rc = sbx_assemble_spans(root.ctx, app, uni, aux, br, n, m0, mr, root.stage[k], stride, frame, root.recv[k]);
+        if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(root.ctx));
+    }
+    if ((e = hipEventRecord(root.recv_done[k], root.recv[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
+    m->recv_recorded[k] = true;
+    for (int i = 0; i < n; ++i) {
+        Rank& r = m->ranks[i];
+        if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+        if ((e = hipEventRecord(r.done[k], r.render[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
+    }
+    if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+    for (int i = 0; i < n; ++i)
+        if ((e = hipStreamWaitEvent(user, m->ranks[i].done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+    if ((e = hipStreamWaitEvent(user, root.recv_done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+    return SBX_OK;
+}
+
 int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void* aux, float* frame, void* stream) {
     if (!m) return SBX_ERR_ARG;
     if (!uni || !frame) return mfail(m, SBX_ERR_ARG, "NULL uniforms or frame");
@@ -345,7 +451,8 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
     // everything this frame does starts after what the caller has already enqueued on `stream` (e.g. the last reader of `frame`)
     if ((e = hipEventRecord(m->start[k], user)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
     struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{root.device};   // whatever path returns
-    const bool slabs = m->exchange == SBX_MULTI_EXCHANGE_SLABS;
+    if (m->exchange == SBX_MULTI_EXCHANGE_SPANS && n > 1) return render_spans(m, app, uni, aux, frame, user, k, W, H);
+    const bool slabs = m->exchange != SBX_MULTI_EXCHANGE_BLOCKS;
     const int ch = slabs ? 3 : 4;                                   // floats per pixel of a peer's slab
     const size_t row_floats = (size_t)W * 4, slab_row = (size_t)W * ch;
     const int rows_max = sbx_split_rows_max(H, br, n, m0, mr);

@@ -352,3 +352,34 @@ def test_planet_atmosphere_through_the_multi_gpu_schedule(renderer):
     for exchange in ("spans", "direct"):
         got, _ = loop_frame(renderer, "planet_atmosphere", w, h, t, 8, exchange)
         assert torch.equal(got.view(torch.int32), full.view(torch.int32)), exchange
+
+
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_library_multi_gpu_span_exchange(renderer, nranks):
+    """sbx_multi with SBX_MULTI_EXCHANGE_SPANS (all ranks on device 0: copies instead of RCCL): same bits as one launch, with
+    root relief, ragged sizes, the BASELINE config-5 frame, frames in flight"""
+    import torch
+    import shaderbox_amd
+    m = shaderbox_amd.MultiRenderer([0] * nranks)
+    m.set_exchange("spans")
+    cases = [("clouds", 1000, 333, .37), ("atmosphere", 1111, 500, .37), ("planet", 900, 400, .37), ("egg", 203, 95, .37)]
+    if nranks == 8:
+        cases.append(("atmosphere", 7680, 4320, .37))
+    for app, w, h, t in cases:
+        full = renderer.render(app, w, h, t)
+        for split in [(8, 1, 1), (8, 1, 2), (4, 0, 1)]:
+            m.set_split(*split)
+            got = m.render(app, w, h, t)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), full.view(torch.int32)), (app, w, h, nranks, split)
+        del full
+    m.set_split(8, 1, 1)
+    s = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.zeros((360, 640, 4), dtype=torch.float32, device="cuda") for _ in range(6)]
+    for i in range(6):
+        with torch.cuda.stream(s[i % 3]):                 # three caller streams over the library's two slots
+            m.render("clouds", 640, 360, .1 * i, out=outs[i])
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert torch.equal(outs[i].view(torch.int32), renderer.render("clouds", 640, 360, .1 * i).view(torch.int32)), i
+    m.close()
