@@ -16,7 +16,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 R = shaderbox_amd.Renderer(0)
 O = Oracle()
-APPS = ["egg", "sdf_ao", "vinyl", "raytracer", "atmosphere", "planet", "clouds", "clouds_best", "clouds_ue4", "clouds_tex"]
+APPS = ["egg", "sdf_ao", "vinyl", "raytracer", "atmosphere", "planet", "clouds", "clouds_best", "clouds_ue4", "clouds_tex", "clouds_sky",
+        "vinyl_gpu", "planet_atmosphere"]
 # APP_CLOUDS' USE_NOISE_TEX build: two small baked volumes (32^3 shape, 16^3 detail) bound on both sides
 _v1, _v2 = R.worley_volume(32), R.worley_volume(16)
 R.set_noise_volumes(_v1, _v2)

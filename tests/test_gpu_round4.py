@@ -383,3 +383,21 @@ def test_library_multi_gpu_span_exchange(renderer, nranks):
     for i in range(6):
         assert torch.equal(outs[i].view(torch.int32), renderer.render("clouds", 640, 360, .1 * i).view(torch.int32)), i
     m.close()
+
+
+def test_points_and_spans_with_noise_textures(renderer, oracle):
+    """APP_CLOUDS' USE_NOISE_TEX build through the point list and the span exchange (the volumes are context state)"""
+    import torch
+    from oracle.oracle import APP_CLOUDS_TEX
+    v1, v2 = renderer.worley_volume(32), renderer.worley_volume(16)
+    renderer.set_noise_volumes(v1, v2)
+    oracle.set_noise_volumes(v1.cpu().numpy(), v2.cpu().numpy())
+    rng = np.random.default_rng(17)
+    w, h, t = 320, 180, 0.37
+    pts = np.stack([rng.uniform(-10, w + 10, 300), rng.uniform(-10, h + 10, 300)], axis=1).astype(np.float32)
+    got = renderer.render_points("clouds_tex", w, h, t, torch.from_numpy(pts)).cpu().numpy()
+    ref = np.stack([oracle.main_image(APP_CLOUDS_TEX, w, h, t, float(x), float(y)) for x, y in pts])
+    assert compare(got, ref) == (0.0, 0)
+    full = renderer.render("clouds_tex", 1000, 400, t)
+    got, _ = loop_frame(renderer, "clouds_tex", 1000, 400, t, 4, "spans", groups=2)
+    assert torch.equal(got.view(torch.int32), full.view(torch.int32))
