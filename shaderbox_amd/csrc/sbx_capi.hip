@@ -668,8 +668,11 @@ int sbx_render_points(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void
     if (!(uni->u_res[0] > 0.f) || !(uni->u_res[1] > 0.f) || std::isinf(uni->u_res[0]) || std::isinf(uni->u_res[1]))
         return fail(ctx, SBX_ERR_ARG, "u_res must be positive and finite");
     if (((uintptr_t)rgba & 15u) != 0) return fail(ctx, SBX_ERR_ARG, "output must be 16-byte aligned");
-    const int rows = (int)((n + POINTS_ROW - 1) / POINTS_ROW);
-    RowMap M{POINTS_ROW, rows, 0, rows, 1, 0, rows, 0, 1, 1, 0, 0, frag, (int)n};
+    // the pseudo-frame: 256 columns, wider for very long lists so that the row count stays far below the grid's y limit (65535
+    // blocks of as little as 2 rows)
+    const int width = POINTS_ROW * (int)((n + (size_t)POINTS_ROW * 100000 - 1) / ((size_t)POINTS_ROW * 100000));
+    const int rows = (int)((n + width - 1) / width);
+    RowMap M{width, rows, 0, rows, 1, 0, rows, 0, 1, 1, 0, 0, frag, (int)n};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
 }
 

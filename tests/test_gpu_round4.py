@@ -401,3 +401,16 @@ def test_points_and_spans_with_noise_textures(renderer, oracle):
     full = renderer.render("clouds_tex", 1000, 400, t)
     got, _ = loop_frame(renderer, "clouds_tex", 1000, 400, t, 4, "spans", groups=2)
     assert torch.equal(got.view(torch.int32), full.view(torch.int32))
+
+
+def test_very_long_point_list(renderer):
+    """27.4 million points in one call (the pseudo-frame widens so that the grid's y extent stays legal): three and a bit copies of
+    every pixel centre of the 3840x2160 APP_CLOUDS frame equal that frame"""
+    import torch
+    w, h, t = 3840, 2160, 0.37
+    frame = renderer.render("clouds", w, h, t).reshape(-1, 4)
+    idx = torch.arange(27_400_001, device="cuda") % (w * h)
+    pts = torch.stack([(idx % w).float() + .5, (idx // w).float() + .5], dim=1).contiguous()
+    got = renderer.render_points("clouds", w, h, t, pts)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), frame[idx].view(torch.int32))
