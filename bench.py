@@ -192,6 +192,12 @@ def main():
     ap.add_argument("--lib-exchange", choices=["slabs", "blocks", "spans"], default="slabs",
                     help="--engine lib: 'slabs' = one send/receive per peer of its whole 3-channel slab + one scatter kernel on the "
                          "root (default); 'blocks' = one send/receive pair per row-block straight into the final rows (round 2)")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="ONE GPU, no process group: run the N-rank schedule of the headline and of config 5 through a loopback world "
+                         "(every rank's real FramePlan, kernels, span tables, assembly on this device), check the frames against one "
+                         "launch, time every rank's part with frames in flight and print the MODELLED N-GPU figures with the exchange "
+                         "budget (n_gpus stays 1, 'emulated_ranks' says so; link rates are assumptions: --link-gbps)")
+    ap.add_argument("--link-gbps", type=float, default=50.0, help="--emulate-ranks: the per-direction xGMI rate of the budget")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -246,6 +252,8 @@ def main():
     torch.cuda.synchronize(dev)
 
     status = 0
+    if args.emulate_ranks > 1 and not use_dist:
+        sys.exit(bench_emulated(args, R, torch, dev, streams, app, W, H, t))
     if use_dist:
         res = dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, rank, args.steps, args.warmup)
         out = None
@@ -456,6 +464,83 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         del whole
     res["plans"] = plans
     return res
+
+
+def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
+    """--emulate-ranks N on one GPU: see the option's help.  Everything printed as 'modelled' is max(root, slowest peer, link)
+    of parts timed on THIS device one after the other; no second GPU, no link, no RCCL kernel was involved."""
+    from shaderbox_amd import shard
+    from shaderbox_amd.distributed import LoopbackWorld
+    n, br = args.emulate_ranks, args.block_rows
+
+    class OneRank:                                       # choose_relief's broadcast of rank 0's pick to itself
+        @staticmethod
+        def broadcast(tensor, src=0):
+            return None
+
+    def per_frame(fn, k=24):
+        for i in range(6):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(k):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3 / k
+    out_cfgs, status = [], 0
+    cfgs = [(app, W, H)] + ([] if args.no_other_configs or app != "clouds" else DIST_OTHER_CONFIGS)
+    for a, w, h in cfgs:
+        frames = [torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(max(2, len(streams)))]
+
+        def whole(i):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                R.render(a, w, h, t, out=frames[i % len(frames)])
+        R.set_timing(False)
+        p1 = per_frame(whole)
+        relief = choose_relief(args.root_rounds, R, OneRank, torch, dev, a, w, h, t, br, n, 0, streams, args.exchange, args.channels)
+        ch = 3 if args.exchange != "gather" else 4
+        ranks_ms = [emulated_frame_ms(R, torch, dev, streams, frames, a, w, h, t, br, n, r, relief[0], relief[1], args.exchange, ch, per_frame)
+                    for r in range(n)]
+        R.set_timing(True)
+        if args.exchange == "spans":
+            pix = R.span_table(a, w, h, t, br, n, relief[0], relief[1])[1]
+            payload = 12 * int(max(pix[1:]))
+        else:
+            payload = (12 if ch == 3 else 16) * w * shard.rank_rows_max(h, br, n, *relief)
+        link_peak, link_real = payload / 76.8e9 * 1e3, payload / (args.link_gbps * 1e9) * 1e3
+        modelled = max(max(ranks_ms), link_real)
+        # the frame of the N-rank schedule itself (FramePlans of all ranks, loopback transfers) against one launch
+        world = LoopbackWorld(n)
+        plans = world.plans(R, w, h, block_rows=br, groups=auto_groups(args.gather_groups, payload), root_rounds=relief[0],
+                            rounds=relief[1], exchange=args.exchange if args.exchange != "gather" else "direct", channels=args.channels)
+        got = LoopbackWorld.render(plans, a, t)
+        ref = R.render(a, w, h, t)
+        torch.cuda.synchronize(dev)
+        bad = int((got.view(torch.int32) != ref.view(torch.int32)).any(dim=-1).sum().item())
+        status = 3 if bad else status
+        out_cfgs.append({"workload": "APP_%s %dx%d u_time=%g" % (a.upper(), w, h, t), "n1_ms_per_frame_pipelined": round(p1, 4),
+                         "relief": "%d/%d" % relief, "exchange": args.exchange, "bytes_per_peer": payload,
+                         "bytes_moved_per_frame": world.bytes_moved,
+                         "link_ms_at_76p8_GBps": round(link_peak, 4), "link_ms_at_%g_GBps" % args.link_gbps: round(link_real, 4),
+                         "root_ms": round(ranks_ms[0], 4), "slowest_peer_ms": round(max(ranks_ms[1:]), 4),
+                         "per_rank_ms": [round(v, 4) for v in ranks_ms],
+                         "modelled_ms_per_frame": round(modelled, 4), "modelled_speedup": round(p1 / modelled, 3),
+                         "modelled_value_mpixels_s": round(w * h / (modelled * 1e-3) / 1e6, 1),
+                         "bound": "link" if link_real >= max(ranks_ms) else ("root" if ranks_ms[0] >= max(ranks_ms[1:]) else "peer compute"),
+                         "parity": {"against": "one-launch render of the same frame", "rows": h, "mismatching_pixels": bad}})
+        del frames, plans, got, ref, world
+        torch.cuda.empty_cache()
+    head = out_cfgs[0]
+    out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": head["modelled_value_mpixels_s"], "unit": "Mpixels/s",
+           "n_gpus": 1, "emulated_ranks": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["modelled_ms_per_frame"],
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "value_is": "MODELLED for %d GPUs from parts timed on ONE: max(root's frame incl. landing and scatter, slowest peer's frame, link "
+                       "time at %g GB/s), compute and transfer overlapped; not a measurement of %d GPUs" % (n, args.link_gbps, n),
+           "config": {"workload": head["workload"], "frames_in_flight": len(streams),
+                      "parallelism": "cyclic %d-row blocks over %d EMULATED ranks on one device, exchange %s" % (br, n, args.exchange)},
+           "emulated": out_cfgs}
+    claim_stdout()(json.dumps(out))
+    return status
 
 
 def dist_line(res, args, app, W, H, t, world):

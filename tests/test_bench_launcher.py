@@ -99,3 +99,15 @@ def test_bench_library_engine_on_one_gpu():
     r2, line2 = run_bench("--gpus", "4", "--engine", "lib", "--lib-exchange", "blocks", "--steps", "4", "--warmup", "1", "--width", "640",
                           "--height", "360", "--no-cpu-baseline")
     assert r2.returncode == 0 and line2["parity"]["mismatching_pixels"] == 0 and "per row-block" in line2["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_emulated_ranks_on_one_gpu():
+    """--emulate-ranks N: every rank's real schedule through a loopback world on the one GPU, frames checked against one launch,
+    the N-GPU figures printed as MODELLED with the exchange budget beside them"""
+    r, line = run_bench("--emulate-ranks", "4", "--width", "960", "--height", "540", "--no-other-configs")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 1 and line["emulated_ranks"] == 4 and "MODELLED" in line["value_is"]
+    e = line["emulated"][0]
+    assert e["parity"]["mismatching_pixels"] == 0 and len(e["per_rank_ms"]) == 4 and e["modelled_speedup"] > 1.0
+    assert e["bytes_moved_per_frame"] > 0 and e["bound"] in ("link", "root", "peer compute")
