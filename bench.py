@@ -553,6 +553,9 @@ def dist_line(res, args, app, W, H, t, world):
     if roofline is not None:
         roofline["rank"] = "slowest (rank %d of the un-overlapped launches %s ms; %d pixels)" % (res["slowest_rank"], res["per_rank_launch_ms"],
                                                                                               res["launch_pixels"])
+        if args.exchange == "spans" and world > 1 and roofline.get("frac") is not None:
+            roofline["frac_is"] += ("; NOTE a span launch renders mostly the frame's EXPENSIVE pixels, so the frame-average instruction "
+                                    "count per pixel understates its work: read this frac as a lower bound")
     ph = res["phases"]
     serial_ms = max((p["render_ms"] + p["exchange_wait_ms"] + p["assemble_ms"]) for p in ph["per_rank"]) if ph else None
     exch = {"direct": "1 grouped RCCL send/recv of the peers' %d-channel slabs to the root (root in place)" % args.channels,
