@@ -633,13 +633,15 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     return SBX_OK;
 }
 
-static int check_common(sbx_ctx* ctx, const sbx_uniforms* uni, const float* rgba, int& W, int& H) {
+static int check_common(sbx_ctx* ctx, const sbx_uniforms* uni, const float* rgba, int& W, int& H, unsigned align_mask = 15u) {
     if (!ctx) return SBX_ERR_ARG;
     if (!uni || !rgba) return fail(ctx, SBX_ERR_ARG, "NULL uniforms or framebuffer");
     W = (int)uni->u_res[0]; H = (int)uni->u_res[1];
     if (W <= 0 || H <= 0 || (float)W != uni->u_res[0] || (float)H != uni->u_res[1] || W > 65536 || H > 65536)
         return fail(ctx, SBX_ERR_ARG, "u_res must be positive integers <= 65536");
-    if (((uintptr_t)rgba & 15u) != 0) return fail(ctx, SBX_ERR_ARG, "framebuffer must be 16-byte aligned");
+    // float4 pixels are stored with one 16-byte store; 3-channel slabs (RowMap.rgb) with three 4-byte stores: a slab piece that
+    // starts at row r0 of an odd-width frame is only 4-byte aligned, and that is fine
+    if (((uintptr_t)rgba & align_mask) != 0) return fail(ctx, SBX_ERR_ARG, align_mask == 15u ? "framebuffer must be 16-byte aligned" : "slab must be 4-byte aligned");
     return SBX_OK;
 }
 
@@ -992,7 +994,7 @@ static int span_table_device(sbx_ctx* ctx, int app, const sbx_uniforms* uni, con
 extern "C" int sbx_render_span_peer(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
                                     int nranks, int root_rounds, int rounds, int r0, int r1, float* rgb, void* stream) {
     int W, H;
-    int rc = check_common(ctx, uni, rgb, W, H);
+    int rc = check_common(ctx, uni, rgb, W, H, 3u);
     if (rc != SBX_OK) return rc;
     if (rank < 1 || rank >= nranks) return fail(ctx, SBX_ERR_ARG, "span slabs are rendered by ranks 1 .. nranks-1");
     const int rows = sbx_split_rank_rows(H, block_rows, rank, nranks, root_rounds, rounds);
@@ -1050,7 +1052,7 @@ static int render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const vo
                         int root_rounds, int rounds, int r0, int r1, int rgb, float* rgba, void* stream) {
     int W, H;
     if (ctx && uni && r0 == r1 && r0 >= 0) return SBX_OK;
-    int rc = check_common(ctx, uni, rgba, W, H);
+    int rc = check_common(ctx, uni, rgba, W, H, rgb ? 3u : 15u);
     if (rc != SBX_OK) return rc;
     const int rows = sbx_split_rank_rows(H, block_rows, rank, nranks, root_rounds, rounds);
     if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");

@@ -414,3 +414,14 @@ def test_very_long_point_list(renderer):
     got = renderer.render_points("clouds", w, h, t, pts)
     torch.cuda.synchronize()
     assert torch.equal(got.view(torch.int32), frame[idx].view(torch.int32))
+
+
+def test_pieces_of_a_three_channel_slab_of_an_odd_width_frame(renderer):
+    """found by tools/soak_spans.py: piece g of a 3-channel slab starts at r0 * W * 12 bytes, which is only 4-byte aligned for odd W;
+    the ABI used to demand 16 (the alignment of float4 pixels) of every output pointer"""
+    import torch
+    for app, w, h, n, groups, exchange in [("egg", 203, 95, 3, 3, "direct"), ("clouds", 333, 187, 4, 4, "direct"),
+                                            ("atmosphere", 1111, 301, 5, 3, "spans")]:
+        full = renderer.render(app, w, h, .37)
+        got, _ = loop_frame(renderer, app, w, h, .37, n, exchange, groups=groups)
+        assert torch.equal(got.view(torch.int32), full.view(torch.int32)), (app, exchange)

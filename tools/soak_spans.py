@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""One-off soak (run on the GPU box): the multi-GPU schedule of every rank through a loopback world (distributed.LoopbackWorld:
+real FramePlans, kernels, span tables, assembly on one device) on random (app, frame size, rank count, block rows, root relief,
+pieces, exchange, time, mouse) against one launch of the same frame, bit for bit; and the point-list entry on random pixel
+subsets of the same frames.    python tools/soak_spans.py [cases = 300] [seed = 1]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import shaderbox_amd
+from shaderbox_amd.distributed import LoopbackWorld
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+R = shaderbox_amd.Renderer(0)
+APPS = ["clouds", "atmosphere", "planet", "egg", "raytracer", "sdf_ao", "clouds_sky", "planet_atmosphere", "clouds_best"]
+bad = 0
+tally = {}
+for c in range(n_cases):
+    app = APPS[int(rng.integers(len(APPS)))]
+    w = int(rng.integers(65, 2600))
+    h = int(rng.integers(9, 900))
+    n = int(rng.choice([2, 3, 4, 5, 8]))
+    br = int(rng.choice([2, 4, 8, 8, 8, 16]))
+    m = int(rng.integers(1, 6))
+    m0 = int(rng.integers(0, m + 1))
+    groups = int(rng.integers(1, 5))
+    exchange = str(rng.choice(["spans", "spans", "spans", "direct"]))
+    t = float(rng.uniform(0, 30))
+    mouse = (float(rng.uniform(0, 6.3)), 0.0) if app.startswith("clouds") and c % 2 else (0.0, 0.0)
+    world = LoopbackWorld(n)
+    plans = world.plans(R, w, h, block_rows=br, groups=groups, root_rounds=m0, rounds=m, exchange=exchange)
+    plans[0].frame.fill_(-7.0)
+    got = LoopbackWorld.render(plans, app, t, mouse=mouse)
+    ref = R.render(app, w, h, t, mouse=mouse)
+    same = (got.view(torch.int32) == ref.view(torch.int32)) | (torch.isnan(got) & torch.isnan(ref))
+    ok = bool(same.all())
+    # a random subset of the frame's pixel centres through the point list
+    k = int(rng.integers(1, 5000))
+    idx = torch.from_numpy(rng.integers(0, w * h, k)).cuda()
+    pts = torch.stack([(idx % w).float() + .5, (idx // w).float() + .5], dim=1).contiguous()
+    pg = R.render_points(app, w, h, t, pts, mouse=mouse)
+    pr = ref.reshape(-1, 4)[idx]
+    ok2 = bool(((pg.view(torch.int32) == pr.view(torch.int32)) | (torch.isnan(pg) & torch.isnan(pr))).all())
+    tally[(app, exchange)] = tally.get((app, exchange), 0) + 1
+    if not (ok and ok2):
+        bad += 1
+        print("MISMATCH", app, w, h, n, br, (m0, m), groups, exchange, t, mouse, "frame" if not ok else "points")
+    del plans, world, got, ref
+print("cases %d: %s" % (n_cases, ", ".join("%s/%s %d" % (a, e, v) for (a, e), v in sorted(tally.items()))))
+print("soak of the multi-GPU schedule and the point list: %d cases, %d with a differing pixel" % (n_cases, bad))
