@@ -49,5 +49,29 @@ for c in range(n_cases):
         bad += 1
         print("MISMATCH", app, w, h, n, br, (m0, m), groups, exchange, t, mouse, "frame" if not ok else "points")
     del plans, world, got, ref
+# the library's own multi-GPU path (sbx_multi_*, all ranks on device 0: copies instead of RCCL), every exchange form
+mbad, mcases = 0, 0
+for n in (2, 3, 5, 8):
+    M = shaderbox_amd.MultiRenderer([0] * n)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for c in range(max(4, n_cases // 16)):
+        app = APPS[int(rng.integers(len(APPS)))]
+        w, h = int(rng.integers(65, 2000)), int(rng.integers(9, 700))
+        m = int(rng.integers(1, 5)); m0 = int(rng.integers(0, m + 1))
+        mode = str(rng.choice(["spans", "slabs", "blocks"]))
+        t = float(rng.uniform(0, 30))
+        M.set_split(int(rng.choice([2, 4, 8, 16])), m0, m)
+        M.set_exchange(mode)
+        with torch.cuda.stream(streams[c % 3]):
+            got = M.render(app, w, h, t)
+        torch.cuda.synchronize()
+        ref = R.render(app, w, h, t)
+        same = (got.view(torch.int32) == ref.view(torch.int32)) | (torch.isnan(got) & torch.isnan(ref))
+        mcases += 1
+        if not bool(same.all()):
+            mbad += 1
+            print("MISMATCH sbx_multi", app, w, h, n, (m0, m), mode, t)
+    M.close()
+print("sbx_multi: %d cases over 2, 3, 5, 8 ranks and the three exchange forms, %d with a differing pixel" % (mcases, mbad))
 print("cases %d: %s" % (n_cases, ", ".join("%s/%s %d" % (a, e, v) for (a, e), v in sorted(tally.items()))))
 print("soak of the multi-GPU schedule and the point list: %d cases, %d with a differing pixel" % (n_cases, bad))
