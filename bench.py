@@ -748,7 +748,7 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
     return {"workload": "APP_%s %dx%d u_time=%g" % (app.upper(), W, H, t), "value": round(W * H / (ms * 1e-3) / 1e6, 2),
             "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "steps": steps, "frames_in_flight": ns,
             "kernel": KERNEL_OF.get(app), "kernel_ms": round(kmean, 4),
-            "serial_value": round(W * H / (kmean * 1e-3) / 1e6, 2),
+            "serial_value": round(W * H / (kmean * 1e-3) / 1e6, 2), "value_serial": round(W * H / (kmean * 1e-3) / 1e6, 2),
             "roofline": roofline,
             "hbm_store_gbps": round(16.0 * W * H / (kmean * 1e-3) / 1e9, 1), "parity": par}
 
