@@ -425,3 +425,33 @@ def test_pieces_of_a_three_channel_slab_of_an_odd_width_frame(renderer):
         full = renderer.render(app, w, h, .37)
         got, _ = loop_frame(renderer, app, w, h, .37, n, exchange, groups=groups)
         assert torch.equal(got.view(torch.int32), full.view(torch.int32)), (app, exchange)
+
+
+def test_main_image_cache_follows_every_input(renderer, oracle):
+    """a random walk over (app, u_res, u_time, u_mouse, aux, fragCoord): whatever the previous call cached, every answer is the
+    oracle's mainImage of the CURRENT arguments"""
+    import shaderbox_amd
+    from oracle.oracle import APP_IDS
+    rng = np.random.default_rng(23)
+    apps = ["clouds", "egg", "sdf_ao", "atmosphere", "raytracer"]
+    app, w, h, t, mouse = "clouds", 48, 27, .37, (0.0, 0.0)
+    aux = None
+    for i in range(160):
+        k = int(rng.integers(0, 7))
+        if k == 0:
+            app = apps[int(rng.integers(len(apps)))]; aux = None
+        elif k == 1:
+            w, h = int(rng.integers(8, 64)), int(rng.integers(8, 40))
+        elif k == 2:
+            t = float(rng.uniform(0, 9))
+        elif k == 3:
+            mouse = (float(rng.uniform(0, 6)), 0.0)
+        elif k == 4 and app == "clouds":
+            aux = shaderbox_amd.clouds_defaults(); aux.cld_coverage = float(rng.uniform(.3, .8))
+        elif k == 4 and app == "sdf_ao":
+            aux = shaderbox_amd.sdf_ao_defaults(); aux.fog_density = float(rng.uniform(.05, .3))
+        fx = float(rng.integers(0, w)) + (.5 if i % 3 else float(rng.uniform(0, 1)))
+        fy = float(rng.integers(0, h)) + .5
+        got = np.array(renderer.main_image(app, w, h, t, (fx, fy), mouse=mouse, aux=aux), dtype=np.float32)
+        ref = oracle.main_image(APP_IDS[app], w, h, t, fx, fy, mouse=mouse, aux=aux)
+        assert compare(got[None], ref[None]) == (0.0, 0), (i, app, w, h, t, mouse, fx, fy)
