@@ -27,7 +27,7 @@ __device__ __forceinline__ D2 ao_sdf_pipe(const FrameSdfAo& F, v3 pos) {        
     p = p - V3(.7f, .5f, 0);
     p = mul(p, F.rx_m90);
     const float c = sd_y_cylinder<HW>(p, size.y + .55f, 2.f * size.z + .1f);
-    const D2 pipe = {hmax_<HW>(b, -c), 2.f};                                                           // op_sub, mat_pipe
+    const D2 pipe = {hmax_neg_<HW>(b, c), 2.f};                                                           // op_sub, mat_pipe
 
     p = pos - V3(0, size.y, 0);
     p = p - V3(-size.x + .525f, size.y, 0);

@@ -65,7 +65,7 @@ __device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {        
     const float defect1 = length(p + V3(6.05f, 0, 0)) - .1f;
     const float defect2 = length(p + V3(-6.05f, 0, 0)) - .1f;
     const float defect = hmin_<HW>(defect1, defect2);
-    return D2{hmax_<HW>(d4.d, -defect), d4.m};                       // op_sub
+    return D2{hmax_neg_<HW>(d4.d, defect), d4.m};                       // op_sub
 }
 // Exact culling (as in kern_egg.hip): `dmin` is the distance the platter already gives at pos; a group of the tonearm
 // whose lower bound exceeds the running minimum cannot be returned by the union and enters it as +inf.
@@ -89,7 +89,7 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
         if (!(CULL && dmin >= 0.f && lb > dmin * 1.001f + 2e-3f)) {
             const float platter = sd_y_cylinder<HW>(pos, 6.25f, 1.f);
             const float base_0 = sd_y_cylinder<HW>(pos - base_p, 3.f, .25f);
-            const float base_1 = hmax_<HW>(base_0, -platter);
+            const float base_1 = hmax_neg_<HW>(base_0, platter);
             const float base_2 = sd_y_cylinder<HW>(pos - base_p, 1.25f, 1.f);
             const float base_12 = hmin_<HW>(base_1, base_2);
             const D2 base_a = {base_12, 5.f};
@@ -139,8 +139,8 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
                              V3(ctg_len2 * 2.f, ctg_h * 3.f, ctg_w * 3.2f));
     const float cut2 = sd_box<HW>(mul(ctg2_p - V3(.3f, .2f, 0), FV(cut2_rz10)), V3(.4f, .2f, .3f));
     const float ctg12 = hmin_<HW>(ctg1, ctg2);
-    const float ctg12c = hmax_<HW>(ctg12, -cut);
-    const D2 cartridge = {hmax_<HW>(ctg12c, -cut2), 5.f};
+    const float ctg12c = hmax_neg_<HW>(ctg12, cut);
+    const D2 cartridge = {hmax_neg_<HW>(ctg12c, cut2), 5.f};
 
     const D2 tone1 = op_add2(base, arm);
     const D2 tone2 = op_add2(headshell, cartridge);

@@ -21,7 +21,11 @@ __device__ __forceinline__ float op_blend(float a, float b, float k) {          
 // target, so a constant fold or a compiler upgrade could pick the other zero; v_min_f32 / v_max_f32 are what the proof is about.
 __device__ __forceinline__ float v_max_f32_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float v_min_f32_(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// max(a, -b) with the negation as the instruction's source modifier (what the compiler did for the builtin; a separate v_xor per
+// op_sub otherwise)
+__device__ __forceinline__ float v_max_f32_neg_(float a, float b) { float r; asm("v_max_f32 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <bool HW> __device__ __forceinline__ float hmax_(float a, float b) { return HW ? v_max_f32_(a, b) : fmax_(a, b); }
+template <bool HW> __device__ __forceinline__ float hmax_neg_(float a, float b) { return HW ? v_max_f32_neg_(a, b) : fmax_(a, -b); }
 template <bool HW> __device__ __forceinline__ float hmin_(float a, float b) { return HW ? v_min_f32_(a, b) : fmin_(a, b); }
 template <bool HW = false>
 __device__ __forceinline__ float sd_box(v3 p, v3 b) {                                          // sdf.h:67-73
@@ -71,7 +75,7 @@ __device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) 
     const float dist = length(cross(C.dir, P - V3(0.f, 0.f, 0.f)));
     const float plane_1 = dot(C.dir, P) + C.len1;
     const float plane_2 = dot(-C.dir, P) + (-C.len0);
-    return hmax_<HW>(hmax_<HW>(dist, -plane_1), -plane_2) - R;   // op_sub(op_sub(dist, p1), p2) - R
+    return hmax_neg_<HW>(hmax_neg_<HW>(dist, plane_1), plane_2) - R;   // op_sub(op_sub(dist, p1), p2) - R
 }
 // sd_capsule(p, a, b, r) with ab = b - a and rd = recip64(dot(ab, ab)) from the frame         sdf.h:162-171
 __device__ __forceinline__ float sd_capsule_f(v3 p, v3 a, v3 ab, double rd, float r) {
