@@ -116,8 +116,24 @@ __device__ __forceinline__ v3 atm_incident_light(v3 ro, v3 rd, v3 sun_dir, const
             const float hm = ATM_EXP_H(ATM_DIV_HM(-height)) * march_step;
             odR += hr;
             odM += hm;
+            // DEAD RAYS.  A view ray below the horizon dives into the planet (there is no ground test in this march, :119-122);
+            // 106 km down exp(-height / hM) overflows and optical_depthM is +inf from then on (709 km: optical_depthR).  Every
+            // later sample's tau = betaR (odR + lR) + 1.1 betaM (odM + lM) is then +inf in all three components — the terms are
+            // non-negative, so no inf - inf — its attenuation exp(-inf) is exactly 0, and what it would add, hr * 0 and hm * 0, is
+            // exactly +0: a sample is only lit when its FIRST light sample is above the ground (:65-67), which the geometry
+            // allows down to ~4 km under it (a light step is at most 1/16 of the way out of the atmosphere), so the hr, hm of a
+            // lit sample are finite (<= e^3.4 * step).  So a lane whose optical depth has overflowed is finished: it skips the
+            // sun marches of its far-side samples (which the reference runs for nothing), and the march ends when the whole
+            // wave is finished.  The band 1.09 < z2 <= 1.4 of the dome — 10 % of a 16:9 frame — paid a sky pixel's full price for
+            // a black pixel before: 7680x4320 3.90 -> 3.66 ms, same bits (tools/ab_time.py; waves that mix finished and live rays still pay).
+#ifndef ATM_DEAD_EXIT
+#define ATM_DEAD_EXIT 1
+#endif
+            const float inf = u2f(0x7f800000u);
+            const bool dead = ATM_DEAD_EXIT && (odR == inf || odM == inf);
+            if (ATM_DEAD_EXIT && __builtin_amdgcn_ballot_w64(!dead) == 0ull) break;      // wave-uniform
             float lR = 0.f, lM = 0.f;
-            if (sun_light<FIN>(s, sun_dir, lR, lM, etab, etab64, K)) {
+            if (!dead && sun_light<FIN>(s, sun_dir, lR, lM, etab, etab64, K)) {
                 const v3 tau = betaR * (odR + lR) + betaM * 1.1f * (odM + lM);
                 // exp(-tau): the guard-less form where every lane that got here has all three tau <= 80 (tau >= 0: sums of
                 // non-negative terms; a NaN fails the test), exp_'s guarded form for the wave otherwise (grazing sun rays)

@@ -859,9 +859,10 @@ static bool span_heavy(const SpanProbe& P, float fx, float fy) {
     }
     case SBX_APP_ATMOSPHERE: {
         // app_atmosphere.h:195-207: acos(1 - z2) is a NaN beyond z2 = 2 and the atmosphere test then fails (:85-88): free pixels.
-        // Below the horizon (1 < z2 <= 2) the view ray dives into the planet from 1 m above the ground; once all 16 view samples
-        // (:119-123) lie under the ground every get_sun_light returns at its first sample (:65-67) and the pixel costs about a
-        // sixth of a sky pixel.  "Heavy" = some view sample is above the ground.
+        // Below the horizon (1 < z2 <= 2) the view ray dives into the planet from 1 m above the ground: under-ground samples are
+        // not lit (get_sun_light returns at its first sample, :65-67), and once exp(-height / hM) has overflowed (106 km down)
+        // the kernel is finished with the ray (sbx_atmosphere.h "dead rays").  "Heavy" = some view sample is above the ground
+        // BEFORE the optical depth overflows: the same march with the host copy of the math spec.
         const float z2 = pc.x * pc.x + pc.y * pc.y;
         if (z2 > 2.0f) return false;
         const float phi = atan2_(pc.y, pc.x), theta = acos_(1.0f - z2);
@@ -873,9 +874,13 @@ static bool span_heavy(const SpanProbe& P, float fx, float fy) {
         if (!(d2 < Ra * Ra)) return false;
         const float t1 = tca + sqrt_(Ra * Ra - d2);
         const float step = t1 / 16.f;
+        float odM = 0.f;
         for (int i = 0; i < 16; ++i) {
             const v3 sp = ro + rd * (((float)i + .5f) * step);
-            if (!(length(sp) - Re < 0.f)) return true;
+            const float height = length(sp) - Re;
+            odM += exp_(-height / 1200.0f) * step;                 // hM: the first of the two optical depths to overflow
+            if (odM > 3e38f) return false;                         // (+inf, or within a rounding of it: the ray is finished)
+            if (!(height < 0.f)) return true;
         }
         return false;
     }

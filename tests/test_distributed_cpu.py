@@ -204,7 +204,7 @@ def test_span_table_is_a_consistent_layout():
             assert at == pix[r]
         assert maxw == max([int(t[1] - t[0]) for t in table if t[3] > 0] + [0])
     # the tables that matter at the BASELINE sizes: what fraction of the peers' pixels still crosses xGMI
-    for app, w, h, lo, hi in [("atmosphere", 7680, 4320, .55, .65), ("planet", 7680, 4320, .55, .65), ("clouds", 3840, 2160, .70, .78)]:
+    for app, w, h, lo, hi in [("atmosphere", 7680, 4320, .48, .58), ("planet", 7680, 4320, .55, .65), ("clouds", 3840, 2160, .70, .78)]:
         table, pix, _ = shaderbox_amd.span_table(app, w, h, 0.37, 8, 8)
         full = sum(shard.rank_rows(h, 8, r, 8) * w for r in range(1, 8))
         assert lo < sum(int(p) for p in pix[1:]) / full < hi, (app, sum(pix[1:]) / full)
