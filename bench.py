@@ -189,7 +189,7 @@ def main():
                     help="N>1: 'dist' = one process per GPU (torch.distributed / RCCL gather, the contract's launch shape); 'lib' = ONE "
                          "process drives the N GPUs through the library's own multi-GPU path (sbx_multi_*: RCCL send/recv per "
                          "row-block straight into the final rows, no assembly pass); with fewer GPUs than N the ranks share devices")
-    ap.add_argument("--lib-exchange", choices=["slabs", "blocks", "spans"], default="slabs",
+    ap.add_argument("--lib-exchange", choices=["slabs", "blocks", "spans", "peer_stores"], default="slabs",
                     help="--engine lib: 'slabs' = one send/receive per peer of its whole 3-channel slab + one scatter kernel on the "
                          "root (default); 'blocks' = one send/receive pair per row-block straight into the final rows (round 2)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
@@ -655,6 +655,7 @@ def bench_lib(args):
                                                      "device copies (ranks share devices: emulation, not a scaling number)",
                                                      {"slabs": "one per peer of its whole 3-channel slab + one scatter kernel",
                                                       "spans": "one per peer of its packed 3-channel spans + one scatter kernel, rank 0 renders the rest",
+                                                      "peer_stores": "none: every rank stores its pixels into rank 0's frame through peer access",
                                                       "blocks": "one per row-block into the final rows"}[args.lib_exchange])))},
            "steady_state": steady, "roofline": roofline, "roofline_hbm": roofline_hbm,
            "parity": {"against": "one-launch render of the same frame", "rows": H, "mismatching_pixels": bad}}

@@ -533,8 +533,9 @@ class MultiRenderer:
         """'slabs' (default): one send / receive per peer of its whole 3-channel slab + one scatter kernel on rank 0;
         'blocks': one send / receive pair per row-block straight into the final rows (the round-2 form);
         'spans': the span exchange — only the expensive interval of every row-block is dealt to the peers and sent, rank 0
-        renders the rest in place (include/sbx.h)."""
-        self._check(self.lib.sbx_multi_set_exchange(self.m, {"slabs": 0, "blocks": 1, "spans": 2}[mode] if isinstance(mode, str) else int(mode)))
+        renders the rest in place (include/sbx.h); 'peer_stores': every rank writes its pixels straight into rank 0's frame
+        through peer access (no RCCL, no slabs, nothing for rank 0 to land or scatter; unmeasured on more than one device)."""
+        self._check(self.lib.sbx_multi_set_exchange(self.m, {"slabs": 0, "blocks": 1, "spans": 2, "peer_stores": 3}[mode] if isinstance(mode, str) else int(mode)))
 
     def set_noise_volumes(self, shape_rgba, detail_rgba):
         self._check(self.lib.sbx_multi_set_noise_volumes(self.m, int(shape_rgba.shape[0]), ctypes.c_void_p(shape_rgba.data_ptr()),

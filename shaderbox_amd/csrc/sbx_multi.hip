@@ -104,6 +104,7 @@ std::string g_create_error;
 struct sbx_multi {
     std::vector<Rank> ranks;
     bool use_rccl = false;
+    bool peer_stores_ok = true;                           // every peer's device can address rank 0's memory (or is rank 0's device)
     int block_rows = 8, root_rounds = 1, rounds = 1;
     int exchange = SBX_MULTI_EXCHANGE_SLABS;
     unsigned calls = 0;
@@ -192,7 +193,9 @@ int sbx_multi_create(int nranks, const int* devices, sbx_multi** out) {
         if (can) {
             (void)hipSetDevice(m->ranks[i].device);
             hipError_t e = hipDeviceEnablePeerAccess(m->ranks[0].device, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); m->peer_stores_ok = false; }
+        } else {
+            m->peer_stores_ok = false;
         }
     }
     const char* no_rccl = getenv("SBX_MULTI_NO_RCCL");      // diagnostic: peer copies instead of RCCL
@@ -276,8 +279,11 @@ int sbx_multi_set_split(sbx_multi* m, int block_rows, int root_rounds, int round
 
 int sbx_multi_set_exchange(sbx_multi* m, int mode) {
     if (!m) return SBX_ERR_ARG;
-    if (mode != SBX_MULTI_EXCHANGE_SLABS && mode != SBX_MULTI_EXCHANGE_BLOCKS && mode != SBX_MULTI_EXCHANGE_SPANS)
+    if (mode != SBX_MULTI_EXCHANGE_SLABS && mode != SBX_MULTI_EXCHANGE_BLOCKS && mode != SBX_MULTI_EXCHANGE_SPANS &&
+        mode != SBX_MULTI_EXCHANGE_PEER_STORES)
         return mfail(m, SBX_ERR_ARG, "unknown exchange mode");
+    if (mode == SBX_MULTI_EXCHANGE_PEER_STORES && !m->peer_stores_ok)
+        return mfail(m, SBX_ERR_UNSUPPORTED, "peer stores need every rank's device to have peer access to rank 0's");
     m->exchange = mode;
     return SBX_OK;
 }
@@ -452,6 +458,24 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
     if ((e = hipEventRecord(m->start[k], user)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
     struct Restore { int dev; ~Restore() { (void)hipSetDevice(dev); } } restore{root.device};   // whatever path returns
     if (m->exchange == SBX_MULTI_EXCHANGE_SPANS && n > 1) return render_spans(m, app, uni, aux, frame, user, k, W, H);
+    if (m->exchange == SBX_MULTI_EXCHANGE_PEER_STORES) {
+        // No slab, no landing area, no scatter, no RCCL: every rank renders its row-blocks IN PLACE into rank 0's frame — a peer's
+        // stores are 16-byte float4 writes, 1 KB per wave, that travel over its xGMI link as the kernel produces them (peer access
+        // to rank 0's memory, enabled at creation).  The exchange step is fused into the render kernels' stores; rank 0 does
+        // nothing for the others.  16 instead of 12 bytes per pixel cross the link.
+        for (int i = 0; i < n; ++i) {
+            Rank& r = m->ranks[i];
+            if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+            if ((e = hipStreamWaitEvent(r.render[k], m->start[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+            const int rc = sbx_render_split_in_place(r.ctx, app, uni, aux, br, i, n, m0, mr, frame, r.render[k]);
+            if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(r.ctx));
+            if ((e = hipEventRecord(r.done[k], r.render[k])) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipEventRecord", e);
+        }
+        if ((e = hipSetDevice(root.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
+        for (int i = 0; i < n; ++i)
+            if ((e = hipStreamWaitEvent(user, m->ranks[i].done[k], 0)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipStreamWaitEvent", e);
+        return SBX_OK;
+    }
     const bool slabs = m->exchange != SBX_MULTI_EXCHANGE_BLOCKS;
     const int ch = slabs ? 3 : 4;                                   // floats per pixel of a peer's slab
     const size_t row_floats = (size_t)W * 4, slab_row = (size_t)W * ch;

@@ -58,7 +58,7 @@ for n in (2, 3, 5, 8):
         app = APPS[int(rng.integers(len(APPS)))]
         w, h = int(rng.integers(65, 2000)), int(rng.integers(9, 700))
         m = int(rng.integers(1, 5)); m0 = int(rng.integers(0, m + 1))
-        mode = str(rng.choice(["spans", "slabs", "blocks"]))
+        mode = str(rng.choice(["spans", "slabs", "blocks", "peer_stores"]))
         t = float(rng.uniform(0, 30))
         M.set_split(int(rng.choice([2, 4, 8, 16])), m0, m)
         M.set_exchange(mode)
@@ -72,6 +72,6 @@ for n in (2, 3, 5, 8):
             mbad += 1
             print("MISMATCH sbx_multi", app, w, h, n, (m0, m), mode, t)
     M.close()
-print("sbx_multi: %d cases over 2, 3, 5, 8 ranks and the three exchange forms, %d with a differing pixel" % (mcases, mbad))
+print("sbx_multi: %d cases over 2, 3, 5, 8 ranks and the four exchange forms, %d with a differing pixel" % (mcases, mbad))
 print("cases %d: %s" % (n_cases, ", ".join("%s/%s %d" % (a, e, v) for (a, e), v in sorted(tally.items()))))
 print("soak of the multi-GPU schedule and the point list: %d cases, %d with a differing pixel" % (n_cases, bad))
