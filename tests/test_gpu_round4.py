@@ -455,3 +455,18 @@ def test_main_image_cache_follows_every_input(renderer, oracle):
         got = np.array(renderer.main_image(app, w, h, t, (fx, fy), mouse=mouse, aux=aux), dtype=np.float32)
         ref = oracle.main_image(APP_IDS[app], w, h, t, fx, fy, mouse=mouse, aux=aux)
         assert compare(got[None], ref[None]) == (0.0, 0), (i, app, w, h, t, mouse, fx, fy)
+
+
+def test_atmosphere_dead_rays_over_sun_positions(renderer, oracle):
+    """k_atmosphere ends a ray's march once its optical depth has overflowed to +inf (sbx_atmosphere.h "dead rays": every later
+    contribution is exactly +0) and skips the angle mapping of waves outside the dome.  Both are claims about IEEE arithmetic for
+    EVERY sun position and ray: frames over the sun's whole swing (|sin(t / 2)| from 0 to 1, src/app_atmosphere.h:177-181), wide
+    and tall aspect ratios, against the oracle, NaN == NaN."""
+    from oracle.oracle import APP_ATMOSPHERE
+    rng = np.random.default_rng(31)
+    times = list(rng.uniform(0, 6.3, 10)) + [0.0, 3.14159, 3.1415927, 1.5707964, 100.0, 1e4]
+    sizes = [(320, 180), (180, 320), (257, 129), (96, 400)]
+    for i, t in enumerate(times):
+        w, h = sizes[i % len(sizes)]
+        got = renderer.render("atmosphere", w, h, float(t)).cpu().numpy()
+        assert compare(got, oracle.render(APP_ATMOSPHERE, w, h, float(t))) == (0.0, 0), (t, w, h)
