@@ -470,3 +470,44 @@ def test_atmosphere_dead_rays_over_sun_positions(renderer, oracle):
         w, h = sizes[i % len(sizes)]
         got = renderer.render("atmosphere", w, h, float(t)).cpu().numpy()
         assert compare(got, oracle.render(APP_ATMOSPHERE, w, h, float(t))) == (0.0, 0), (t, w, h)
+
+
+def test_span_entry_points_reject_bad_arguments(renderer):
+    """the span entry points fail with SBX_ERR_ARG (never render something else): rank 0 as a peer, a slab range that does not start
+    on a block, a bad split, a frame whose table is not on the device yet inside a stream capture"""
+    import ctypes
+    import torch
+    import shaderbox_amd
+    lib, ctx = renderer.lib, renderer.ctx
+    u = renderer.uniforms(640, 360, .37)
+    slab = torch.zeros(640 * 360 * 3, dtype=torch.float32, device="cuda")
+    frame = torch.zeros((360, 640, 4), dtype=torch.float32, device="cuda")
+    sp = ctypes.c_void_p(slab.data_ptr()); fp = ctypes.c_void_p(frame.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    app = shaderbox_amd.app_id("clouds")
+    assert lib.sbx_render_span_peer(ctx, app, ctypes.byref(u), None, 8, 0, 4, 1, 1, 0, 1 << 30, sp, st) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_render_span_peer(ctx, app, ctypes.byref(u), None, 8, 4, 4, 1, 1, 0, 1 << 30, sp, st) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_render_span_peer(ctx, app, ctypes.byref(u), None, 8, 1, 4, 1, 1, 3, 1 << 30, sp, st) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_render_span_root(ctx, app, ctypes.byref(u), None, 8, 4, 3, 2, fp, st) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_render_span_root(ctx, 99, ctypes.byref(u), None, 8, 4, 1, 1, fp, st) < 0
+    assert lib.sbx_assemble_spans(ctx, app, ctypes.byref(u), None, 8, 4, 1, 1, None, 1000, fp, st) == shaderbox_amd.SBX_ERR_ARG
+    assert lib.sbx_span_table(99, ctypes.byref(u), None, 8, 4, 1, 1, None, None, None) < 0
+    # a table that is not on the device yet cannot be uploaded inside a capture: a clean error, and the capture stays usable
+    u2 = renderer.uniforms(648, 360, .37)
+    frame2 = torch.zeros((360, 648, 4), dtype=torch.float32, device="cuda")
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            rc = lib.sbx_render_span_root(ctx, app, ctypes.byref(u2), None, 8, 5, 1, 1, ctypes.c_void_p(frame2.data_ptr()),
+                                          ctypes.c_void_p(s.cuda_stream))
+            frame2.add_(0.0)                          # something to capture
+    assert rc == shaderbox_amd.SBX_ERR_ARG and b"span table" in lib.sbx_last_error(ctx)
+    # outside the capture the same call works and, once the table is there, it can be captured and replayed
+    assert lib.sbx_render_span_root(ctx, app, ctypes.byref(u2), None, 8, 5, 1, 1, ctypes.c_void_p(frame2.data_ptr()), st) == 0
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g2, stream=s):
+            assert lib.sbx_render_span_root(ctx, app, ctypes.byref(u2), None, 8, 1, 1, 1, ctypes.c_void_p(frame2.data_ptr()),
+                                            ctypes.c_void_p(s.cuda_stream)) in (0, shaderbox_amd.SBX_ERR_ARG)
