@@ -157,6 +157,14 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();      // census build (tools/egg_census.py): 100 MHz counter
     int st_trace = 0, st_shadow = 0;
 #endif
+#ifndef EGG_VCONST
+#define EGG_VCONST 1       // the constants every sdf() call starts with — the turntable rotation and the cull sphere — in VGPRs: a VALU
+#endif                     // instruction with an SGPR source issues at half rate on gfx950 (profiles/r02_ubench_issue.txt)
+    if (EGG_VCONST) {
+        asm volatile("" : "+v"(F.rot_y.c0.x), "+v"(F.rot_y.c0.y), "+v"(F.rot_y.c0.z), "+v"(F.rot_y.c1.x), "+v"(F.rot_y.c1.y),
+                          "+v"(F.rot_y.c1.z), "+v"(F.rot_y.c2.x), "+v"(F.rot_y.c2.y), "+v"(F.rot_y.c2.z));
+        asm volatile("" : "+v"(F.oc.x), "+v"(F.oc.y), "+v"(F.oc.z), "+v"(F.orad));
+    }
     int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     if (EGG_HOT_FIRST && hot.w > 0) hot_first_tile(hot, (int)gridDim.x, bx, by);          // wave-uniform
     const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
