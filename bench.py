@@ -84,7 +84,8 @@ VALU_ISSUE_CYCLES = 2.0             # wave64 VALU instruction on a SIMD-32 (MI35
 NOMINAL_CLOCK_HZ = 2.4e9
 LANES_PER_SIMD_CYCLE = 32           # a SIMD-32 retires half a wave64 instruction per cycle
 PEAK_LANEOPS_NOMINAL_T = N_SIMD * LANES_PER_SIMD_CYCLE * NOMINAL_CLOCK_HZ / 1e12     # 78.6 T lane-ops/s
-PMC_ROUND = "r04"                   # committed per-launch counters: profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json
+PMC_ROUND = "r04"
+COLL_DEV = None                     # device of the small bookkeeping collectives (set in main: the GPU under RCCL, the CPU under gloo)                   # committed per-launch counters: profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json
 # the other BASELINE.json configs that fit one GPU: (app, W, H) — C2, C3, C5 (both apps)
 OTHER_CONFIGS = [("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320)]
 KERNEL_OF = {"clouds": "k_clouds", "egg": "k_egg", "raytracer": "k_raytracer", "atmosphere": "k_atmosphere",
@@ -198,6 +199,10 @@ def main():
                          "launch, time every rank's part with frames in flight and print the MODELLED N-GPU figures with the exchange "
                          "budget (n_gpus stays 1, 'emulated_ranks' says so; link rates are assumptions: --link-gbps)")
     ap.add_argument("--link-gbps", type=float, default=50.0, help="--emulate-ranks: the per-direction xGMI rate of the budget")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N>1 process group: 'nccl' = RCCL (the product path); 'gloo' = TEST ONLY: the ranks may share a GPU (rank r on "
+                         "device r mod device count), point-to-point transfers are staged through host memory "
+                         "(distributed.HostStagedDist) — runs the whole N > 1 program on a 1-GPU box, measures nothing about xGMI")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -231,9 +236,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)      # test form: ranks may share a device
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    global COLL_DEV
+    COLL_DEV = dev if args.backend == "nccl" else torch.device("cpu")      # where the small bookkeeping collectives live
     torch.cuda.set_device(dev)
     R = shaderbox_amd.Renderer(local_rank)
     R.set_timing(True)
@@ -246,8 +258,8 @@ def main():
         with torch.cuda.stream(st):
             R.render(app, 64, 36, t)
     if dist is not None:                                # the first RCCL transfer sets up the peer links
-        tiny = torch.zeros(4, device=dev)
-        dist.gather(tiny, [torch.zeros(4, device=dev) for _ in range(world)] if rank == 0 else None, dst=0)
+        tiny = torch.zeros(4, device=COLL_DEV)
+        dist.gather(tiny, [torch.zeros(4, device=COLL_DEV) for _ in range(world)] if rank == 0 else None, dst=0)
         dist.barrier()
     torch.cuda.synchronize(dev)
 
@@ -404,7 +416,11 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         else:
             payload = (12 if (args.exchange == "direct" and args.channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
     groups = auto_groups(args.gather_groups, payload)
-    plans = [FramePlan(R, dist, W, H, br, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=args.exchange,
+    fdist = dist
+    if args.backend == "gloo":
+        from shaderbox_amd.distributed import HostStagedDist
+        fdist = HostStagedDist(dist, torch)
+    plans = [FramePlan(R, fdist, W, H, br, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=args.exchange,
                        channels=args.channels) for _ in range(ns)]
 
     def step(i=0):
@@ -445,7 +461,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     del scratch
     sync()
     mine = torch.tensor([elapsed, sum(km) / len(km), min(km), float(rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, args.exchange))],
-                        dtype=torch.float64, device=dev)
+                        dtype=torch.float64, device=COLL_DEV)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     phases = dist_phases(plans[0], torch, dist, dev, app, t, world, rank)
@@ -570,6 +586,8 @@ def dist_line(res, args, app, W, H, t, world):
                        "frames_in_flight": ns,
                        "parallelism": "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + %s (in %d pipelined "
                                       "pieces) + assemble" % (args.block_rows, world, relief[0], relief[1], exch, res["groups"])},
+            "backend": "RCCL" if args.backend == "nccl" else "gloo with host-staged transfers (TEST form: ranks may share a GPU, nothing here "
+                                                                "says anything about xGMI)",
             "exchange": {"kind": args.exchange, "bytes_per_peer": res["payload_bytes_per_peer"], "pieces": res["groups"],
                          "link_ms_at_76p8_GBps": round(res["payload_bytes_per_peer"] / 76.8e9 * 1e3, 4),
                          "what": "the largest peer payload of one frame; one xGMI link per peer, 76.8 GB/s per direction at its peak"},
@@ -944,7 +962,7 @@ def dist_phases(plan, torch, dist, dev, app, t, world, rank, reps=5):
         for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
             acc.setdefault(name, []).append(e0.elapsed_time(e1))
     names = ["render", "exchange", "assemble", "end"]
-    mine = torch.tensor([sum(acc.get(n, [0.0])) / max(len(acc.get(n, [0.0])), 1) for n in names], dtype=torch.float64, device=dev)
+    mine = torch.tensor([sum(acc.get(n, [0.0])) / max(len(acc.get(n, [0.0])), 1) for n in names], dtype=torch.float64, device=COLL_DEV or dev)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     if rank != 0:
@@ -983,7 +1001,7 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
     if spec != "auto":
         m0, m = (int(v) for v in spec.split("/"))
         return (m0, m)
-    pick = torch.zeros(2, dtype=torch.int64, device=dev)
+    pick = torch.zeros(2, dtype=torch.int64, device=COLL_DEV or dev)
     if rank == 0:
         ch = channels if exchange == "direct" else (3 if exchange == "spans" else 4)
         st = streams                                    # the loop's own streams (no extra hardware queues)

@@ -281,3 +281,55 @@ class LoopbackWorld:
         for p in plans[1:]:
             p.render(app, time, **kw)
         return plans[0].render(app, time, **kw)
+
+
+class HostStagedDist:
+    """torch.distributed as FramePlan uses it, for process groups whose backend cannot move device tensors point to point (gloo):
+    every send / receive goes through a pinned host buffer.  It exists so that the WHOLE N > 1 program — one process per rank,
+    real rendezvous, real collectives, FramePlan's schedule, bench.py's orchestration — can run where the ranks cannot form an RCCL
+    communicator (several ranks on the one GPU of a test box: RCCL refuses duplicate devices).  Not a product path: bench.py uses
+    it only under `--backend gloo`, and says so in its line."""
+
+    isend, irecv = "isend", "irecv"
+
+    class _Op:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Work:
+        def __init__(self, fn):
+            self._fn = fn
+
+        def wait(self):
+            if self._fn is not None:
+                self._fn()
+                self._fn = None
+            return True
+
+    def __init__(self, dist, torch):
+        self._d, self._t = dist, torch
+        self.P2POp = HostStagedDist._Op
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def get_rank(self):
+        return self._d.get_rank()
+
+    def batch_isend_irecv(self, ops):
+        t = self._t
+        works = []
+        for op in ops:
+            if op.op == self.isend:
+                host = op.tensor.detach().to("cpu")                  # (synchronises with the producing launch)
+                w = self._d.isend(host, op.peer)
+                works.append(HostStagedDist._Work(lambda w=w, host=host: w.wait()))
+            else:
+                host = t.empty(op.tensor.shape, dtype=op.tensor.dtype, device="cpu")
+                w = self._d.irecv(host, op.peer)
+
+                def done(w=w, host=host, dst=op.tensor):
+                    w.wait()
+                    dst.copy_(host)
+                works.append(HostStagedDist._Work(done))
+        return works

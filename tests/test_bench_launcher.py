@@ -111,3 +111,27 @@ def test_bench_emulated_ranks_on_one_gpu():
     e = line["emulated"][0]
     assert e["parity"]["mismatching_pixels"] == 0 and len(e["per_rank_ms"]) == 4 and e["modelled_speedup"] > 1.0
     assert e["bytes_moved_per_frame"] > 0 and e["bound"] in ("link", "root", "peer compute")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,exchange", [(2, "spans"), (3, "direct")])
+def test_bench_whole_multi_rank_program_on_one_gpu(n, exchange):
+    """`bench.py --gpus N --backend gloo`: N real processes (self-launched ranks, rendezvous, the relief calibration and its broadcast,
+    FramePlan's schedule with its pieces, the all_gathers of the per-rank figures, config 5 at 7680x4320 through the same schedule,
+    phases, parity) with the ranks SHARING the box's one GPU — RCCL refuses duplicate devices, so the transfers are staged through the
+    host (distributed.HostStagedDist).  Everything but the transport is the code the driver's N = 2, 4, 8 runs execute."""
+    args = ["--gpus", str(n), "--backend", "gloo", "--exchange", exchange, "--steps", "4", "--warmup", "1", "--width", "960",
+            "--height", "540", "--no-cpu-baseline"]
+    if n == 3:
+        args.append("--no-other-configs")
+    r, line = run_bench(*args, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == n and "gloo" in line["backend"] and line["exchange"]["kind"] == exchange
+    assert line["parity"]["mismatching_pixels"] == 0 and line["parity"]["rows"] == 540
+    assert len(line["phases"]["per_rank"]) == n and all(p["render_ms"] > 0 for p in line["phases"]["per_rank"])
+    assert line["value"] > 0 and line["value_serial"] > 0 and line["roofline"]["bound"] == "valu"
+    if n == 2:
+        oc = line["other_configs"]
+        assert [c["kernel"] for c in oc] == ["k_atmosphere", "k_planet"]
+        assert all(c["parity"]["mismatching_pixels"] == 0 and len(c["phases"]["per_rank"]) == 2 for c in oc)
+        assert all(c["exchange"]["bytes_per_peer"] < 0.7 * 12 * 7680 * 2160 for c in oc)      # spans: well under half a frame of RGB
