@@ -578,6 +578,8 @@ def dist_line(res, args, app, W, H, t, world):
             "gather": "1 RCCL gather of RGBA slabs",
             "spans": "1 grouped RCCL send/recv of the peers' packed 3-channel SPANS (the root renders its blocks and everything "
                      "outside the spans in place)"}[args.exchange]
+    if args.backend != "nccl":
+        exch = exch.replace("RCCL", "gloo (host-staged, TEST form)")
     return {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(pixels / (ms_per_step * 1e-3) / 1e6, 3),
             "unit": "Mpixels/s", "n_gpus": world, "steps": res["steps"], "warmup": res["warmup"],
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
