@@ -14,7 +14,8 @@ One-time initialisation (code-object load, APP_CLOUDS' y table, first submission
 framebuffers, RCCL peer set-up) happens once before the W warm-up steps and is not a step.
 
 N = 1 : the frame is one kernel launch.
-N > 1 : one process per GPU (torch.distributed / RCCL).  `python bench.py --gpus N` launched as a plain command starts
+N > 1 : one process per GPU (torch.distributed / RCCL; `--exchange auto` tries the span exchange and the whole-slab exchange on the
+        ranks at hand and runs the faster, `exchange.chosen` in the line).  `python bench.py --gpus N` launched as a plain command starts
         its own N ranks (re-executes itself under torch.distributed.run on 127.0.0.1); launched by torch.distributed.run
         it uses the ranks it is given.  The SAME frame is sharded as cyclic 8-row blocks (shaderbox_amd/shard.py), every
         rank renders its blocks, ONE exchange over xGMI brings the slabs to rank 0, and one small kernel scatters them to
@@ -161,8 +162,9 @@ def main():
     ap.add_argument("--gather-groups", default="auto",
                     help="N>1: issue the one exchange in this many pipelined pieces ('auto': one per ~12 MB of a peer's payload, "
                          "so a 4K slab goes out whole and an 8K one in 3 pieces; 1 = one plain exchange)")
-    ap.add_argument("--exchange", choices=["spans", "direct", "gather"], default="spans",
-                    help="N>1 (engine dist): 'spans' = only the expensive interval of every row-block is dealt to the peers and "
+    ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather"], default="auto",
+                    help="N>1 (engine dist): 'auto' (default) = try 'spans' and 'direct' on the ranks at hand (a few pipelined frames each) "
+                         "and run the faster; 'spans' = only the expensive interval of every row-block is dealt to the peers and "
                          "sent, the root renders the rest in place (distributed.py; config 5's 49.8 MB per peer become 29.7 MB); "
                          "'direct' = the root renders its blocks in place and receives the peers' whole slabs by ONE grouped "
                          "send/recv; 'gather' = dist.gather of equal RGBA slabs + assembly of all of them (round 1)")
@@ -408,28 +410,70 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     from shaderbox_amd.distributed import FramePlan
     ns = len(streams)
     br = args.block_rows
-    relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, args.exchange, args.channels)
-    payload = 0
-    if world > 1:
-        if args.exchange == "spans":
-            payload = 12 * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
-        else:
-            payload = (12 if (args.exchange == "direct" and args.channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
-    groups = auto_groups(args.gather_groups, payload)
     fdist = dist
     if args.backend == "gloo":
         from shaderbox_amd.distributed import HostStagedDist
         fdist = HostStagedDist(dist, torch)
-    plans = [FramePlan(R, fdist, W, H, br, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=args.exchange,
-                       channels=args.channels) for _ in range(ns)]
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def prepare(exchange):
+        """relief (calibrated on rank 0 for THIS exchange), payload, pieces and the ranks' plans"""
+        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, exchange, args.channels)
+        payload = 0
+        if world > 1:
+            if exchange == "spans":
+                payload = 12 * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
+            else:
+                payload = (12 if (exchange == "direct" and args.channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
+        groups = auto_groups(args.gather_groups, payload)
+        plans = [FramePlan(R, fdist, W, H, br, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=exchange,
+                           channels=args.channels) for _ in range(ns)]
+        return relief, payload, groups, plans
+
+    # `--exchange auto` (default): the span exchange sends fewer bytes but gives the root more to render; which one wins depends on
+    # what the links deliver, and that is only known on the node — so both are TRIED on the ranks at hand (a few pipelined frames
+    # each, barrier + synchronize around them, the slowest rank's time) and the faster one runs the timed region.  With one rank
+    # there is nothing to exchange: spans.
+    trials = None
+    if args.exchange != "auto":
+        exchange = args.exchange
+        relief, payload, groups, plans = prepare(exchange)
+    elif world == 1:
+        exchange = "spans"
+        relief, payload, groups, plans = prepare(exchange)
+    else:
+        trials, best = {}, None
+        for ex in ("spans", "direct"):
+            cand = prepare(ex)
+            cplans = cand[3]
+            for i in range(ns + 1):
+                with torch.cuda.stream(streams[i % ns]):
+                    cplans[i % ns].render(app, t)
+            sync()
+            t0 = time.perf_counter()
+            ktrial = 8
+            for i in range(ktrial):
+                with torch.cuda.stream(streams[i % ns]):
+                    cplans[i % ns].render(app, t)
+            sync()
+            dt = torch.tensor([(time.perf_counter() - t0) * 1e3 / ktrial], dtype=torch.float64, device=COLL_DEV or dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            trials[ex] = round(float(dt.item()), 4)
+            if best is None or trials[ex] < best[0]:
+                best = (trials[ex], ex, cand)
+            del cand, cplans
+            torch.cuda.empty_cache()
+        exchange = best[1]
+        relief, payload, groups, plans = best[2]
+        best = None
 
     def step(i=0):
         with torch.cuda.stream(streams[i % ns]):
             plans[i % ns].render(app, t)              # the rank's launch(es) + the ONE exchange + assembly on rank 0
 
-    def sync():
-        dist.barrier()
-        torch.cuda.synchronize(dev)
     for i in range(ns):                                 # builds the span layout, touches every buffer (page mapping)
         step(i)
     sync()
@@ -448,7 +492,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     frame0 = plans[0].frame
     scratch = None
     for _ in range(min(max(steps, 3), 8)):
-        if args.exchange == "spans":
+        if exchange == "spans":
             if rank == 0:
                 R.render_span_root(app, W, H, t, br, world, frame0, root_rounds=relief[0], rounds=relief[1])
             else:
@@ -460,12 +504,13 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         km.append(R.last_kernel_ms())
     del scratch
     sync()
-    mine = torch.tensor([elapsed, sum(km) / len(km), min(km), float(rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, args.exchange))],
+    mine = torch.tensor([elapsed, sum(km) / len(km), min(km), float(rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, exchange))],
                         dtype=torch.float64, device=COLL_DEV)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     phases = dist_phases(plans[0], torch, dist, dev, app, t, world, rank)
-    res = {"relief": relief, "groups": groups, "payload_bytes_per_peer": payload, "ns": ns, "steps": steps, "warmup": warmup}
+    res = {"relief": relief, "groups": groups, "payload_bytes_per_peer": payload, "ns": ns, "steps": steps, "warmup": warmup,
+           "exchange": exchange, "exchange_trials_ms": trials}
     if rank == 0:
         per = [[float(x) for x in v] for v in allr]
         slow = max(range(world), key=lambda r: per[r][1])
@@ -513,29 +558,36 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
                 R.render(a, w, h, t, out=frames[i % len(frames)])
         R.set_timing(False)
         p1 = per_frame(whole)
-        relief = choose_relief(args.root_rounds, R, OneRank, torch, dev, a, w, h, t, br, n, 0, streams, args.exchange, args.channels)
-        ch = 3 if args.exchange != "gather" else 4
-        ranks_ms = [emulated_frame_ms(R, torch, dev, streams, frames, a, w, h, t, br, n, r, relief[0], relief[1], args.exchange, ch, per_frame)
-                    for r in range(n)]
+        # 'auto': both exchange forms are modelled, the faster one is reported (what the ranks of a real node decide by trying both)
+        pick = None
+        for ex in (("spans", "direct") if args.exchange == "auto" else (args.exchange,)):
+            relief = choose_relief(args.root_rounds, R, OneRank, torch, dev, a, w, h, t, br, n, 0, streams, ex, args.channels)
+            ch = 3 if ex != "gather" else 4
+            R.set_timing(False)
+            ranks_ms = [emulated_frame_ms(R, torch, dev, streams, frames, a, w, h, t, br, n, r, relief[0], relief[1], ex, ch, per_frame)
+                        for r in range(n)]
+            if ex == "spans":
+                pix = R.span_table(a, w, h, t, br, n, relief[0], relief[1])[1]
+                payload = 12 * int(max(pix[1:]))
+            else:
+                payload = (12 if ch == 3 else 16) * w * shard.rank_rows_max(h, br, n, *relief)
+            link_peak, link_real = payload / 76.8e9 * 1e3, payload / (args.link_gbps * 1e9) * 1e3
+            modelled = max(max(ranks_ms), link_real)
+            if pick is None or modelled < pick[0]:
+                pick = (modelled, ex, relief, ch, ranks_ms, payload, link_peak, link_real)
+        modelled, exchange, relief, ch, ranks_ms, payload, link_peak, link_real = pick
         R.set_timing(True)
-        if args.exchange == "spans":
-            pix = R.span_table(a, w, h, t, br, n, relief[0], relief[1])[1]
-            payload = 12 * int(max(pix[1:]))
-        else:
-            payload = (12 if ch == 3 else 16) * w * shard.rank_rows_max(h, br, n, *relief)
-        link_peak, link_real = payload / 76.8e9 * 1e3, payload / (args.link_gbps * 1e9) * 1e3
-        modelled = max(max(ranks_ms), link_real)
         # the frame of the N-rank schedule itself (FramePlans of all ranks, loopback transfers) against one launch
         world = LoopbackWorld(n)
         plans = world.plans(R, w, h, block_rows=br, groups=auto_groups(args.gather_groups, payload), root_rounds=relief[0],
-                            rounds=relief[1], exchange=args.exchange if args.exchange != "gather" else "direct", channels=args.channels)
+                            rounds=relief[1], exchange=exchange if exchange != "gather" else "direct", channels=args.channels)
         got = LoopbackWorld.render(plans, a, t)
         ref = R.render(a, w, h, t)
         torch.cuda.synchronize(dev)
         bad = int((got.view(torch.int32) != ref.view(torch.int32)).any(dim=-1).sum().item())
         status = 3 if bad else status
         out_cfgs.append({"workload": "APP_%s %dx%d u_time=%g" % (a.upper(), w, h, t), "n1_ms_per_frame_pipelined": round(p1, 4),
-                         "relief": "%d/%d" % relief, "exchange": args.exchange, "bytes_per_peer": payload,
+                         "relief": "%d/%d" % relief, "exchange": exchange, "bytes_per_peer": payload,
                          "bytes_moved_per_frame": world.bytes_moved,
                          "link_ms_at_76p8_GBps": round(link_peak, 4), "link_ms_at_%g_GBps" % args.link_gbps: round(link_real, 4),
                          "root_ms": round(ranks_ms[0], 4), "slowest_peer_ms": round(max(ranks_ms[1:]), 4),
@@ -569,7 +621,7 @@ def dist_line(res, args, app, W, H, t, world):
     if roofline is not None:
         roofline["rank"] = "slowest (rank %d of the un-overlapped launches %s ms; %d pixels)" % (res["slowest_rank"], res["per_rank_launch_ms"],
                                                                                               res["launch_pixels"])
-        if args.exchange == "spans" and world > 1 and roofline.get("frac") is not None:
+        if res["exchange"] == "spans" and world > 1 and roofline.get("frac") is not None:
             roofline["frac_is"] += ("; NOTE a span launch renders mostly the frame's EXPENSIVE pixels, so the frame-average instruction "
                                     "count per pixel understates its work: read this frac as a lower bound")
     ph = res["phases"]
@@ -577,7 +629,7 @@ def dist_line(res, args, app, W, H, t, world):
     exch = {"direct": "1 grouped RCCL send/recv of the peers' %d-channel slabs to the root (root in place)" % args.channels,
             "gather": "1 RCCL gather of RGBA slabs",
             "spans": "1 grouped RCCL send/recv of the peers' packed 3-channel SPANS (the root renders its blocks and everything "
-                     "outside the spans in place)"}[args.exchange]
+                     "outside the spans in place)"}[res["exchange"]]
     if args.backend != "nccl":
         exch = exch.replace("RCCL", "gloo (host-staged, TEST form)")
     return {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": round(pixels / (ms_per_step * 1e-3) / 1e6, 3),
@@ -590,7 +642,9 @@ def dist_line(res, args, app, W, H, t, world):
                                       "pieces) + assemble" % (args.block_rows, world, relief[0], relief[1], exch, res["groups"])},
             "backend": "RCCL" if args.backend == "nccl" else "gloo with host-staged transfers (TEST form: ranks may share a GPU, nothing here "
                                                                 "says anything about xGMI)",
-            "exchange": {"kind": args.exchange, "bytes_per_peer": res["payload_bytes_per_peer"], "pieces": res["groups"],
+            "exchange": {"kind": res["exchange"], "chosen": "measured on these ranks: ms per pipelined frame %s" % res["exchange_trials_ms"]
+                         if res.get("exchange_trials_ms") else "as asked (--exchange)" if args.exchange != "auto" else "one rank: nothing to choose",
+                         "bytes_per_peer": res["payload_bytes_per_peer"], "pieces": res["groups"],
                          "link_ms_at_76p8_GBps": round(res["payload_bytes_per_peer"] / 76.8e9 * 1e3, 4),
                          "what": "the largest peer payload of one frame; one xGMI link per peer, 76.8 GB/s per direction at its peak"},
             "value_serial": round(pixels / (serial_ms * 1e-3) / 1e6, 3) if serial_ms else None,
