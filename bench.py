@@ -22,7 +22,12 @@ N > 1 : one process per GPU (torch.distributed / RCCL; `--exchange auto` tries t
         their rows.  Total work is fixed -> "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
         The line also carries `phases` (per rank: render_ms / exchange_wait_ms / assemble_ms of serial frames timed with
         events after the timed region) and `steady_state` (the frames completed between the end of the first burst of
-        `frames_in_flight` frames and the start of the last one, rank 0: the pipeline's rate without ramp-in and drain).
+        `frames_in_flight` frames and the start of the last one, rank 0: the pipeline's rate without ramp-in and drain),
+        `exchange` (kind, how it was chosen, bytes per peer, pieces, link time at the xGMI peak), `value_serial`, and
+        `other_configs` = BASELINE config 5 (APP_ATMOSPHERE and APP_PLANET 7680x4320) through the same schedule.
+One GPU only: `--emulate-ranks N` runs every rank's schedule through a loopback world on this device, checks the frames against
+        one launch and prints MODELLED N-GPU figures with the exchange budget; `--gpus N --backend gloo` runs the whole N-process
+        program with the ranks sharing the GPU and the transfers staged through the host (a test form: its rates mean nothing).
 
 Extra objects on the JSON line (N = 1 unless noted):
   roofline     : dominant kernel (the app's render kernel).  The path is VALU-bound (no MFMA, 16 B/pixel of HBM traffic),
@@ -47,8 +52,8 @@ Extra objects on the JSON line (N = 1 unless noted):
                  derived from the committed per-launch instruction count under profiles/ (named in `pmc_source`) at the
                  nominal clock.
   roofline_hbm : the same kernel against HBM (16 B/pixel written once): far from the bound by design.
-  serial       : Mpixels/s of one un-overlapped launch (SURVEY.md §8d defines the metric per launch; `value` has
-                 `frames_in_flight` launches overlapping).
+  serial       : Mpixels/s of one un-overlapped launch, median of 10 after 2 warm-ups (SURVEY.md §8d defines the metric per launch;
+                 `value` has `frames_in_flight` launches overlapping); also as the top-level key `value_serial`.
   parity       : rows of the timed GPU frame against the CPU oracle's rows of the same frame (the ones cpu_baseline
                  renders): max |diff| and pixels with any differing bit.  > 1e-4 -> non-zero exit status.
                  N > 1: the assembled frame against a one-launch render of the same frame on rank 0 (bit-identical).
