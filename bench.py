@@ -1017,12 +1017,14 @@ def dist_phases(plan, torch, dist, dev, app, t, world, rank, reps=5):
         dist.barrier()
         torch.cuda.synchronize(dev)
         mark("start")
+        h0 = time.perf_counter()
         plan.render(app, t, mark=mark)
+        acc.setdefault("host", []).append((time.perf_counter() - h0) * 1e3)      # what the host thread spends submitting one frame
         mark("end")
         torch.cuda.synchronize(dev)
         for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
             acc.setdefault(name, []).append(e0.elapsed_time(e1))
-    names = ["render", "exchange", "assemble", "end"]
+    names = ["render", "exchange", "assemble", "end", "host"]
     mine = torch.tensor([sum(acc.get(n, [0.0])) / max(len(acc.get(n, [0.0])), 1) for n in names], dtype=torch.float64, device=COLL_DEV or dev)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
@@ -1032,7 +1034,9 @@ def dist_phases(plan, torch, dist, dev, app, t, world, rank, reps=5):
                     "send is out / the root's receives have landed (the root posts them before its render, so this is what the "
                     "render did not hide), assemble = the root's scatter kernel",
             "per_rank": [{"rank": i, "render_ms": round(float(v[0]), 4), "exchange_wait_ms": round(float(v[1]), 4),
-                          "assemble_ms": round(float(v[2] + v[3]), 4)} for i, v in enumerate(allr)]}
+                          "assemble_ms": round(float(v[2] + v[3]), 4), "host_submit_ms": round(float(v[4]), 4)} for i, v in enumerate(allr)],
+            "host_submit_ms_is": "wall time of the host thread inside one frame's calls (launches, the grouped send / receive, waits are "
+                                 "stream-level): if it approaches ms_per_step the pipeline is bound by the host, not by the GPUs"}
 
 
 def relief_candidates(max_rounds=8):
