@@ -197,9 +197,10 @@ def main():
                     help="N>1: 'dist' = one process per GPU (torch.distributed / RCCL gather, the contract's launch shape); 'lib' = ONE "
                          "process drives the N GPUs through the library's own multi-GPU path (sbx_multi_*: RCCL send/recv per "
                          "row-block straight into the final rows, no assembly pass); with fewer GPUs than N the ranks share devices")
-    ap.add_argument("--lib-exchange", choices=["slabs", "blocks", "spans", "peer_stores"], default="slabs",
-                    help="--engine lib: 'slabs' = one send/receive per peer of its whole 3-channel slab + one scatter kernel on the "
-                         "root (default); 'blocks' = one send/receive pair per row-block straight into the final rows (round 2)")
+    ap.add_argument("--lib-exchange", choices=["slabs", "blocks", "spans", "peer_stores"], default="spans",
+                    help="--engine lib: 'spans' (default) = the span exchange inside the library; 'slabs' = one send/receive per peer of its "
+                         "whole 3-channel slab + one scatter kernel on the root; 'blocks' = one send/receive pair per row-block straight "
+                         "into the final rows (round 2); 'peer_stores' = every rank stores into rank 0's frame through peer access")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="ONE GPU, no process group: run the N-rank schedule of the headline and of config 5 through a loopback world "
                          "(every rank's real FramePlan, kernels, span tables, assembly on this device), check the frames against one "
