@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.backend == "gloo" and args.exchange == "gather":
+        raise SystemExit("--backend gloo stages point-to-point transfers only: use --exchange auto, spans or direct")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.engine == "lib" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         claim_stdout()
