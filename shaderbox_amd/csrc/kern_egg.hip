@@ -25,8 +25,12 @@ namespace sbx {
 // Is everything but the ground plane farther away than the ground?  Every other member of the union is
 // >= .7 * (|p - oc| - orad) (FrameEgg, built in sbx_capi.hip), so with K = 1.43 (ground + 1e-3) + orad (1.43 > 1/.7),
 // |p - oc| > K puts all of them strictly above the ground's distance: sdf() is the ground plane, exactly.
-__device__ __forceinline__ bool egg_far(const FrameEgg& F, v3 p, float ground_d) {
-    const v3 q = p - F.oc;
+// The test runs on the WORLD point P against the centre carried to world space (FrameEgg.ocw): |P - ocw| is |p - oc| up to the 1e-6
+// by which a rounded rotation matrix changes a length, far inside the 0.1 % by which 1.43 exceeds 1 / .7 — so a point that is far
+// never pays for the turntable rotation (round 4: the culled call is ~28 instead of ~45 instructions; sky and ground waves are
+// mostly such calls).  Any valid cull returns the same bits: it only ever claims what the full union would have returned.
+__device__ __forceinline__ bool egg_far(const FrameEgg& F, v3 P, float ground_d) {
+    const v3 q = P - F.ocw;
     const float K = (ground_d + 1e-3f) * 1.43f + F.orad;
     return ground_d >= 0.f && dot(q, q) > K * K;
 }
@@ -34,12 +38,12 @@ __device__ __forceinline__ bool egg_far(const FrameEgg& F, v3 p, float ground_d)
 // CULL = false (sbx_set_variant 1) evaluates every member everywhere: the reference form, kept for the parity sweeps
 template <bool CULL>
 __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
-    const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                         // :40-41
     const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
     {
         const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};       // sd_plane :136-138
-        if (CULL && egg_far(F, p, ground.d)) return ground;
+        if (CULL && egg_far(F, P, ground.d)) return ground;
     }
+    const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                         // :40-41
     // Members are evaluated cheapest first with a running minimum `dmin`; a member whose lower bound exceeds it
     // cannot be the union's result and enters as +inf (op_add2 is a strict `<`, so the winner and its material
     // are unchanged).  Lower bounds (all with >= 1e-3 of slack over the rounding of the evaluation itself):
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     if (EGG_VCONST) {
         asm volatile("" : "+v"(F.rot_y.c0.x), "+v"(F.rot_y.c0.y), "+v"(F.rot_y.c0.z), "+v"(F.rot_y.c1.x), "+v"(F.rot_y.c1.y),
                           "+v"(F.rot_y.c1.z), "+v"(F.rot_y.c2.x), "+v"(F.rot_y.c2.y), "+v"(F.rot_y.c2.z));
-        asm volatile("" : "+v"(F.oc.x), "+v"(F.oc.y), "+v"(F.oc.z), "+v"(F.orad));
+        asm volatile("" : "+v"(F.ocw.x), "+v"(F.ocw.y), "+v"(F.ocw.z), "+v"(F.orad));
     }
     int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     if (EGG_HOT_FIRST && hot.w > 0) hot_first_tile(hot, (int)gridDim.x, bx, by);          // wave-uniform

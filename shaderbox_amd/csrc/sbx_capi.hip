@@ -213,6 +213,7 @@ static FrameEgg build_egg(const sbx_uniforms& U) {
     for (int i = 0; i < 8; ++i) R = fmax_(R, length(cs[i] - c) + rs[i]);
     F.oc = c;
     F.orad = R * 1.001f + 1e-3f;
+    F.ocw = mul(transpose(F.rot_y), c + V3(0, 0.5f, 3.5f));        // p = rot_y P - (0, .5, 3.5)  <=>  P = rot_y^T (p + (0, .5, 3.5))
     return F;
 }
 

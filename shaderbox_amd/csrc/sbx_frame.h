@@ -147,6 +147,7 @@ struct FrameEgg {
     CylFrame foot_l, foot_r;    //                                      app_egg.h:120-128
     v3 foot_ml, foot_mr;        // midpoints of the toe cylinders in p space: -foot - toe/16 (kern_egg.hip)
     v3 oc; float orad;          // sphere around everything but the ground plane, in sdf()'s p space (kern_egg.hip egg_far)
+    v3 ocw;                     // the same centre in WORLD space, rot_y^T (oc + (0, .5, 3.5)): the cull test needs no rotation
 };
 
 // ---- APP_RAYTRACER (src/app_raytracer.h, cornell_box.h) -------------------------------------
