@@ -36,8 +36,9 @@ __device__ __forceinline__ bool egg_far(const FrameEgg& F, v3 P, float ground_d)
 }
 
 // CULL = false (sbx_set_variant 1) evaluates every member everywhere: the reference form, kept for the parity sweeps
-template <bool CULL>
-__device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
+// W: the square roots' witness (sbx_sdf.h): Wit<true> takes the five-instruction roots and records arguments outside their domain
+template <bool CULL, class W>
+__device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P, W& w) {
     const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
     {
         const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};       // sd_plane :136-138
@@ -62,7 +63,7 @@ __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
     {
         const float K = dmin * 1.001f + (1.03f + 2e-3f);
         if (!(pos_d && dot(pw, pw) > K * K))
-            bike.d = length(V2(length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f;              // sd_torus sdf.h:75-83
+            bike.d = w.length(V2(w.length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f;              // sd_torus sdf.h:75-83
     }
     dmin = fmin_(dmin, bike.d);
 
@@ -71,8 +72,8 @@ __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
     {
         const float K = (dmin + (.0625f + .05f + 1e-3f)) * 1.4143f + 1e-3f;
         const v3 ql = p - F.foot_ml, qr = p - F.foot_mr;
-        if (!(pos_d && dot(ql, ql) > K * K)) left_foot.d = sd_cylinder0(F.foot_l, p + F.left_foot, thick);     // :120-123
-        if (!(pos_d && dot(qr, qr) > K * K)) right_foot.d = sd_cylinder0(F.foot_r, p + F.right_foot, thick);   // :125-128
+        if (!(pos_d && dot(ql, ql) > K * K)) left_foot.d = sd_cylinder0<false>(F.foot_l, p + F.left_foot, thick, w);     // :120-123
+        if (!(pos_d && dot(qr, qr) > K * K)) right_foot.d = sd_cylinder0<false>(F.foot_r, p + F.right_foot, thick, w);   // :125-128
     }
     const D2 feet = op_add2(left_foot, right_foot);
     dmin = fmin_(dmin, feet.d);
@@ -83,9 +84,9 @@ __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
         const v3 qe = p - V3(0, egg_y, 0);
         const float K = dmin * 1.001f + (.95f + 3e-3f);
         if (!(pos_d && dot(qe, qe) > K * K)) {
-            const float egg_m = length(p - V3(0, egg_y, 0)) - 0.475f;                  // :47-49
-            const float egg_b = length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
-            const float egg_t = length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
+            const float egg_m = w.length(p - V3(0, egg_y, 0)) - 0.475f;                  // :47-49
+            const float egg_b = w.length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
+            const float egg_t = w.length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
             const float egg_1 = op_blend(egg_m, egg_b, .5f);
             egg.d = op_blend(egg_1, egg_t, .5f);
         }
@@ -94,19 +95,19 @@ __device__ __forceinline__ D2 egg_sdf(const FrameEgg& F, v3 P) {
 
     const D2 _1 = op_add2(feet, bike);
     const D2 _2 = op_add2(egg, _1);
-    const float leg_l = (CULL && bezier_far(F.leg_l, p, thick, dmin)) ? inf : sd_bezier_x(F.leg_l, p, thick);     // :102-118
-    const float leg_r = (CULL && bezier_far(F.leg_r, p, thick, dmin)) ? inf : sd_bezier_x(F.leg_r, p, thick);
+    const float leg_l = (CULL && bezier_far(F.leg_l, p, thick, dmin)) ? inf : sd_bezier_x(F.leg_l, p, thick, w);     // :102-118
+    const float leg_r = (CULL && bezier_far(F.leg_r, p, thick, dmin)) ? inf : sd_bezier_x(F.leg_r, p, thick, w);
     const D2 legs = op_add2(D2{leg_l, mat_egg}, D2{leg_r, mat_egg});
     const D2 _3 = op_add2(legs, _2);
     return op_add2(ground, _3);
 }
 
-template <bool CULL>
-__device__ __forceinline__ float egg_shadowmarch(const FrameEgg& F, v3 ro, v3 rd) {   // :161-186
+template <bool CULL, class W>
+__device__ __forceinline__ float egg_shadowmarch(const FrameEgg& F, v3 ro, v3 rd, W& w) {   // :161-186
     float t = 0.f, umbra = 1.f;
     for (int i = 0; i < 20; ++i) {
         const v3 p = ro + rd * t;
-        const D2 d = egg_sdf<CULL>(F, p);
+        const D2 d = egg_sdf<CULL>(F, p, w);
         if (t > 10.f) break;
         if (d.d < 0.001f) return 0.1f;
         t += d.d;
@@ -155,12 +156,63 @@ __device__ __forceinline__ void hot_first_tile(const HotRect& R, int gx, int& bx
     bx = c - (c / gx) * gx;
 }
 
-template <bool CULL>
+#ifndef EGG_WITNESS
+#define EGG_WITNESS 1      // five-instruction square roots with a recorded domain (sbx_sdf.h Wit): 0 = the IEEE roots only
+#endif
+
+// One pixel up to (colour, depth) — render_scene :190-231 — with the roots of witness `w`
+template <bool CULL, class W>
+__device__ __forceinline__ void egg_pixel(const FrameEgg& F, v3 ro, v3 rd, W& w, v3& color, float& depth, int& st_trace, int& st_shadow) {
+    depth = -1e8f;                                          // :188, fresh per pixel
+    color = V3(.1f, .1f, .7f);                              // background :9-12
+    st_trace = 0; st_shadow = 0;
+    float t = 0.f;
+    // The trace only FINDS the hit; what the reference does inside the loop at the hit (`:205-228`: depth, the 20-step shadow
+    // march of ground pixels, the flat colours, `break`) runs after the loop, once per wave with all of its hit lanes, instead of
+    // once per distinct hit iteration of the wave with the few lanes that hit in that iteration.  Per lane the same operations
+    // on the same values in the same order.  1920x1080: 0.54 -> 0.27 ms.  (Trace and shadow march as ONE loop around one copy of
+    // the sdf — lanes with a ground hit start their shadow march while neighbours still trace —
+    // is slower: 0.283 vs 0.273 ms, 4K 0.68 vs 0.64; the per-lane phase logic costs more than the shorter waves save.)
+    bool hit = false;
+    int mat = 0;
+    v3 hp = V3(0, 0, 0);
+    for (int i = 0; i < 80; ++i) {                          // render_scene :190-231
+        if (EGG_PRIO_STEP > 0 && i == EGG_PRIO_STEP) __builtin_amdgcn_s_setprio(EGG_PRIO);   // a long wave: ahead of the short ones on its SIMD
+        const v3 p = ro + rd * t;
+        const D2 d = egg_sdf<CULL>(F, p, w);
+        if (t > 15.f) break;
+        if (d.d < 0.001f) { hit = true; mat = (int)d.m; hp = p; break; }
+        t += d.d;
+#ifdef SBX_EGG_STATS
+        ++st_trace;
+#endif
+    }
+#ifdef SBX_EGG_STATS
+    if (hit && mat == 3) st_shadow = 1;
+#endif
+    if (hit) {
+        if (mat == 1 || mat == 2) depth = fmax_(depth, hp.z);
+        float s = 1.f;
+        if (mat == 3) {
+            const v3 sh_dir = V3(0, 1, 1);
+            s = egg_shadowmarch<CULL>(F, hp + sh_dir * 0.05f, sh_dir, w);
+        }
+        v3 base = V3(1, 1, 1);                              // illuminate :29-35
+        if (mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
+        else if (mat == 1) base = V3(0.9f, 0.95f, 0.95f);
+        else if (mat == 2) base = V3(.2f, .2f, .2f);
+        color = base * s;
+    }
+}
+
+// WIT: 0 = IEEE roots; 1 = witnessed roots (the shipped form); 2 = the same with the witness's lower edge at 1.0, so that waves
+// near any primitive's axis DO record and re-run (sbx_set_variant 2: the test of the re-run path — same frame required)
+template <bool CULL, int WIT>
 __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float* __restrict__ out, HotRect hot) {
 #ifdef SBX_EGG_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();      // census build (tools/egg_census.py): 100 MHz counter
-    int st_trace = 0, st_shadow = 0;
 #endif
+    int st_trace = 0, st_shadow = 0;
 #ifndef EGG_VCONST
 #define EGG_VCONST 1       // the constants every sdf() call starts with — the turntable rotation and the cull sphere — in VGPRs: a VALU
 #endif                     // instruction with an SGPR source issues at half rate on gfx950 (profiles/r02_ubench_issue.txt)
@@ -179,44 +231,19 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
 
-    float depth = -1e8f;                                    // :188, fresh per pixel
-    v3 color = V3(.1f, .1f, .7f);                           // background :9-12
-    float t = 0.f;
-    // The trace only FINDS the hit; what the reference does inside the loop at the hit (`:205-228`: depth, the 20-step shadow
-    // march of ground pixels, the flat colours, `break`) runs after the loop, once per wave with all of its hit lanes, instead of
-    // once per distinct hit iteration of the wave with the few lanes that hit in that iteration.  Per lane the same operations
-    // on the same values in the same order.  1920x1080: 0.54 -> 0.27 ms.  (Trace and shadow march as ONE loop around one copy of
-    // the sdf — lanes with a ground hit start their shadow march while neighbours still trace —
-    // is slower: 0.283 vs 0.273 ms, 4K 0.68 vs 0.64; the per-lane phase logic costs more than the shorter waves save.)
-    bool hit = false;
-    int mat = 0;
-    v3 hp = V3(0, 0, 0);
-    for (int i = 0; i < 80; ++i) {                          // render_scene :190-231
-        if (EGG_PRIO_STEP > 0 && i == EGG_PRIO_STEP) __builtin_amdgcn_s_setprio(EGG_PRIO);   // a long wave: ahead of the short ones on its SIMD
-        const v3 p = ro + rd * t;
-        const D2 d = egg_sdf<CULL>(F, p);
-        if (t > 15.f) break;
-        if (d.d < 0.001f) { hit = true; mat = (int)d.m; hp = p; break; }
-        t += d.d;
-#ifdef SBX_EGG_STATS
-        ++st_trace;
-#endif
-    }
-#ifdef SBX_EGG_STATS
-    if (hit && mat == 3) st_shadow = 1;
-#endif
-    if (hit) {
-        if (mat == 1 || mat == 2) depth = fmax_(depth, hp.z);
-        float s = 1.f;
-        if (mat == 3) {
-            const v3 sh_dir = V3(0, 1, 1);
-            s = egg_shadowmarch<CULL>(F, hp + sh_dir * 0.05f, sh_dir);
+    float depth;
+    v3 color;
+    if (WIT != 0) {
+        Wit<true> w;
+        if (WIT == 2) w.lo = 0x3F800000u;
+        egg_pixel<CULL>(F, ro, rd, w, color, depth, st_trace, st_shadow);
+        if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {      // some lane took a root outside the proved interval: the IEEE forms
+            Wit<false> w0;
+            egg_pixel<CULL>(F, ro, rd, w0, color, depth, st_trace, st_shadow);
         }
-        v3 base = V3(1, 1, 1);                              // illuminate :29-35
-        if (mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
-        else if (mat == 1) base = V3(0.9f, 0.95f, 0.95f);
-        else if (mat == 2) base = V3(.2f, .2f, .2f);
-        color = base * s;
+    } else {
+        Wit<false> w0;
+        egg_pixel<CULL>(F, ro, rd, w0, color, depth, st_trace, st_shadow);
     }
     // bars overlay :233-251
     const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);
@@ -284,8 +311,10 @@ void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, i
     const dim3 grid = grid_for<EGG_TW, EGG_TX>(M);
     const HotRect hot = egg_hot_rect(F, M, grid);
     static const int pad = []() { const char* e = std::getenv("SBX_DEBUG_LDS_PAD"); return e ? std::atoi(e) : EGG_LDS_PAD; }();
-    if (variant == 1) hipLaunchKernelGGL(k_egg<false>, grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
-    else hipLaunchKernelGGL(k_egg<true>, grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
+    if (variant == 1) hipLaunchKernelGGL((k_egg<false, 0>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
+    else if (variant == 2) hipLaunchKernelGGL((k_egg<true, 2>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
+    else if (variant == 3) hipLaunchKernelGGL((k_egg<true, 0>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
+    else hipLaunchKernelGGL((k_egg<true, EGG_WITNESS>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
 }
 
 }  // namespace sbx

@@ -27,6 +27,7 @@ struct sbx_ctx {
     int device = 0;
     bool timing = false;
     int variant = 0;
+    int sdf_roots = 0;                     // sbx_set_variant 2 / 3: the SDF kernels' square-root witness test build / IEEE roots
     // APP_CLOUDS y tables: CLOUDS_YTAB_RING slots for eager launches + CLOUDS_YTAB_CAPTURE slots that only launches
     // recorded into a stream capture use (a captured graph bakes the slot pointer in, so eager rebuilds must never
     // touch it, and the build is always part of the graph).
@@ -605,7 +606,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
                                                     // a captured launch is replayed later, possibly over volumes re-bound in place with
                                                     // other texel ranges: no bounds baked into a graph (the plain exp_ / IEEE divide)
                                                     (ctx->tex_bounds_valid && !capturing) ? ctx->tex_bounds : nullptr); break;
-    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, cull_variant); break;
+    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, cull_variant == 1 ? 1 : ctx->sdf_roots); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
     case SBX_APP_SDF_AO: {
@@ -1144,8 +1145,9 @@ int sbx_pack_unorm8(sbx_ctx* ctx, int width, int rows, const float* rgba, unsign
 
 int sbx_set_variant(sbx_ctx* ctx, int variant) {
     if (!ctx) return SBX_ERR_ARG;
-    if (variant < 0 || variant > 1) return fail(ctx, SBX_ERR_ARG, "unknown kernel variant");
-    ctx->variant = variant;
+    if (variant < 0 || variant > 3) return fail(ctx, SBX_ERR_ARG, "unknown kernel variant");
+    ctx->variant = variant == 1 ? 1 : 0;
+    ctx->sdf_roots = variant >= 2 ? variant : 0;
     return SBX_OK;
 }
 int sbx_set_timing(sbx_ctx* ctx, int enabled) {

@@ -6,6 +6,28 @@
 namespace sbx {
 
 struct D2 { float d, m; };   // (distance, material id); op_add keeps the nearer              sdf.h:5-11
+
+// WITNESSED SQUARE ROOTS (round 4).  The compiler's IEEE sqrt is 16 VALU instructions (input scaling for tiny arguments, v_sqrt_f32,
+// a two-sided one-ulp fix-up, a class test for 0 / inf); sqrt_rs_ (sbx_math.h) is 5 and EQUAL to it for every argument in
+// [2^-102, +inf) — all of them were run (profiles/r03_sqrt_rsq_exhaustive.txt) — but returns NaN for 0 and +inf and is inexact
+// below 2^-102.  A squared length in an SDF is none of those except ON a primitive's axis or centre, which no kernel can rule out
+// for an arbitrary frame.  So a lane RECORDS every argument outside the proved interval (two integer instructions, the flag
+// accumulates in an SGPR pair) and the kernel, after its whole pixel, re-runs the pixel with the IEEE forms if any lane of the wave
+// recorded one (wave-uniform branch; never taken on the frames measured).  No branch inside the SDF — a per-lane choice between
+// the forms at each root cost more than it saved (sbx_math.h, sqrt_n_) — and a pixel's bits are the IEEE forms' either way:
+// without a record every root it took is one of the exhaustively compared ones.
+// Wit<false> is the plain form (no record), what every caller without a witness gets.
+template <bool FAST> struct Wit {
+    bool bad = false;
+    unsigned lo = 0x0C800000u;                                   // 2^-102; the test build raises it (k_egg<., 2>) to exercise the re-run
+    __device__ __forceinline__ float sqrt(float x) {
+        if (!FAST) return sqrt_(x);
+        bad |= (f2u(x) - lo) >= (0x7F800000u - lo);              // 0, tiny, +inf, NaN, negative: all outside [lo, +inf)
+        return sqrt_rs_(x);
+    }
+    __device__ __forceinline__ float length(v2 v) { return sqrt(dot(v, v)); }
+    __device__ __forceinline__ float length(v3 v) { return sqrt(dot(v, v)); }
+};
 __device__ __forceinline__ D2 op_add2(D2 a, D2 b) { return a.d < b.d ? a : b; }
 
 __device__ __forceinline__ float op_blend(float a, float b, float k) {                         // sdf.h:38-47
@@ -38,7 +60,8 @@ __device__ __forceinline__ float sd_y_cylinder(v3 p, float r, float h) {        
 __device__ __forceinline__ float det2(v2 a, v2 b) { return a.x * b.y - b.x * a.y; }             // sdf.h:114-119
 
 // sd_bezier(a, b, c, p, thickness).x, point-dependent part (frame = bezier_frame(a, b, c))    sdf.h:120-159
-__device__ __forceinline__ float sd_bezier_x(const BezierFrame& B, v3 p, float thickness) {
+template <class W>
+__device__ __forceinline__ float sd_bezier_x(const BezierFrame& B, v3 p, float thickness, W& w) {
     const v3 q = p - B.b;
     const v3 p3 = V3(dot(q, B.u), dot(q, B.v), dot(q, B.w));
     const v2 pxy = V2(p3.x, p3.y);
@@ -56,7 +79,11 @@ __device__ __forceinline__ float sd_bezier_x(const BezierFrame& B, v3 p, float t
     const float bp = 2.0f * det2(d10, d0p);
     const float t = clamp_((ap + bp) / (2.0f * a + b + d), 0.0f, 1.0f);
     const v2 cp = mix2(mix2(b0, b1, t), mix2(b1, b2, t), t);
-    return 0.85f * (sqrt_(dot(cp, cp) + p3.z * p3.z) - thickness);
+    return 0.85f * (w.sqrt(dot(cp, cp) + p3.z * p3.z) - thickness);
+}
+__device__ __forceinline__ float sd_bezier_x(const BezierFrame& B, v3 p, float thickness) {
+    Wit<false> w;
+    return sd_bezier_x(B, p, thickness, w);
 }
 // Can the tube be left out of a union whose other members already give distance dmin >= 0 at p?  sd_bezier returns
 // .85 * (D - thickness) with D the distance from p to a point of the curve, and the curve lies inside the sphere
@@ -70,12 +97,17 @@ __device__ __forceinline__ bool bezier_far(const BezierFrame& B, v3 p, float thi
     return dmin >= 0.f && dot(q, q) > K * K;
 }
 // sd_cylinder(P, 0, P1, R), point-dependent part (frame = cyl_frame(0, P1))                    sdf.h:95-109
-template <bool HW = false>      // (HW: dist = a length is never -0 and the negated planes are second operands)
-__device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) {
-    const float dist = length(cross(C.dir, P - V3(0.f, 0.f, 0.f)));
+template <bool HW, class W>      // (HW: dist = a length is never -0 and the negated planes are second operands)
+__device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R, W& w) {
+    const float dist = w.length(cross(C.dir, P - V3(0.f, 0.f, 0.f)));
     const float plane_1 = dot(C.dir, P) + C.len1;
     const float plane_2 = dot(-C.dir, P) + (-C.len0);
     return hmax_neg_<HW>(hmax_neg_<HW>(dist, plane_1), plane_2) - R;   // op_sub(op_sub(dist, p1), p2) - R
+}
+template <bool HW = false>
+__device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) {
+    Wit<false> w;
+    return sd_cylinder0<HW>(C, P, R, w);
 }
 // sd_capsule(p, a, b, r) with ab = b - a and rd = recip64(dot(ab, ab)) from the frame         sdf.h:162-171
 __device__ __forceinline__ float sd_capsule_f(v3 p, v3 a, v3 ab, double rd, float r) {

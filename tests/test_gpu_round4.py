@@ -511,3 +511,30 @@ def test_span_entry_points_reject_bad_arguments(renderer):
         with torch.cuda.graph(g2, stream=s):
             assert lib.sbx_render_span_root(ctx, app, ctypes.byref(u2), None, 8, 1, 1, 1, ctypes.c_void_p(frame2.data_ptr()),
                                             ctypes.c_void_p(s.cuda_stream)) in (0, shaderbox_amd.SBX_ERR_ARG)
+
+
+def test_egg_witnessed_square_roots(renderer, oracle):
+    """k_egg takes sqrt_rs_ (five instructions, equal to the IEEE root on [2^-102, inf) by exhaustion) and records any argument
+    outside that interval; a wave with a record re-runs its pixels with the IEEE roots (csrc/sbx_sdf.h Wit).  Variant 2 raises the
+    recording edge to 1.0, so every wave near a primitive re-runs; variant 3 is the culled kernel with the IEEE roots only;
+    variant 1 the plain kernel.  All four and the oracle: the same bits, over poses, odd sizes and mouse positions."""
+    from oracle.oracle import APP_EGG
+    rng = np.random.default_rng(77)
+    cases = [(240, 135, .37, (0.0, 0.0)), (333, 187, 2.9, (100.0, 20.0))]
+    cases += [(int(rng.integers(64, 400)), int(rng.integers(48, 260)), float(rng.uniform(0, 40)),
+               (float(rng.uniform(0, 300)), float(rng.uniform(0, 200)))) for _ in range(10)]
+    try:
+        for i, (w, h, t, mouse) in enumerate(cases):
+            frames = []
+            for v in (0, 2, 3, 1):
+                renderer.set_variant(v)
+                frames.append(renderer.render("egg", w, h, t, mouse=mouse).cpu().numpy())
+            for v, f in zip((2, 3, 1), frames[1:]):
+                assert compare(frames[0], f) == (0.0, 0), (v, w, h, t, mouse)
+            if i < 4:
+                assert compare(frames[0], oracle.render(APP_EGG, w, h, t, mouse=mouse)) == (0.0, 0), (w, h, t, mouse)
+    finally:
+        renderer.set_variant(0)
+    with pytest.raises(Exception):
+        renderer.set_variant(4)
+    renderer.set_variant(0)
