@@ -261,8 +261,9 @@ int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms);
 /* Diagnostic knob: 0 = default kernels; 1 = the plain cross-check kernels where one exists: APP_CLOUDS with every
  * lane hashing its own lattice corners (no cache, no staging, no tables); APP_EGG / APP_SDF_AO / APP_VINYL with every
  * member of the SDF union evaluated everywhere (no culling); APP_PLANET without its exact skips.
- * 2 / 3 = the default kernels, except APP_EGG: 2 = its square-root witness with the recording edge raised to 1.0, so that the
- * re-run path (csrc/sbx_sdf.h, Wit) executes on ordinary frames; 3 = the culled kernel with the IEEE roots only.
+ * 2 / 3 = the default kernels, except APP_EGG / APP_SDF_AO / APP_VINYL(_GPU): 2 = their square-root witness with the recording
+ * edge raised to 1.0, so that the re-run path (csrc/sbx_sdf.h, Wit) executes on ordinary frames; 3 = the culled kernels with the
+ * IEEE roots only.
  * All variants are specified to produce identical bits (tests/test_gpu_parity.py sweeps them against each other). */
 int sbx_set_variant(sbx_ctx* ctx, int variant);
 

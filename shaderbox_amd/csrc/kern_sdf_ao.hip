@@ -19,20 +19,20 @@ namespace sbx {
 #ifndef AO_HW_MINMAX
 #define AO_HW_MINMAX 1
 #endif
-template <bool HW>
-__device__ __forceinline__ D2 ao_sdf_pipe(const FrameSdfAo& F, v3 pos) {                          // :54-113
+template <bool HW, class W>      // W: the square roots' witness (sbx_sdf.h Wit)
+__device__ __forceinline__ D2 ao_sdf_pipe(const FrameSdfAo& F, v3 pos, W& w) {                          // :54-113
     const v3 size = V3(1.3f, 1.f, 1.25f);                                                          // :52
     v3 p = pos - V3(0, size.y, 0);
     const float b = sd_box<HW>(p, size);
     p = p - V3(.7f, .5f, 0);
     p = mul(p, F.rx_m90);
-    const float c = sd_y_cylinder<HW>(p, size.y + .55f, 2.f * size.z + .1f);
+    const float c = sd_y_cylinder<HW>(p, size.y + .55f, 2.f * size.z + .1f, w);
     const D2 pipe = {hmax_neg_<HW>(b, c), 2.f};                                                           // op_sub, mat_pipe
 
     p = pos - V3(0, size.y, 0);
     p = p - V3(-size.x + .525f, size.y, 0);
     p = mul(p, F.rx_m90);
-    const D2 coping = {sd_y_cylinder<HW>(p, .025f, 2.f * size.z), 5.f};                                // mat_coping
+    const D2 coping = {sd_y_cylinder<HW>(p, .025f, 2.f * size.z, w), 5.f};                                // mat_coping
 
     p = pos - V3(0, size.y * 2.f, 0);
     const float rail = sd_box<HW>(p + V3(size.x, -.25f, 0), V3(.025f, .05f, size.z));
@@ -66,8 +66,8 @@ __device__ __forceinline__ bool ao_pipe_far(v3 s, float dmin) {
     return dmin >= 0.f && lb > dmin * 1.001f + 2e-3f;
 }
 
-template <bool CULL>   // false (sbx_set_variant 1): both ramps evaluated everywhere, the reference form
-__device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos) {                                // :115-150
+template <bool CULL, class W>   // CULL false (sbx_set_variant 1): both ramps evaluated everywhere, the reference form
+__device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos, W& w) {                                // :115-150
     constexpr bool HW = CULL && AO_HW_MINMAX;
     const v3 size = V3(1.3f, 1.f, 1.25f);
     const float B = .15f;
@@ -79,26 +79,26 @@ __device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos) {             
     const float inf = u2f(0x7f800000u);
     const v3 s1 = p + V3(1.25f * size.x, 0, 0);
     D2 pipe1 = {inf, 2.f};
-    if (!(CULL && ao_pipe_far(s1, dmin))) pipe1 = ao_sdf_pipe<HW>(F, s1);
+    if (!(CULL && ao_pipe_far(s1, dmin))) pipe1 = ao_sdf_pipe<HW>(F, s1, w);
     p = p - V3(1.25f * size.x, 0, 0);
     p = mul(p, F.ry_180);
     D2 pipe2 = {inf, 2.f};
-    if (!(CULL && ao_pipe_far(p, dmin))) pipe2 = ao_sdf_pipe<HW>(F, p);
+    if (!(CULL && ao_pipe_far(p, dmin))) pipe2 = ao_sdf_pipe<HW>(F, p, w);
     const D2 pipe = op_add2(pipe1, pipe2);
     const D2 g = op_add2(ground, ref);
     const D2 b = op_add2(pipe, bottom);
     return op_add2(b, g);
 }
 
-template <bool CULL>
-__global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo F, RowMap M, float* __restrict__ out) {
-    const Pixel px = pixel_of_thread(M);
-    if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, px.fx, px.fy);
-    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
+#ifndef AO_WITNESS
+#define AO_WITNESS 1       // witnessed five-instruction square roots (sbx_sdf.h Wit), as in k_egg: 0 = the IEEE roots only
+#endif
 
-    v3 rgb = V3(.1f, .1f, .7f);                                   // background :9-12
-    float t = 0.f;
+// One pixel up to (rgb, t) — render_impl :245-285 — with the roots of witness `w`
+template <bool CULL, class W>
+__device__ __forceinline__ void ao_pixel(const FrameSdfAo& F, v3 ro, v3 rd, W& w, v3& rgb, float& t) {
+    rgb = V3(.1f, .1f, .7f);                                      // background :9-12
+    t = 0.f;
     // The trace only FINDS the hit; the reference's hit block (`:258-281`: 6-tap normal, 5-tap AO, lights, material, `break`)
     // runs after the loop, once per wave with all of its hit lanes instead of once per distinct hit iteration of the wave.
     // Per lane the same operations on the same values in the same order.
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
     v3 p = V3(0, 0, 0);
     for (int i = 0; i < 70; ++i) {                                // render_impl :245-285
         const v3 pi = ro + rd * t;
-        const D2 d = ao_sdf<CULL>(F, pi);
+        const D2 d = ao_sdf<CULL>(F, pi, w);
         if (t > 20.f) break;
         if (d.d < .005f) { hit = true; mat = (int)d.m; p = pi; break; }
         t += d.d;
@@ -117,14 +117,14 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
             // sdf_normal :152-163
             const float e = 0.001f;
             const v3 n = normalize(V3(
-                ao_sdf<CULL>(F, p + V3(e, 0, 0)).d - ao_sdf<CULL>(F, p - V3(e, 0, 0)).d,
-                ao_sdf<CULL>(F, p + V3(0, e, 0)).d - ao_sdf<CULL>(F, p - V3(0, e, 0)).d,
-                ao_sdf<CULL>(F, p + V3(0, 0, e)).d - ao_sdf<CULL>(F, p - V3(0, 0, e)).d));
+                ao_sdf<CULL>(F, p + V3(e, 0, 0), w).d - ao_sdf<CULL>(F, p - V3(e, 0, 0), w).d,
+                ao_sdf<CULL>(F, p + V3(0, e, 0), w).d - ao_sdf<CULL>(F, p - V3(0, e, 0), w).d,
+                ao_sdf<CULL>(F, p + V3(0, 0, e), w).d - ao_sdf<CULL>(F, p - V3(0, 0, e), w).d));
             // sdf_ao :165-181
             float occlusion = 0.f, inv2k = 1.f;
             for (float k = 1.f; k <= 5.f; k += 1.f) {
                 const v3 q = p + .5f * k * n;
-                const float dd = ao_sdf<CULL>(F, q).d;
+                const float dd = ao_sdf<CULL>(F, q, w).d;
                 // pow(2, k) of the math spec is exactly 2^k for k = 1..5 (log2(2) = 1 and 2^integer are exact in its
                 // binary64 sequence), so 1 / pow(2, k) is the exact power of two below
                 inv2k *= .5f;
@@ -151,6 +151,28 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
             rgb = accum * mat_c;
         }
     }
+}
+
+template <bool CULL, int WIT>      // WIT: 0 IEEE roots, 1 witnessed roots, 2 the witness's test edge (sbx_set_variant 2), as k_egg
+__global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo F, RowMap M, float* __restrict__ out) {
+    const Pixel px = pixel_of_thread(M);
+    if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
+    v3 rgb;
+    float t;
+    if (WIT != 0) {
+        Wit<true> w;
+        if (WIT == 2) w.lo = 0x3F800000u;
+        ao_pixel<CULL>(F, ro, rd, w, rgb, t);
+        if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {
+            Wit<false> w0;
+            ao_pixel<CULL>(F, ro, rd, w0, rgb, t);
+        }
+    } else {
+        Wit<false> w0;
+        ao_pixel<CULL>(F, ro, rd, w0, rgb, t);
+    }
     // fog :287-311 (t is the march length at exit)
     const float fog_factor = F.fog_density * exp_(-ro.y * F.fog_falloff)
                            * (1.f - exp_(-t * rd.y * F.fog_falloff))
@@ -160,8 +182,10 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
 }
 
 void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant) {
-    if (variant == 1) hipLaunchKernelGGL(k_sdf_ao<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
-    else hipLaunchKernelGGL(k_sdf_ao<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    if (variant == 1) hipLaunchKernelGGL((k_sdf_ao<false, 0>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else if (variant == 2) hipLaunchKernelGGL((k_sdf_ao<true, 2>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else if (variant == 3) hipLaunchKernelGGL((k_sdf_ao<true, 0>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL((k_sdf_ao<true, AO_WITNESS>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

@@ -46,24 +46,24 @@ __device__ __forceinline__ float vinyl_logo(const FrameVinyl& F, v3 pos, float t
     const float x = sd_box<HW>(pos, V3(1.5f, thick, 1.35f));
     return hmax_<HW>(hmin_<HW>(v1, v2), x);                              // op_intersect(op_add(v1, v2), x)
 }
-template <bool HW>
-__device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {                       // :87-125
+template <bool HW, class W>      // W: the square roots' witness (sbx_sdf.h Wit)
+__device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p, W& w) {                       // :87-125
     const float thick = .1f;
-    const D2 lead_in = {sd_y_cylinder<HW>(p, 6.f, thick - .05f), 2.f};
-    const D2 groove = {sd_y_cylinder<HW>(p, 5.9f, thick), 1.f};
-    const D2 dead_wax = {sd_y_cylinder<HW>(p, 3.f, thick), 2.f};
-    const D2 label = {sd_y_cylinder<HW>(p, 2.f, thick), 3.f};
+    const D2 lead_in = {sd_y_cylinder<HW>(p, 6.f, thick - .05f, w), 2.f};
+    const D2 groove = {sd_y_cylinder<HW>(p, 5.9f, thick, w), 1.f};
+    const D2 dead_wax = {sd_y_cylinder<HW>(p, 3.f, thick, w), 2.f};
+    const D2 label = {sd_y_cylinder<HW>(p, 2.f, thick, w), 3.f};
     const D2 logo = {vinyl_logo<HW>(F, p, thick - .0175f), 4.f};
-    const float spc = sd_y_cylinder<HW>(p, .10f, .6f);
-    const float sps = length(p - V3(0, .3f, 0)) - .10f;
+    const float spc = sd_y_cylinder<HW>(p, .10f, .6f, w);
+    const float sps = w.length(p - V3(0, .3f, 0)) - .10f;
     const D2 spindle = {hmin_<HW>(spc, sps), 5.f};
     const D2 d0 = op_add2(groove, lead_in);
     const D2 d1 = op_add2(d0, dead_wax);
     const D2 d2 = op_add2(label, logo);
     const D2 d3 = op_add2(d1, d2);
     const D2 d4 = op_add2(d3, spindle);
-    const float defect1 = length(p + V3(6.05f, 0, 0)) - .1f;
-    const float defect2 = length(p + V3(-6.05f, 0, 0)) - .1f;
+    const float defect1 = w.length(p + V3(6.05f, 0, 0)) - .1f;
+    const float defect2 = w.length(p + V3(-6.05f, 0, 0)) - .1f;
     const float defect = hmin_<HW>(defect1, defect2);
     return D2{hmax_neg_<HW>(d4.d, defect), d4.m};                       // op_sub
 }
@@ -77,8 +77,8 @@ __device__ __forceinline__ D2 vinyl_platter(const FrameVinyl& F, v3 p) {        
 //    (offsets and half-sizes of :163-232 added up); a box evaluated in a rotated frame is a max-norm distance
 //    >= Euclidean / sqrt3, the collar's max(axis, slabs) form >= Euclidean / sqrt2 minus its size, and max(x, -cut) >= x:
 //    every member is >= .577 (|p - a3| - 1.3) - so with K = 1.74 (dmin + 1e-3) + 1.35, |p - a3| > K puts them all above dmin.
-template <bool CULL>   // false (sbx_set_variant 1): no culling, the reference form
-__device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float dmin) {        // :127-255
+template <bool CULL, class W>   // CULL false (sbx_set_variant 1): no culling, the reference form
+__device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float dmin, W& w) {        // :127-255
     constexpr bool HW = CULL && VIN_HW_MINMAX;
     const float inf = u2f(0x7f800000u);
     const v3 base_p = V3(-7, 0, -5);
@@ -87,27 +87,27 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
         const v3 q = pos - base_p;
         const float lb = hmax_<HW>(abs_(q.x) - 3.01f, hmax_<HW>(abs_(q.y) - 1.26f, abs_(q.z) - 3.01f));
         if (!(CULL && dmin >= 0.f && lb > dmin * 1.001f + 2e-3f)) {
-            const float platter = sd_y_cylinder<HW>(pos, 6.25f, 1.f);
-            const float base_0 = sd_y_cylinder<HW>(pos - base_p, 3.f, .25f);
+            const float platter = sd_y_cylinder<HW>(pos, 6.25f, 1.f, w);
+            const float base_0 = sd_y_cylinder<HW>(pos - base_p, 3.f, .25f, w);
             const float base_1 = hmax_neg_<HW>(base_0, platter);
-            const float base_2 = sd_y_cylinder<HW>(pos - base_p, 1.25f, 1.f);
+            const float base_2 = sd_y_cylinder<HW>(pos - base_p, 1.25f, 1.f, w);
             const float base_12 = hmin_<HW>(base_1, base_2);
             const D2 base_a = {base_12, 5.f};
-            const D2 base_b = {sd_y_cylinder<HW>(pos - base_p, 0.5f, 2.5f), 5.f};
+            const D2 base_b = {sd_y_cylinder<HW>(pos - base_p, 0.5f, 2.5f, w), 5.f};
             base = op_add2(base_a, base_b);
         }
     }
 
     const v3 p = mul(pos, FV(wobble));
     const float R = .1f;
-    const float arm1 = sd_capsule_f(p, FV(arm1.a), FV(arm1.ab), FV(arm1.rd), R);
-    const float arm2 = sd_capsule_f(p, FV(arm2.a), FV(arm2.ab), FV(arm2.rd), R);
-    const float arm3 = sd_capsule_f(p, FV(arm3.a), FV(arm3.ab), FV(arm3.rd), R);
+    const float arm1 = sd_capsule_f(p, FV(arm1.a), FV(arm1.ab), FV(arm1.rd), R, w);
+    const float arm2 = sd_capsule_f(p, FV(arm2.a), FV(arm2.ab), FV(arm2.rd), R, w);
+    const float arm3 = sd_capsule_f(p, FV(arm3.a), FV(arm3.ab), FV(arm3.rd), R, w);
     const float arm_link1 = hmin_<HW>(arm1, arm2);
     const float arm_link2 = hmin_<HW>(arm_link1, arm3);
     const float dmin2 = hmin_<HW>(hmin_<HW>(dmin, base.d), arm_link2);
     const BezierFrame abz = FV(armb);
-    const float armb = (CULL && bezier_far(abz, p, R, dmin2)) ? inf : sd_bezier_x(abz, p, R);
+    const float armb = (CULL && bezier_far(abz, p, R, dmin2)) ? inf : sd_bezier_x(abz, p, R, w);
     const D2 arm = {hmin_<HW>(arm_link2, armb), 5.f};
     {
         const v3 q = p - FV(a3);
@@ -120,7 +120,7 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
 
     const v3 clr_p = p - FV(a3);
     const float clr_r = R * 1.5f;
-    const float collar = sd_cylinder0<HW>(FV(collar), clr_p, clr_r);
+    const float collar = sd_cylinder0<HW>(FV(collar), clr_p, clr_r, w);
     const float fl_w = .045f, fl_h = .020f;
     const float fl_len1 = clr_r * 1.f;
     const float fl_len2 = fl_len1 * 1.2f;
@@ -146,10 +146,10 @@ __device__ __forceinline__ D2 vinyl_tonearm(const FrameVinyl& F, v3 pos, float d
     const D2 tone2 = op_add2(headshell, cartridge);
     return op_add2(tone1, tone2);
 }
-template <bool CULL>
-__device__ __forceinline__ D2 vinyl_sdf(const FrameVinyl& F, v3 pos) {                         // :257-265
-    const D2 plat = vinyl_platter<(CULL && VIN_HW_MINMAX)>(F, mul(pos, FV(platter_rot)));
-    const D2 arm = vinyl_tonearm<CULL>(F, pos, plat.d);
+template <bool CULL, class W>
+__device__ __forceinline__ D2 vinyl_sdf(const FrameVinyl& F, v3 pos, W& w) {                   // :257-265
+    const D2 plat = vinyl_platter<(CULL && VIN_HW_MINMAX)>(F, mul(pos, FV(platter_rot)), w);
+    const D2 arm = vinyl_tonearm<CULL>(F, pos, plat.d, w);
     return op_add2(plat, arm);
 }
 __device__ __forceinline__ float saw(float x) { return x - floor_(x); }                        // :280-283
@@ -167,28 +167,15 @@ __device__ __forceinline__ v3 vinyl_base_color(int mat) {                       
     }
 }
 
-template <bool CULL>
-__global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
-#if VI_LDS_FRAME
-    // the frame block (~220 floats of rotations and primitive frames) in LDS: sbx_ldsframe.h
-    __shared__ FrameVinyl Fs;
-    lds_frame_fill<FrameVinyl, WG_THREADS>(Fs);
-#define VI_F(ptr) Fs
-#define VI_LAUNDER(ptr)
-    const FrameVinyl* fp = nullptr;
-    (void)fp;
-#else
-#define VI_F(ptr) F
-#define VI_LAUNDER(ptr)
-    const FrameVinyl* fp = nullptr;
-    (void)fp;
+#ifndef VI_WITNESS
+#define VI_WITNESS 1       // witnessed five-instruction square roots in sdf() (sbx_sdf.h Wit), as in k_egg: 0 = the IEEE roots only
 #endif
-    const Pixel px = pixel_of_thread(M);
-    if (!px.valid) return;
-    const v2 pc = point_cam(F.cam, px.fx, px.fy);
-    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
 
-    v3 color = V3(1, 1, 1);                                     // background :15-18
+// One pixel up to its colour — render :406-457 — with the sdf's roots of witness `w`.  F: the kernel argument (camera, sun, steps:
+// SGPRs); Fs: the block sdf() reads (the LDS copy, or F itself).
+template <bool CULL, class W>
+__device__ __forceinline__ void vinyl_pixel(const FrameVinyl& F, const FrameVinyl& Fs, v3 ro, v3 rd, W& w, v3& color) {
+    color = V3(1, 1, 1);                                        // background :15-18
     float t = 0.f;
     // The trace only FINDS the hit; the reference's hit block (`:436-452`: 20-step soft shadow, anisotropic or 6-tap-normal
     // shading, `break`) runs after the loop, once per wave with all of its hit lanes instead of once per distinct hit iteration
@@ -198,8 +185,7 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
     v3 p = V3(0, 0, 0);
     for (int i = 0; i < F.steps; ++i) {                           // render :427-455; 60 (C++ build) or 180 steps :411-416
         const v3 pi = ro + rd * t;
-        VI_LAUNDER(fp);
-        const D2 d = vinyl_sdf<CULL>(VI_F(fp), pi);
+        const D2 d = vinyl_sdf<CULL>(Fs, pi, w);
         if (t > 40.f) break;
         if (d.d < .005f) { hit = true; mat = (int)d.m; p = pi; break; }
         t += d.d;
@@ -212,8 +198,7 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
                 const v3 so = p + F.sun_dir * 0.05f;
                 float ts = 0.f;
                 for (int k = 0; k < 20; ++k) {
-                    VI_LAUNDER(fp);
-                    const D2 ds = vinyl_sdf<CULL>(VI_F(fp), so + F.sun_dir * ts);
+                                const D2 ds = vinyl_sdf<CULL>(Fs, so + F.sun_dir * ts, w);
                     if (ts > 5.f) break;
                     if (ds.d < .005f) { sh = .05f; break; }
                     ts += ds.d;
@@ -259,9 +244,9 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
             } else {
                 const float e = 0.001f;                              // sdf_normal :267-278
                 const v3 n = normalize(V3(
-                    vinyl_sdf<CULL>(VI_F(fp), p + V3(e, 0, 0)).d - vinyl_sdf<CULL>(VI_F(fp), p - V3(e, 0, 0)).d,
-                    vinyl_sdf<CULL>(VI_F(fp), p + V3(0, e, 0)).d - vinyl_sdf<CULL>(VI_F(fp), p - V3(0, e, 0)).d,
-                    vinyl_sdf<CULL>(VI_F(fp), p + V3(0, 0, e)).d - vinyl_sdf<CULL>(VI_F(fp), p - V3(0, 0, e)).d));
+                    vinyl_sdf<CULL>(Fs, p + V3(e, 0, 0), w).d - vinyl_sdf<CULL>(Fs, p - V3(e, 0, 0), w).d,
+                    vinyl_sdf<CULL>(Fs, p + V3(0, e, 0), w).d - vinyl_sdf<CULL>(Fs, p - V3(0, e, 0), w).d,
+                    vinyl_sdf<CULL>(Fs, p + V3(0, 0, e), w).d - vinyl_sdf<CULL>(Fs, p - V3(0, 0, e), w).d));
                 const v3 diffuse = base * fmax_(0.f, dot(L, n));
                 const v3 H = normalize(V + L);
                 const v3 specular = pow_(fmax_(0.f, dot(H, n)), 50.f) * V3(1, 1, 1);
@@ -270,12 +255,43 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
             color = lit * sh;
         }
     }
+}
+
+template <bool CULL, int WIT>      // WIT: 0 IEEE roots, 1 witnessed roots, 2 the witness's test edge (sbx_set_variant 2), as k_egg
+__global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
+#if VI_LDS_FRAME
+    // the frame block (~220 floats of rotations and primitive frames) in LDS: sbx_ldsframe.h
+    __shared__ FrameVinyl Fs;
+    lds_frame_fill<FrameVinyl, WG_THREADS>(Fs);
+#define VI_FS Fs
+#else
+#define VI_FS F
+#endif
+    const Pixel px = pixel_of_thread(M);
+    if (!px.valid) return;
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
+    v3 color;
+    if (WIT != 0) {
+        Wit<true> w;
+        if (WIT == 2) w.lo = 0x3F800000u;
+        vinyl_pixel<CULL>(F, VI_FS, ro, rd, w, color);
+        if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {
+            Wit<false> w0;
+            vinyl_pixel<CULL>(F, VI_FS, ro, rd, w0, color);
+        }
+    } else {
+        Wit<false> w0;
+        vinyl_pixel<CULL>(F, VI_FS, ro, rd, w0, color);
+    }
     store_rgba(M, out, px.idx, to_srgb(color));
 }
 
 void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant) {
-    if (variant == 1) hipLaunchKernelGGL(k_vinyl<false>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
-    else hipLaunchKernelGGL(k_vinyl<true>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    if (variant == 1) hipLaunchKernelGGL((k_vinyl<false, 0>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else if (variant == 2) hipLaunchKernelGGL((k_vinyl<true, 2>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else if (variant == 3) hipLaunchKernelGGL((k_vinyl<true, 0>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL((k_vinyl<true, VI_WITNESS>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

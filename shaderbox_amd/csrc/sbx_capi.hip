@@ -599,6 +599,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     }
     int rc = SBX_OK;
     const int cull_variant = tame_time(uni->u_time) ? ctx->variant : 1;
+    const int sdf_variant = cull_variant == 1 ? 1 : ctx->sdf_roots;      // EGG / SDF_AO / VINYL: 2 / 3 = the witness's test build / IEEE roots
     switch (app) {
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
     case SBX_APP_CLOUDS_SKY: launch_clouds(build_clouds(*uni, AC, true), M, rgba, s, ctx->variant, nullptr, 0, false); break;
@@ -606,19 +607,19 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
                                                     // a captured launch is replayed later, possibly over volumes re-bound in place with
                                                     // other texel ranges: no bounds baked into a graph (the plain exp_ / IEEE divide)
                                                     (ctx->tex_bounds_valid && !capturing) ? ctx->tex_bounds : nullptr); break;
-    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, cull_variant == 1 ? 1 : ctx->sdf_roots); break;
+    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, sdf_variant); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
     case SBX_APP_SDF_AO: {
         sbx_aux_sdf_ao A;
         if (aux) A = *(const sbx_aux_sdf_ao*)aux; else sbx_aux_sdf_ao_defaults(&A);
-        launch_sdf_ao(build_sdf_ao(*uni, A), M, rgba, s, cull_variant);
+        launch_sdf_ao(build_sdf_ao(*uni, A), M, rgba, s, sdf_variant);
         break;
     }
     case SBX_APP_PLANET: launch_planet(build_planet(*uni), M, rgba, s, cull_variant); break;
     case SBX_APP_PLANET_ATMOSPHERE: launch_planet(build_planet(*uni, true), M, rgba, s, cull_variant); break;
-    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni, 60), M, rgba, s, cull_variant); break;
-    case SBX_APP_VINYL_GPU: launch_vinyl(build_vinyl(*uni, 180), M, rgba, s, cull_variant); break;
+    case SBX_APP_VINYL: launch_vinyl(build_vinyl(*uni, 60), M, rgba, s, sdf_variant); break;
+    case SBX_APP_VINYL_GPU: launch_vinyl(build_vinyl(*uni, 180), M, rgba, s, sdf_variant); break;
     case SBX_APP_CLOUDS_BEST: launch_clouds_best(build_clouds_best(*uni), M, rgba, s); break;
     case SBX_APP_CLOUDS_UE4: {
         sbx_aux_clouds_ue4 A;

@@ -53,9 +53,14 @@ template <bool HW = false>
 __device__ __forceinline__ float sd_box(v3 p, v3 b) {                                          // sdf.h:67-73
     return hmax_<HW>(abs_(p.x) - b.x, hmax_<HW>(abs_(p.y) - b.y, abs_(p.z) - b.z));
 }
+template <bool HW, class W>
+__device__ __forceinline__ float sd_y_cylinder(v3 p, float r, float h, W& w) {                  // sdf.h:85-93
+    return hmax_<HW>(w.length(V2(p.x, p.z)) - r, abs_(p.y) - h / 2.f);
+}
 template <bool HW = false>
-__device__ __forceinline__ float sd_y_cylinder(v3 p, float r, float h) {                        // sdf.h:85-93
-    return hmax_<HW>(length(V2(p.x, p.z)) - r, abs_(p.y) - h / 2.f);
+__device__ __forceinline__ float sd_y_cylinder(v3 p, float r, float h) {
+    Wit<false> w;
+    return sd_y_cylinder<HW>(p, r, h, w);
 }
 __device__ __forceinline__ float det2(v2 a, v2 b) { return a.x * b.y - b.x * a.y; }             // sdf.h:114-119
 
@@ -110,9 +115,14 @@ __device__ __forceinline__ float sd_cylinder0(const CylFrame& C, v3 P, float R) 
     return sd_cylinder0<HW>(C, P, R, w);
 }
 // sd_capsule(p, a, b, r) with ab = b - a and rd = recip64(dot(ab, ab)) from the frame         sdf.h:162-171
-__device__ __forceinline__ float sd_capsule_f(v3 p, v3 a, v3 ab, double rd, float r) {
+template <class W>
+__device__ __forceinline__ float sd_capsule_f(v3 p, v3 a, v3 ab, double rd, float r, W& w) {
     const float t = clamp_(div_by(dot(p - a, ab), rd), 0.f, 1.f);
-    return length((ab * t + a) - p) - r;
+    return w.length((ab * t + a) - p) - r;
+}
+__device__ __forceinline__ float sd_capsule_f(v3 p, v3 a, v3 ab, double rd, float r) {
+    Wit<false> w;
+    return sd_capsule_f(p, a, ab, rd, r, w);
 }
 
 }  // namespace sbx

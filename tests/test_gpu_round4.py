@@ -513,26 +513,27 @@ def test_span_entry_points_reject_bad_arguments(renderer):
                                             ctypes.c_void_p(s.cuda_stream)) in (0, shaderbox_amd.SBX_ERR_ARG)
 
 
-def test_egg_witnessed_square_roots(renderer, oracle):
-    """k_egg takes sqrt_rs_ (five instructions, equal to the IEEE root on [2^-102, inf) by exhaustion) and records any argument
-    outside that interval; a wave with a record re-runs its pixels with the IEEE roots (csrc/sbx_sdf.h Wit).  Variant 2 raises the
-    recording edge to 1.0, so every wave near a primitive re-runs; variant 3 is the culled kernel with the IEEE roots only;
-    variant 1 the plain kernel.  All four and the oracle: the same bits, over poses, odd sizes and mouse positions."""
-    from oracle.oracle import APP_EGG
+@pytest.mark.parametrize("app", ["egg", "sdf_ao", "vinyl", "vinyl_gpu"])
+def test_witnessed_square_roots_of_the_sdf_kernels(renderer, oracle, app):
+    """k_egg / k_sdf_ao / k_vinyl take sqrt_rs_ (five instructions, equal to the IEEE root on [2^-102, inf) by exhaustion) in sdf()
+    and record any argument outside that interval; a wave with a record re-runs its pixels with the IEEE roots (csrc/sbx_sdf.h Wit).
+    Variant 2 raises the recording edge to 1.0, so every wave near a primitive re-runs; variant 3 is the culled kernel with the IEEE
+    roots only; variant 1 the plain kernel.  All four and the oracle: the same bits, over poses, odd sizes and mouse positions."""
+    from oracle.oracle import APP_IDS
     rng = np.random.default_rng(77)
     cases = [(240, 135, .37, (0.0, 0.0)), (333, 187, 2.9, (100.0, 20.0))]
     cases += [(int(rng.integers(64, 400)), int(rng.integers(48, 260)), float(rng.uniform(0, 40)),
-               (float(rng.uniform(0, 300)), float(rng.uniform(0, 200)))) for _ in range(10)]
+               (float(rng.uniform(0, 300)), float(rng.uniform(0, 200)))) for _ in range(8)]
     try:
         for i, (w, h, t, mouse) in enumerate(cases):
             frames = []
             for v in (0, 2, 3, 1):
                 renderer.set_variant(v)
-                frames.append(renderer.render("egg", w, h, t, mouse=mouse).cpu().numpy())
+                frames.append(renderer.render(app, w, h, t, mouse=mouse).cpu().numpy())
             for v, f in zip((2, 3, 1), frames[1:]):
-                assert compare(frames[0], f) == (0.0, 0), (v, w, h, t, mouse)
-            if i < 4:
-                assert compare(frames[0], oracle.render(APP_EGG, w, h, t, mouse=mouse)) == (0.0, 0), (w, h, t, mouse)
+                assert compare(frames[0], f) == (0.0, 0), (app, v, w, h, t, mouse)
+            if i < 3:
+                assert compare(frames[0], oracle.render(APP_IDS[app], w, h, t, mouse=mouse)) == (0.0, 0), (app, w, h, t, mouse)
     finally:
         renderer.set_variant(0)
     with pytest.raises(Exception):
