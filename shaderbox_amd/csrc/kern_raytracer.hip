@@ -8,6 +8,7 @@
 // setup_cornell_box cornell_box.h:39-87) and arrives as kernel arguments in SGPRs.
 #include "sbx_device.h"
 #include "sbx_ldsframe.h"
+#include "sbx_witness.h"
 
 #ifndef RT_LDS_FRAME
 #define RT_LDS_FRAME 1      // the scene block (130 floats: does not fit the SGPR file) in LDS, read at its uses (sbx_ldsframe.h)
@@ -47,14 +48,15 @@ __device__ __forceinline__ void hit_plane(v3 ro, v3 rd, const RtPlane& p, Hit& h
     hit.o = ro + rd * t;
     hit.n = dot(p.n, rd) < 0 ? p.n : -p.n;          // faceforward(N, I, Nref = N)  util.h:85-93
 }
-__device__ __forceinline__ void hit_sphere(v3 ro, v3 rd, const RtSphere& s, Hit& hit) {   // intersect.h:7-33
+template <class W>      // W: the witness of the fast roots and normalisations (sbx_witness.h)
+__device__ __forceinline__ void hit_sphere(v3 ro, v3 rd, const RtSphere& s, Hit& hit, W& w) {   // intersect.h:7-33
     const v3 rc = s.o - ro;
     const float radius2 = s.r * s.r;
     const float tca = dot(rc, rd);
     if (tca < 0.f) return;
     const float d2 = dot(rc, rc) - tca * tca;
     if (d2 > radius2) return;
-    const float thc = sqrt_(radius2 - d2);
+    const float thc = w.sqrt(radius2 - d2);
     float t0 = tca - thc;
     const float t1 = tca + thc;
     if (t0 < 0.f) t0 = t1;
@@ -66,14 +68,15 @@ __device__ __forceinline__ void hit_sphere(v3 ro, v3 rd, const RtSphere& s, Hit&
     const v3 dn = impact - s.o;
     hit.n = V3(div_by(dn.x, s.rr), div_by(dn.y, s.rr), div_by(dn.z, s.rr));     // (impact - origin) / radius, exact (sbx_math.h)
 }
-__device__ __forceinline__ Hit trace(const FrameRaytracer& F, v3 ro, v3 rd, int mat_to_ignore) {   // :70-86
+template <class W>
+__device__ __forceinline__ Hit trace(const FrameRaytracer& F, v3 ro, v3 rd, int mat_to_ignore, W& w) {   // :70-86
     Hit hit;
     hit.t = (float)(1e8f + 1e1f); hit.mat = -1; hit.n = V3(0, 0, 0); hit.o = V3(0, 0, 0);   // no_hit def.h:78-83
 #pragma unroll
     for (int i = 0; i < 6; ++i) hit_plane(ro, rd, rt_ld(F.planes[i]), hit);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-        if (rt_ld(F.spheres[i].mat) != mat_to_ignore) hit_sphere(ro, rd, rt_ld(F.spheres[i]), hit);
+        if (rt_ld(F.spheres[i].mat) != mat_to_ignore) hit_sphere(ro, rd, rt_ld(F.spheres[i]), hit, w);
     return hit;
 }
 // get_material: linear scan; an id outside 0..7 yields the zero-initialised material (App. B5)
@@ -90,8 +93,9 @@ __device__ __forceinline__ RtMaterial material_of(const FrameRaytracer& F, int i
 #endif
     return m;
 }
-__device__ __forceinline__ v3 cook_torrance(v3 V, v3 L, const Hit& hit, const RtMaterial& mat) {   // light.h:64-92
-    const v3 H = normalize(L + V);
+template <class W>
+__device__ __forceinline__ v3 cook_torrance(v3 V, v3 L, const Hit& hit, const RtMaterial& mat, W& w) {   // light.h:64-92
+    const v3 H = w.normalize(L + V);
     const float NdotL = dot(hit.n, L), NdotH = dot(hit.n, H), NdotV = dot(hit.n, V), VdotH = dot(V, H);
     const float geo_a = (2.f * NdotH * NdotV) / VdotH;
     const float geo_b = (2.f * NdotH * NdotL) / VdotH;
@@ -105,16 +109,57 @@ __device__ __forceinline__ v3 cook_torrance(v3 V, v3 L, const Hit& hit, const Rt
     const float specular = (geo_term * rough_term * fresnel_term) / (3.14159265359f * NdotV * NdotL);
     return fmax_(0.f, NdotL) * (specular + mat.base_color);
 }
-__device__ __forceinline__ v3 rt_illuminate(const FrameRaytracer& F, v3 eye, const Hit& hit) {   // :46-68
+template <class W>
+__device__ __forceinline__ v3 rt_illuminate(const FrameRaytracer& F, v3 eye, const Hit& hit, W& w) {   // :46-68
     const RtMaterial mat = material_of(F, hit.mat);
     if (hit.mat == 0) return rt_ld(F.mats[0].base_color);        // mat_debug: flat
     v3 accum = V3(.01f, .01f, .01f);                              // ambient_light light.h:16
-    const v3 V = normalize(eye - hit.o);
-    const v3 L = normalize(rt_ld(F.light) - hit.o);               // point light, light.h:18-27
-    accum = accum + cook_torrance(V, L, hit, mat);
+    const v3 V = w.normalize(eye - hit.o);
+    const v3 L = w.normalize(rt_ld(F.light) - hit.o);             // point light, light.h:18-27
+    accum = accum + cook_torrance(V, L, hit, mat, w);
     return accum;
 }
 
+#ifndef RT_WITNESS
+#define RT_WITNESS 1       // fast roots and normalisations with a recorded domain (sbx_witness.h): 0 = the IEEE forms only
+#endif
+
+// One pixel's colour — render :88-136 — with the roots / normalisations of witness `w`.  Fs: the scene block (LDS copy or F).
+template <class W>
+__device__ __forceinline__ v3 rt_pixel(const FrameRaytracer& F, const FrameRaytracer& Fs, v2 pc, W& w) {
+    const v3 eye = F.cam.eye;
+    v3 ro = eye, rd = primary_dir(F.cam, pc, w);
+
+    v3 color = V3(0, 0, 0), accum = V3(1, 1, 1);
+    for (int i = 0; i < 2; ++i) {                                 // :96-133
+        const Hit hit = trace(Fs, ro, rd, -1, w);
+        if (hit.t >= 1e8f) {
+            color = color + accum * V3(0, 0, 0);                  // background :13-16
+            break;
+        }
+        const float f = fresnel_factor(1.f, 1.f, dot(hit.n, -rd));
+        color = color + (1.f - f) * accum * rt_illuminate(Fs, eye, hit, w);   // primary origin on every bounce (:105)
+        if (i == 0) {                                             // shadow ray :108-121
+            const v3 shadow_line = rt_ld(Fs.light) - hit.o;
+            const v3 shadow_dir = w.normalize(shadow_line);
+            const Hit sh = trace(Fs, hit.o + shadow_dir * 1e-4f, shadow_dir, 0, w);
+            if (sh.t < w.length(shadow_line)) color = color * 0.1f;
+        }
+        const RtMaterial mat = material_of(Fs, hit.mat);
+        if (mat.reflectivity > 0.f) {
+            accum = accum * f;
+            // reflect(hit.normal, ray.direction): arguments swapped in the reference (:127), kept
+            const v3 refl = w.normalize(hit.n - 2.f * dot(rd, hit.n) * rd);
+            ro = hit.o + refl * 1e-4f;
+            rd = refl;
+        } else {
+            break;
+        }
+    }
+    return color;
+}
+
+template <int WIT>      // 0 IEEE forms, 1 witnessed fast forms, 2 the witness's test edge (sbx_set_variant 2)
 __global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowMap M, float* __restrict__ out) {
 #if RT_LDS_FRAME
     __shared__ FrameRaytracer Fs;
@@ -126,40 +171,26 @@ __global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowM
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
-    const v3 eye = F.cam.eye;
-    v3 ro = eye, rd = primary_dir(F.cam, pc);
-
-    v3 color = V3(0, 0, 0), accum = V3(1, 1, 1);
-    for (int i = 0; i < 2; ++i) {                                 // :96-133
-        const Hit hit = trace(RT_F, ro, rd, -1);
-        if (hit.t >= 1e8f) {
-            color = color + accum * V3(0, 0, 0);                  // background :13-16
-            break;
+    v3 color;
+    if (WIT != 0) {
+        Wit<true> w;
+        if (WIT == 2) w.lo = 0x3F800000u;
+        color = rt_pixel(F, RT_F, pc, w);
+        if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {      // some lane left the fast forms' proved domain: the IEEE forms
+            Wit<false> w0;
+            color = rt_pixel(F, RT_F, pc, w0);
         }
-        const float f = fresnel_factor(1.f, 1.f, dot(hit.n, -rd));
-        color = color + (1.f - f) * accum * rt_illuminate(RT_F, eye, hit);   // primary origin on every bounce (:105)
-        if (i == 0) {                                             // shadow ray :108-121
-            const v3 shadow_line = rt_ld(RT_F.light) - hit.o;
-            const v3 shadow_dir = normalize(shadow_line);
-            const Hit sh = trace(RT_F, hit.o + shadow_dir * 1e-4f, shadow_dir, 0);
-            if (sh.t < length(shadow_line)) color = color * 0.1f;
-        }
-        const RtMaterial mat = material_of(RT_F, hit.mat);
-        if (mat.reflectivity > 0.f) {
-            accum = accum * f;
-            // reflect(hit.normal, ray.direction): arguments swapped in the reference (:127), kept
-            const v3 refl = normalize(hit.n - 2.f * dot(rd, hit.n) * rd);
-            ro = hit.o + refl * 1e-4f;
-            rd = refl;
-        } else {
-            break;
-        }
+    } else {
+        Wit<false> w0;
+        color = rt_pixel(F, RT_F, pc, w0);
     }
     store_rgba(M, out, px.idx, to_srgb(color));
 }
 
-void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_raytracer, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s, int variant) {
+    if (variant == 2) hipLaunchKernelGGL(k_raytracer<2>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else if (variant == 1 || variant == 3) hipLaunchKernelGGL(k_raytracer<0>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    else hipLaunchKernelGGL(k_raytracer<RT_WITNESS>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
 }
 
 }  // namespace sbx

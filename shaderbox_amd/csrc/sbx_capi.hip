@@ -608,7 +608,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
                                                     // other texel ranges: no bounds baked into a graph (the plain exp_ / IEEE divide)
                                                     (ctx->tex_bounds_valid && !capturing) ? ctx->tex_bounds : nullptr); break;
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, sdf_variant); break;
-    case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s); break;
+    case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s, ctx->variant == 1 ? 1 : ctx->sdf_roots); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
     case SBX_APP_SDF_AO: {
         sbx_aux_sdf_ao A;

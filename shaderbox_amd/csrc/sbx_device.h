@@ -109,7 +109,7 @@ float minmax_key_to_float(unsigned k);
 void launch_extract_r(const float* rgba, float* r, size_t n, hipStream_t s);
 void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out, size_t n, hipStream_t s);
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant);
-void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s);
+void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s);
 void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant);

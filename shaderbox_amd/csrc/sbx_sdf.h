@@ -2,32 +2,12 @@
 // point-independent part of the costly primitives split off into per-frame "frames" (host-evaluated).
 #pragma once
 #include "sbx_frame.h"
+#include "sbx_witness.h"
 
 namespace sbx {
 
 struct D2 { float d, m; };   // (distance, material id); op_add keeps the nearer              sdf.h:5-11
 
-// WITNESSED SQUARE ROOTS (round 4).  The compiler's IEEE sqrt is 16 VALU instructions (input scaling for tiny arguments, v_sqrt_f32,
-// a two-sided one-ulp fix-up, a class test for 0 / inf); sqrt_rs_ (sbx_math.h) is 5 and EQUAL to it for every argument in
-// [2^-102, +inf) — all of them were run (profiles/r03_sqrt_rsq_exhaustive.txt) — but returns NaN for 0 and +inf and is inexact
-// below 2^-102.  A squared length in an SDF is none of those except ON a primitive's axis or centre, which no kernel can rule out
-// for an arbitrary frame.  So a lane RECORDS every argument outside the proved interval (two integer instructions, the flag
-// accumulates in an SGPR pair) and the kernel, after its whole pixel, re-runs the pixel with the IEEE forms if any lane of the wave
-// recorded one (wave-uniform branch; never taken on the frames measured).  No branch inside the SDF — a per-lane choice between
-// the forms at each root cost more than it saved (sbx_math.h, sqrt_n_) — and a pixel's bits are the IEEE forms' either way:
-// without a record every root it took is one of the exhaustively compared ones.
-// Wit<false> is the plain form (no record), what every caller without a witness gets.
-template <bool FAST> struct Wit {
-    bool bad = false;
-    unsigned lo = 0x0C800000u;                                   // 2^-102; the test build raises it (k_egg<., 2>) to exercise the re-run
-    __device__ __forceinline__ float sqrt(float x) {
-        if (!FAST) return sqrt_(x);
-        bad |= (f2u(x) - lo) >= (0x7F800000u - lo);              // 0, tiny, +inf, NaN, negative: all outside [lo, +inf)
-        return sqrt_rs_(x);
-    }
-    __device__ __forceinline__ float length(v2 v) { return sqrt(dot(v, v)); }
-    __device__ __forceinline__ float length(v3 v) { return sqrt(dot(v, v)); }
-};
 __device__ __forceinline__ D2 op_add2(D2 a, D2 b) { return a.d < b.d ? a : b; }
 
 __device__ __forceinline__ float op_blend(float a, float b, float k) {                         // sdf.h:38-47

@@ -513,10 +513,11 @@ def test_span_entry_points_reject_bad_arguments(renderer):
                                             ctypes.c_void_p(s.cuda_stream)) in (0, shaderbox_amd.SBX_ERR_ARG)
 
 
-@pytest.mark.parametrize("app", ["egg", "sdf_ao", "vinyl", "vinyl_gpu"])
+@pytest.mark.parametrize("app", ["egg", "sdf_ao", "vinyl", "vinyl_gpu", "raytracer"])
 def test_witnessed_square_roots_of_the_sdf_kernels(renderer, oracle, app):
     """k_egg / k_sdf_ao / k_vinyl take sqrt_rs_ (five instructions, equal to the IEEE root on [2^-102, inf) by exhaustion) in sdf()
-    and record any argument outside that interval; a wave with a record re-runs its pixels with the IEEE roots (csrc/sbx_sdf.h Wit).
+    and record any argument outside that interval; a wave with a record re-runs its pixels with the IEEE roots (csrc/sbx_witness.h);
+    k_raytracer does the same with its roots and its normalisations (zero components of a normalised vector are recorded too).
     Variant 2 raises the recording edge to 1.0, so every wave near a primitive re-runs; variant 3 is the culled kernel with the IEEE
     roots only; variant 1 the plain kernel.  All four and the oracle: the same bits, over poses, odd sizes and mouse positions."""
     from oracle.oracle import APP_IDS
