@@ -162,7 +162,8 @@ __device__ __forceinline__ void hot_first_tile(const HotRect& R, int gx, int& bx
 
 // One pixel up to (colour, depth) — render_scene :190-231 — with the roots of witness `w`
 template <bool CULL, class W>
-__device__ __forceinline__ void egg_pixel(const FrameEgg& F, v3 ro, v3 rd, W& w, v3& color, float& depth, int& st_trace, int& st_shadow) {
+__device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, W& w, v3& color, float& depth, int& st_trace, int& st_shadow) {
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc, w);
     depth = -1e8f;                                          // :188, fresh per pixel
     color = V3(.1f, .1f, .7f);                              // background :9-12
     st_trace = 0; st_shadow = 0;
@@ -229,21 +230,19 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
-    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
-
     float depth;
     v3 color;
     if (WIT != 0) {
         Wit<true> w;
         if (WIT == 2) w.lo = 0x3F800000u;
-        egg_pixel<CULL>(F, ro, rd, w, color, depth, st_trace, st_shadow);
+        egg_pixel<CULL>(F, pc, w, color, depth, st_trace, st_shadow);
         if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {      // some lane took a root outside the proved interval: the IEEE forms
             Wit<false> w0;
-            egg_pixel<CULL>(F, ro, rd, w0, color, depth, st_trace, st_shadow);
+            egg_pixel<CULL>(F, pc, w0, color, depth, st_trace, st_shadow);
         }
     } else {
         Wit<false> w0;
-        egg_pixel<CULL>(F, ro, rd, w0, color, depth, st_trace, st_shadow);
+        egg_pixel<CULL>(F, pc, w0, color, depth, st_trace, st_shadow);
     }
     // bars overlay :233-251
     const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);

@@ -90,13 +90,17 @@ __device__ __forceinline__ D2 ao_sdf(const FrameSdfAo& F, v3 pos, W& w) {       
     return op_add2(b, g);
 }
 
+#ifndef AO_WIT_DIR
+#define AO_WIT_DIR 0       // the primary direction through the witness's normalize too: 81 VGPRs, 5 instead of 6 waves
+#endif
 #ifndef AO_WITNESS
 #define AO_WITNESS 1       // witnessed five-instruction square roots (sbx_sdf.h Wit), as in k_egg: 0 = the IEEE roots only
 #endif
 
 // One pixel up to (rgb, t) — render_impl :245-285 — with the roots of witness `w`
 template <bool CULL, class W>
-__device__ __forceinline__ void ao_pixel(const FrameSdfAo& F, v3 ro, v3 rd, W& w, v3& rgb, float& t) {
+__device__ __forceinline__ void ao_pixel(const FrameSdfAo& F, v3 ro, v2 pc, W& w, v3& rgb, float& t, v3& rd) {
+    rd = AO_WIT_DIR ? primary_dir(F.cam, pc, w) : primary_dir(F.cam, pc);
     rgb = V3(.1f, .1f, .7f);                                      // background :9-12
     t = 0.f;
     // The trace only FINDS the hit; the reference's hit block (`:258-281`: 6-tap normal, 5-tap AO, lights, material, `break`)
@@ -116,7 +120,7 @@ __device__ __forceinline__ void ao_pixel(const FrameSdfAo& F, v3 ro, v3 rd, W& w
         if (hit) {
             // sdf_normal :152-163
             const float e = 0.001f;
-            const v3 n = normalize(V3(
+            const v3 n = normalize(V3(          // (the IEEE form: a flat surface's normal has exact zero components, which the witness records)
                 ao_sdf<CULL>(F, p + V3(e, 0, 0), w).d - ao_sdf<CULL>(F, p - V3(e, 0, 0), w).d,
                 ao_sdf<CULL>(F, p + V3(0, e, 0), w).d - ao_sdf<CULL>(F, p - V3(0, e, 0), w).d,
                 ao_sdf<CULL>(F, p + V3(0, 0, e), w).d - ao_sdf<CULL>(F, p - V3(0, 0, e), w).d));
@@ -158,20 +162,20 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
-    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
-    v3 rgb;
+    const v3 ro = F.cam.eye;
+    v3 rgb, rd;
     float t;
     if (WIT != 0) {
         Wit<true> w;
         if (WIT == 2) w.lo = 0x3F800000u;
-        ao_pixel<CULL>(F, ro, rd, w, rgb, t);
+        ao_pixel<CULL>(F, ro, pc, w, rgb, t, rd);
         if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {
             Wit<false> w0;
-            ao_pixel<CULL>(F, ro, rd, w0, rgb, t);
+            ao_pixel<CULL>(F, ro, pc, w0, rgb, t, rd);
         }
     } else {
         Wit<false> w0;
-        ao_pixel<CULL>(F, ro, rd, w0, rgb, t);
+        ao_pixel<CULL>(F, ro, pc, w0, rgb, t, rd);
     }
     // fog :287-311 (t is the march length at exit)
     const float fog_factor = F.fog_density * exp_(-ro.y * F.fog_falloff)

@@ -174,7 +174,8 @@ __device__ __forceinline__ v3 vinyl_base_color(int mat) {                       
 // One pixel up to its colour — render :406-457 — with the sdf's roots of witness `w`.  F: the kernel argument (camera, sun, steps:
 // SGPRs); Fs: the block sdf() reads (the LDS copy, or F itself).
 template <bool CULL, class W>
-__device__ __forceinline__ void vinyl_pixel(const FrameVinyl& F, const FrameVinyl& Fs, v3 ro, v3 rd, W& w, v3& color) {
+__device__ __forceinline__ void vinyl_pixel(const FrameVinyl& F, const FrameVinyl& Fs, v2 pc, W& w, v3& color) {
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc, w);
     color = V3(1, 1, 1);                                        // background :15-18
     float t = 0.f;
     // The trace only FINDS the hit; the reference's hit block (`:436-452`: 20-step soft shadow, anisotropic or 6-tap-normal
@@ -207,7 +208,7 @@ __device__ __forceinline__ void vinyl_pixel(const FrameVinyl& F, const FrameViny
             }
             // illuminate :293-377
             v3 L = F.sun_dir;
-            v3 V = normalize(ro - p);
+            v3 V = w.normalize(ro - p);
             const v3 base = vinyl_base_color(mat);
             v3 lit;
             if (mat == 1 || mat == 2) {
@@ -231,7 +232,7 @@ __device__ __forceinline__ void vinyl_pixel(const FrameVinyl& F, const FrameViny
                 }
                 const v3 T = cross(B, N);
                 const float ro_diff = 1.f, ro_spec = .0725f, a_x = .025f, a_y = .5f;
-                const v3 H = normalize(V + L);
+                const v3 H = w.normalize(V + L);
                 const float dotLN = dot(L, N);
                 const v3 diffuse = base * (ro_diff / 3.14159265359f) * fmax_(0.f, dotLN);
                 const float spec_a = ro_spec / sqrt_(dotLN * dot(V, N));
@@ -243,12 +244,12 @@ __device__ __forceinline__ void vinyl_pixel(const FrameVinyl& F, const FrameViny
                 lit = diffuse + specular;
             } else {
                 const float e = 0.001f;                              // sdf_normal :267-278
-                const v3 n = normalize(V3(
+                const v3 n = normalize(V3(      // (the IEEE form: flat surfaces give exact zero components, which the witness records)
                     vinyl_sdf<CULL>(Fs, p + V3(e, 0, 0), w).d - vinyl_sdf<CULL>(Fs, p - V3(e, 0, 0), w).d,
                     vinyl_sdf<CULL>(Fs, p + V3(0, e, 0), w).d - vinyl_sdf<CULL>(Fs, p - V3(0, e, 0), w).d,
                     vinyl_sdf<CULL>(Fs, p + V3(0, 0, e), w).d - vinyl_sdf<CULL>(Fs, p - V3(0, 0, e), w).d));
                 const v3 diffuse = base * fmax_(0.f, dot(L, n));
-                const v3 H = normalize(V + L);
+                const v3 H = w.normalize(V + L);
                 const v3 specular = pow_(fmax_(0.f, dot(H, n)), 50.f) * V3(1, 1, 1);
                 lit = diffuse + specular;
             }
@@ -270,19 +271,18 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
-    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc);
     v3 color;
     if (WIT != 0) {
         Wit<true> w;
         if (WIT == 2) w.lo = 0x3F800000u;
-        vinyl_pixel<CULL>(F, VI_FS, ro, rd, w, color);
+        vinyl_pixel<CULL>(F, VI_FS, pc, w, color);
         if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {
             Wit<false> w0;
-            vinyl_pixel<CULL>(F, VI_FS, ro, rd, w0, color);
+            vinyl_pixel<CULL>(F, VI_FS, pc, w0, color);
         }
     } else {
         Wit<false> w0;
-        vinyl_pixel<CULL>(F, VI_FS, ro, rd, w0, color);
+        vinyl_pixel<CULL>(F, VI_FS, pc, w0, color);
     }
     store_rgba(M, out, px.idx, to_srgb(color));
 }

@@ -1,6 +1,7 @@
 import sys, time, torch
 sys.path.insert(0, "/root/repo")
-import shaderbox_amd
+import os, shaderbox_amd
+if os.environ.get("SBX_LIB"): shaderbox_amd.LIB_PATH = os.environ["SBX_LIB"]
 R = shaderbox_amd.Renderer(0)
 APP = sys.argv[1] if len(sys.argv) > 1 else "egg"
 for (w, h) in ((1920, 1080), (3840, 2160)):
