@@ -253,6 +253,19 @@ int sbx_assemble_spans(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const voi
 int sbx_pack_unorm8(sbx_ctx* ctx, int width, int rows, const float* rgba, unsigned char* out, int flip_y,
                     void* stream);
 
+/* OUTPUT FORMAT of the frame-granular entry points (default SBX_FORMAT_RGBA32F).  With SBX_FORMAT_RGBA8 every pixel a render
+ * call writes — whole frames, strips, a rank's slabs (4- or "3-channel"), span slabs, in-place renders — is ONE 32-bit word
+ * R | G << 8 | B << 16 | 255 << 24 by the Direct3D float -> UNORM rule of sbx_pack_unorm8 (the display format of the
+ * reference's hosts: hlsltoy's R8G8B8A8_UNORM back buffer), written by the render kernel itself instead of its float pixel: the
+ * `float*` buffers of those calls then hold width * rows words (4-byte aligned), and the assembly calls (sbx_assemble*,
+ * sbx_assemble_peers with any `channels`, sbx_assemble_spans) move such words.  A frame rendered this way equals
+ * sbx_pack_unorm8(flip_y = 0) of the float frame, bit for bit.  What it is for: a multi-GPU exchange that carries 4 instead of
+ * 12 bytes per pixel (a 7680x4320 frame at 8 GPUs is bound by the 7 xGMI links into the root in float pixels), and a frame
+ * that is written once in the format it is shown in.  sbx_render_points, sbx_main_image and sbx_main_image_batch always
+ * return float colours. */
+enum { SBX_FORMAT_RGBA32F = 0, SBX_FORMAT_RGBA8 = 1 };
+int sbx_set_output_format(sbx_ctx* ctx, int format);
+
 /* Per-launch timing: when enabled, every render call brackets its kernel with HIP events on the
  * launch stream; sbx_last_kernel_ms() synchronises on the last pair and returns the duration. */
 int sbx_set_timing(sbx_ctx* ctx, int enabled);

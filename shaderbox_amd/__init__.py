@@ -28,6 +28,7 @@ APPS = {"APP_PLANET": APP_PLANET, "APP_CLOUDS": APP_CLOUDS, "APP_VINYL": APP_VIN
         "APP_PLANET_ATMOSPHERE": APP_PLANET_ATMOSPHERE}   # config 5's composite: APP_PLANET with APP_ATMOSPHERE's sky as background (include/sbx.h)        # APP_VINYL with the 180 march steps of its GLSL / HLSL builds (src/app_vinyl.h:411-416)
 
 SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE, SBX_ERR_FAULT = 0, -1, -2, -3, -4, -5
+SBX_FORMAT_RGBA32F, SBX_FORMAT_RGBA8 = 0, 1
 
 
 class SbxError(RuntimeError):
@@ -101,6 +102,7 @@ def load_library(path=None):
     lib.sbx_render_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, fp, vp]
     lib.sbx_render_rank.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, fp, vp]
     lib.sbx_pack_unorm8.argtypes = [vp, ci, ci, fp, vp, ci, vp]
+    lib.sbx_set_output_format.argtypes = [vp, ci]
     lib.sbx_main_image.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ctypes.POINTER(ctypes.c_float * 2),
                                    ctypes.POINTER(ctypes.c_float * 4)]
     lib.sbx_main_image_batch.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ctypes.c_size_t, fp, fp]
@@ -196,7 +198,8 @@ def span_table(app, width, height, time, block_rows, nranks, root_rounds=1, roun
 
 class Renderer:
     """One sbx_ctx on one GPU.  Framebuffers are float32 torch tensors [rows, W, 4] on that GPU,
-    row 0 = bottom row of the strip (reference convention, src/main.h:40-43)."""
+    row 0 = bottom row of the strip (reference convention, src/main.h:40-43) — or, after set_output_format("rgba8"), uint8
+    tensors [rows, W, 4] (one R8G8B8A8_UNORM word per pixel, include/sbx.h), slabs included."""
 
     def __init__(self, device=0):
         import torch
@@ -211,6 +214,7 @@ class Renderer:
             raise SbxError(rc, "sbx_create failed (need a gfx950 device; there is no fallback)")
         self.ctx = h
         self.tdev = torch.device("cuda", self.device)
+        self.pixel_dtype = torch.float32
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -243,15 +247,29 @@ class Renderer:
     def _auxp(aux):
         return ctypes.cast(ctypes.byref(aux), ctypes.c_void_p) if aux is not None else None
 
+    def set_output_format(self, fmt):
+        """'rgba32f' (default) or 'rgba8': what the frame-granular calls write per pixel (sbx_set_output_format).  With 'rgba8'
+        every frame / strip / slab buffer is a uint8 tensor with 4 bytes per pixel; points and main_image stay float."""
+        code = {"rgba32f": SBX_FORMAT_RGBA32F, "rgba8": SBX_FORMAT_RGBA8}[fmt]
+        self._check(self.lib.sbx_set_output_format(self.ctx, code))
+        self.pixel_dtype = self.torch.uint8 if code == SBX_FORMAT_RGBA8 else self.torch.float32
+
+    @property
+    def rgba8(self):
+        return self.pixel_dtype == self.torch.uint8
+
     def empty(self, shape, zero=False):
-        """float32 device buffer (used by distributed.FramePlan)"""
+        """device buffer of the current pixel type (used by distributed.FramePlan)"""
         f = self.torch.zeros if zero else self.torch.empty
-        return f(tuple(shape), dtype=self.torch.float32, device=self.tdev)
+        return f(tuple(shape), dtype=self.pixel_dtype, device=self.tdev)
+
+    def _is_pixels(self, t):
+        return t.is_cuda and t.dtype == self.pixel_dtype and t.is_contiguous()
 
     def _buffer(self, rows, width, out):
         if out is None:
-            return self.torch.empty((rows, width, 4), dtype=self.torch.float32, device=self.tdev)
-        assert out.is_cuda and out.dtype == self.torch.float32 and out.is_contiguous()
+            return self.torch.empty((rows, width, 4), dtype=self.pixel_dtype, device=self.tdev)
+        assert self._is_pixels(out)
         assert out.numel() >= rows * width * 4
         return out
 
@@ -328,7 +346,7 @@ class Renderer:
         u = self.uniforms(width, height, time, mouse)
         if r1 <= r0:
             return slab
-        assert slab.is_cuda and slab.dtype == self.torch.float32 and slab.is_contiguous() and slab.shape[-1] in (3, 4)
+        assert self._is_pixels(slab) and slab.shape[-1] in ((4,) if self.rgba8 else (3, 4))
         assert slab.shape[1] == int(width) and slab.shape[0] >= r1
         view = slab[r0:r1]
         fn = self.lib.sbx_render_split_rgb if slab.shape[-1] == 3 else self.lib.sbx_render_split
@@ -340,7 +358,7 @@ class Renderer:
                              root_rounds=1, rounds=1):
         """The rows of `rank` at their global positions of the full-size `frame` [H, W, 4]; other rows are not touched."""
         u = self.uniforms(width, height, time, mouse)
-        assert frame.is_cuda and frame.dtype == self.torch.float32 and frame.is_contiguous()
+        assert self._is_pixels(frame)
         assert tuple(frame.shape) == (int(height), int(width), 4)
         self._check(self.lib.sbx_render_split_in_place(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
                                                        rank, nranks, root_rounds, rounds, ctypes.c_void_p(frame.data_ptr()),
@@ -354,9 +372,10 @@ class Renderer:
     def render_span_peer(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0), aux=None,
                          root_rounds=1, rounds=1):
         """Slab rows [r0, r1) (whole blocks) of peer `rank`, spans only, packed 3 floats per pixel into `slab` (a flat float32
-        device buffer of >= 3 * rank_pixels[rank] floats: the table's offsets are absolute within it)."""
+        device buffer of >= 3 * rank_pixels[rank] floats: the table's offsets are absolute within it; 'rgba8': 4 bytes per
+        pixel of a flat uint8 buffer)."""
         u = self.uniforms(width, height, time, mouse)
-        assert slab.is_cuda and slab.dtype == self.torch.float32 and slab.is_contiguous()
+        assert self._is_pixels(slab)
         self._check(self.lib.sbx_render_span_peer(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, rank, nranks,
                                                   root_rounds, rounds, int(r0), int(r1), ctypes.c_void_p(slab.data_ptr()),
                                                   self._stream()))
@@ -367,7 +386,7 @@ class Renderer:
         """The owner's launch of the span exchange, in place over the whole `frame` [H, W, 4]: rank 0's row-blocks in full and
         every other block outside its span."""
         u = self.uniforms(width, height, time, mouse)
-        assert frame.is_cuda and frame.dtype == self.torch.float32 and frame.is_contiguous()
+        assert self._is_pixels(frame)
         assert tuple(frame.shape) == (int(height), int(width), 4)
         self._check(self.lib.sbx_render_span_root(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, nranks,
                                                   root_rounds, rounds, ctypes.c_void_p(frame.data_ptr()), self._stream()))
@@ -378,8 +397,8 @@ class Renderer:
         """Scatter the peers' packed span slabs (`peers`: flat float32, slab of rank r at (r - 1) * stride_pixels * 3) into
         `frame`, alpha = 1; everything else in the frame is left as sbx_render_span_root wrote it."""
         u = self.uniforms(width, height, time, mouse)
-        assert peers.is_cuda and peers.dtype == self.torch.float32 and peers.is_contiguous()
-        assert peers.numel() >= (int(nranks) - 1) * int(stride_pixels) * 3
+        assert self._is_pixels(peers) and self._is_pixels(frame)
+        assert peers.numel() >= (int(nranks) - 1) * int(stride_pixels) * (4 if self.rgba8 else 3)
         self._check(self.lib.sbx_assemble_spans(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, nranks,
                                                 root_rounds, rounds, ctypes.c_void_p(peers.data_ptr()), int(stride_pixels),
                                                 ctypes.c_void_p(frame.data_ptr()), self._stream()))
@@ -392,10 +411,10 @@ class Renderer:
             return frame
         ch = int(peers.shape[-1])
         need = (int(nranks) - 1) * shard.rank_rows_max(int(height), int(block_rows), int(nranks), root_rounds, rounds) * int(width) * ch
-        if not (peers.is_cuda and peers.dtype == self.torch.float32 and peers.is_contiguous() and ch in (3, 4)
-                and peers.numel() >= need):
-            raise ValueError("peers must be a contiguous float32 device tensor of >= (nranks-1) * rows_max * W * C = %d floats" % need)
-        assert frame.is_cuda and frame.dtype == self.torch.float32 and frame.is_contiguous()
+        if not (self._is_pixels(peers) and ch in ((4,) if self.rgba8 else (3, 4)) and peers.numel() >= need):
+            raise ValueError("peers must be a contiguous device tensor of >= (nranks-1) * rows_max * W * C = %d elements of the "
+                             "renderer's pixel type" % need)
+        assert self._is_pixels(frame)
         assert tuple(frame.shape) == (int(height), int(width), 4)
         self._check(self.lib.sbx_assemble_peers(self.ctx, int(width), int(height), block_rows, nranks, root_rounds, rounds, ch,
                                                 ctypes.c_void_p(peers.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
@@ -406,10 +425,9 @@ class Renderer:
         """Root side: scatter the rank-major gathered slabs to their global rows -> [H, W, 4]."""
         frame = self._buffer(int(height), int(width), out)
         need = int(nranks) * shard.rank_rows_max(int(height), int(block_rows), int(nranks), root_rounds, rounds) * int(width) * 4
-        if not (gathered.is_cuda and gathered.dtype == self.torch.float32 and gathered.is_contiguous()
-                and gathered.numel() >= need):
-            raise ValueError("gathered must be a contiguous float32 device tensor of >= nranks * rows_max * W * 4 = %d floats"
-                             % need)
+        if not (self._is_pixels(gathered) and gathered.numel() >= need):
+            raise ValueError("gathered must be a contiguous device tensor of >= nranks * rows_max * W * 4 = %d elements of the "
+                             "renderer's pixel type" % need)
         self._check(self.lib.sbx_assemble_split(self.ctx, int(width), int(height), block_rows, nranks, root_rounds, rounds,
                                                 ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(frame.data_ptr()),
                                                 self._stream()))

@@ -10,9 +10,11 @@ namespace sbx {
 // threads move consecutive pixels of a row, so both the read and the write are coalesced 16-B
 // accesses.  Each XCD streams whole rows; there is no reuse to tile for.
 // The split is RowMap's (sbx_frame.h): cycles of `rounds` rounds, rank 0 left out of the rounds >= root_rounds.
+// (PX: float4 pixels, or `unsigned` = one R8G8B8A8_UNORM word per pixel, sbx_set_output_format)
+template <class PX>
 __global__ void __launch_bounds__(256) k_assemble(int width, int height, int block_rows, int nranks, int root_rounds,
-                                                   int rounds, int rows_max, const float4* __restrict__ gathered,
-                                                   float4* __restrict__ frame) {
+                                                   int rounds, int rows_max, const PX* __restrict__ gathered,
+                                                   PX* __restrict__ frame) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)width * height;
     if (i >= total) return;
@@ -30,18 +32,22 @@ __global__ void __launch_bounds__(256) k_assemble(int width, int height, int blo
 }
 
 void launch_assemble(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
-                     const float* gathered, float* frame, hipStream_t s) {
+                     const float* gathered, float* frame, hipStream_t s, bool rgba8) {
     const size_t total = (size_t)width * height;
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, width, height, block_rows,
-                       nranks, root_rounds, rounds, rows_max, reinterpret_cast<const float4*>(gathered),
-                       reinterpret_cast<float4*>(frame));
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (rgba8)
+        hipLaunchKernelGGL(k_assemble<unsigned>, grid, block, 0, s, width, height, block_rows, nranks, root_rounds, rounds, rows_max,
+                           reinterpret_cast<const unsigned*>(gathered), reinterpret_cast<unsigned*>(frame));
+    else
+        hipLaunchKernelGGL(k_assemble<float4>, grid, block, 0, s, width, height, block_rows, nranks, root_rounds, rounds, rows_max,
+                           reinterpret_cast<const float4*>(gathered), reinterpret_cast<float4*>(frame));
 }
 
 // The root of the direct exchange renders its own row-blocks IN PLACE (sbx_render_split_in_place), so only the peers' rows
 // move: `peers` = the slabs of ranks 1 .. nranks-1 (rank-major, rows_max rows each), C floats per pixel — 3 when the slabs
 // crossed xGMI without their alpha (RowMap.rgb), which is the constant 1 of main.h:52 and is written here.  Rows of rank 0
 // are left alone.  One thread per frame pixel; reads and writes of a wave are contiguous (64 x 12 or 16 B in, 64 x 16 B out).
-template <int C>
+template <int C>      // C = 1: R8G8B8A8_UNORM words on both sides (sbx_set_output_format)
 __global__ void __launch_bounds__(256) k_assemble_peers(int width, int height, int block_rows, int nranks, int root_rounds,
                                                          int rounds, int rows_max, const float* __restrict__ peers,
                                                          float4* __restrict__ frame) {
@@ -58,7 +64,9 @@ __global__ void __launch_bounds__(256) k_assemble_peers(int width, int height, i
     if (rank == 0) return;                                   // rendered where it belongs
     const int local_blk = cycle * rounds + round;
     const size_t src = ((size_t)(rank - 1) * rows_max + (size_t)local_blk * block_rows + in_blk) * width + x;
-    if (C == 4) {
+    if (C == 1) {
+        reinterpret_cast<unsigned*>(frame)[i] = reinterpret_cast<const unsigned*>(peers)[src];
+    } else if (C == 4) {
         frame[i] = reinterpret_cast<const float4*>(peers)[src];
     } else {
         const float* p = peers + src * 3;
@@ -69,7 +77,10 @@ void launch_assemble_peers(int width, int height, int block_rows, int nranks, in
                            int channels, const float* peers, float* frame, hipStream_t s) {
     const size_t total = (size_t)width * height;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (channels == 3)
+    if (channels == 1)
+        hipLaunchKernelGGL(k_assemble_peers<1>, grid, block, 0, s, width, height, block_rows, nranks, root_rounds, rounds, rows_max,
+                           peers, reinterpret_cast<float4*>(frame));
+    else if (channels == 3)
         hipLaunchKernelGGL(k_assemble_peers<3>, grid, block, 0, s, width, height, block_rows, nranks, root_rounds, rounds, rows_max,
                            peers, reinterpret_cast<float4*>(frame));
     else
@@ -80,6 +91,7 @@ void launch_assemble_peers(int width, int height, int block_rows, int nranks, in
 // The span exchange (RowMap.span): a peer's slab holds, block after block, only the span [x0, x1) of each of its row-blocks,
 // 3 floats per pixel; slab r - 1 starts at peers + (r - 1) * stride_pixels * 3.  One thread per frame pixel; pixels of rank 0's
 // blocks and pixels outside their block's span were rendered in place by the owner (sbx_render_span_root) and are left alone.
+template <bool RGBA8>      // RGBA8: one R8G8B8A8_UNORM word per pixel on both sides (sbx_set_output_format)
 __global__ void __launch_bounds__(256) k_assemble_spans(int width, int height, int block_rows, const int4* __restrict__ span,
                                                          const float* __restrict__ peers, size_t stride_pixels,
                                                          float4* __restrict__ frame) {
@@ -91,14 +103,23 @@ __global__ void __launch_bounds__(256) k_assemble_spans(int width, int height, i
     const int4 T = span[g];
     if (T.w == 0 || x < T.x || x >= T.y) return;
     const size_t src = (size_t)(T.w - 1) * stride_pixels + (size_t)T.z + (size_t)(y - g * block_rows) * (size_t)(T.y - T.x) + (size_t)(x - T.x);
+    if (RGBA8) {
+        reinterpret_cast<unsigned*>(frame)[i] = reinterpret_cast<const unsigned*>(peers)[src];
+        return;
+    }
     const float* p = peers + src * 3;
     frame[i] = make_float4(p[0], p[1], p[2], 1.0f);                // alpha: the constant of main.h:52
 }
 void launch_assemble_spans(int width, int height, int block_rows, const int4* span, const float* peers, size_t stride_pixels,
-                           float* frame, hipStream_t s) {
+                           float* frame, hipStream_t s, bool rgba8) {
     const size_t total = (size_t)width * height;
-    hipLaunchKernelGGL(k_assemble_spans, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, width, height, block_rows, span,
-                       peers, stride_pixels, reinterpret_cast<float4*>(frame));
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (rgba8)
+        hipLaunchKernelGGL(k_assemble_spans<true>, grid, block, 0, s, width, height, block_rows, span, peers, stride_pixels,
+                           reinterpret_cast<float4*>(frame));
+    else
+        hipLaunchKernelGGL(k_assemble_spans<false>, grid, block, 0, s, width, height, block_rows, span, peers, stride_pixels,
+                           reinterpret_cast<float4*>(frame));
 }
 
 // float RGBA -> R8G8B8A8_UNORM, the back-buffer write of hlsltoy (util/hlsltoy/src/hlsltoy.cpp:79,192), by the
@@ -111,11 +132,7 @@ __global__ void __launch_bounds__(256) k_pack_unorm8(int width, int rows, int fl
     if (i >= total) return;
     const int y = (int)(i / width), x = (int)(i - (size_t)y * width);
     const float4 c = in[i];
-    auto q = [](float v) -> unsigned {
-        if (!(v > 0.f)) return 0u;                   // NaN, -x, -0, +0
-        if (v > 1.f) v = 1.f;
-        return (unsigned)(v * 255.f + .5f);
-    };
+    auto q = [](float v) -> unsigned { return unorm8_(v); };     // sbx_device.h: the rule store_rgba's RGBA8 mode applies too
     const size_t o = (size_t)(flip ? rows - 1 - y : y) * width + x;
     out[o] = q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
 }

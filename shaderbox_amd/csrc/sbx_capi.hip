@@ -27,6 +27,7 @@ struct sbx_ctx {
     int device = 0;
     bool timing = false;
     int variant = 0;
+    int out_format = 0;                    // sbx_set_output_format: 0 float pixels, 1 R8G8B8A8_UNORM words
     int sdf_roots = 0;                     // sbx_set_variant 2 / 3: the SDF kernels' square-root witness test build / IEEE roots
     // APP_CLOUDS y tables: CLOUDS_YTAB_RING slots for eager launches + CLOUDS_YTAB_CAPTURE slots that only launches
     // recorded into a stream capture use (a captured graph bakes the slot pointer in, so eager rebuilds must never
@@ -644,19 +645,27 @@ static int check_common(sbx_ctx* ctx, const sbx_uniforms* uni, const float* rgba
         return fail(ctx, SBX_ERR_ARG, "u_res must be positive integers <= 65536");
     // float4 pixels are stored with one 16-byte store; 3-channel slabs (RowMap.rgb) with three 4-byte stores: a slab piece that
     // starts at row r0 of an odd-width frame is only 4-byte aligned, and that is fine
+    if (ctx->out_format) align_mask = 3u;                     // one 4-byte store per pixel
     if (((uintptr_t)rgba & align_mask) != 0) return fail(ctx, SBX_ERR_ARG, align_mask == 15u ? "framebuffer must be 16-byte aligned" : "slab must be 4-byte aligned");
     return SBX_OK;
 }
 
-int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int y0, int y1, float* rgba,
-                    void* stream) {
+// what RowMap.rgb says about the output of a frame-granular entry point: the context's format wins (sbx_set_output_format)
+static int out_rgb(const sbx_ctx* ctx, int rgb) { return ctx->out_format ? 2 : rgb; }
+
+static int render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int y0, int y1, float* rgba,
+                       void* stream, bool float_pixels) {
     int W, H;
     if (ctx && uni && y0 == y1 && y0 >= 0 && (float)y0 <= uni->u_res[1]) return SBX_OK;   // empty strip: nothing to write
     int rc = check_common(ctx, uni, rgba, W, H);
     if (rc != SBX_OK) return rc;
     if (y0 < 0 || y1 < y0 || y1 > H) return fail(ctx, SBX_ERR_ARG, "bad row range");
-    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0, 0, 1, 1, 0};
+    RowMap M{W, H, y0, (y1 - y0) > 0 ? (y1 - y0) : 1, 1, 0, y1 - y0, 0, 1, 1, 0, float_pixels ? 0 : out_rgb(ctx, 0)};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
+}
+int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int y0, int y1, float* rgba,
+                    void* stream) {
+    return render_rows(ctx, app, uni, aux, y0, y1, rgba, stream, false);
 }
 
 // mainImage at `n` arbitrary fragCoords (device arrays): one launch laid out as a pseudo-frame (RowMap.frag)
@@ -762,7 +771,7 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
             }
             ctx->mi_floats = n;
         }
-        const int rc = sbx_render_rows(ctx, app, uni, aux, 0, H, ctx->mi_dev, nullptr);
+        const int rc = render_rows(ctx, app, uni, aux, 0, H, ctx->mi_dev, nullptr, true);     // (the cache holds float pixels whatever the context's output format)
         if (rc != SBX_OK) return rc;
         // pinned destination: one DMA transfer at the link's rate behind the kernel, then one wait
         if ((e = hipMemcpyAsync(ctx->mi_host, ctx->mi_dev, n * sizeof(float), hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
@@ -1017,7 +1026,7 @@ extern "C" int sbx_render_span_peer(sbx_ctx* ctx, int app, const sbx_uniforms* u
     if (rc != SBX_OK) return rc;
     if (mw <= 0) return SBX_OK;                                    // every span of the peers is empty: nothing to render or send
     // `rgb` is the start of the rank's packed slab: the table's offsets are absolute within it
-    RowMap M{mw, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0, 1, nullptr, 0, dev, 1};
+    RowMap M{mw, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0, out_rgb(ctx, 1), nullptr, 0, dev, 1};
     return render_mapped(ctx, app, uni, aux, M, rgb, stream);
 }
 extern "C" int sbx_render_span_root(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks,
@@ -1032,7 +1041,7 @@ extern "C" int sbx_render_span_root(sbx_ctx* ctx, int app, const sbx_uniforms* u
     rc = span_table_device(ctx, app, uni, aux, block_rows, nranks, root_rounds, rounds, (hipStream_t)stream, &dev, &mw, nullptr);
     if (rc != SBX_OK) return rc;
     // one launch over the whole frame, in place: rank 0's blocks in full, everybody else's outside their spans
-    RowMap M{W, H, 0, H, 1, 0, H, 0, 1, 1, 1, 0, nullptr, 0, dev, 2};
+    RowMap M{W, H, 0, H, 1, 0, H, 0, 1, 1, 1, out_rgb(ctx, 0), nullptr, 0, dev, 2};
     M.block_rows = block_rows;                                     // (row_to_y of a contiguous map: y = r for any block size)
     return render_mapped(ctx, app, uni, aux, M, frame, stream);
 }
@@ -1050,7 +1059,7 @@ extern "C" int sbx_assemble_spans(sbx_ctx* ctx, int app, const sbx_uniforms* uni
     rc = span_table_device(ctx, app, uni, aux, block_rows, nranks, root_rounds, rounds, (hipStream_t)stream, &dev, &mw, nullptr);
     if (rc != SBX_OK) return rc;
     if (mw <= 0) return SBX_OK;
-    launch_assemble_spans(W, H, block_rows, dev, peers, (size_t)stride_pixels, frame, (hipStream_t)stream);
+    launch_assemble_spans(W, H, block_rows, dev, peers, (size_t)stride_pixels, frame, (hipStream_t)stream, ctx->out_format != 0);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "assemble launch", e);
     return SBX_OK;
@@ -1067,7 +1076,7 @@ static int render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const vo
     if (r0 < 0 || r1 < r0) return fail(ctx, SBX_ERR_ARG, "bad slab row range");
     if (r1 > rows) r1 = rows;                 // the slab is padded to the split's rows_max; the tail has no pixels
     if (r0 >= r1) return SBX_OK;
-    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0, rgb};
+    RowMap M{W, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0, out_rgb(ctx, rgb)};
     return render_mapped(ctx, app, uni, aux, M, rgba, stream);
 }
 int sbx_render_split(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
@@ -1086,7 +1095,7 @@ int sbx_render_split_in_place(sbx_ctx* ctx, int app, const sbx_uniforms* uni, co
     const int rows = sbx_split_rank_rows(H, block_rows, rank, nranks, root_rounds, rounds);
     if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
     if (rows == 0) return SBX_OK;
-    RowMap M{W, H, 0, block_rows, nranks, rank, rows, 0, root_rounds, rounds, 1};
+    RowMap M{W, H, 0, block_rows, nranks, rank, rows, 0, root_rounds, rounds, 1, out_rgb(ctx, 0)};
     return render_mapped(ctx, app, uni, aux, M, frame, stream);
 }
 int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
@@ -1106,7 +1115,8 @@ int sbx_assemble_split(sbx_ctx* ctx, int width, int height, int block_rows, int 
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     launch_assemble(width, height, block_rows, nranks, root_rounds, rounds,
-                    sbx_split_rows_max(height, block_rows, nranks, root_rounds, rounds), gathered, frame, (hipStream_t)stream);
+                    sbx_split_rows_max(height, block_rows, nranks, root_rounds, rounds), gathered, frame, (hipStream_t)stream,
+                    ctx->out_format != 0);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "assemble launch", e);
     return SBX_OK;
@@ -1121,7 +1131,7 @@ int sbx_assemble_peers(sbx_ctx* ctx, int width, int height, int block_rows, int 
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     launch_assemble_peers(width, height, block_rows, nranks, root_rounds, rounds,
-                          sbx_split_rows_max(height, block_rows, nranks, root_rounds, rounds), channels, peers, frame,
+                          sbx_split_rows_max(height, block_rows, nranks, root_rounds, rounds), ctx->out_format ? 1 : channels, peers, frame,
                           (hipStream_t)stream);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "assemble launch", e);
@@ -1144,6 +1154,12 @@ int sbx_pack_unorm8(sbx_ctx* ctx, int width, int rows, const float* rgba, unsign
     return SBX_OK;
 }
 
+int sbx_set_output_format(sbx_ctx* ctx, int format) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (format != SBX_FORMAT_RGBA32F && format != SBX_FORMAT_RGBA8) return fail(ctx, SBX_ERR_ARG, "unknown output format");
+    ctx->out_format = format;
+    return SBX_OK;
+}
 int sbx_set_variant(sbx_ctx* ctx, int variant) {
     if (!ctx) return SBX_ERR_ARG;
     if (variant < 0 || variant > 3) return fail(ctx, SBX_ERR_ARG, "unknown kernel variant");

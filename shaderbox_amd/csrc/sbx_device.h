@@ -83,10 +83,19 @@ inline dim3 grid_for(const RowMap& M) {
     constexpr int TH = 64 / TW, W = TW * TX;
     return dim3((M.width + W - 1) / W, (M.nrows + TH - 1) / TH);
 }
+// float -> UNORM8 by the Direct3D rule (the write into hlsltoy's R8G8B8A8_UNORM back buffer, util/hlsltoy/src/hlsltoy.cpp:79,192):
+// NaN -> 0, clamp to [0, 1], scale by 255, add .5, truncate
+__device__ __forceinline__ unsigned unorm8_(float v) {
+    if (!(v > 0.f)) return 0u;                       // NaN, -x, -0, +0
+    if (v > 1.f) v = 1.f;
+    return (unsigned)(v * 255.f + .5f);
+}
 __device__ __forceinline__ void store_rgba(const RowMap& M, float* out, size_t idx, v3 c) {
-    if (M.rgb) {                                                               // wave-uniform (a kernel argument)
+    if (M.rgb == 1) {                                                          // wave-uniform (a kernel argument)
         float* o = out + idx * 3;                                              // 64 lanes: 768 contiguous bytes
         o[0] = c.x; o[1] = c.y; o[2] = c.z;
+    } else if (M.rgb == 2) {                                                   // SBX_FORMAT_RGBA8: one 4-byte store per pixel, alpha 255
+        reinterpret_cast<unsigned*>(out)[idx] = unorm8_(c.x) | (unorm8_(c.y) << 8) | (unorm8_(c.z) << 16) | 0xff000000u;
     } else {
         reinterpret_cast<float4*>(out)[idx] = make_float4(c.x, c.y, c.z, 1.0f);   // main.h:52
     }
@@ -117,7 +126,7 @@ void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, h
 void launch_clouds_ue4(const FrameCloudsUe4& F, const RowMap& M, float* out, hipStream_t s);
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_assemble(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
-                     const float* gathered, float* frame, hipStream_t s);
+                     const float* gathered, float* frame, hipStream_t s, bool rgba8);
 void launch_assemble_peers(int width, int height, int block_rows, int nranks, int root_rounds, int rounds, int rows_max,
                            int channels, const float* peers, float* frame, hipStream_t s);
 hipError_t bind_fault_clouds(unsigned* word);
@@ -125,7 +134,7 @@ hipError_t bind_fault_clouds_ue4(unsigned* word);
 hipError_t bind_fault_planet(unsigned* word);
 void launch_raise_fault(unsigned code, hipStream_t s);
 void launch_assemble_spans(int width, int height, int block_rows, const int4* span, const float* peers, size_t stride_pixels,
-                           float* frame, hipStream_t s);
+                           float* frame, hipStream_t s, bool rgba8);
 void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);
 void launch_worley_volume(int size, float* out, hipStream_t s);

@@ -30,6 +30,11 @@ Two forms of that one exchange (`exchange=`):
   and the same kernel, so the table can only cost balance, never a pixel), then scatters the packed slabs.  Still exactly one
   exchange step.  At 7680x4320 a peer's 49.8 MB become 29.7 MB (ATMOSPHERE, PLANET); at 4K APP_CLOUDS 12.4 -> 9.2 MB.
 
+Pixel format: the plan moves whatever pixels its renderer writes.  After `renderer.set_output_format("rgba8")` (include/sbx.h
+SBX_FORMAT_RGBA8: the render kernels write one R8G8B8A8_UNORM word per pixel, the reference hosts' display format) every slab,
+landing area and frame of the plan is a uint8 tensor with 4 bytes per pixel — a third of the float exchange's bytes on every link
+and in the root's HBM; the assembled frame equals pack_unorm8 of the float frame.
+
 `renderer` is duck-typed (render_rank_rows / render_rank_in_place / assemble / assemble_peers / empty):
 shaderbox_amd.Renderer on GPUs; the CPU tests drive the same code over gloo with an oracle-backed stand-in.
 """
@@ -50,7 +55,11 @@ class FramePlan:
         if channels not in (3, 4):
             raise ValueError("channels must be 3 or 4")
         self.r, self.dist = renderer, dist
+        self.rgba8 = bool(getattr(renderer, "rgba8", False))
+        if self.rgba8:
+            channels = 4                                       # 4 BYTES per pixel: one word, whatever the exchange
         self.exchange, self.channels = exchange, int(channels)
+        self.span_epp = 4 if self.rgba8 else 3                 # buffer elements per pixel of a span slab
         self.width, self.height, self.block_rows = int(width), int(height), int(block_rows)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
@@ -112,20 +121,20 @@ class FramePlan:
         d = self.dist
         self.p2p = []
         if self.rank == 0:
-            self.peers = self.r.empty((max(self.world - 1, 1) * max(self.span_stride, 1) * 3,), zero=True)
+            self.peers = self.r.empty((max(self.world - 1, 1) * max(self.span_stride, 1) * self.span_epp,), zero=True)
             for a, b in self.ranges:
                 ops = []
                 for i in range(1, self.world):
                     lo, hi = pixel_range(i, a, b)
                     if hi > lo:
                         base = (i - 1) * self.span_stride
-                        ops.append(d.P2POp(d.irecv, self.peers[(base + lo) * 3:(base + hi) * 3], i))
+                        ops.append(d.P2POp(d.irecv, self.peers[(base + lo) * self.span_epp:(base + hi) * self.span_epp], i))
                 self.p2p.append(ops)
         else:
-            self.slab = self.r.empty((max(self.span_pixels[self.rank], 1) * 3,), zero=True)
+            self.slab = self.r.empty((max(self.span_pixels[self.rank], 1) * self.span_epp,), zero=True)
             for a, b in self.ranges:
                 lo, hi = pixel_range(self.rank, a, b)
-                self.p2p.append([d.P2POp(d.isend, self.slab[lo * 3:hi * 3], 0)] if hi > lo else [])
+                self.p2p.append([d.P2POp(d.isend, self.slab[lo * self.span_epp:hi * self.span_epp], 0)] if hi > lo else [])
         self._span_key = key
 
     def _render_spans(self, app, time, mouse, aux, mark):

@@ -540,3 +540,110 @@ def test_witnessed_square_roots_of_the_sdf_kernels(renderer, oracle, app):
     with pytest.raises(Exception):
         renderer.set_variant(4)
     renderer.set_variant(0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SBX_FORMAT_RGBA8: the kernels write the display format themselves (include/sbx.h sbx_set_output_format)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def renderer8():
+    import shaderbox_amd
+    r = shaderbox_amd.Renderer(0)
+    r.set_output_format("rgba8")
+    yield r
+    r.close()
+
+
+@pytest.mark.parametrize("app", ALL_APPS)
+def test_rgba8_frames_equal_the_packed_float_frames(renderer, renderer8, app):
+    """a frame, a strip and a rank's slab written as R8G8B8A8_UNORM words by the render kernel == sbx_pack_unorm8 of the float
+    pixels, for every app (NaN pixels pack to 0 on both sides), odd sizes included"""
+    import torch
+    if app == "clouds_tex":
+        pytest.skip("needs noise volumes (covered by test_rgba8_with_noise_textures)")
+    for w, h, t in [(320, 180, .37), (333, 187, 2.9)]:
+        f = renderer.render(app, w, h, t)
+        want = renderer.pack_unorm8(f, flip_y=False)
+        got = renderer8.render(app, w, h, t)
+        assert got.dtype == torch.uint8 and tuple(got.shape) == (h, w, 4)
+        assert torch.equal(got, want), (app, w, h, t)
+        strip = renderer8.render(app, w, h, t, rows=(41, 97))
+        assert torch.equal(strip, want[41:97]), (app, w, h, "strip")
+        slab = renderer8.render_rank(app, w, h, t, 8, 2, 3)
+        ref = renderer.pack_unorm8(renderer.render_rank(app, w, h, t, 8, 2, 3), flip_y=False)
+        from shaderbox_amd import shard
+        n = shard.rank_rows(h, 8, 2, 3)
+        assert torch.equal(slab[:n], ref[:n]), (app, w, h, "rank slab")
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_rgba8_through_the_multi_rank_schedules(renderer, renderer8, n):
+    """every exchange form of FramePlan with 4-byte pixels: the assembled uint8 frame == the packed float frame of one launch;
+    a third of the float exchange's bytes cross the links"""
+    import torch
+    for app, w, h, t, exchange, groups, relief in [("clouds", 1000, 333, .37, "spans", 2, (1, 1)), ("atmosphere", 1111, 500, 1.5, "spans", 1, (1, 2)),
+                                                   ("planet", 640, 360, .37, "direct", 2, (3, 4)), ("egg", 641, 357, 1.0, "direct", 1, (1, 1)),
+                                                   ("raytracer", 500, 300, .37, "direct", 2, (1, 1)), ("atmosphere", 800, 450, .37, "direct", 3, (0, 1))]:
+        want = renderer.pack_unorm8(renderer.render(app, w, h, t), flip_y=False)
+        from shaderbox_amd.distributed import LoopbackWorld
+        world = LoopbackWorld(n)
+        plans = world.plans(renderer8, w, h, block_rows=8, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=exchange)
+        for _ in range(2):
+            plans[0].frame.fill_(7)
+            got = LoopbackWorld.render(plans, app, t)
+        torch.cuda.synchronize()
+        assert got.dtype == torch.uint8 and torch.equal(got, want), (app, w, h, n, exchange)
+        fworld = LoopbackWorld(n)
+        fplans = fworld.plans(renderer, w, h, block_rows=8, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=exchange)
+        LoopbackWorld.render(fplans, app, t)
+        torch.cuda.synchronize()
+        assert abs(fworld.bytes_moved - 3.0 * world.bytes_moved / 2) <= 64, (fworld.bytes_moved, world.bytes_moved)   # (two rgba8 frames)
+    # the gather form's assembly (whole RGBA slabs of every rank, the root's included)
+    from shaderbox_amd import shard
+    w, h, t, app = 333, 187, .37, "sdf_ao"
+    rows_max = shard.rank_rows_max(h, 8, n)
+    gathered = torch.zeros((n, rows_max, w, 4), dtype=torch.uint8, device="cuda")
+    for r in range(n):
+        renderer8.render_rank(app, w, h, t, 8, r, n, out=gathered[r])
+    got = renderer8.assemble(gathered, w, h, 8, n)
+    assert torch.equal(got, renderer.pack_unorm8(renderer.render(app, w, h, t), flip_y=False))
+
+
+def test_rgba8_leaves_points_and_main_image_float(renderer, renderer8, oracle):
+    """sbx_render_points / sbx_main_image(_batch) return float colours whatever the context's output format, and the format can be
+    switched back; unknown formats are refused"""
+    import torch
+    import shaderbox_amd
+    w, h, t = 200, 120, .37
+    pts = torch.tensor([[10.5, 20.5], [100.25, 60.75], [-3.0, 500.0]], dtype=torch.float32, device="cuda")
+    a = renderer8.render_points("egg", w, h, t, pts)
+    b = renderer.render_points("egg", w, h, t, pts)
+    assert a.dtype == torch.float32 and torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert renderer8.main_image("raytracer", w, h, t, (10.5, 20.5)) == renderer.main_image("raytracer", w, h, t, (10.5, 20.5))
+    assert renderer8.main_image("raytracer", w, h, t, (11.5, 20.5)) == renderer.main_image("raytracer", w, h, t, (11.5, 20.5))
+    r = shaderbox_amd.Renderer(0)
+    try:
+        r.set_output_format("rgba8")
+        r.set_output_format("rgba32f")
+        f = r.render("egg", w, h, t)
+        assert f.dtype == torch.float32 and torch.equal(f.view(torch.int32), renderer.render("egg", w, h, t).view(torch.int32))
+        assert r.lib.sbx_set_output_format(r.ctx, 7) == shaderbox_amd.SBX_ERR_ARG
+    finally:
+        r.close()
+
+
+def test_rgba8_with_noise_textures(renderer):
+    import torch
+    import shaderbox_amd
+    r = shaderbox_amd.Renderer(0)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(5)
+        shape = torch.rand((32, 32, 32, 4), generator=g).cuda()
+        detail = torch.rand((16, 16, 16, 4), generator=g).cuda()
+        r.set_noise_volumes(shape, detail)
+        f = r.render("clouds_tex", 320, 180, .37)
+        want = r.pack_unorm8(f, flip_y=False)
+        r.set_output_format("rgba8")
+        assert torch.equal(r.render("clouds_tex", 320, 180, .37), want)
+    finally:
+        r.close()
