@@ -352,6 +352,9 @@ int sbx_multi_ranks(const sbx_multi* m);
 int sbx_multi_uses_rccl(const sbx_multi* m);             /* 1: RCCL send/recv, 0: device / peer copies */
 int sbx_multi_set_split(sbx_multi* m, int block_rows, int root_rounds, int rounds);
 int sbx_multi_set_variant(sbx_multi* m, int variant);
+/* sbx_set_output_format on every rank: with SBX_FORMAT_RGBA8 `frame` of sbx_multi_render holds width * height 32-bit words and
+ * every exchange form moves 4 bytes per pixel. */
+int sbx_multi_set_output_format(sbx_multi* m, int format);
 /* The two noise volumes of SBX_APP_CLOUDS_TEX (device memory on rank 0's device), handed to every rank; synchronous. */
 int sbx_multi_set_noise_volumes(sbx_multi* m, int shape_size, const float* shape_rgba, int detail_size,
                                 const float* detail_rgba);

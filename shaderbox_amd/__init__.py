@@ -138,6 +138,7 @@ def load_library(path=None):
     lib.sbx_multi_uses_rccl.argtypes = [vp]
     lib.sbx_multi_set_split.argtypes = [vp, ci, ci, ci]
     lib.sbx_multi_set_variant.argtypes = [vp, ci]
+    lib.sbx_multi_set_output_format.argtypes = [vp, ci]
     lib.sbx_multi_set_exchange.argtypes = [vp, ci]
     lib.sbx_multi_create_error.argtypes = []
     lib.sbx_multi_create_error.restype = ctypes.c_char_p
@@ -544,6 +545,12 @@ class MultiRenderer:
     def set_split(self, block_rows=8, root_rounds=1, rounds=1):
         self._check(self.lib.sbx_multi_set_split(self.m, int(block_rows), int(root_rounds), int(rounds)))
 
+    def set_output_format(self, fmt):
+        """'rgba32f' or 'rgba8' on every rank (sbx_multi_set_output_format): render() then returns / fills uint8 [H, W, 4]"""
+        code = {"rgba32f": SBX_FORMAT_RGBA32F, "rgba8": SBX_FORMAT_RGBA8}[fmt]
+        self._check(self.lib.sbx_multi_set_output_format(self.m, code))
+        self.pixel_dtype = self.torch.uint8 if code == SBX_FORMAT_RGBA8 else self.torch.float32
+
     def set_variant(self, variant):
         self._check(self.lib.sbx_multi_set_variant(self.m, int(variant)))
 
@@ -562,9 +569,10 @@ class MultiRenderer:
     def render(self, app, width, height, time, mouse=(0.0, 0.0), aux=None, out=None):
         """The whole frame over all ranks; asynchronous on the current stream of devices[0]."""
         u = Renderer.uniforms(width, height, time, mouse)
+        dt = getattr(self, "pixel_dtype", self.torch.float32)
         if out is None:
-            out = self.torch.empty((int(height), int(width), 4), dtype=self.torch.float32, device=self.tdev)
-        assert out.is_cuda and out.dtype == self.torch.float32 and out.is_contiguous() and out.numel() >= int(height) * int(width) * 4
+            out = self.torch.empty((int(height), int(width), 4), dtype=dt, device=self.tdev)
+        assert out.is_cuda and out.dtype == dt and out.is_contiguous() and out.numel() >= int(height) * int(width) * 4
         stream = ctypes.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
         self._check(self.lib.sbx_multi_render(self.m, app_id(app), ctypes.byref(u), Renderer._auxp(aux),
                                               ctypes.c_void_p(out.data_ptr()), stream))

@@ -107,6 +107,7 @@ struct sbx_multi {
     bool peer_stores_ok = true;                           // every peer's device can address rank 0's memory (or is rank 0's device)
     int block_rows = 8, root_rounds = 1, rounds = 1;
     int exchange = SBX_MULTI_EXCHANGE_SLABS;
+    int out_format = SBX_FORMAT_RGBA32F;                  // SBX_FORMAT_RGBA8: every pixel anywhere is ONE 32-bit word (counted as one "float" below)
     unsigned calls = 0;
     hipEvent_t start[kInFlight] = {};
     bool recv_recorded[kInFlight] = {false, false};       // root.recv_done[k] has been recorded at least once
@@ -288,6 +289,16 @@ int sbx_multi_set_exchange(sbx_multi* m, int mode) {
     return SBX_OK;
 }
 
+int sbx_multi_set_output_format(sbx_multi* m, int format) {
+    if (!m) return SBX_ERR_ARG;
+    if (format != SBX_FORMAT_RGBA32F && format != SBX_FORMAT_RGBA8) return mfail(m, SBX_ERR_ARG, "unknown output format");
+    for (Rank& r : m->ranks) {
+        const int rc = sbx_set_output_format(r.ctx, format);
+        if (rc != SBX_OK) return mfail(m, rc, sbx_last_error(r.ctx));
+    }
+    m->out_format = format;
+    return SBX_OK;
+}
 int sbx_multi_set_variant(sbx_multi* m, int variant) {
     if (!m) return SBX_ERR_ARG;
     for (Rank& r : m->ranks) {
@@ -344,13 +355,14 @@ static int render_spans(sbx_multi* m, int app, const sbx_uniforms* uni, const vo
     const int br = m->block_rows, m0 = m->root_rounds, mr = m->rounds;
     Rank& root = m->ranks[0];
     hipError_t e;
+    const size_t epp = m->out_format == SBX_FORMAT_RGBA8 ? 1 : 3;      // 32-bit words per pixel of a span slab
     std::vector<int64_t> pix(n, 0);
     const int nb = sbx_span_table(app, uni, aux, br, n, m0, mr, nullptr, pix.data(), nullptr);
     if (nb < 0) return mfail(m, nb, "bad span table arguments (app, u_res or split)");
     int64_t stride = 0;
     for (int i = 1; i < n; ++i) stride = pix[i] > stride ? pix[i] : stride;
     stride = (stride + 63) / 64 * 64;
-    const size_t need_stage = (size_t)(n - 1) * (size_t)stride * 3;
+    const size_t need_stage = (size_t)(n - 1) * (size_t)stride * epp;
     if (need_stage > root.stage_floats) {
         sync_all_ranks(m);
         (void)hipSetDevice(root.device);
@@ -371,7 +383,7 @@ static int render_spans(sbx_multi* m, int app, const sbx_uniforms* uni, const vo
         if (i == 0) {
             rc = sbx_render_span_root(r.ctx, app, uni, aux, br, n, m0, mr, frame, r.render[k]);
         } else {
-            const size_t need = (size_t)(pix[i] > 0 ? pix[i] : 1) * 3;
+            const size_t need = (size_t)(pix[i] > 0 ? pix[i] : 1) * epp;
             if (need > r.slab_floats) {
                 sync_all_ranks(m);
                 (void)hipSetDevice(r.device);
@@ -398,9 +410,9 @@ static int render_spans(sbx_multi* m, int app, const sbx_uniforms* uni, const vo
         for (int i = 1; i < n && nr == 0; ++i) {
             if (pix[i] <= 0) continue;
             Rank& r = m->ranks[i];
-            const size_t floats = (size_t)pix[i] * 3;
+            const size_t floats = (size_t)pix[i] * epp;
             if (check(g_rccl.Send(r.slab[k], floats, kNcclFloat, 0, r.comm, r.render[k]), "ncclSend", i))
-                check(g_rccl.Recv(root.stage[k] + (size_t)(i - 1) * (size_t)stride * 3, floats, kNcclFloat, i, root.comm, root.recv[k]), "ncclRecv", i);
+                check(g_rccl.Recv(root.stage[k] + (size_t)(i - 1) * (size_t)stride * epp, floats, kNcclFloat, i, root.comm, root.recv[k]), "ncclRecv", i);
         }
         const nccl_result_t ne = g_rccl.GroupEnd();
         if (nr != 0) return mfail(m, SBX_ERR_HIP, "RCCL " + where + ": " + g_rccl.GetErrorString(nr));
@@ -410,8 +422,8 @@ static int render_spans(sbx_multi* m, int app, const sbx_uniforms* uni, const vo
             Rank& r = m->ranks[i];
             if ((e = hipSetDevice(r.device)) != hipSuccess) return mfail(m, SBX_ERR_HIP, "hipSetDevice", e);
             if (pix[i] > 0) {
-                float* dst = root.stage[k] + (size_t)(i - 1) * (size_t)stride * 3;
-                const size_t bytes = (size_t)pix[i] * 3 * sizeof(float);
+                float* dst = root.stage[k] + (size_t)(i - 1) * (size_t)stride * epp;
+                const size_t bytes = (size_t)pix[i] * epp * sizeof(float);
                 if (r.device == root.device) e = hipMemcpyAsync(dst, r.slab[k], bytes, hipMemcpyDeviceToDevice, r.render[k]);
                 else e = hipMemcpyPeerAsync(dst, root.device, r.slab[k], r.device, bytes, r.render[k]);
                 if (e != hipSuccess) return mfail(m, SBX_ERR_HIP, "span slab copy", e);
@@ -477,8 +489,9 @@ int sbx_multi_render(sbx_multi* m, int app, const sbx_uniforms* uni, const void*
         return SBX_OK;
     }
     const bool slabs = m->exchange != SBX_MULTI_EXCHANGE_BLOCKS;
-    const int ch = slabs ? 3 : 4;                                   // floats per pixel of a peer's slab
-    const size_t row_floats = (size_t)W * 4, slab_row = (size_t)W * ch;
+    const bool rgba8 = m->out_format == SBX_FORMAT_RGBA8;
+    const int ch = rgba8 ? 1 : (slabs ? 3 : 4);                      // 32-bit words per pixel of a peer's slab
+    const size_t row_floats = (size_t)W * (rgba8 ? 1 : 4), slab_row = (size_t)W * ch;
     const int rows_max = sbx_split_rows_max(H, br, n, m0, mr);
     if (rows_max < 0) return mfail(m, SBX_ERR_ARG, "bad split");
     if (n > 1 && slabs) {                                           // the root's landing area: (n - 1) slabs of rows_max rows

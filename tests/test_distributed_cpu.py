@@ -15,12 +15,18 @@ import torch.multiprocessing as mp
 class OracleRenderer:
     """CPU stand-in with the duck-typed surface FramePlan needs (render_rank / assemble / empty)."""
 
-    def __init__(self):
+    def __init__(self, rgba8=False):
         from oracle.oracle import Oracle
         self.o = Oracle()
+        self.rgba8 = bool(rgba8)               # SBX_FORMAT_RGBA8: every buffer holds 4 BYTES per pixel (include/sbx.h)
+        self.epp = 4 if rgba8 else 3           # elements per pixel of a span slab
 
     def empty(self, shape, zero=False):
-        return torch.zeros(tuple(shape), dtype=torch.float32)
+        return torch.zeros(tuple(shape), dtype=torch.uint8 if self.rgba8 else torch.float32)
+
+    def px(self, img):
+        """the oracle's float RGBA rows as this renderer's pixels"""
+        return torch.from_numpy(pack_unorm8(img)) if self.rgba8 else torch.from_numpy(img)
 
     def render_rank_rows(self, app, width, height, time, block_rows, rank, nranks, r0, r1, slab, mouse=(0.0, 0.0),
                          aux=None, root_rounds=1, rounds=1):
@@ -29,7 +35,7 @@ class OracleRenderer:
         rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)[r0:r1]
         if rows:
             img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
-            slab[r0:r0 + len(rows)] = torch.from_numpy(img)[..., :slab.shape[-1]]      # 3-channel slabs: no alpha
+            slab[r0:r0 + len(rows)] = self.px(img)[..., :slab.shape[-1]]      # 3-channel slabs: no alpha
         return slab
 
     def render_rank_in_place(self, app, width, height, time, block_rows, rank, nranks, frame, mouse=(0.0, 0.0), aux=None,
@@ -39,7 +45,7 @@ class OracleRenderer:
         rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)
         if rows:
             img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
-            frame[rows] = torch.from_numpy(img)
+            frame[rows] = self.px(img)
         return frame
 
     def assemble_peers(self, peers, width, height, block_rows, nranks, frame, root_rounds=1, rounds=1):
@@ -49,7 +55,7 @@ class OracleRenderer:
             if r > 0:
                 frame[y, :, :ch] = peers[r - 1, local]
                 if ch == 3:
-                    frame[y, :, 3] = 1.0
+                    frame[y, :, 3] = 1.0            # (float slabs without alpha only)
         return frame
 
     # -- the span exchange: mirrors of sbx_render_span_peer / sbx_render_span_root / k_assemble_spans over the REAL span table
@@ -66,12 +72,13 @@ class OracleRenderer:
         rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)[r0:r1]
         rows = [y for y in rows if table[y // block_rows][1] > table[y // block_rows][0]]
         if rows:
-            img = torch.from_numpy(self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2))
+            img = self.px(self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2))
+            e = self.epp
             for k, y in enumerate(rows):
                 x0, x1, off, owner = (int(v) for v in table[y // block_rows])
                 assert owner == rank
                 at = off + (y % block_rows) * (x1 - x0)
-                slab[at * 3:(at + x1 - x0) * 3] = img[k, x0:x1, :3].reshape(-1)
+                slab[at * e:(at + x1 - x0) * e] = img[k, x0:x1, :e].reshape(-1)
         return slab
 
     def render_span_root(self, app, width, height, time, block_rows, nranks, frame, mouse=(0.0, 0.0), aux=None, root_rounds=1,
@@ -80,7 +87,7 @@ class OracleRenderer:
         table, _, _ = self.span_table(app, width, height, time, block_rows, nranks, root_rounds, rounds, mouse, aux)
         rows = [y for y in range(height) if table[y // block_rows][3] == 0 or
                 table[y // block_rows][1] - table[y // block_rows][0] < width]
-        img = torch.from_numpy(self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2))
+        img = self.px(self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2))
         for k, y in enumerate(rows):
             x0, x1, off, owner = (int(v) for v in table[y // block_rows])
             if owner == 0:
@@ -97,8 +104,10 @@ class OracleRenderer:
             x0, x1, off, owner = (int(v) for v in table[y // block_rows])
             if owner > 0 and x1 > x0:
                 at = (owner - 1) * stride_pixels + off + (y % block_rows) * (x1 - x0)
-                frame[y, x0:x1, :3] = peers[at * 3:(at + x1 - x0) * 3].reshape(x1 - x0, 3)
-                frame[y, x0:x1, 3] = 1.0
+                e = self.epp
+                frame[y, x0:x1, :e] = peers[at * e:(at + x1 - x0) * e].reshape(x1 - x0, e)
+                if e == 3:
+                    frame[y, x0:x1, 3] = 1.0
         return frame
 
     def assemble(self, gathered, width, height, block_rows, nranks, out=None, root_rounds=1, rounds=1):
@@ -108,17 +117,27 @@ class OracleRenderer:
         return out
 
 
-def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1, 1), exchange="direct", channels=3):
+def pack_unorm8(img):
+    """numpy statement of the Direct3D float -> UNORM8 rule (sbx_pack_unorm8 / store_rgba's RGBA8 mode): NaN and v <= 0 -> 0,
+    v > 1 -> 255, else trunc(v * 255 + .5) in binary32"""
+    v = np.asarray(img, dtype=np.float32)
+    with np.errstate(invalid="ignore"):
+        pos = v > 0
+        c = np.where(pos, np.minimum(v, np.float32(1)), np.float32(0)).astype(np.float32)
+        return (c * np.float32(255) + np.float32(.5)).astype(np.uint8)
+
+
+def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1, 1), exchange="direct", channels=3, rgba8=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from shaderbox_amd.distributed import FramePlan
-    plan = FramePlan(OracleRenderer(), dist, w, h, br, groups=groups, root_rounds=relief[0], rounds=relief[1],
+    plan = FramePlan(OracleRenderer(rgba8), dist, w, h, br, groups=groups, root_rounds=relief[0], rounds=relief[1],
                      exchange=exchange, channels=channels)
     frame = None
     for _ in range(2):                       # buffers are reused across frames
         if rank == 0:
-            plan.frame.fill_(-7.0)           # every pixel of the frame must be written again
+            plan.frame.fill_(7 if rgba8 else -7.0)           # every pixel of the frame must be written again
         frame = plan.render(app, t)
     if rank == 0:
         np.save(result_path, frame.numpy())
@@ -183,6 +202,22 @@ def test_span_exchange_assembles_the_single_process_frame(tmp_path, oracle, worl
     got = np.load(path)
     ref = oracle.render(APP_IDS[app], w, h, 0.37)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,app,w,h,br,groups,relief,exchange", [(2, "atmosphere", 448, 252, 8, 2, (1, 1), "spans"),
+                                                                      (3, "clouds", 128, 72, 4, 3, (1, 2), "spans"),
+                                                                      (2, "egg", 64, 45, 8, 3, (1, 1), "direct"),
+                                                                      (3, "raytracer", 64, 50, 5, 2, (0, 2), "direct"),
+                                                                      (2, "egg", 64, 45, 8, 2, (1, 1), "gather")])
+def test_rgba8_exchange_assembles_the_packed_frame(tmp_path, oracle, world, app, w, h, br, groups, relief, exchange):
+    """SBX_FORMAT_RGBA8: FramePlan with 4-byte pixels everywhere (slabs, landing areas, frame) over gloo == the packed
+    single-process frame"""
+    from oracle.oracle import APP_IDS
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, groups, path, relief, exchange, 3, True), nprocs=world, join=True)
+    got = np.load(path)
+    ref = pack_unorm8(oracle.render(APP_IDS[app], w, h, 0.37))
+    assert got.dtype == np.uint8 and got.shape == ref.shape and np.array_equal(got, ref)
 
 
 def test_span_table_is_a_consistent_layout():

@@ -647,3 +647,29 @@ def test_rgba8_with_noise_textures(renderer):
         assert torch.equal(r.render("clouds_tex", 320, 180, .37), want)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("nranks", [3, 8])
+def test_rgba8_through_the_library_multi_gpu_engine(renderer, nranks):
+    """sbx_multi_set_output_format(SBX_FORMAT_RGBA8) with every exchange form of the library engine (all ranks on device 0: copies
+    instead of RCCL): the uint8 frame == the packed float frame; switching back gives the float frame again"""
+    import torch
+    import shaderbox_amd
+    m = shaderbox_amd.MultiRenderer([0] * nranks)
+    try:
+        for exchange in ("slabs", "blocks", "spans", "peer_stores"):
+            m.set_exchange(exchange)
+            for app, w, h, t, split in [("clouds", 1000, 333, .37, (8, 1, 1)), ("atmosphere", 1111, 500, .37, (8, 1, 2)), ("egg", 203, 95, .37, (4, 0, 1))]:
+                m.set_split(*split)
+                f = renderer.render(app, w, h, t)
+                want = renderer.pack_unorm8(f, flip_y=False)
+                m.set_output_format("rgba8")
+                got = m.render(app, w, h, t)
+                torch.cuda.synchronize()
+                assert got.dtype == torch.uint8 and torch.equal(got, want), (exchange, app, w, h, split)
+                m.set_output_format("rgba32f")
+                got = m.render(app, w, h, t)
+                torch.cuda.synchronize()
+                assert torch.equal(got.view(torch.int32), f.view(torch.int32)), (exchange, app, "float again")
+    finally:
+        m.close()
