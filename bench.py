@@ -207,6 +207,10 @@ def main():
                          "launch, time every rank's part with frames in flight and print the MODELLED N-GPU figures with the exchange "
                          "budget (n_gpus stays 1, 'emulated_ranks' says so; link rates are assumptions: --link-gbps)")
     ap.add_argument("--link-gbps", type=float, default=50.0, help="--emulate-ranks: the per-direction xGMI rate of the budget")
+    ap.add_argument("--format", choices=["rgba32f", "rgba8"], default="rgba32f",
+                    help="--emulate-ranks only: the pixels the kernels write and the exchange carries — float (the metric's frame), or "
+                         "SBX_FORMAT_RGBA8, the 4-byte display format of the reference's hosts (include/sbx.h); the N = 1 figure the "
+                         "speed-up refers to is measured in the same format")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N>1 process group: 'nccl' = RCCL (the product path); 'gloo' = TEST ONLY: the ranks may share a GPU (rank r on "
                          "device r mod device count), point-to-point transfers are staged through host memory "
@@ -274,7 +278,10 @@ def main():
     torch.cuda.synchronize(dev)
 
     status = 0
+    if args.format != "rgba32f" and not (args.emulate_ranks > 1 and not use_dist):
+        sys.exit("--format rgba8 is an option of --emulate-ranks (the measured metric is the float frame)")
     if args.emulate_ranks > 1 and not use_dist:
+        R.set_output_format(args.format)
         sys.exit(bench_emulated(args, R, torch, dev, streams, app, W, H, t))
     if use_dist:
         res = dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, rank, args.steps, args.warmup)
@@ -559,7 +566,7 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
     out_cfgs, status = [], 0
     cfgs = [(app, W, H)] + ([] if args.no_other_configs or app != "clouds" else DIST_OTHER_CONFIGS)
     for a, w, h in cfgs:
-        frames = [torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(max(2, len(streams)))]
+        frames = [torch.empty((h, w, 4), dtype=R.pixel_dtype, device=dev) for _ in range(max(2, len(streams)))]
 
         def whole(i):
             with torch.cuda.stream(streams[i % len(streams)]):
@@ -576,9 +583,9 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
                         for r in range(n)]
             if ex == "spans":
                 pix = R.span_table(a, w, h, t, br, n, relief[0], relief[1])[1]
-                payload = 12 * int(max(pix[1:]))
+                payload = (4 if R.rgba8 else 12) * int(max(pix[1:]))
             else:
-                payload = (12 if ch == 3 else 16) * w * shard.rank_rows_max(h, br, n, *relief)
+                payload = (4 if R.rgba8 else (12 if ch == 3 else 16)) * w * shard.rank_rows_max(h, br, n, *relief)
             link_peak, link_real = payload / 76.8e9 * 1e3, payload / (args.link_gbps * 1e9) * 1e3
             modelled = max(max(ranks_ms), link_real)
             if pick is None or modelled < pick[0]:
@@ -595,7 +602,7 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
         bad = int((got.view(torch.int32) != ref.view(torch.int32)).any(dim=-1).sum().item())
         status = 3 if bad else status
         out_cfgs.append({"workload": "APP_%s %dx%d u_time=%g" % (a.upper(), w, h, t), "n1_ms_per_frame_pipelined": round(p1, 4),
-                         "relief": "%d/%d" % relief, "exchange": exchange, "bytes_per_peer": payload,
+                         "relief": "%d/%d" % relief, "exchange": exchange, "pixel_format": args.format, "bytes_per_peer": payload,
                          "bytes_moved_per_frame": world.bytes_moved,
                          "link_ms_at_76p8_GBps": round(link_peak, 4), "link_ms_at_%g_GBps" % args.link_gbps: round(link_real, 4),
                          "root_ms": round(ranks_ms[0], 4), "slowest_peer_ms": round(max(ranks_ms[1:]), 4),
@@ -1074,7 +1081,7 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
         ch = channels if exchange == "direct" else (3 if exchange == "spans" else 4)
         st = streams                                    # the loop's own streams (no extra hardware queues)
         nb = max(2, len(st))
-        frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(nb)]
+        frames = [torch.empty((H, W, 4), dtype=getattr(R, "pixel_dtype", torch.float32), device=dev) for _ in range(nb)]
 
         def per_frame(fn, k=18):
             for i in range(4):
@@ -1106,19 +1113,23 @@ def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0,
     rank 0 and by tools/strip_scaling.py; it knows nothing about the links."""
     from shaderbox_amd import shard
     nb = len(frames)
+    pdt = getattr(R, "pixel_dtype", torch.float32)          # uint8 after R.set_output_format("rgba8"): 4 bytes per pixel anywhere
+    epp = 4 if pdt == torch.uint8 else 3                    # buffer elements per pixel of a span slab
+    if pdt == torch.uint8:
+        ch = 4
     if exchange == "spans":
         _, pix, _ = R.span_table(app, W, H, t, br, world, m0, m)
         stride = (int(max(pix[1:])) + 63) // 64 * 64
         if r > 0:
-            slabs = [torch.empty((max(int(pix[r]), 1) * 3,), dtype=torch.float32, device=dev) for _ in range(nb)]
+            slabs = [torch.empty((max(int(pix[r]), 1) * epp,), dtype=pdt, device=dev) for _ in range(nb)]
 
             def peer(i):
                 with torch.cuda.stream(st[i % len(st)]):
                     R.render_span_peer(app, W, H, t, br, r, world, 0, 1 << 30, slabs[i % nb], root_rounds=m0, rounds=m)
             return per_frame(peer)
         total = sum(int(p) for p in pix[1:])
-        src = torch.zeros((max(total, 1) * 3,), dtype=torch.float32, device=dev)
-        land = [torch.zeros(((world - 1) * max(stride, 1) * 3,), dtype=torch.float32, device=dev) for _ in range(nb)]
+        src = torch.zeros((max(total, 1) * epp,), dtype=pdt, device=dev)
+        land = [torch.zeros(((world - 1) * max(stride, 1) * epp,), dtype=pdt, device=dev) for _ in range(nb)]
 
         def root(i):
             with torch.cuda.stream(st[i % len(st)]):
@@ -1127,14 +1138,14 @@ def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0,
                 R.assemble_spans(app, W, H, t, br, world, land[i % nb], stride, frames[i % nb], root_rounds=m0, rounds=m)
         return per_frame(root)
     rmax = shard.rank_rows_max(H, br, world, m0, m)
-    slabs = [torch.empty((rmax, W, ch), dtype=torch.float32, device=dev) for _ in range(nb)]
+    slabs = [torch.empty((rmax, W, ch), dtype=pdt, device=dev) for _ in range(nb)]
     if r > 0:
         def peer(i):
             with torch.cuda.stream(st[i % len(st)]):
                 R.render_rank_rows(app, W, H, t, br, r, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
         return per_frame(peer)
-    src = torch.zeros((world - 1, rmax, W, ch), dtype=torch.float32, device=dev)
-    land = [torch.zeros((world, rmax, W, ch), dtype=torch.float32, device=dev) for _ in range(nb)]
+    src = torch.zeros((world - 1, rmax, W, ch), dtype=pdt, device=dev)
+    land = [torch.zeros((world, rmax, W, ch), dtype=pdt, device=dev) for _ in range(nb)]
 
     def root(i):
         with torch.cuda.stream(st[i % len(st)]):

@@ -36,6 +36,7 @@ ap.add_argument("--exchanges", default="spans,direct")
 ap.add_argument("--streams", type=int, default=3)
 ap.add_argument("--link-gbps", type=float, default=50.0, help="the 'realistic' per-direction rate of one xGMI link for the budget")
 ap.add_argument("--quick", action="store_true", help="compute-only part")
+ap.add_argument("--format", choices=["rgba32f", "rgba8"], default="rgba32f", help="pixels written and exchanged (include/sbx.h SBX_FORMAT_RGBA8)")
 a = ap.parse_args()
 if os.environ.get("SBX_LIB"):              # an A/B library of tools/ab_build.py instead of the shipped one
     shaderbox_amd.LIB_PATH = os.environ["SBX_LIB"]
@@ -46,6 +47,8 @@ spec.loader.exec_module(bench)
 app, W, H, t = a.app, a.width, a.height, a.time
 dev = torch.device("cuda", 0)
 R = shaderbox_amd.Renderer(0)
+R.set_output_format(a.format)
+BPP = 4 if R.rgba8 else 12                  # bytes per pixel on a link
 R.set_timing(True)
 streams = [torch.cuda.Stream() for _ in range(a.streams)]   # created once: HIP maps streams onto a few hardware queues
 for s in streams:
@@ -74,7 +77,7 @@ def per_frame(fn, k=24):
     return (time.perf_counter() - t0) * 1e3 / k
 
 
-frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(len(streams))]
+frames = [torch.empty((H, W, 4), dtype=R.pixel_dtype, device=dev) for _ in range(len(streams))]
 t1 = timed(lambda: R.render(app, W, H, t, out=frames[0]))
 
 
@@ -86,10 +89,11 @@ def whole(i):
 R.set_timing(False)
 p1 = per_frame(whole)
 R.set_timing(True)
+print("pixel format %s (%d bytes per pixel on a link)" % (a.format, BPP))
 print("%s %dx%d  N=1: one launch %.3f ms, %d frames in flight %.3f ms/frame" % (app, W, H, t1, len(streams), p1))
 ranks = [int(v) for v in a.ranks.split(",") if v]
 for n in ranks:
-    slab = torch.empty((shard.rank_rows_max(H, 8, n), W, 4), dtype=torch.float32, device=dev)
+    slab = torch.empty((shard.rank_rows_max(H, 8, n), W, 4), dtype=R.pixel_dtype, device=dev)
     ts = [timed(lambda r=r: R.render_rank(app, W, H, t, 8, r, n, out=slab)) for r in range(n)]
     print("  N=%d one launch per rank (8-row blocks, whole rows): min %.3f max %.3f ms -> compute-only %.2fx (ideal %d)"
           % (n, min(ts), max(ts), t1 / max(ts), n))
@@ -106,11 +110,11 @@ for n in ranks:
         for m0, m in bench.relief_candidates():
             if exchange == "spans":
                 _, pix, _ = R.span_table(app, W, H, t, 8, n, m0, m)
-                payload = 12 * int(max(pix[1:]))
-                total = 12 * sum(int(p) for p in pix[1:])
+                payload = BPP * int(max(pix[1:]))
+                total = BPP * sum(int(p) for p in pix[1:])
             else:
-                payload = 12 * W * shard.rank_rows_max(H, 8, n, m0, m)
-                total = 12 * W * sum(shard.rank_rows(H, 8, r, n, m0, m) for r in range(1, n))
+                payload = BPP * W * shard.rank_rows_max(H, 8, n, m0, m)
+                total = BPP * W * sum(shard.rank_rows(H, 8, r, n, m0, m) for r in range(1, n))
             root_ms = bench.emulated_frame_ms(R, torch, dev, streams, frames, app, W, H, t, 8, n, 0, m0, m, exchange, ch, per_frame)
             peer_ms = max(bench.emulated_frame_ms(R, torch, dev, streams, frames, app, W, H, t, 8, n, r, m0, m, exchange, ch, per_frame)
                           for r in sorted({1, n - 1}))
