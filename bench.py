@@ -799,15 +799,23 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
         step(i)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    for i in range(4):
+        step(i)
+    torch.cuda.synchronize(dev)
+    est = (time.perf_counter() - t0) * 1e3 / 4
+    # a sub-millisecond kernel after seconds of host work (the previous config's oracle rows) starts at idle clocks: ~30 ms of
+    # back-to-back launches first, so that neither figure below is the DVFS ramp's ...
+    for _ in range(max(3, min(300, int(30.0 / max(est, .01))))):
+        R.render(app, W, H, t, out=frames[0])
+    torch.cuda.synchronize(dev)
+    # ... and a timed region of at least ~20 ms: ten 0.15 ms frames are 1.5 ms, of which the ramp-in of the first launches and the
+    # final synchronisation are a fifth (EGG 1080p read 0.150 ms per frame that way against 0.121 over 60 frames)
+    steps = max(steps, min(400, int(20.0 / max(est, .01))))
+    t0 = time.perf_counter()
     for i in range(steps):
         step(i)
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) * 1e3 / steps
-    # a sub-millisecond kernel after seconds of host work (the previous config's oracle rows) starts at idle clocks: ~30 ms of
-    # back-to-back launches first, so that the un-overlapped figure is the kernel's, not the DVFS ramp's
-    for _ in range(max(3, min(300, int(30.0 / max(ms, .01))))):
-        R.render(app, W, H, t, out=frames[0])
-    torch.cuda.synchronize(dev)
     k = []
     for i in range(13):                       # median of >= 10 launches after 2 warm-ups (the first two are dropped)
         R.render(app, W, H, t, out=frames[0])
