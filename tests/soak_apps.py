@@ -52,14 +52,17 @@ for app in APPS:
             worst = max(worst, int(diff.sum()))
             print("MISMATCH %s frame %d: %d pixels; %dx%d t=%r mouse=%r" % (app, i, int(diff.sum()), W, H, t, mouse))
     plain = ""
-    if app in ("egg", "sdf_ao", "vinyl", "planet"):
+    if app in ("egg", "sdf_ao", "vinyl", "vinyl_gpu", "raytracer", "planet"):      # (RAYTRACER: variant 1 = its IEEE roots / normalisations)
         pb = 0
         for i in range(max(4, n // 4)):
             t = float(rng.uniform(0, 60))
             mouse = (float(rng.uniform(0, 1280)), float(rng.uniform(0, 720))) if i % 2 else (0.0, 0.0)
             R.set_variant(0); a = R.render(app, 1280, 720, t, mouse=mouse).clone()
-            R.set_variant(1); b = R.render(app, 1280, 720, t, mouse=mouse)
+            R.set_variant(1); b = R.render(app, 1280, 720, t, mouse=mouse).clone()
             same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+            if app != "planet" and i % 2 == 0:          # the recorded-domain roots with their re-run forced (variant 2: sbx_witness.h)
+                R.set_variant(2); c = R.render(app, 1280, 720, t, mouse=mouse)
+                same &= (a.view(torch.int32) == c.view(torch.int32)) | (torch.isnan(a) & torch.isnan(c))
             if not bool(same.all()):
                 pb += 1
                 print("MISMATCH %s vs plain form: %d pixels; t=%r mouse=%r" % (app, int((~same).any(-1).sum()), t, mouse))
