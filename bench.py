@@ -802,7 +802,8 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
     for i in range(4):
         step(i)
     torch.cuda.synchronize(dev)
-    est = (time.perf_counter() - t0) * 1e3 / 4
+    dt = (time.perf_counter() - t0) * 1e3 / 4
+    est = dt
     # a sub-millisecond kernel after seconds of host work (the previous config's oracle rows) starts at idle clocks: ~30 ms of
     # back-to-back launches first, so that neither figure below is the DVFS ramp's ...
     for _ in range(max(3, min(300, int(30.0 / max(est, .01))))):
