@@ -27,7 +27,10 @@ SOURCES = ["kern_clouds.hip", "kern_clouds_tex.hip", "kern_egg.hip", "kern_raytr
 # kernel here (CLOUDS 8.7 -> 6.5 ms, PLANET 57 -> 41 ms, SDF_AO 1.75 -> 1.37 ms at 4K/8K): a packed op issues
 # in ~4.7 cycles against 2 x 2.9 for the scalar pair (profiles/r01_ubench_valu.txt), needs its constants in
 # VGPR pairs (no literals), and the extra live registers cost a wave of occupancy.
-EXTRA = {}
+# per-source extras.  kern_atmosphere.hip: the GCN max-ILP scheduling strategy — its march is long chains of binary64 fma (the exp
+# cores) that the default occupancy-first strategy serialises more than it must: 7680x4320 3.51 -> 3.42 ms (2 in flight 3.46 ->
+# 3.36), same bits.  Tried on every other kernel source (profiles/r04_log.md): no gain, or a loss (clouds_best +15 %, vinyl +6 %).
+EXTRA = {"kern_atmosphere.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _headers():

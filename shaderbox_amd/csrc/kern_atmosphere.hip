@@ -15,7 +15,7 @@
 namespace sbx {
 
 template <bool FIN>
-__global__ void __launch_bounds__(64 * ATM_TX) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
+__global__ void __launch_bounds__(64 * ATM_TX, 6) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
     constexpr bool T64 = FIN && ATM_EXP_REG && ATM_EXP64 && !ATM_EXP4K;
     __shared__ double etab[32];
     __shared__ double etab64[T64 ? 64 : 1];               // exp_reg64_'s table (builds without exp_reg4k_)

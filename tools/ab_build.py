@@ -32,7 +32,9 @@ def build_one(spec):
     flags = [f for f in flags.split(",") if f]
     out = os.path.join(ROOT, "build", "ab")
     obj = os.path.join(out, "%s_%s.o" % (name, os.path.splitext(src)[0]))
-    cmd = [b.HIPCC] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", obj]
+    extra = [] if "NOEXTRA" in flags else b.EXTRA.get(src, [])          # NOEXTRA: without the source's own extras of build.py
+    flags = [f for f in flags if f != "NOEXTRA"]
+    cmd = [b.HIPCC] + b.FLAGS + extra + flags + ["-c", os.path.join(b.CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         return "FAILED %s %s\n%s" % (name, flags, r.stderr[-3000:])
