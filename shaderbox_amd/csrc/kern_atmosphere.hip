@@ -14,8 +14,11 @@
 
 namespace sbx {
 
+#ifndef ATM_MIN_WAVES
+#define ATM_MIN_WAVES 6     // (the max-ILP strategy of this source, build.py, takes what registers it is given: 147 for the plain kernel without a bound)
+#endif
 template <bool FIN>
-__global__ void __launch_bounds__(64 * ATM_TX, 6) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
+__global__ void __launch_bounds__(64 * ATM_TX, ATM_MIN_WAVES) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
     constexpr bool T64 = FIN && ATM_EXP_REG && ATM_EXP64 && !ATM_EXP4K;
     __shared__ double etab[32];
     __shared__ double etab64[T64 ? 64 : 1];               // exp_reg64_'s table (builds without exp_reg4k_)
