@@ -980,6 +980,7 @@ def rooflines(app, launch_pixels, frame_pixels, kmean_ms, kmin_ms, pmc):
         alg = ops * launch_pixels / (kmean_ms * 1e-3) / 1e12
         r["useful_work_ratio"] = {"value": round(alg / PEAK_FP32_VECTOR_TFLOPS, 5), "achieved": round(alg, 4),
                                   "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s", "ops_per_pixel": ops,
+                                  "vs_scalar_issue_ceiling": round(alg / 39.3, 5),       # 256 CU x 64 lanes x 2.4 GHz
                                   "what": "reference-algorithm scalar fp ops (SURVEY.md 8d) / un-overlapped launch time / fp32 vector "
                                           "peak: a speed-up measure, NOT utilisation (the kernel executes far fewer operations than "
                                           "the reference algorithm for the same bits, so it may exceed 1)"}
