@@ -2,7 +2,9 @@
 // every frame as binary PPM (sRGB 8-bit, top row first) and/or raw float32 RGBA (row 0 = bottom).
 //
 //   sbx_render --app clouds --res 3840x2160 [--time 0.37] [--frames N --dt S] [--mouse X,Y] [--gpus N [--exchange spans|slabs|blocks]]
-//              [--ppm out_%04d.ppm] [--f32 out_%04d.f32]
+//              [--ppm out_%04d.ppm] [--f32 out_%04d.f32] [--rgba8]
+//     --rgba8: the kernels write the 8-bit display format themselves (SBX_FORMAT_RGBA8, include/sbx.h): 4 bytes per pixel in
+//              HBM, in the multi-GPU exchange and over PCIe; the same .ppm bytes as the float frame packed afterwards; no --f32
 //     APP_CLOUDS aux block (the ImGui panel of hlsltoy, util/hlsltoy/src/hlsltoy.cpp:466-483):
 //              [--wind x,y,z] [--sun x,y,z] [--sun-color r,g,b] [--sun-power P] [--sky-radius R] [--sky-height Y]
 //              [--sigma S] [--coverage C] [--thick T] [--steps N] [--light-steps N]
@@ -90,7 +92,7 @@ int main(int argc, char** argv) {
     sbx_aux_sdf_ao as;
     sbx_aux_clouds_defaults(&ac);
     sbx_aux_sdf_ao_defaults(&as);
-    bool have_ac = false, have_as = false;
+    bool have_ac = false, have_as = false, rgba8_out = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -109,6 +111,7 @@ int main(int argc, char** argv) {
         else if (a == "--mouse") { if (sscanf(next(), "%f,%f", &mx, &my) != 2) { fprintf(stderr, "--mouse X,Y\n"); return 2; } }
         else if (a == "--ppm") ppm = next();
         else if (a == "--f32") f32 = next();
+        else if (a == "--rgba8") rgba8_out = true;
         else if (a == "--noise-tex") noise_tex = next();
         else if (a == "--wind") { vec3(ac.wind_dir); have_ac = true; }
         else if (a == "--sun") { vec3(ac.sun_dir); have_ac = true; }
@@ -128,6 +131,7 @@ int main(int argc, char** argv) {
     const int id = app_from_name(app);
     if (id < 0) { fprintf(stderr, "unknown app %s\n", app.c_str()); return 2; }
     if (frames < 1 || gpus < 1) { fprintf(stderr, "--frames and --gpus must be >= 1\n"); return 2; }
+    if (rgba8_out && !f32.empty()) { fprintf(stderr, "--rgba8 renders 8-bit pixels: there is no float frame for --f32\n"); return 2; }
     for (const std::string* p : {&ppm, &f32})
         if (!pattern_ok(*p)) { fprintf(stderr, "bad file pattern %s: one %%d / %%0Nd conversion at most, a literal percent as %%%%\n", p->c_str()); return 2; }
     const void* aux = nullptr;
@@ -174,14 +178,18 @@ int main(int argc, char** argv) {
         (void)hipDeviceSynchronize();
         (void)hipFree(d1); (void)hipFree(d2);
     }
+    if (rgba8_out) {
+        rc = multi ? sbx_multi_set_output_format(multi, SBX_FORMAT_RGBA8) : sbx_set_output_format(ctx, SBX_FORMAT_RGBA8);
+        if (rc != SBX_OK) { fprintf(stderr, "output format: %s\n", multi ? sbx_multi_last_error(multi) : sbx_last_error(ctx)); return 1; }
+    }
     // the frame, the 8-bit copy and the timing events belong to rank 0's device (the sbx_multi_* calls leave it current;
     // set again here so that nothing below depends on that)
     (void)hipSetDevice(0);
     const size_t n = (size_t)W * H * 4, npx = (size_t)W * H;
     float* dev = nullptr;
     unsigned char* dev8 = nullptr;
-    if (hipMalloc((void**)&dev, n * sizeof(float)) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
-    if (!ppm.empty() && hipMalloc((void**)&dev8, npx * 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
+    if (hipMalloc((void**)&dev, (rgba8_out ? npx : n) * sizeof(float)) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }   // (--rgba8: one word per pixel)
+    if (!ppm.empty() && !rgba8_out && hipMalloc((void**)&dev8, npx * 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
     std::vector<float> host(f32.empty() ? 0 : n);
     std::vector<unsigned char> rgba8(ppm.empty() ? 0 : npx * 4), rgb(ppm.empty() ? 0 : npx * 3);
     hipEvent_t e0, e1;
@@ -206,10 +214,20 @@ int main(int argc, char** argv) {
         }
         if (!ppm.empty()) {
             // the back-buffer write of hlsltoy (R8G8B8A8_UNORM, top row first) on the device, then 4 B/pixel over PCIe
+            if (rgba8_out) {
+                // the kernels wrote this format already (row 0 = bottom): 4 B/pixel over PCIe, the rows turned here
+                if (hipMemcpy(rgba8.data(), dev, npx * 4, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "hipMemcpy failed\n"); return 1; }
+                for (int y = 0; y < H; ++y) {
+                    const unsigned char* src = &rgba8[(size_t)(H - 1 - y) * W * 4];
+                    unsigned char* dst = &rgb[(size_t)y * W * 3];
+                    for (int x = 0; x < W; ++x) { dst[x * 3] = src[x * 4]; dst[x * 3 + 1] = src[x * 4 + 1]; dst[x * 3 + 2] = src[x * 4 + 2]; }
+                }
+            } else {
             rc = sbx_pack_unorm8(ctx, W, H, dev, dev8, /*flip_y=*/1, nullptr);
             if (rc != SBX_OK) { fprintf(stderr, "sbx_pack_unorm8: %s\n", sbx_last_error(ctx)); return 1; }
             if (hipMemcpy(rgba8.data(), dev8, npx * 4, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "hipMemcpy failed\n"); return 1; }
             for (size_t i = 0; i < npx; ++i) { rgb[i * 3] = rgba8[i * 4]; rgb[i * 3 + 1] = rgba8[i * 4 + 1]; rgb[i * 3 + 2] = rgba8[i * 4 + 2]; }
+            }
             FILE* fp = fopen(frame_name(ppm, f, frames).c_str(), "wb");
             if (!fp) { perror("fopen"); return 1; }
             fprintf(fp, "P6\n%d %d\n255\n", W, H);

@@ -196,3 +196,17 @@ def test_cli_multi_gpu_and_noise_textures(built, oracle, tmp_path):
         assert np.array_equal(got.view(np.uint32), oracle.render(APP_CLOUDS_TEX, 160, 90, .37).view(np.uint32))
     r = subprocess.run([os.path.join(built, "sbx_render"), "--app", "clouds_tex", "--res", "32x18"], capture_output=True, text=True)
     assert r.returncode == 2 and "--noise-tex" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_rgba8_writes_the_same_ppm(built, tmp_path):
+    """--rgba8: the kernels write the 8-bit display format (SBX_FORMAT_RGBA8) — one GPU and the library's multi-GPU engine — and
+    the .ppm is byte for byte the one of the float frame packed afterwards; --f32 is refused with it"""
+    exe = os.path.join(built, "sbx_render")
+    for app, extra in (("egg", []), ("atmosphere", ["--gpus", "3"]), ("clouds", ["--gpus", "2", "--exchange", "slabs"])):
+        a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+        subprocess.run([exe, "--app", app, "--res", "203x117", "--ppm", a] + extra, check=True)
+        subprocess.run([exe, "--app", app, "--res", "203x117", "--ppm", b, "--rgba8"] + extra, check=True)
+        assert open(a, "rb").read() == open(b, "rb").read(), (app, extra)
+    r = subprocess.run([exe, "--app", "egg", "--res", "32x32", "--rgba8", "--f32", str(tmp_path / "x.f32")], capture_output=True, text=True)
+    assert r.returncode == 2 and "--rgba8" in r.stderr
