@@ -301,7 +301,9 @@ int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, 
  * per point: "noise_iq" (src/noise_iq.h:11-29, out[0]); "hash_w" (src/noise_worley.h:5-17);
  * "noise_w" (:20-51; params[0] = domain_repeat; out = sqrt F1, sqrt F2, |cell id|);
  * "fbm_worley_tile" (src/fbm.h:8 as instantiated at util/ddsvolgen/src/ddsvolgen.cpp:52;
- * params = lacunarity, init_gain, gain; out[0]). */
+ * params = lacunarity, init_gain, gain; out[0]).
+ * Test hooks of the recorded-domain forms (csrc/sbx_witness.h): "normalize" = v / length(v) in the IEEE form, "wit_normalize" = the
+ * fast form (sqrt_rs_, v_rcp_f32 + one Newton step, three div3_), "wit_record" = out[0] 1 where that form's domain record fires. */
 int sbx_noise_eval(sbx_ctx* ctx, const char* fn, const float* xyz, const float* params, float* out,
                    size_t n, void* stream);
 /* The size^3 RGBA32F noise volume util/ddsvolgen bakes (ddsvolgen.cpp:101-117): R =

@@ -8,6 +8,7 @@
 // hash_w multiplies sin by 43758.5453123, so only the shared correctly rounded sin gives parity.
 #include "sbx_device.h"
 #include "sbx_noise.h"
+#include "sbx_witness.h"
 
 namespace sbx {
 
@@ -63,6 +64,10 @@ __global__ void __launch_bounds__(256) k_noise_eval(int fn, const float* __restr
     case 1: r = hash_w(p); break;
     case 2: r = noise_w(p, p0); break;
     case 3: r.x = fbm_worley_tile(p, p0, p1, p2); break;
+    // test hooks of sbx_witness.h: normalize in its IEEE form, in the recorded-domain fast form, and the record itself
+    case 4: r = normalize(p); break;
+    case 5: { Wit<true> w; r = w.normalize(p); break; }
+    case 6: { Wit<true> w; (void)w.normalize(p); r.x = w.bad ? 1.f : 0.f; break; }
     }
     out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
 }
@@ -78,7 +83,7 @@ __global__ void __launch_bounds__(256) k_worley_volume(int size, float4* __restr
 }
 
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s) {
-    if (fn < 0 || fn > 3) return -1;
+    if (fn < 0 || fn > 6) return -1;
     hipLaunchKernelGGL(k_noise_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, xyz, par[0], par[1], par[2], out, n);
     return 0;
 }

@@ -1207,12 +1207,12 @@ int sbx_noise_eval(sbx_ctx* ctx, const char* fn, const float* xyz, const float* 
                    void* stream) {
     if (!ctx) return SBX_ERR_ARG;
     if (!fn || !xyz || !out) return fail(ctx, SBX_ERR_ARG, "NULL argument");
-    static const char* names[] = {"noise_iq", "hash_w", "noise_w", "fbm_worley_tile"};
+    static const char* names[] = {"noise_iq", "hash_w", "noise_w", "fbm_worley_tile", "normalize", "wit_normalize", "wit_record"};
     int id = -1;
-    for (int i = 0; i < 4; ++i) if (std::strcmp(fn, names[i]) == 0) id = i;
+    for (int i = 0; i < 7; ++i) if (std::strcmp(fn, names[i]) == 0) id = i;
     if (id < 0) return fail(ctx, SBX_ERR_ARG, "unknown noise function");
     const float zero[3] = {0.f, 0.f, 0.f};
-    if (id >= 2 && !params) return fail(ctx, SBX_ERR_ARG, "noise_w / fbm_worley_tile need params");
+    if ((id == 2 || id == 3) && !params) return fail(ctx, SBX_ERR_ARG, "noise_w / fbm_worley_tile need params");
     if (n == 0) return SBX_OK;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);

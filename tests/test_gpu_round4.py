@@ -673,3 +673,45 @@ def test_rgba8_through_the_library_multi_gpu_engine(renderer, nranks):
                 assert torch.equal(got.view(torch.int32), f.view(torch.int32)), (exchange, app, "float again")
     finally:
         m.close()
+
+
+def test_witnessed_normalize_equals_ieee_where_it_does_not_record(renderer):
+    """sbx_witness.h Wit::normalize — sqrt_rs_, v_rcp_f32 + one Newton step, three div3_ — against v / length(v) in IEEE arithmetic
+    (numpy binary32, the dot product in the spec's association) on 24 M vectors whose components span 2^-75 ... 2^30 with zeros,
+    denormals, infinities and NaNs mixed in: wherever the form does NOT record, it is the IEEE result bit for bit (and the device's
+    own IEEE form agrees with numpy everywhere); the record fires for every vector with a zero, tiny or non-finite component or a
+    squared length outside [2^-102, 2^40), and on ordinary vectors it does not fire"""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(99)
+    for block in range(6):
+        n = 4_000_000
+        e = torch.rand((n, 3), generator=g) * 105.0 - 75.0                         # exponents
+        if block % 2 == 0:
+            e = torch.rand((n, 3), generator=g) * 12.0 - 6.0                       # ordinary magnitudes
+        m = 1.0 + torch.rand((n, 3), generator=g)
+        sgn = torch.where(torch.rand((n, 3), generator=g) < .5, -1.0, 1.0)
+        v = (sgn * m * torch.pow(torch.tensor(2.0, dtype=torch.float64), e.double())).float()
+        if block == 1:                                                             # special values in a tenth of the rows
+            k = n // 10
+            sp = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e-42, -1e-45, 3e38], dtype=torch.float32)
+            idx = torch.randint(0, 8, (k,), generator=g)
+            col = torch.randint(0, 3, (k,), generator=g)
+            v[torch.arange(k), col] = sp[idx]
+        fast = renderer.noise("wit_normalize", v.cuda()).cpu().numpy()
+        ieee = renderer.noise("normalize", v.cuda()).cpu().numpy()
+        rec = renderer.noise("wit_record", v.cuda()).cpu().numpy()[:, 0] != 0
+        a = v.numpy()
+        with np.errstate(all="ignore"):
+            xx, yy, zz = a[:, 0] * a[:, 0], a[:, 1] * a[:, 1], a[:, 2] * a[:, 2]
+            x = (xx + yy) + zz
+            l = np.sqrt(x)
+            ref = a / l[:, None]
+        same = lambda p, q: (p.view(np.uint32) == q.view(np.uint32)) | (np.isnan(p) & np.isnan(q))
+        assert same(ieee, ref).all(), "the device's IEEE normalize against numpy"
+        ok = same(fast, ref).all(axis=1)
+        assert ok[~rec].all(), (block, int((~ok & ~rec).sum()))
+        mn = np.float32(2.0 ** -126)
+        must = ~((xx >= mn) & (yy >= mn) & (zz >= mn) & (x >= np.float32(2.0 ** -102)) & (x < np.float32(2.0 ** 40)))
+        assert (rec == must).all(), (block, int((rec != must).sum()))
+        if block % 2 == 0:
+            assert not rec.any()
