@@ -277,7 +277,10 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
 // (tools/ab_time.py, 7680x4320, same bits: no parking 7.36 ms, 112 B of scratch per lane, 1.72 GB of HBM traffic per frame
 //  against the 0.53 GB framebuffer; hit-shading parking 7.29 ms, 60 B, ~1.0 GB; parking the cloud march's ray and integrator
 //  as well: no spills there to remove, 7.66 ms; recomputing pixel and ray in the epilogue instead of keeping them: 7.54 ms)
-#define PL_PARK_N 10
+#ifndef PL_PARK_MARCH
+#define PL_PARK_MARCH 0    // the two results of the terrain march that only the shading reads (height term, t of the last step) in LDS
+#endif                     // slots 10-11 during both marches instead of in registers
+#define PL_PARK_N (PL_PARK_MARCH ? 12 : 10)
 // ATM: the config-5 composite SBX_APP_PLANET_ATMOSPHERE (include/sbx.h; SURVEY.md §8a note: "planet background() replaced by
 // get_incident_light"): wherever APP_PLANET shows its background() (app_planet.h:316-318, 364-366) the pixel shows APP_ATMOSPHERE's
 // sky instead — get_incident_light (app_atmosphere.h:78-160) for a ray from 1 m above the ground (:204-207) along the VIEW
@@ -330,6 +333,10 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
         float t = 0.f;
         v2 df = V2(1, PL_MAX_HEIGHT);
         v3 pos = V3(0, 0, 0);
+#ifndef PL_TLAST
+#define PL_TLAST 1         // the march keeps the t of its last committed step instead of the step's point (one register for three, across
+#endif                     // both marches); the point is computed again — same operations, same operands — where the hit is shaded
+        float t_pos = 0.f;
         float max_cld = PL_MAX_RAY_DIST;
         bool tm = hit_atm;
         for (int i = 0; i < 120; ++i) {
@@ -339,8 +346,16 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
             const v3 p = mul(F.rot, o - V3(0, 0, 0));
             const v2 d = terrain_map<3, SKIP>(S, p, tm, lane);
             if (tm) {
-                pos = p;
+#if PL_PARK && PL_PARK_MARCH && PL_TLAST
+                {
+                    volatile float* const pm = &park[threadIdx.x >> 6][lane];
+                    pm[10 * 64] = d.y; pm[11 * 64] = t;
+                    df.x = d.x;
+                }
+#else
+                if (PL_TLAST) t_pos = t; else pos = p;
                 df = d;
+#endif
                 if (df.x < .005f) { max_cld = t; tm = false; }
                 else t += df.x * .4567f;
             }
@@ -373,6 +388,13 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
         const bool hitl = hit_atm && (df.x < .005f);              // :349
         v3 c_hit = V3(0, 0, 0);
         if (wave_any(hitl)) {
+#if PL_PARK && PL_PARK_MARCH && PL_TLAST
+            {
+                volatile float* const pm = &park[threadIdx.x >> 6][lane];
+                df.y = pm[10 * 64]; t_pos = pm[11 * 64];           // (lanes without an atmosphere hit never wrote them and are not shaded)
+            }
+#endif
+            if (PL_TLAST) pos = mul(F.rot, (hit_o + t_pos * rd) - V3(0, 0, 0));   // the point of the last committed step, as the march computed it
             // illuminate :238-298
             float h = df.y;
             const float e = 0.001f;
