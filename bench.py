@@ -34,12 +34,12 @@ Extra objects on the JSON line (N = 1 unless noted):
                  so bound = "valu", and the object reports EXECUTED work, which cannot exceed the peak:
                    achieved            VALU lane-operations the kernel actually issued per second: SQ_INSTS_VALU x 64 lanes /
                                        the launch's duration in the same rocprofv3 pass
-                   peak                1024 SIMD-32 x 32 lanes x the shader clock of that pass (GRBM_GUI_ACTIVE / 8 XCDs /
-                                       duration; DVFS holds this kernel near 2.1 GHz); peak_at_2p4ghz = 78.6 T lane-ops/s is
-                                       the same at the nominal clock (MI355X_MICROARCH.md: 4 SIMD-32 per CU, 2-cycle wave64 issue)
-                   frac                achieved / peak = SQ_INSTS_VALU x 2 issue cycles / (1024 SIMDs x active cycles): the share
-                                       of the VALU issue slots that carried an instruction; frac_at_2p4ghz = the same against
-                                       the nominal-clock peak with the UN-profiled launch duration (HIP events)
+                   peak                FIXED: 1024 SIMD-32 x 32 lanes x 2.4 GHz = 78.64 T lane-ops/s (MI355X_MICROARCH.md: 4 SIMD-32
+                                       per CU, 2-cycle wave64 issue), whatever clock DVFS held
+                   frac                achieved / peak (the primary figure).  frac_at_measured_clock = SQ_INSTS_VALU x 2 issue
+                                       cycles / (1024 SIMDs x active cycles): the share of the VALU issue slots of the cycles that
+                                       actually happened (shader clock = GRBM_GUI_ACTIVE / 8 XCDs / duration); frac_unprofiled_duration
+                                       = the profiled instruction count over the UN-profiled launch duration (HIP events), fixed peak
                    useful_work_ratio   NOT a utilisation figure: the REFERENCE algorithm's scalar fp ops per launch (SURVEY.md
                                        §8d per-pixel count x pixels) / un-overlapped launch duration / 157.3 TFLOP/s.  It can
                                        exceed 1 because the kernel executes far fewer operations than the reference algorithm
@@ -91,6 +91,7 @@ NOMINAL_CLOCK_HZ = 2.4e9
 LANES_PER_SIMD_CYCLE = 32           # a SIMD-32 retires half a wave64 instruction per cycle
 PEAK_LANEOPS_NOMINAL_T = N_SIMD * LANES_PER_SIMD_CYCLE * NOMINAL_CLOCK_HZ / 1e12     # 78.6 T lane-ops/s
 PMC_ROUND = "r04"
+LANDING = {"wgs_per_peer": 2, "link_gbps": 50.0}     # how the emulated root lands the peers' payloads (main() sets it from the flags)
 COLL_DEV = None                     # device of the small bookkeeping collectives (set in main: the GPU under RCCL, the CPU under gloo)                   # committed per-launch counters: profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json
 # the other BASELINE.json configs that fit one GPU: (app, W, H) — C2, C3, C5 (both apps)
 OTHER_CONFIGS = [("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320)]
@@ -167,9 +168,11 @@ def main():
     ap.add_argument("--gather-groups", default="auto",
                     help="N>1: issue the one exchange in this many pipelined pieces ('auto': one per ~12 MB of a peer's payload, "
                          "so a 4K slab goes out whole and an 8K one in 3 pieces; 1 = one plain exchange)")
-    ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather"], default="auto",
-                    help="N>1 (engine dist): 'auto' (default) = try 'spans' and 'direct' on the ranks at hand (a few pipelined frames each) "
-                         "and run the faster; 'spans' = only the expensive interval of every row-block is dealt to the peers and "
+    ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather", "stores"], default="auto",
+                    help="N>1 (engine dist): 'auto' (default) = try 'stores', 'spans' and 'direct' on the ranks at hand (a few pipelined frames "
+                         "each) and run the fastest; 'stores' = the peers map the root's frame (HIP IPC) and render their row-blocks IN PLACE "
+                         "into it: the exchange is their own pixel stores over xGMI (12 bytes per pixel with --channels 3), the root lands, "
+                         "receives and scatters nothing (distributed.py, include/sbx.h sbx_shared_*); 'spans' = only the expensive interval of every row-block is dealt to the peers and "
                          "sent, the root renders the rest in place (distributed.py; config 5's 49.8 MB per peer become 29.7 MB); "
                          "'direct' = the root renders its blocks in place and receives the peers' whole slabs by ONE grouped "
                          "send/recv; 'gather' = dist.gather of equal RGBA slabs + assembly of all of them (round 1)")
@@ -207,6 +210,11 @@ def main():
                          "launch, time every rank's part with frames in flight and print the MODELLED N-GPU figures with the exchange "
                          "budget (n_gpus stays 1, 'emulated_ranks' says so; link rates are assumptions: --link-gbps)")
     ap.add_argument("--link-gbps", type=float, default=50.0, help="--emulate-ranks: the per-direction xGMI rate of the budget")
+    ap.add_argument("--rccl-wgs-per-peer", type=int, default=2,
+                    help="the emulated root of the send/recv exchanges (relief calibration, --emulate-ranks, tools/strip_scaling.py): "
+                         "RCCL's grouped receive is modelled as this many 256-thread workgroups PER PEER that stay resident for the time "
+                         "the peer's payload needs on its link (--link-gbps) and write it into the landing area at that pace "
+                         "(include/sbx_test.h sbx_model_landing); 0 = round 4's stand-in, a plain device copy at HBM speed")
     ap.add_argument("--format", choices=["rgba32f", "rgba8"], default="rgba32f",
                     help="--emulate-ranks only: the pixels the kernels write and the exchange carries — float (the metric's frame), or "
                          "SBX_FORMAT_RGBA8, the 4-byte display format of the reference's hosts (include/sbx.h); the N = 1 figure the "
@@ -215,9 +223,17 @@ def main():
                     help="N>1 process group: 'nccl' = RCCL (the product path); 'gloo' = TEST ONLY: the ranks may share a GPU (rank r on "
                          "device r mod device count), point-to-point transfers are staged through host memory "
                          "(distributed.HostStagedDist) — runs the whole N > 1 program on a 1-GPU box, measures nothing about xGMI")
+    ap.add_argument("--preroll-ms", type=float, default=40.0,
+                    help="N = 1: back-to-back frames for at least this long BEFORE the warm-up steps (not steps, not timed): the first ~25 ms "
+                         "of launches after host work run at ramping clocks (profiles/r04_streams3_trace.txt), and 5 warm-up frames are 11 ms")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5,
+                    help="N = 1: after the timed region, frames back to back for this long with the shader clock and the board power "
+                         "sampled beside them -> the `sustained` object (0 = skip)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    global LANDING
+    LANDING = {"wgs_per_peer": args.rccl_wgs_per_peer, "link_gbps": args.link_gbps} if args.rccl_wgs_per_peer > 0 else None
     if args.backend == "gloo" and args.exchange == "gather":
         raise SystemExit("--backend gloo stages point-to-point transfers only: use --exchange auto, spans or direct")
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -333,6 +349,14 @@ def main():
     for f in frames:
         f.zero_()                                       # first touch of the framebuffers (page mapping) is not rendering
     torch.cuda.synchronize(dev)
+    # pre-roll: the chip comes out of seconds of host work (imports, context, first touches) at idle clocks and needs ~25 ms of
+    # launches to reach the clock it then holds; the driver's 5 warm-up frames are 11 ms.  Frames until --preroll-ms have passed.
+    preroll_frames, t0 = 0, time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < args.preroll_ms:
+        for i in range(ns):
+            step(i)
+        torch.cuda.synchronize(dev)
+        preroll_frames += ns
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -363,18 +387,23 @@ def main():
            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)" % (app.upper(), W, H, t),
-                      "frames_in_flight": ns, "parallelism": "1 GPU, one launch per frame"},
+                      "frames_in_flight": ns, "parallelism": "1 GPU, one launch per frame",
+                      "preroll": "%d untimed frames (>= %g ms) before the warm-up steps" % (preroll_frames, args.preroll_ms)},
            # `value` has frames_in_flight launches overlapping (the timed region's wall clock); `value_serial` is SURVEY.md 8d's
            # form: one un-overlapped launch, HIP events.  Compare like with like across N: value with value, serial with serial.
            "value_serial": serial,
            "serial": {"value": serial, "unit": "Mpixels/s", "what": "one un-overlapped launch (HIP events), %d pixels" % pixels},
            "steady_state": steady_state(step_done, ns, pixels),
            "roofline": roofline, "roofline_hbm": roofline_hbm}
+    last_timed = frames[(args.steps - 1) % ns].clone() if not args.no_cpu_baseline else None
+    if args.sustained_seconds > 0:
+        out["sustained"] = sustained(torch, dev, step, ns, W * H, args.sustained_seconds, value, serial)
     if not args.no_cpu_baseline:
         base, rows, ref = cpu_baseline(app, W, H, t, args.cpu_row_stride)
         out["cpu_baseline"] = base
         # parity of the TIMED frame: the oracle rows just rendered against the same rows of the GPU frame
-        gpu = frames[(args.steps - 1) % ns][rows].cpu().numpy()
+        gpu = last_timed[rows].cpu().numpy()
+        del last_timed
         out["parity"] = parity(gpu, ref, len(rows))
         if not (out["parity"]["max_abs_diff"] <= 1e-4):
             status = 3
@@ -442,14 +471,15 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
             if exchange == "spans":
                 payload = 12 * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
             else:
-                payload = (12 if (exchange == "direct" and args.channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
+                payload = (12 if (exchange in ("direct", "stores") and args.channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
         groups = auto_groups(args.gather_groups, payload)
         plans = [FramePlan(R, fdist, W, H, br, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=exchange,
                            channels=args.channels) for _ in range(ns)]
         return relief, payload, groups, plans
 
-    # `--exchange auto` (default): the span exchange sends fewer bytes but gives the root more to render; which one wins depends on
-    # what the links deliver, and that is only known on the node — so both are TRIED on the ranks at hand (a few pipelined frames
+    # `--exchange auto` (default): the store exchange costs the root nothing but puts every pixel store on a link; the span exchange
+    # sends fewer bytes but gives the root more to render; whole slabs cost the root a landing and a scatter; which one wins depends
+    # on what the links deliver, and that is only known on the node — so all three are TRIED on the ranks at hand (a few pipelined frames
     # each, barrier + synchronize around them, the slowest rank's time) and the faster one runs the timed region.  With one rank
     # there is nothing to exchange: spans.
     trials = None
@@ -461,7 +491,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         relief, payload, groups, plans = prepare(exchange)
     else:
         trials, best = {}, None
-        for ex in ("spans", "direct"):
+        for ex in ("stores", "spans", "direct"):
             cand = prepare(ex)
             cplans = cand[3]
             for i in range(ns + 1):
@@ -575,9 +605,10 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
         p1 = per_frame(whole)
         # 'auto': both exchange forms are modelled, the faster one is reported (what the ranks of a real node decide by trying both)
         pick = None
-        for ex in (("spans", "direct") if args.exchange == "auto" else (args.exchange,)):
+        tried = {}
+        for ex in (("stores", "spans", "direct") if args.exchange == "auto" else (args.exchange,)):
             relief = choose_relief(args.root_rounds, R, OneRank, torch, dev, a, w, h, t, br, n, 0, streams, ex, args.channels)
-            ch = 3 if ex != "gather" else 4
+            ch = (args.channels if ex == "stores" else 3) if ex != "gather" else 4
             R.set_timing(False)
             ranks_ms = [emulated_frame_ms(R, torch, dev, streams, frames, a, w, h, t, br, n, r, relief[0], relief[1], ex, ch, per_frame)
                         for r in range(n)]
@@ -588,6 +619,9 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
                 payload = (4 if R.rgba8 else (12 if ch == 3 else 16)) * w * shard.rank_rows_max(h, br, n, *relief)
             link_peak, link_real = payload / 76.8e9 * 1e3, payload / (args.link_gbps * 1e9) * 1e3
             modelled = max(max(ranks_ms), link_real)
+            tried[ex] = {"relief": "%d/%d" % relief, "root_ms": round(ranks_ms[0], 4), "slowest_peer_ms": round(max(ranks_ms[1:]), 4),
+                         "bytes_per_peer": payload, "link_ms": round(link_real, 4), "modelled_ms_per_frame": round(modelled, 4),
+                         "modelled_speedup": round(p1 / modelled, 3)}
             if pick is None or modelled < pick[0]:
                 pick = (modelled, ex, relief, ch, ranks_ms, payload, link_peak, link_real)
         modelled, exchange, relief, ch, ranks_ms, payload, link_peak, link_real = pick
@@ -602,7 +636,8 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
         bad = int((got.view(torch.int32) != ref.view(torch.int32)).any(dim=-1).sum().item())
         status = 3 if bad else status
         out_cfgs.append({"workload": "APP_%s %dx%d u_time=%g" % (a.upper(), w, h, t), "n1_ms_per_frame_pipelined": round(p1, 4),
-                         "relief": "%d/%d" % relief, "exchange": exchange, "pixel_format": args.format, "bytes_per_peer": payload,
+                         "relief": "%d/%d" % relief, "exchange": exchange, "exchanges_tried": tried, "pixel_format": args.format,
+                         "bytes_per_peer": payload,
                          "bytes_moved_per_frame": world.bytes_moved,
                          "link_ms_at_76p8_GBps": round(link_peak, 4), "link_ms_at_%g_GBps" % args.link_gbps: round(link_real, 4),
                          "root_ms": round(ranks_ms[0], 4), "slowest_peer_ms": round(max(ranks_ms[1:]), 4),
@@ -619,6 +654,9 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "value_is": "MODELLED for %d GPUs from parts timed on ONE: max(root's frame incl. landing and scatter, slowest peer's frame, link "
                        "time at %g GB/s), compute and transfer overlapped; not a measurement of %d GPUs" % (n, args.link_gbps, n),
+           "landing_model": ("RCCL's grouped receive on the root = %d workgroups per peer resident for the link time at %g GB/s, writing the "
+                             "payload at that pace (sbx_model_landing)" % (LANDING["wgs_per_peer"], LANDING["link_gbps"])) if LANDING
+                            else "a device copy of the payload at HBM speed (round 4's stand-in)",
            "config": {"workload": head["workload"], "frames_in_flight": len(streams),
                       "parallelism": "cyclic %d-row blocks over %d EMULATED ranks on one device, exchange %s" % (br, n, args.exchange)},
            "emulated": out_cfgs}
@@ -643,6 +681,8 @@ def dist_line(res, args, app, W, H, t, world):
     serial_ms = max((p["render_ms"] + p["exchange_wait_ms"] + p["assemble_ms"]) for p in ph["per_rank"]) if ph else None
     exch = {"direct": "1 grouped RCCL send/recv of the peers' %d-channel slabs to the root (root in place)" % args.channels,
             "gather": "1 RCCL gather of RGBA slabs",
+            "stores": "the peers' own %d-byte pixel stores into the root's frame, mapped through HIP IPC (no RCCL call, no landing area, "
+                      "no scatter; two flag kernels per rank and frame)" % (12 if args.channels == 3 else 16),
             "spans": "1 grouped RCCL send/recv of the peers' packed 3-channel SPANS (the root renders its blocks and everything "
                      "outside the spans in place)"}[res["exchange"]]
     if args.backend != "nccl":
@@ -654,7 +694,8 @@ def dist_line(res, args, app, W, H, t, world):
             "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)" % (app.upper(), W, H, t),
                        "frames_in_flight": ns,
                        "parallelism": "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + %s (in %d pipelined "
-                                      "pieces) + assemble" % (args.block_rows, world, relief[0], relief[1], exch, res["groups"])},
+                                      "pieces)%s" % (args.block_rows, world, relief[0], relief[1], exch, res["groups"],
+                                                     "" if res["exchange"] == "stores" else " + assemble")},
             "backend": "RCCL" if args.backend == "nccl" else "gloo with host-staged transfers (TEST form: ranks may share a GPU, nothing here "
                                                                 "says anything about xGMI)",
             "exchange": {"kind": res["exchange"], "chosen": "measured on these ranks: ms per pipelined frame %s" % res["exchange_trials_ms"]
@@ -758,6 +799,92 @@ def bench_lib(args):
     claim_stdout()(json.dumps(out))
     M.close()
     return status
+
+
+class GpuSampler:
+    """shader clock and board power of one GPU, sampled from sysfs by a thread (no subprocess per sample): pp_dpm_sclk's starred
+    level or hwmon freq1_input, hwmon power1_average / power1_input.  What the box does not expose stays None."""
+
+    def __init__(self, index=0, period_s=.02):
+        import glob
+        import threading
+        self.period = period_s
+        self.clk, self.pw = [], []
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        self.dpm = cards[index] if index < len(cards) else None
+        base = os.path.dirname(self.dpm) if self.dpm else None
+        hw = sorted(glob.glob(os.path.join(base, "hwmon", "hwmon*"))) if base else []
+        self.freq = next((os.path.join(h, "freq1_input") for h in hw if os.path.exists(os.path.join(h, "freq1_input"))), None)
+        self.power = next((os.path.join(h, n) for h in hw for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        mhz = None
+        try:
+            if self.freq:
+                mhz = float(open(self.freq).read()) / 1e6
+            elif self.dpm:
+                for line in open(self.dpm):
+                    if "*" in line:
+                        mhz = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
+        w = None
+        try:
+            if self.power:
+                w = float(open(self.power).read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        return mhz, w
+
+    def _run(self):
+        while not self._stop.is_set():
+            mhz, w = self._read()
+            if mhz:
+                self.clk.append(mhz)
+            if w:
+                self.pw.append(w)
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join()
+
+    @staticmethod
+    def _stat(v, nd):
+        return None if not v else {"mean": round(sum(v) / len(v), nd), "min": round(min(v), nd), "max": round(max(v), nd), "samples": len(v)}
+
+    def summary(self):
+        return {"sclk_mhz": self._stat(self.clk, 0), "power_w": self._stat(self.pw, 1),
+                "source": "sysfs: %s, %s" % (self.freq or self.dpm, self.power)}
+
+
+def sustained(torch, dev, step, ns, pixels, seconds, value, serial):
+    """what the chip SUSTAINS: the timed region's loop (frames_in_flight launches overlapping) kept up for `seconds`, outside the
+    timed region, with the shader clock and the board power sampled beside it.  `value` is K frames after a short warm-up; this is
+    thousands of frames at whatever clock the power limit allows."""
+    n, t0 = 0, time.perf_counter()
+    with GpuSampler(dev.index or 0) as smp:
+        while time.perf_counter() - t0 < seconds:
+            for i in range(8 * ns):
+                step(i)
+            torch.cuda.synchronize(dev)
+            n += 8 * ns
+        dt = time.perf_counter() - t0
+    ms = dt * 1e3 / n
+    v = pixels / (ms * 1e-3) / 1e6
+    out = {"value": round(v, 3), "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "frames": n, "seconds": round(dt, 3),
+           "frames_in_flight": ns, "value_over_sustained": round(value / v, 4), "value_serial_over_sustained": round(serial / v, 4),
+           "what": "the timed loop (same launches, same streams) held for %.1f s after the timed region; sclk / power sampled every 20 ms "
+                   "from sysfs.  value_over_sustained within +-3 %% = the K-frame window measured the steady state; above = it caught a "
+                   "boost the power limit does not sustain" % seconds}
+    out.update(smp.summary())
+    return out
 
 
 def steady_state(step_done, ns, pixels):
@@ -971,9 +1098,12 @@ def rooflines(app, launch_pixels, frame_pixels, kmean_ms, kmin_ms, pmc):
     roofline_hbm = {"bound": "hbm", "kernel": kernel, "achieved": round(hbm, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(hbm / PEAK_HBM_GBPS, 5), "bytes_per_pixel": 16, "traffic": None}
     r = {"bound": "valu", "kernel": kernel, "achieved": None, "peak": None, "unit": "T lane-ops/s", "frac": None,
-         "frac_is": "executed work: VALU lane-operations issued (SQ_INSTS_VALU x 64) / time, against 1024 SIMD-32 x 32 lanes x "
-                    "shader clock = share of the VALU issue slots that carried an instruction (<= 1 by construction)",
-         "peak_at_2p4ghz": round(PEAK_LANEOPS_NOMINAL_T, 2), "frac_at_2p4ghz": None,
+         "frac_is": "executed work: VALU lane-operations issued (SQ_INSTS_VALU x 64) / the profiled launch's duration, against the FIXED "
+                    "peak 1024 SIMD-32 x 32 lanes x 2.4 GHz = 78.64 T lane-ops/s (MI355X_MICROARCH.md); frac_at_measured_clock = the "
+                    "same against the peak at the shader clock the launch actually ran at (the share of the issue slots that carried "
+                    "an instruction, <= 1 by construction); frac_unprofiled_duration = the profiled instruction count over the "
+                    "UN-profiled launch duration (HIP events) against the fixed peak",
+         "frac_unprofiled_duration": None,
          "pixels_per_launch": launch_pixels, "kernel_ms": round(kmean_ms, 4), "kernel_ms_min": round(kmin_ms, 4),
          "traffic": None, "valu_busy_pct": None, "pmc_source": pmc.get("source") if pmc else None}
     if ops is not None:
@@ -992,16 +1122,21 @@ def rooflines(app, launch_pixels, frame_pixels, kmean_ms, kmin_ms, pmc):
     r["valu_insts_per_launch"] = round(insts)
     r["valu_insts_per_pixel"] = round(pmc["SQ_INSTS_VALU"] / frame_pixels, 2)
     nominal = insts * 64.0 / (kmean_ms * 1e-3) / 1e12
-    r["frac_at_2p4ghz"] = round(nominal / PEAK_LANEOPS_NOMINAL_T, 4)
+    r["frac_unprofiled_duration"] = round(nominal / PEAK_LANEOPS_NOMINAL_T, 4)
     live = not pmc.get("committed") and scale == 1.0 and "GRBM_GUI_ACTIVE" in pmc and pmc.get("kernel_ms_profiled")
     if live:
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = shader cycles the profiled launch was active, whatever the clock
+        # PRIMARY: the instructions of the profiled launch / ITS duration (same rocprofv3 pass) against the guide's FIXED peak,
+        # 1024 SIMD-32 x 32 lanes x 2.4 GHz = 78.64 T lane-ops/s — whatever clock DVFS actually held.
+        # SECONDARY: the same against the peak at the MEASURED shader clock (GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 =
+        # shader cycles the launch was active) = the share of the issue slots of the cycles that happened.
         active = pmc["GRBM_GUI_ACTIVE"] / 8.0
         dur = pmc["kernel_ms_profiled"] * 1e-3
         clock = active / dur
         r["achieved"] = round(insts * 64.0 / dur / 1e12, 3)
-        r["peak"] = round(N_SIMD * LANES_PER_SIMD_CYCLE * clock / 1e12, 3)
-        r["frac"] = round(insts * VALU_ISSUE_CYCLES / (N_SIMD * active), 4)
+        r["peak"] = round(PEAK_LANEOPS_NOMINAL_T, 2)
+        r["frac"] = round(insts * 64.0 / dur / 1e12 / PEAK_LANEOPS_NOMINAL_T, 4)
+        r["peak_at_measured_clock"] = round(N_SIMD * LANES_PER_SIMD_CYCLE * clock / 1e12, 3)
+        r["frac_at_measured_clock"] = round(insts * VALU_ISSUE_CYCLES / (N_SIMD * active), 4)
         r["shader_clock_ghz_profiled"] = round(clock / 1e9, 3)
         r["kernel_ms_profiled"] = round(pmc["kernel_ms_profiled"], 4)
     else:
@@ -1009,8 +1144,8 @@ def rooflines(app, launch_pixels, frame_pixels, kmean_ms, kmin_ms, pmc):
         # per pixel x this launch's pixels, against the nominal-clock peak
         r["achieved"] = round(nominal, 3)
         r["peak"] = round(PEAK_LANEOPS_NOMINAL_T, 2)
-        r["frac"] = r["frac_at_2p4ghz"]
-        r["frac_is"] += "; here from the committed per-pixel instruction count x this launch's pixels at the nominal 2.4 GHz"
+        r["frac"] = r["frac_unprofiled_duration"]
+        r["frac_is"] += "; here from the committed per-pixel instruction count x this launch's pixels"
     if "WRITE_SIZE" in pmc and "FETCH_SIZE" in pmc and scale == 1.0:      # KB; gfx950: FETCH_SIZE counts half of a wide streaming read
         traffic = int(pmc["WRITE_SIZE"] * 1024 + 2 * pmc["FETCH_SIZE"] * 1024)
         r["traffic"] = roofline_hbm["traffic"] = traffic
@@ -1086,6 +1221,8 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
     if spec != "auto":
         m0, m = (int(v) for v in spec.split("/"))
         return (m0, m)
+    if exchange == "stores":
+        return (1, 1)                                   # the root does nothing for the others: the plain split, nothing to calibrate
     pick = torch.zeros(2, dtype=torch.int64, device=COLL_DEV or dev)
     if rank == 0:
         ch = channels if exchange == "direct" else (3 if exchange == "spans" else 4)
@@ -1116,17 +1253,59 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
     return (int(pick[0].item()), int(pick[1].item()))
 
 
+def land(R, torch, dst, src, peers):
+    """the peers' payloads arriving in the root's HBM.  With LANDING set: sbx_model_landing — `wgs_per_peer` workgroups per peer
+    stay resident for as long as ONE peer's payload needs on its link (the peers arrive in parallel over their own links) and
+    write all the bytes at that pace: the CUs and the HBM writes of RCCL's grouped receive.  Without: a device copy at HBM speed
+    (round 4's stand-in, which holds the whole chip for a few microseconds instead of a few CUs for the link time)."""
+    n = src.numel() * src.element_size()
+    if LANDING and n % 16 == 0 and n > 0 and peers > 0:
+        us = n / peers / (LANDING["link_gbps"] * 1e9) * 1e6
+        R.model_landing(src, dst, n, LANDING["wgs_per_peer"] * peers, us)
+    else:
+        dst.view(-1)[:src.numel()].copy_(src.view(-1))
+
+
 def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0, m, exchange, ch, per_frame):
     """ms per frame of rank `r`'s part of a `world`-rank frame, ALL of it on this one device with the launches in flight on the
-    streams `st`: a peer = its launch; the root = its launch + the landing of the peers' payloads in its HBM (a device copy of
-    that many bytes standing in for what RCCL's receive kernels write) + the assembly kernel.  Used by the relief calibration on
-    rank 0 and by tools/strip_scaling.py; it knows nothing about the links."""
+    streams `st`: a peer = its launch; the root = its launch + the landing of the peers' payloads in its HBM (`land`: a model of
+    RCCL's receive kernels) + the assembly kernel; under the store exchange the root is an ordinary rank (its launch and the two
+    flag kernels), and so is a peer (which renders in place into a frame on this device).  Used by the relief calibration on
+    rank 0, by --emulate-ranks and by tools/strip_scaling.py; it knows nothing about the links."""
     from shaderbox_amd import shard
     nb = len(frames)
     pdt = getattr(R, "pixel_dtype", torch.float32)          # uint8 after R.set_output_format("rgba8"): 4 bytes per pixel anywhere
     epp = 4 if pdt == torch.uint8 else 3                    # buffer elements per pixel of a span slab
     if pdt == torch.uint8:
         ch = 4
+    if exchange == "stores":
+        # one shared frame per stream, as FramePlan keeps them; a peer is driven together with its owner's "go" (one more flag kernel
+        # than a real peer launches: on the pessimistic side)
+        owners = [R.shared_create(H * W * (4 if pdt == torch.uint8 else 16), 1 if r == 0 else 2) for _ in range(nb)]
+        peers = [R.shared_open(o.export()) for o in owners] if r > 0 else []
+        views = [o.tensor((H, W, 4)) for o in owners]
+
+        def one(i):
+            with torch.cuda.stream(st[i % len(st)]):
+                o = owners[i % nb]
+                o.begin(0)
+                if r == 0:
+                    R.render_rank_in_place(app, W, H, t, br, 0, world, views[i % nb], root_rounds=m0, rounds=m, channels=ch)
+                    o.end(0)
+                else:
+                    p = peers[i % nb]
+                    p.begin(1)
+                    R.render_rank_in_place(app, W, H, t, br, r, world, p, root_rounds=m0, rounds=m, channels=ch)
+                    p.end(1)
+        try:
+            return per_frame(one)
+        finally:
+            torch.cuda.synchronize(dev)
+            del views
+            for p in peers:
+                p.close()
+            for o in owners:
+                o.close()
     if exchange == "spans":
         _, pix, _ = R.span_table(app, W, H, t, br, world, m0, m)
         stride = (int(max(pix[1:])) + 63) // 64 * 64
@@ -1138,14 +1317,16 @@ def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0,
                     R.render_span_peer(app, W, H, t, br, r, world, 0, 1 << 30, slabs[i % nb], root_rounds=m0, rounds=m)
             return per_frame(peer)
         total = sum(int(p) for p in pix[1:])
-        src = torch.zeros((max(total, 1) * epp,), dtype=pdt, device=dev)
-        land = [torch.zeros(((world - 1) * max(stride, 1) * epp,), dtype=pdt, device=dev) for _ in range(nb)]
+        tot_el = (max(total, 1) * epp + 15) // 16 * 16          # (whole 16-byte units for the landing model)
+        src = torch.zeros((tot_el,), dtype=pdt, device=dev)
+        land_el = max((world - 1) * max(stride, 1) * epp, tot_el)
+        lands = [torch.zeros((land_el,), dtype=pdt, device=dev) for _ in range(nb)]
 
         def root(i):
             with torch.cuda.stream(st[i % len(st)]):
                 R.render_span_root(app, W, H, t, br, world, frames[i % nb], root_rounds=m0, rounds=m)
-                land[i % nb][:src.numel()].copy_(src)
-                R.assemble_spans(app, W, H, t, br, world, land[i % nb], stride, frames[i % nb], root_rounds=m0, rounds=m)
+                land(R, torch, lands[i % nb], src, world - 1)
+                R.assemble_spans(app, W, H, t, br, world, lands[i % nb], stride, frames[i % nb], root_rounds=m0, rounds=m)
         return per_frame(root)
     rmax = shard.rank_rows_max(H, br, world, m0, m)
     slabs = [torch.empty((rmax, W, ch), dtype=pdt, device=dev) for _ in range(nb)]
@@ -1155,19 +1336,19 @@ def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0,
                 R.render_rank_rows(app, W, H, t, br, r, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
         return per_frame(peer)
     src = torch.zeros((world - 1, rmax, W, ch), dtype=pdt, device=dev)
-    land = [torch.zeros((world, rmax, W, ch), dtype=pdt, device=dev) for _ in range(nb)]
+    lands = [torch.zeros((world, rmax, W, ch), dtype=pdt, device=dev) for _ in range(nb)]
 
     def root(i):
         with torch.cuda.stream(st[i % len(st)]):
-            g, f = land[i % nb], frames[i % nb]
+            g, f = lands[i % nb], frames[i % nb]
             if exchange == "direct":
                 R.render_rank_in_place(app, W, H, t, br, 0, world, f, root_rounds=m0, rounds=m)
-                g[1:].copy_(src)
+                land(R, torch, g[1:], src, world - 1)
                 R.assemble_peers(g[1:], W, H, br, world, f, root_rounds=m0, rounds=m)
             else:
                 R.render_rank_rows(app, W, H, t, br, 0, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
                 g[0].copy_(slabs[i % nb])
-                g[1:].copy_(src)
+                land(R, torch, g[1:], src, world - 1)
                 R.assemble(g, W, H, br, world, out=f, root_rounds=m0, rounds=m)
     return per_frame(root)
 

@@ -33,7 +33,11 @@
 extern "C" {
 #endif
 
-#define SBX_ABI_VERSION 1
+/* Bumped whenever an entry point, enum value or struct layout of this header changes (2 = round 5: the store exchange
+ * sbx_shared_*, sbx_stats, sbx_abi_version itself; the test hooks moved to sbx_test.h).  A host checks
+ * sbx_abi_version() == SBX_ABI_VERSION after loading the library: include/sbx_mainimage.hpp and shaderbox_amd.load_library do. */
+#define SBX_ABI_VERSION 2
+int sbx_abi_version(void);
 
 /* App selector = the reference's APP_* project defines, in README.md:15-22 order, plus
  * APP_SDF_AO (src/uniform_buffer.h:56, util/hlsltoy/src/hlsltoy.cpp:488). */
@@ -246,6 +250,40 @@ int sbx_render_span_root(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
 int sbx_assemble_spans(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks,
                        int root_rounds, int rounds, const float* peers, int64_t stride_pixels, float* frame, void* stream);
 
+/* ---- The store exchange: the peers render IN PLACE into the owner's frame ------------------------------------------------
+ * (The reference has no multi-device path; this is the form of the ONE exchange step in which the frame's owner
+ * does nothing for the others: no landing area, no receive kernels, no scatter pass.)  The owner allocates the frame through the
+ * library and exports it; every peer — another PROCESS on another (or the same) GPU: hipIpcGetMemHandle / hipIpcOpenMemHandle; or
+ * another rank of the same process: the pointer itself — maps it and renders its row-blocks of the split straight into it with
+ * sbx_render_split_in_place[_rgb]: the exchange is the render kernels' own pixel stores over xGMI, 16 bytes per pixel (float4),
+ * 12 (sbx_render_split_in_place_rgb: three dwords; the alpha of every pixel is the constant 1 of src/main.h:52, written once when the
+ * frame is created) or 4 (SBX_FORMAT_RGBA8).  Two small flag kernels per frame and rank order it, through a page of fine-grained
+ * memory next to the frame:
+ *     owner:  sbx_shared_frame_begin (stream-ordered behind whatever read the previous frame: tells the peers the frame may be
+ *             overwritten) .. its own sbx_render_split_in_place .. sbx_shared_frame_end (the stream continues when every peer's
+ *             rows of THIS frame are in place);
+ *     peer r: sbx_shared_frame_begin (waits for the owner's go) .. sbx_render_split_in_place .. sbx_shared_frame_end (signals).
+ * Every rank calls begin / end once per frame, in order; frames of one sbx_shared are sequential, a host keeps several frames in
+ * flight with several sbx_shared (one per stream).  A wait that sees no signal for ~10 s raises the device's fault word
+ * (sbx_fault_status) instead of hanging.  Pixels are written by the app's full kernel from their global coordinates, so the frame
+ * is bit-identical to a one-GPU render.
+ * sbx_shared_create: `frame_bytes` = height * width * (16 or 4); nranks >= 1.  sbx_shared_export fills an opaque handle that may
+ * be sent to the other processes by any means (it holds no pointers valid elsewhere); sbx_shared_open maps it on `ctx`'s device.
+ * sbx_shared_frame = the frame's address in THIS process.  Closing the owner's object frees the frame: close the peers' first. */
+typedef struct sbx_shared sbx_shared;
+typedef struct sbx_shared_handle { unsigned char opaque[192]; } sbx_shared_handle;
+int sbx_shared_create(sbx_ctx* ctx, size_t frame_bytes, int nranks, sbx_shared** out);
+int sbx_shared_export(sbx_shared* s, sbx_shared_handle* handle);
+int sbx_shared_open(sbx_ctx* ctx, const sbx_shared_handle* handle, sbx_shared** out);
+void sbx_shared_close(sbx_shared* s);
+float* sbx_shared_frame(sbx_shared* s);
+int sbx_shared_frame_begin(sbx_shared* s, int rank, void* stream);
+int sbx_shared_frame_end(sbx_shared* s, int rank, void* stream);
+/* sbx_render_split_in_place writing only R, G, B of every float4 pixel (three dwords at a 16-byte stride); under
+ * SBX_FORMAT_RGBA8 it is sbx_render_split_in_place. */
+int sbx_render_split_in_place_rgb(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                                  int nranks, int root_rounds, int rounds, float* frame, void* stream);
+
 /* The write into hlsltoy's DXGI_FORMAT_R8G8B8A8_UNORM back buffer (util/hlsltoy/src/hlsltoy.cpp:79,192): float RGBA
  * rows -> 8-bit RGBA by the Direct3D float -> UNORM rule (NaN -> 0, clamp to [0, 1], * 255 + .5, truncate).
  * `rgba` and `out` are device pointers (width * rows pixels each); flip_y != 0 writes the top row first
@@ -266,44 +304,30 @@ int sbx_pack_unorm8(sbx_ctx* ctx, int width, int rows, const float* rgba, unsign
 enum { SBX_FORMAT_RGBA32F = 0, SBX_FORMAT_RGBA8 = 1 };
 int sbx_set_output_format(sbx_ctx* ctx, int format);
 
+/* Counters of a context since its creation (or the last sbx_reset_stats): what a host or a test reads to see what its calls
+ * turned into.  render_launches = render-kernel launches enqueued by any entry point; main_image_hits = sbx_main_image calls
+ * served from the cached frame; main_image_frames = whole frames sbx_main_image rendered; main_image_points = one-point launches. */
+typedef struct sbx_stats {
+    uint64_t render_launches;
+    uint64_t main_image_hits;
+    uint64_t main_image_frames;
+    uint64_t main_image_points;
+    uint64_t _reserved[4];
+} sbx_stats;
+int sbx_get_stats(sbx_ctx* ctx, sbx_stats* out);
+int sbx_reset_stats(sbx_ctx* ctx);
+
 /* Per-launch timing: when enabled, every render call brackets its kernel with HIP events on the
  * launch stream; sbx_last_kernel_ms() synchronises on the last pair and returns the duration. */
 int sbx_set_timing(sbx_ctx* ctx, int enabled);
 int sbx_last_kernel_ms(sbx_ctx* ctx, float* ms);
-
-/* Diagnostic knob: 0 = default kernels; 1 = the plain cross-check kernels where one exists: APP_CLOUDS with every
- * lane hashing its own lattice corners (no cache, no staging, no tables); APP_EGG / APP_SDF_AO / APP_VINYL with every
- * member of the SDF union evaluated everywhere (no culling); APP_PLANET without its exact skips.
- * 2 / 3 = the default kernels, except APP_EGG / APP_SDF_AO / APP_VINYL(_GPU): 2 = their square-root witness with the recording
- * edge raised to 1.0, so that the re-run path (csrc/sbx_sdf.h, Wit) executes on ordinary frames; 3 = the culled kernels with the
- * IEEE roots only.
- * All variants are specified to produce identical bits (tests/test_gpu_parity.py sweeps them against each other). */
-int sbx_set_variant(sbx_ctx* ctx, int variant);
-
-/* Device evaluation of the math spec, elementwise over device arrays (for parity tests):
- * fn in {"sin","cos","tan","exp","pow","acos","atan2","hash","div","div_rd","exp_h13","pow_h","sqrt_n","sqrt_ieee","exp_reg","exp_reg_plain","exp_reg64","exp_reg64_plain","exp_small","exp_small_plain","exp_reg4k","sin_b40","div3","sqrt_rs","divn","srgb_pow","pow_spec"}; b may be NULL
- * for unary fns ("exp_reg*": kernel-internal forms of exp — 32-entry table / degree 6 and 64-entry / degree 5, each with and without
- * the three-address asm — used by the regular-frame k_clouds and by k_atmosphere's density terms, equal to
- * "exp" for |x| <= 80; "exp_reg4k": the 4096-entry / degree-3 form of k_atmosphere's density terms, equal to "exp" for |x| <= 80;
- * "sin_b40": sin with a degree-15 polynomial, the hash passes' form, equal to "sin" for |x| <= 2^40;
- * "exp_small*": the degree-8 polynomial without argument reduction that the regular-frame k_clouds uses when
- * every argument lies in [-0.205, -0], equal to "exp" on that whole interval and at +0).
- * "div3" = a/b as q0 = a * RN(1/b), q = fma(fma(-q0, b, a), RN(1/b), q0): equal to "div" away from overflow and underflow;
- * "divn" = a/b through v_rcp_f32, one Newton step and div3's three instructions (equal to "div" away from overflow / underflow);
- * "pow_spec" = pow exactly as stated in the oracle ("pow" is the device's shorter instruction sequence for the same operations);
- * "srgb_pow" = pow(x, 1/2.2f) in the short form to_srgb uses on the device (equal to "pow" with b = 1/2.2f on all 2^32 arguments);
- * "sqrt_rs" = v_rsq_f32 and one corrected step: equal to "sqrt_ieee" for finite x >= 2^-102;
- * "div" = IEEE a/b, "div_rd" = the same quotient through the binary64 reciprocal of b (must be identical). */
-int sbx_math_eval(sbx_ctx* ctx, const char* fn, const float* a, const float* b, float* out,
-                  size_t n, void* stream);
 
 /* The noise library as standalone functions over n points (xyz interleaved, device arrays), 3 floats out
  * per point: "noise_iq" (src/noise_iq.h:11-29, out[0]); "hash_w" (src/noise_worley.h:5-17);
  * "noise_w" (:20-51; params[0] = domain_repeat; out = sqrt F1, sqrt F2, |cell id|);
  * "fbm_worley_tile" (src/fbm.h:8 as instantiated at util/ddsvolgen/src/ddsvolgen.cpp:52;
  * params = lacunarity, init_gain, gain; out[0]).
- * Test hooks of the recorded-domain forms (csrc/sbx_witness.h): "normalize" = v / length(v) in the IEEE form, "wit_normalize" = the
- * fast form (sqrt_rs_, v_rcp_f32 + one Newton step, three div3_), "wit_record" = out[0] 1 where that form's domain record fires. */
+ * (include/sbx_test.h documents three more names that exist for the parity tests of the recorded-domain forms.) */
 int sbx_noise_eval(sbx_ctx* ctx, const char* fn, const float* xyz, const float* params, float* out,
                    size_t n, void* stream);
 /* The size^3 RGBA32F noise volume util/ddsvolgen bakes (ddsvolgen.cpp:101-117): R =
@@ -323,10 +347,6 @@ int sbx_worley_volume(sbx_ctx* ctx, int size, float* rgba, void* stream);
  * call (same stream, or an event). */
 int sbx_set_noise_volumes(sbx_ctx* ctx, int shape_size, const float* shape_rgba, int detail_size,
                           const float* detail_rgba, void* stream);
-/* SampleLevel(linear, wrap, lod 0).r of a size^3 RGBA32F device volume at n points (xyz interleaved, device):
- * the texture-filter spec on its own, for parity tests. */
-int sbx_tex3d_eval(sbx_ctx* ctx, int size, const float* rgba, const float* xyz, float* out, size_t n, void* stream);
-
 /* ---- Multi-GPU frames inside the library (SURVEY.md §8b "Ownership", §8e "Collective") -----------------------------
  * One process drives `nranks` ranks; devices[i] is the HIP device of rank i, rank 0 owns the frame.  With all devices
  * distinct the library creates its communicator with ncclCommInitAll (rccl.h:236; librccl is dlopen'ed here, not linked)
@@ -353,7 +373,6 @@ void sbx_multi_destroy(sbx_multi* m);
 int sbx_multi_ranks(const sbx_multi* m);
 int sbx_multi_uses_rccl(const sbx_multi* m);             /* 1: RCCL send/recv, 0: device / peer copies */
 int sbx_multi_set_split(sbx_multi* m, int block_rows, int root_rounds, int rounds);
-int sbx_multi_set_variant(sbx_multi* m, int variant);
 /* sbx_set_output_format on every rank: with SBX_FORMAT_RGBA8 `frame` of sbx_multi_render holds width * height 32-bit words and
  * every exchange form moves 4 bytes per pixel. */
 int sbx_multi_set_output_format(sbx_multi* m, int format);
@@ -375,11 +394,10 @@ int sbx_multi_rccl_selftest(int device, int* step);
  * needs at most 64 rounds and is bounded at 4096; reaching the bound would mean wrong pixels.  Instead of passing silently the
  * wave sets a sticky word in pinned host memory (one per device): from then on every render call on a context of that device
  * returns SBX_ERR_FAULT — checked on entry, without synchronising — and sbx_last_error says why, until sbx_clear_fault (which
- * waits for the device first).  sbx_fault_status = the check on its own (e.g. after synchronising a frame);
- * sbx_debug_raise_fault launches one wave through the fault path (tests). */
+ * waits for the device first).  sbx_fault_status = the check on its own (e.g. after synchronising a frame).  The waits of the
+ * store exchange (sbx_shared_frame_begin / _end) report a signal that never arrived the same way. */
 int sbx_fault_status(sbx_ctx* ctx);
 int sbx_clear_fault(sbx_ctx* ctx);
-int sbx_debug_raise_fault(sbx_ctx* ctx, void* stream);
 
 const char* sbx_last_error(sbx_ctx* ctx);
 const char* sbx_version(void);

@@ -10,6 +10,13 @@
 // launch and copies it to the host; every call then returns its pixel from that frame.  So an
 // unmodified per-pixel host loop keeps working and costs one GPU frame per frame.
 //
+// Threads.  The reference's globals are thread_local (src/def.h:7-8) because its harness may call mainImage()
+// from many threads at once, each with private scene state.  Here the UNIFORMS are thread_local too, but the
+// library context is ONE per process: all host threads that ask for pixels of the same frame share one launch
+// and one host copy (sbx_main_image serves hits without a lock, include/sbx.h), instead of one context, one
+// launch and one 133 MB frame per thread.  Threads with different uniforms at the same time are served from
+// the context's two cached frames; more than two distinct frames in flight re-render on every switch.
+//
 //   g++ -std=c++17 -DAPP_CLOUDS host.cpp -I include -L shaderbox_amd/lib -lsbx -L /opt/rocm/lib -lamdhip64
 //                                                                       (see host/Makefile; no HIP headers needed)
 //
@@ -53,19 +60,23 @@ inline thread_local float2_t iResolution{{0, 0}};
 inline thread_local float iGlobalTime = 0.f;
 inline thread_local float4_t iMouse{{0, 0, 0, 0}};
 
-// one library context per host thread (the reference's globals are thread_local too, src/def.h:7-8)
+// ONE library context per process, created by whichever thread asks first (C++11 guarantees the one-time, thread-safe
+// construction of a function-local static); the library's ABI is checked against this header's.
 struct Context {
     sbx_ctx* ctx = nullptr;
-    ~Context() { if (ctx) sbx_destroy(ctx); }
-    sbx_ctx* get() {
-        if (!ctx) {
-            const int rc = sbx_create(0, &ctx);
-            if (rc != SBX_OK) throw std::runtime_error("sbx_create failed (" + std::to_string(rc) + "): a gfx950 GPU is required");
-        }
-        return ctx;
+    Context() {
+        if (sbx_abi_version() != SBX_ABI_VERSION)
+            throw std::runtime_error("libsbx.so has ABI " + std::to_string(sbx_abi_version()) + ", this header was written for ABI " +
+                                     std::to_string(SBX_ABI_VERSION));
+        const int rc = sbx_create(0, &ctx);
+        if (rc != SBX_OK) throw std::runtime_error("sbx_create failed (" + std::to_string(rc) + "): a gfx950 GPU is required");
     }
+    ~Context() { if (ctx) sbx_destroy(ctx); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    sbx_ctx* get() { return ctx; }
 };
-inline Context& context() { static thread_local Context c; return c; }
+inline Context& context() { static Context c; return c; }
 
 }  // namespace sbx_host
 

@@ -24,11 +24,12 @@ APPS = {"APP_PLANET": APP_PLANET, "APP_CLOUDS": APP_CLOUDS, "APP_VINYL": APP_VIN
         "APP_CLOUDS_TEX": APP_CLOUDS_TEX,      # APP_CLOUDS + USE_NOISE_TEX (src/app_clouds.h:9)
         "APP_CLOUDS_UE4": APP_CLOUDS_UE4,      # ue4/volumetric_clouds/Shaders/app_clouds.usf (host mapping: include/sbx.h)
         "APP_CLOUDS_SKY": APP_CLOUDS_SKY,      # APP_CLOUDS + SKY_SPHERE (src/app_clouds.h:8,14-19,154-162)
-        "APP_VINYL_GPU": APP_VINYL_GPU,
-        "APP_PLANET_ATMOSPHERE": APP_PLANET_ATMOSPHERE}   # config 5's composite: APP_PLANET with APP_ATMOSPHERE's sky as background (include/sbx.h)        # APP_VINYL with the 180 march steps of its GLSL / HLSL builds (src/app_vinyl.h:411-416)
+        "APP_VINYL_GPU": APP_VINYL_GPU,        # APP_VINYL with the 180 march steps of its GLSL / HLSL builds (src/app_vinyl.h:411-416)
+        "APP_PLANET_ATMOSPHERE": APP_PLANET_ATMOSPHERE}   # config 5's composite: APP_PLANET with APP_ATMOSPHERE's sky as background (include/sbx.h)
 
 SBX_OK, SBX_ERR_ARG, SBX_ERR_UNSUPPORTED, SBX_ERR_HIP, SBX_ERR_NO_DEVICE, SBX_ERR_FAULT = 0, -1, -2, -3, -4, -5
 SBX_FORMAT_RGBA32F, SBX_FORMAT_RGBA8 = 0, 1
+SBX_ABI_VERSION = 2                          # include/sbx.h; load_library() refuses a libsbx.so built from another header
 
 
 class SbxError(RuntimeError):
@@ -62,6 +63,16 @@ class AuxSdfAo(ctypes.Structure):           # sbx_aux_sdf_ao (cbuffer b1, APP_SD
     _fields_ = [("fog_density", ctypes.c_float), ("fog_falloff", ctypes.c_float), ("_pad", ctypes.c_float * 2)]
 
 
+class Stats(ctypes.Structure):              # sbx_stats
+    _fields_ = [("render_launches", ctypes.c_uint64), ("main_image_hits", ctypes.c_uint64),
+                ("main_image_frames", ctypes.c_uint64), ("main_image_points", ctypes.c_uint64),
+                ("_reserved", ctypes.c_uint64 * 4)]
+
+
+class SharedHandle(ctypes.Structure):       # sbx_shared_handle
+    _fields_ = [("opaque", ctypes.c_ubyte * 192)]
+
+
 def app_id(app):
     """Accepts an int, 'APP_CLOUDS', 'clouds', ..."""
     if isinstance(app, int):
@@ -90,6 +101,14 @@ def load_library(path=None):
         pass
     lib = ctypes.CDLL(path)
     vp, ci, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    try:
+        lib.sbx_abi_version.argtypes = []
+        got = int(lib.sbx_abi_version())
+    except AttributeError:
+        got = 1                              # (libraries before ABI 2 do not export the function)
+    if got != SBX_ABI_VERSION:
+        raise ImportError("%s has ABI %d, this package binds ABI %d (include/sbx.h): rebuild with `python -m shaderbox_amd.build`"
+                          % (path, got, SBX_ABI_VERSION))
     lib.sbx_aux_clouds_defaults.argtypes = [ctypes.POINTER(AuxClouds)]
     lib.sbx_aux_clouds_defaults.restype = None
     lib.sbx_aux_sdf_ao_defaults.argtypes = [ctypes.POINTER(AuxSdfAo)]
@@ -152,6 +171,22 @@ def load_library(path=None):
     lib.sbx_last_error.argtypes = [vp]
     lib.sbx_last_error.restype = ctypes.c_char_p
     lib.sbx_version.restype = ctypes.c_char_p
+    lib.sbx_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    lib.sbx_reset_stats.argtypes = [vp]
+    # the store exchange (include/sbx.h sbx_shared_*)
+    lib.sbx_shared_create.argtypes = [vp, ctypes.c_size_t, ci, ctypes.POINTER(vp)]
+    lib.sbx_shared_export.argtypes = [vp, ctypes.POINTER(SharedHandle)]
+    lib.sbx_shared_open.argtypes = [vp, ctypes.POINTER(SharedHandle), ctypes.POINTER(vp)]
+    lib.sbx_shared_close.argtypes = [vp]
+    lib.sbx_shared_close.restype = None
+    lib.sbx_shared_frame.argtypes = [vp]
+    lib.sbx_shared_frame.restype = vp
+    lib.sbx_shared_frame_begin.argtypes = [vp, ci, vp]
+    lib.sbx_shared_frame_end.argtypes = [vp, ci, vp]
+    lib.sbx_render_split_in_place_rgb.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, fp, vp]
+    # include/sbx_test.h (test hooks and the landing model of the scaling tools)
+    lib.sbx_shared_set_timeout_ms.argtypes = [vp, ci]
+    lib.sbx_model_landing.argtypes = [vp, vp, vp, ctypes.c_size_t, ci, ctypes.c_float, vp]
     return lib
 
 
@@ -195,6 +230,71 @@ def span_table(app, width, height, time, block_rows, nranks, root_rounds=1, roun
     if rc < 0:
         raise SbxError(rc, "sbx_span_table: bad arguments")
     return table, pix, int(mw.value)
+
+
+class _RawDeviceArray:
+    """A device pointer as an object torch.as_tensor understands (__cuda_array_interface__, no copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class SharedFrame:
+    """One sbx_shared (include/sbx.h, the store exchange): a frame in the OWNER's device memory that the other ranks of a split
+    map and render into in place.  The owner gets it from Renderer.shared_create and may view it as a tensor; a peer gets it from
+    Renderer.shared_open(handle bytes) and only ever passes its address to the render calls (the memory is another device's, or
+    another process's)."""
+
+    def __init__(self, renderer, handle, owner, nbytes):
+        self.r, self.h, self.owner, self.nbytes = renderer, handle, bool(owner), int(nbytes)
+
+    @property
+    def ptr(self):
+        return int(self.r.lib.sbx_shared_frame(self.h) or 0)
+
+    def export(self):
+        """the opaque handle as bytes, to be sent to the other ranks by any means (only the owner exports)"""
+        hd = SharedHandle()
+        self.r._check(self.r.lib.sbx_shared_export(self.h, ctypes.byref(hd)))
+        return bytes(hd.opaque)
+
+    def tensor(self, shape, dtype=None):
+        """the owner's view of the frame as a device tensor (no copy)"""
+        torch = self.r.torch
+        dtype = dtype or self.r.pixel_dtype
+        assert self.owner, "only the owner views the frame as a tensor; peers hold an address in another device / process"
+        n = 1
+        for v in shape:
+            n *= int(v)
+        assert n * (1 if dtype == torch.uint8 else 4) <= self.nbytes
+        t = torch.as_tensor(_RawDeviceArray(self.ptr, shape, "|u1" if dtype == torch.uint8 else "<f4"), device=self.r.tdev)
+        assert t.data_ptr() == self.ptr, "torch copied the shared frame instead of viewing it"
+        t._sbx_keepalive = self
+        return t
+
+    def begin(self, rank):
+        """owner (rank 0): the frame may be overwritten from here on in stream order; peer: wait for that"""
+        self.r._check(self.r.lib.sbx_shared_frame_begin(self.h, int(rank), self.r._stream()))
+
+    def end(self, rank):
+        """peer: my rows of this frame are in place; owner: the stream continues when every peer's are"""
+        self.r._check(self.r.lib.sbx_shared_frame_end(self.h, int(rank), self.r._stream()))
+
+    def set_timeout_ms(self, ms):
+        self.r._check(self.r.lib.sbx_shared_set_timeout_ms(self.h, int(ms)))
+
+    def close(self):
+        if self.h:
+            self.r.lib.sbx_shared_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.r.ctx:
+                self.close()
+        except Exception:
+            pass
 
 
 class Renderer:
@@ -356,15 +456,52 @@ class Renderer:
         return slab
 
     def render_rank_in_place(self, app, width, height, time, block_rows, rank, nranks, frame, mouse=(0.0, 0.0), aux=None,
-                             root_rounds=1, rounds=1):
-        """The rows of `rank` at their global positions of the full-size `frame` [H, W, 4]; other rows are not touched."""
+                             root_rounds=1, rounds=1, channels=4):
+        """The rows of `rank` at their global positions of the full-size `frame` [H, W, 4]; other rows are not touched.
+        `frame` is a tensor of this device or a SharedFrame (the store exchange: the owner's frame mapped by a peer).
+        channels = 3: only R, G, B of every float4 pixel are written (sbx_render_split_in_place_rgb; the alpha is in the frame)."""
         u = self.uniforms(width, height, time, mouse)
-        assert self._is_pixels(frame)
-        assert tuple(frame.shape) == (int(height), int(width), 4)
-        self._check(self.lib.sbx_render_split_in_place(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows,
-                                                       rank, nranks, root_rounds, rounds, ctypes.c_void_p(frame.data_ptr()),
-                                                       self._stream()))
+        if isinstance(frame, SharedFrame):
+            assert frame.nbytes >= int(height) * int(width) * (4 if self.rgba8 else 16)
+            ptr = frame.ptr
+        else:
+            assert self._is_pixels(frame)
+            assert tuple(frame.shape) == (int(height), int(width), 4)
+            ptr = frame.data_ptr()
+        fn = self.lib.sbx_render_split_in_place_rgb if int(channels) == 3 else self.lib.sbx_render_split_in_place
+        self._check(fn(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, rank, nranks, root_rounds, rounds,
+                       ctypes.c_void_p(ptr), self._stream()))
         return frame
+
+    # -- the store exchange (include/sbx.h sbx_shared_*) --------------------------------------------------------
+    def shared_create(self, nbytes, nranks):
+        """a frame of `nbytes` bytes on this device that `nranks` ranks render into (this renderer is its owner, rank 0)"""
+        h = ctypes.c_void_p()
+        self._check(self.lib.sbx_shared_create(self.ctx, int(nbytes), int(nranks), ctypes.byref(h)))
+        return SharedFrame(self, h, True, nbytes)
+
+    def shared_open(self, handle_bytes):
+        """map the frame another rank exported (SharedFrame.export()) for rendering from this device"""
+        hd = SharedHandle()
+        assert len(handle_bytes) == ctypes.sizeof(hd)
+        ctypes.memmove(ctypes.byref(hd), bytes(handle_bytes), ctypes.sizeof(hd))
+        h = ctypes.c_void_p()
+        self._check(self.lib.sbx_shared_open(self.ctx, ctypes.byref(hd), ctypes.byref(h)))
+        import struct
+        return SharedFrame(self, h, False, struct.unpack_from("<Q", bytes(handle_bytes), 136)[0])     # (frame_bytes of the handle blob)
+
+    def model_landing(self, src, dst, nbytes, workgroups, duration_us):
+        """include/sbx_test.h sbx_model_landing: the scaling tools' stand-in for RCCL's receive kernels on the frame's owner"""
+        self._check(self.lib.sbx_model_landing(self.ctx, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), int(nbytes),
+                                               int(workgroups), float(duration_us), self._stream()))
+
+    def stats(self):
+        st = Stats()
+        self._check(self.lib.sbx_get_stats(self.ctx, ctypes.byref(st)))
+        return {k: int(getattr(st, k)) for k in ("render_launches", "main_image_hits", "main_image_frames", "main_image_points")}
+
+    def reset_stats(self):
+        self._check(self.lib.sbx_reset_stats(self.ctx))
 
     # -- the span exchange: only the expensive part of each row-block is sharded (include/sbx.h) ------------------
     def span_table(self, app, width, height, time, block_rows, nranks, root_rounds=1, rounds=1, mouse=(0.0, 0.0), aux=None):

@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-gpu-flush-denormals-to-zero", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mfma",
          "-Wall", "-Wno-unused-function"]
 SOURCES = ["kern_clouds.hip", "kern_clouds_tex.hip", "kern_egg.hip", "kern_raytracer.hip", "kern_atmosphere.hip", "kern_sdf_ao.hip",
-           "kern_planet.hip", "kern_vinyl.hip", "kern_clouds_best.hip", "kern_clouds_ue4.hip", "kern_util.hip", "kern_noise.hip", "sbx_capi.hip", "sbx_multi.hip"]
+           "kern_planet.hip", "kern_vinyl.hip", "kern_clouds_best.hip", "kern_clouds_ue4.hip", "kern_util.hip", "kern_noise.hip", "sbx_capi.hip", "sbx_multi.hip", "sbx_shared.hip"]
 # -fno-slp-vectorize: measured on MI355X, the SLP vectoriser's v_pk_{mul,add}_f32 are a net loss for every
 # kernel here (CLOUDS 8.7 -> 6.5 ms, PLANET 57 -> 41 ms, SDF_AO 1.75 -> 1.37 ms at 4K/8K): a packed op issues
 # in ~4.7 cycles against 2 x 2.9 for the scalar pair (profiles/r01_ubench_valu.txt), needs its constants in

@@ -6,8 +6,10 @@
 // shared math spec, launch the app's kernel on the caller's stream.  There is NO CPU fallback: without
 // a gfx950 device sbx_create fails with SBX_ERR_NO_DEVICE.
 #include "../../include/sbx.h"
+#include "../../include/sbx_test.h"
 #include "sbx_device.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -65,11 +67,31 @@ struct sbx_ctx {
     unsigned* tex_scan = nullptr;    // 6 device words: min / max keys and NaN flag of the two volumes (sbx_set_noise_volumes)
     float tex_bounds[4] = {0, 0, 0, 0};   // {lo1, hi1, lo2, hi2} of the texels; valid only if tex_bounds_valid
     bool tex_bounds_valid = false;
-    // sbx_main_image: the frame of the last (app, uniforms, aux) seen, on the device and on the host
+    // sbx_main_image: the frames of the last MI_FRAMES distinct (app, uniforms, aux) seen, each in pinned host memory behind a
+    // sequence lock — host threads that hit read their pixel WITHOUT any lock or shared write (the reference's harness calls
+    // mainImage from many threads, src/def.h:7-8); only a miss takes mi_lock and renders.  `gen` is even while an entry is stable
+    // and odd while the rendering thread rewrites it; a reader that sees the same even value before and after its reads has read
+    // one frame.  The key words are relaxed atomics because readers look at them while a writer may be storing.
+    static constexpr int MI_FRAMES = 2;
+    static constexpr int MI_KEY_WORDS = 2 + (int)(sizeof(sbx_uniforms) + sizeof(sbx_aux_clouds)) / 4;
+    struct MiEntry {
+        std::atomic<uint64_t> gen{0};
+        std::atomic<float*> host{nullptr};       // pinned (hipHostMalloc): the frame comes back with one asynchronous copy
+        std::atomic<uint32_t> key[MI_KEY_WORDS];
+        size_t cap_floats = 0;                   // (writer only, under mi_lock)
+        uint64_t born = 0;
+        bool used = false;
+    };
+    MiEntry mi[MI_FRAMES];
+    uint64_t mi_clock = 0;
     float* mi_dev = nullptr;
     size_t mi_floats = 0;
-    float* mi_host = nullptr;        // pinned (hipHostMalloc): the frame comes back with one asynchronous copy
-    bool mi_valid = false;
+    std::vector<float*> mi_retired;              // pinned buffers outgrown by a larger frame: a reader may still be inside one, so
+                                                 // they outlive the resize (the oldest goes when eight are waiting; all at destroy)
+    // sbx_get_stats; the hit counter is striped over cache lines (it is bumped once per pixel by every host thread)
+    struct alignas(64) Stripe { std::atomic<uint64_t> n{0}; };
+    Stripe st_hits[16];
+    std::atomic<uint64_t> st_launches{0}, st_frames{0}, st_points{0};
     // sbx_main_image_batch / off-centre sbx_main_image: staging of a point list (device: 2 + 4 floats per point; host: pinned)
     float* pt_dev = nullptr;
     float* pt_host = nullptr;
@@ -79,10 +101,6 @@ struct sbx_ctx {
     struct SpanSlot { std::vector<int> key; std::vector<int> table; int4* dev = nullptr; int max_w = 0; size_t cap = 0; };
     SpanSlot span_slots[4];
     unsigned span_next = 0;
-    int mi_app = -1;
-    sbx_uniforms mi_uni{};
-    unsigned char mi_aux[sizeof(sbx_aux_clouds)] = {0};
-    int mi_aux_bytes = -1;
     std::string err;
 };
 
@@ -106,6 +124,16 @@ static int bind_fault_word(int device) {
     return SBX_OK;
 }
 
+namespace sbx {
+unsigned* fault_word_device(int device) {
+    unsigned* dev = nullptr;
+    if (device < 0 || device >= 64 || !g_fault_word[device]) return nullptr;
+    if (hipHostGetDevicePointer((void**)&dev, g_fault_word[device], 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return dev;
+}
+int ctx_device(const sbx_ctx* ctx) { return ctx->device; }
+}  // namespace sbx
+
 static int fail(sbx_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
     if (ctx) {
         ctx->err = what;
@@ -113,6 +141,8 @@ static int fail(sbx_ctx* ctx, int code, const char* what, hipError_t e = hipSucc
     }
     return code;
 }
+
+namespace sbx { int ctx_fail(sbx_ctx* ctx, int code, const char* what, hipError_t e) { return fail(ctx, code, what, e); } }
 
 // ---------------------------------------------------------------------------------------------
 // frame builders: the frame-constant part of setup_camera()/setup_scene()/sdf() per app
@@ -420,6 +450,7 @@ int sbx_create(int device, sbx_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SBX_ERR_NO_DEVICE;   // kernels exist for gfx950 only
     sbx_ctx* ctx = new sbx_ctx();
     ctx->device = device;
+    for (auto& en : ctx->mi) for (auto& w : en.key) w.store(0xffffffffu, std::memory_order_relaxed);
     if (hipSetDevice(device) != hipSuccess ||
         hipMalloc((void**)&ctx->ytab, (size_t)(CLOUDS_YTAB_RING + CLOUDS_YTAB_CAPTURE) * CLOUDS_YTAB_BYTES) != hipSuccess ||
         bind_fault_word(device) != SBX_OK) {
@@ -438,7 +469,8 @@ void sbx_destroy(sbx_ctx* ctx) {
     if (ctx->ytab_big) (void)hipFree(ctx->ytab_big);
     if (ctx->have_ytab_big_event) (void)hipEventDestroy(ctx->ytab_big_ready);
     if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
-    if (ctx->mi_host) (void)hipHostFree(ctx->mi_host);
+    for (auto& en : ctx->mi) if (en.host.load()) (void)hipHostFree(en.host.load());
+    for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_dev) (void)hipFree(ctx->pt_dev);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
     for (auto& sl : ctx->span_slots) if (sl.dev) (void)hipFree(sl.dev);
@@ -551,10 +583,14 @@ static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, fl
 
 static const char* kFaultText = "an earlier launch on this device hit the bound of the hash cache's miss loop (sbx_hashcache.h): its "
                                 "pixels are invalid; re-render after sbx_clear_fault";
-static bool device_fault(const sbx_ctx* ctx) {
+static const char* kFaultTextWait = "a wait of the store exchange (sbx_shared_frame_begin / _end) on this device gave up: a rank's signal did not "
+                                    "arrive in time, the frame is incomplete; re-render after sbx_clear_fault";
+static unsigned device_fault_code(const sbx_ctx* ctx) {
     const unsigned* w = (ctx->device >= 0 && ctx->device < 64) ? g_fault_word[ctx->device] : nullptr;
-    return w && *(volatile const unsigned*)w != 0u;
+    return w ? *(volatile const unsigned*)w : 0u;
 }
+static bool device_fault(const sbx_ctx* ctx) { return device_fault_code(ctx) != 0u; }
+static const char* fault_text(const sbx_ctx* ctx) { return device_fault_code(ctx) == 2u ? kFaultTextWait : kFaultText; }
 
 // Domain of the margin-based culls of EGG / SDF_AO / VINYL (bounding spheres and boxes around members placed by rotations) and
 // of PLANET's |o|^2 band test (a rotation preserves the norm): their proofs take the frame's rotations to BE rotations.  The
@@ -572,7 +608,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     if (M.nrows == 0) return SBX_OK;
-    if (device_fault(ctx)) return fail(ctx, SBX_ERR_FAULT, kFaultText);
+    if (device_fault(ctx)) return fail(ctx, SBX_ERR_FAULT, fault_text(ctx));
     // argument checks come before anything is enqueued or recorded
     if (app < SBX_APP_PLANET || app > SBX_APP_PLANET_ATMOSPHERE) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
     sbx_aux_clouds AC;
@@ -599,6 +635,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         (void)hipEventRecord(tp->ev0, s);
     }
     int rc = SBX_OK;
+    ctx->st_launches.fetch_add(1, std::memory_order_relaxed);
     const int cull_variant = tame_time(uni->u_time) ? ctx->variant : 1;
     const int sdf_variant = cull_variant == 1 ? 1 : ctx->sdf_roots;      // EGG / SDF_AO / VINYL: 2 / 3 = the witness's test build / IEEE roots
     switch (app) {
@@ -734,11 +771,49 @@ int sbx_main_image_batch(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     return main_image_points(ctx, app, uni, aux, n, fragCoords, fragColors);
 }
 
+// ---- sbx_main_image: the per-pixel entry over cached frames ----------------------------------------------------------------
+static int mi_aux_bytes(int app, const void* aux) {
+    return !aux ? 0 : ((app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX || app == SBX_APP_CLOUDS_SKY) ? (int)sizeof(sbx_aux_clouds)
+                       : (app == SBX_APP_SDF_AO ? (int)sizeof(sbx_aux_sdf_ao)
+                       : (app == SBX_APP_CLOUDS_UE4 ? (int)sizeof(sbx_aux_clouds_ue4) : 0)));
+}
+// the cache key of a frame as words: app, aux size, the uniforms, the aux block (zero padded)
+static void mi_make_key(int app, const sbx_uniforms* uni, const void* aux, uint32_t key[sbx_ctx::MI_KEY_WORDS]) {
+    std::memset(key, 0, sizeof(uint32_t) * sbx_ctx::MI_KEY_WORDS);
+    const int ab = mi_aux_bytes(app, aux);
+    key[0] = (uint32_t)app; key[1] = (uint32_t)ab;
+    std::memcpy(key + 2, uni, sizeof(*uni));
+    if (ab) std::memcpy(key + 2 + sizeof(*uni) / 4, aux, (size_t)ab);
+}
+// Lock-free lookup: true and the pixel if some entry holds this frame and stayed untouched while it was read.
+static bool mi_lookup(sbx_ctx* ctx, const uint32_t* key, size_t pixel, float out[4]) {
+    for (auto& en : ctx->mi) {
+        const uint64_t g1 = en.gen.load(std::memory_order_acquire);
+        if (g1 & 1u) continue;                                                   // being rewritten
+        bool same = true;
+        for (int i = 0; i < sbx_ctx::MI_KEY_WORDS && same; ++i) same = en.key[i].load(std::memory_order_relaxed) == key[i];
+        if (!same) continue;
+        const float* h = en.host.load(std::memory_order_relaxed);
+        if (!h) continue;
+        float c[4];
+        std::memcpy(c, h + pixel * 4, sizeof(c));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (en.gen.load(std::memory_order_relaxed) != g1) continue;              // rewritten under us: not a hit
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+        return true;
+    }
+    return false;
+}
+static unsigned mi_stripe() {
+    static std::atomic<unsigned> next{0};
+    static thread_local unsigned mine = next.fetch_add(1, std::memory_order_relaxed) & 15u;
+    return mine;
+}
+
 int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, const float fragCoord[2],
                    float fragColor[4]) {
     if (!ctx) return SBX_ERR_ARG;
-    std::lock_guard<std::mutex> g(ctx->mi_lock);
-    if (!uni || !fragCoord || !fragColor) return fail(ctx, SBX_ERR_ARG, "NULL argument");
+    if (!uni || !fragCoord || !fragColor) { std::lock_guard<std::mutex> g(ctx->mi_lock); return fail(ctx, SBX_ERR_ARG, "NULL argument"); }
     // Is fragCoord the centre of a pixel of the frame?  Then the pixel comes from the frame cached for (app, uniforms, aux).
     // ANY other coordinate — off-centre (a supersampling host), outside the frame, NaN, or a frame whose u_res is not a whole
     // number of pixels — is evaluated exactly where it is, by a one-point launch: mainImage is a function of fragCoord
@@ -749,40 +824,81 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
     const bool whole = W > 0 && H > 0 && (float)W == W_f && (float)H == H_f && W <= 65536 && H <= 65536;
     const float cx = std::floor(fx), cy = std::floor(fy);
     const bool centre = whole && fx == cx + .5f && fy == cy + .5f && cx >= 0.f && cy >= 0.f && cx < W_f && cy < H_f;
-    if (!centre) return main_image_points(ctx, app, uni, aux, 1, fragCoord, fragColor);
-    const int aux_bytes = !aux ? 0 : ((app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_TEX || app == SBX_APP_CLOUDS_SKY) ? (int)sizeof(sbx_aux_clouds)
-                                      : (app == SBX_APP_SDF_AO ? (int)sizeof(sbx_aux_sdf_ao)
-                                      : (app == SBX_APP_CLOUDS_UE4 ? (int)sizeof(sbx_aux_clouds_ue4) : 0)));
-    const bool hit = ctx->mi_valid && ctx->mi_app == app && std::memcmp(&ctx->mi_uni, uni, sizeof(*uni)) == 0 &&
-                     ctx->mi_aux_bytes == aux_bytes && (aux_bytes == 0 || std::memcmp(ctx->mi_aux, aux, aux_bytes) == 0);
-    if (!hit) {
-        ctx->mi_valid = false;
-        const size_t n = (size_t)W * (size_t)H * 4;
-        hipError_t e = hipSetDevice(ctx->device);
-        if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
-        if (n != ctx->mi_floats) {
-            if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
-            if (ctx->mi_host) (void)hipHostFree(ctx->mi_host);
-            ctx->mi_dev = nullptr; ctx->mi_host = nullptr; ctx->mi_floats = 0;
-            if ((e = hipMalloc((void**)&ctx->mi_dev, n * sizeof(float))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
-            if ((e = hipHostMalloc((void**)&ctx->mi_host, n * sizeof(float), hipHostMallocDefault)) != hipSuccess) {
-                (void)hipFree(ctx->mi_dev); ctx->mi_dev = nullptr;
-                return fail(ctx, SBX_ERR_HIP, "hipHostMalloc", e);
-            }
-            ctx->mi_floats = n;
-        }
-        const int rc = render_rows(ctx, app, uni, aux, 0, H, ctx->mi_dev, nullptr, true);     // (the cache holds float pixels whatever the context's output format)
-        if (rc != SBX_OK) return rc;
-        // pinned destination: one DMA transfer at the link's rate behind the kernel, then one wait
-        if ((e = hipMemcpyAsync(ctx->mi_host, ctx->mi_dev, n * sizeof(float), hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
-            (e = hipStreamSynchronize(nullptr)) != hipSuccess)
-            return fail(ctx, SBX_ERR_HIP, "frame copy", e);
-        ctx->mi_app = app; ctx->mi_uni = *uni; ctx->mi_aux_bytes = aux_bytes;
-        if (aux_bytes) std::memcpy(ctx->mi_aux, aux, aux_bytes);
-        ctx->mi_valid = true;
+    if (!centre) {
+        std::lock_guard<std::mutex> g(ctx->mi_lock);
+        ctx->st_points.fetch_add(1, std::memory_order_relaxed);
+        return main_image_points(ctx, app, uni, aux, 1, fragCoord, fragColor);
     }
-    const float* p = &ctx->mi_host[((size_t)(int)cy * W + (int)cx) * 4];
-    fragColor[0] = p[0]; fragColor[1] = p[1]; fragColor[2] = p[2]; fragColor[3] = p[3];
+    uint32_t key[sbx_ctx::MI_KEY_WORDS];
+    mi_make_key(app, uni, aux, key);
+    const size_t pixel = (size_t)(int)cy * (size_t)W + (size_t)(int)cx;
+    // the hit path: no lock, no shared write but a striped counter
+    if (mi_lookup(ctx, key, pixel, fragColor)) {
+        ctx->st_hits[mi_stripe()].n.fetch_add(1, std::memory_order_relaxed);
+        return SBX_OK;
+    }
+    std::lock_guard<std::mutex> g(ctx->mi_lock);
+    if (mi_lookup(ctx, key, pixel, fragColor)) {                                 // another thread rendered it while we waited
+        ctx->st_hits[mi_stripe()].n.fetch_add(1, std::memory_order_relaxed);
+        return SBX_OK;
+    }
+    // miss: render the frame into the entry that was filled longest ago (an unused one first)
+    sbx_ctx::MiEntry* en = &ctx->mi[0];
+    for (auto& c : ctx->mi) if (!c.used || (en->used && c.born < en->born)) { en = &c; if (!c.used) break; }
+    const size_t n = (size_t)W * (size_t)H * 4;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    const uint64_t g0 = en->gen.load(std::memory_order_relaxed);
+    en->gen.store(g0 + 1, std::memory_order_relaxed);                            // odd: readers stay away / discard what they read
+    std::atomic_thread_fence(std::memory_order_release);
+    for (auto& w : en->key) w.store(0xffffffffu, std::memory_order_relaxed);     // (no frame has app = -1)
+    en->used = false;
+    if (n > ctx->mi_floats) {
+        if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
+        ctx->mi_dev = nullptr; ctx->mi_floats = 0;
+        if ((e = hipMalloc((void**)&ctx->mi_dev, n * sizeof(float))) != hipSuccess) { en->gen.store(g0 + 2, std::memory_order_release); return fail(ctx, SBX_ERR_HIP, "hipMalloc", e); }
+        ctx->mi_floats = n;
+    }
+    if (n > en->cap_floats) {
+        float* fresh = nullptr;
+        if ((e = hipHostMalloc((void**)&fresh, n * sizeof(float), hipHostMallocDefault)) != hipSuccess) { en->gen.store(g0 + 2, std::memory_order_release); return fail(ctx, SBX_ERR_HIP, "hipHostMalloc", e); }
+        if (float* old = en->host.load(std::memory_order_relaxed)) {
+            ctx->mi_retired.push_back(old);                                      // a reader may still be copying its pixel out of it
+            if (ctx->mi_retired.size() > 8) { (void)hipHostFree(ctx->mi_retired.front()); ctx->mi_retired.erase(ctx->mi_retired.begin()); }
+        }
+        en->host.store(fresh, std::memory_order_relaxed);
+        en->cap_floats = n;
+    }
+    float* host = en->host.load(std::memory_order_relaxed);
+    const int rc = render_rows(ctx, app, uni, aux, 0, H, ctx->mi_dev, nullptr, true);     // (the cache holds float pixels whatever the context's output format)
+    if (rc != SBX_OK) { en->gen.store(g0 + 2, std::memory_order_release); return rc; }
+    // pinned destination: one DMA transfer at the link's rate behind the kernel, then one wait
+    if ((e = hipMemcpyAsync(host, ctx->mi_dev, n * sizeof(float), hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
+        (e = hipStreamSynchronize(nullptr)) != hipSuccess) {
+        en->gen.store(g0 + 2, std::memory_order_release);
+        return fail(ctx, SBX_ERR_HIP, "frame copy", e);
+    }
+    ctx->st_frames.fetch_add(1, std::memory_order_relaxed);
+    for (int i = 0; i < sbx_ctx::MI_KEY_WORDS; ++i) en->key[i].store(key[i], std::memory_order_relaxed);
+    en->used = true; en->born = ++ctx->mi_clock;
+    en->gen.store(g0 + 2, std::memory_order_release);                            // even again: published
+    std::memcpy(fragColor, host + pixel * 4, 4 * sizeof(float));
+    return SBX_OK;
+}
+
+int sbx_get_stats(sbx_ctx* ctx, sbx_stats* out) {
+    if (!ctx || !out) return SBX_ERR_ARG;
+    std::memset(out, 0, sizeof(*out));
+    out->render_launches = ctx->st_launches.load(std::memory_order_relaxed);
+    for (auto& st : ctx->st_hits) out->main_image_hits += st.n.load(std::memory_order_relaxed);
+    out->main_image_frames = ctx->st_frames.load(std::memory_order_relaxed);
+    out->main_image_points = ctx->st_points.load(std::memory_order_relaxed);
+    return SBX_OK;
+}
+int sbx_reset_stats(sbx_ctx* ctx) {
+    if (!ctx) return SBX_ERR_ARG;
+    ctx->st_launches.store(0); ctx->st_frames.store(0); ctx->st_points.store(0);
+    for (auto& st : ctx->st_hits) st.n.store(0);
     return SBX_OK;
 }
 
@@ -1098,6 +1214,17 @@ int sbx_render_split_in_place(sbx_ctx* ctx, int app, const sbx_uniforms* uni, co
     RowMap M{W, H, 0, block_rows, nranks, rank, rows, 0, root_rounds, rounds, 1, out_rgb(ctx, 0)};
     return render_mapped(ctx, app, uni, aux, M, frame, stream);
 }
+int sbx_render_split_in_place_rgb(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                                  int nranks, int root_rounds, int rounds, float* frame, void* stream) {
+    int W, H;
+    int rc = check_common(ctx, uni, frame, W, H);
+    if (rc != SBX_OK) return rc;
+    const int rows = sbx_split_rank_rows(H, block_rows, rank, nranks, root_rounds, rounds);
+    if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
+    if (rows == 0) return SBX_OK;
+    RowMap M{W, H, 0, block_rows, nranks, rank, rows, 0, root_rounds, rounds, 1, out_rgb(ctx, 3)};      // 3: R, G, B of float4 pixels
+    return render_mapped(ctx, app, uni, aux, M, frame, stream);
+}
 int sbx_render_rank(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
                     int nranks, float* rgba, void* stream) {
     return sbx_render_split(ctx, app, uni, aux, block_rows, rank, nranks, 1, 1, 0, 0x7fffffff, rgba, stream);
@@ -1255,7 +1382,17 @@ int sbx_set_noise_volumes(sbx_ctx* ctx, int shape_size, const float* shape_rgba,
         if ((e = hipMalloc((void**)&ctx->noise_tex2, n2 * sizeof(float))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
         ctx->noise_tex2_size = detail_size;
     }
-    ctx->mi_valid = false;                                         // a cached sbx_main_image frame may have used the old volumes
+    {   // cached sbx_main_image frames may have used the old volumes
+        std::lock_guard<std::mutex> g(ctx->mi_lock);
+        for (auto& en : ctx->mi) {
+            const uint64_t g0 = en.gen.load(std::memory_order_relaxed);
+            en.gen.store(g0 + 1, std::memory_order_relaxed);
+            std::atomic_thread_fence(std::memory_order_release);
+            for (auto& w : en.key) w.store(0xffffffffu, std::memory_order_relaxed);
+            en.used = false;
+            en.gen.store(g0 + 2, std::memory_order_release);
+        }
+    }
     launch_extract_r(shape_rgba, ctx->noise_tex, n1, (hipStream_t)stream);
     launch_extract_r(detail_rgba, ctx->noise_tex2, n2, (hipStream_t)stream);
     e = hipGetLastError();
@@ -1294,7 +1431,7 @@ int sbx_tex3d_eval(sbx_ctx* ctx, int size, const float* rgba, const float* xyz, 
 
 int sbx_fault_status(sbx_ctx* ctx) {
     if (!ctx) return SBX_ERR_ARG;
-    return device_fault(ctx) ? fail(ctx, SBX_ERR_FAULT, kFaultText) : SBX_OK;
+    return device_fault(ctx) ? fail(ctx, SBX_ERR_FAULT, fault_text(ctx)) : SBX_OK;
 }
 int sbx_clear_fault(sbx_ctx* ctx) {
     if (!ctx) return SBX_ERR_ARG;
@@ -1318,6 +1455,7 @@ const char* sbx_last_error(sbx_ctx* ctx) {
     if (device_fault(ctx) && ctx->err.find("hash cache") == std::string::npos) { ctx->err += ctx->err.empty() ? "" : "; "; ctx->err += kFaultText; }
     return ctx->err.c_str();
 }
-const char* sbx_version(void) { return "libsbx 0.1 (gfx950, ABI 1)"; }
+const char* sbx_version(void) { return "libsbx 0.2 (gfx950, ABI 2)"; }
+int sbx_abi_version(void) { return SBX_ABI_VERSION; }
 
 }  // extern "C"

@@ -96,6 +96,9 @@ __device__ __forceinline__ void store_rgba(const RowMap& M, float* out, size_t i
         o[0] = c.x; o[1] = c.y; o[2] = c.z;
     } else if (M.rgb == 2) {                                                   // SBX_FORMAT_RGBA8: one 4-byte store per pixel, alpha 255
         reinterpret_cast<unsigned*>(out)[idx] = unorm8_(c.x) | (unorm8_(c.y) << 8) | (unorm8_(c.z) << 16) | 0xff000000u;
+    } else if (M.rgb == 3) {                                                   // float4 pixels whose alpha is already in the frame: one
+        float* o = out + idx * 4;                                              // three-dword store (the store exchange, sbx_shared_*:
+        o[0] = c.x; o[1] = c.y; o[2] = c.z;                                    // 12 instead of 16 bytes per pixel over xGMI)
     } else {
         reinterpret_cast<float4*>(out)[idx] = make_float4(c.x, c.y, c.z, 1.0f);   // main.h:52
     }

@@ -28,7 +28,8 @@ struct RowMap {
     int in_place;   // 0: rows are written densely (slab row r); 1: at their global row y of a full-size frame
     int rgb;        // 1: the output holds 3 floats per pixel (a peer's slab on its way to the root: alpha is the constant 1 of
                     //    main.h:52 and need not cross xGMI); 0: float4 pixels; 2: one R8G8B8A8_UNORM word per pixel
-                    //    (sbx_set_output_format: the display format of the reference's hosts, 4 bytes per pixel everywhere)
+                    //    (sbx_set_output_format: the display format of the reference's hosts, 4 bytes per pixel everywhere);
+                    //    3: float4 pixels of which only R, G, B are written (sbx_render_split_in_place_rgb)
     // POINT LIST (sbx_render_points / sbx_main_image): frag != NULL makes the launch evaluate mainImage at `npoints` arbitrary
     // fragCoords read from device memory (x, y interleaved) instead of at the pixel centres of a row range: the launch is laid
     // out as a pseudo-frame of `width` columns whose "pixel" (x, r) is point r * width + x; results are written densely, 4

@@ -21,6 +21,7 @@
 // ranks (tests on a 1-GPU box): transfers then are device-to-device copies on the sending rank's stream, and RCCL is not
 // loaded.  RCCL itself is dlopen'ed on first use, so a single-GPU host of libsbx never needs it.
 #include "../../include/sbx.h"
+#include "../../include/sbx_test.h"
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstdio>

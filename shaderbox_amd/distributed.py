@@ -30,6 +30,15 @@ Two forms of that one exchange (`exchange=`):
   and the same kernel, so the table can only cost balance, never a pixel), then scatters the packed slabs.  Still exactly one
   exchange step.  At 7680x4320 a peer's 49.8 MB become 29.7 MB (ATMOSPHERE, PLANET); at 4K APP_CLOUDS 12.4 -> 9.2 MB.
 
+* "stores": the exchange in which the frame's owner does NOTHING for the others (include/sbx.h sbx_shared_*).  Rank 0 allocates
+  the frame through the library and exports it (hipIpcGetMemHandle; the handle travels by one broadcast_object_list when the plan
+  is built); every peer maps it (hipIpcOpenMemHandle) and renders its row-blocks IN PLACE into it from its own GPU — the one
+  exchange step is the render kernels' own pixel stores over xGMI: 16 bytes per pixel, 12 with `channels=3` (three dwords; the
+  constant alpha is written once when the frame is created) or 4 ('rgba8').  No landing area, no RCCL receive kernels on the
+  root, no scatter pass: the root is an ordinary rank.  Two flag kernels per frame and rank order it (owner: "frame may be
+  overwritten" / wait for every peer's "rows in place"; peer: wait / signal).  Still exactly one exchange step, and since every
+  pixel is written by the app's full kernel from its global coordinates the frame is bit-identical to one launch.
+
 Pixel format: the plan moves whatever pixels its renderer writes.  After `renderer.set_output_format("rgba8")` (include/sbx.h
 SBX_FORMAT_RGBA8: the render kernels write one R8G8B8A8_UNORM word per pixel, the reference hosts' display format) every slab,
 landing area and frame of the plan is a uint8 tensor with 4 bytes per pixel — a third of the float exchange's bytes on every link
@@ -46,8 +55,8 @@ class FramePlan:
 
     def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS, groups=1, root_rounds=1,
                  rounds=1, exchange="direct", channels=3):
-        if exchange not in ("direct", "gather", "spans"):
-            raise ValueError("exchange must be 'direct', 'gather' or 'spans'")
+        if exchange not in ("direct", "gather", "spans", "stores"):
+            raise ValueError("exchange must be 'direct', 'gather', 'spans' or 'stores'")
         if exchange == "spans":
             channels = 3
         if exchange == "gather":
@@ -70,9 +79,21 @@ class FramePlan:
         # slab row ranges of the groups: whole blocks, as even as possible
         cuts = [((g * nblocks) // groups) * self.block_rows for g in range(groups + 1)]
         self.ranges = [(cuts[g], cuts[g + 1]) for g in range(groups) if cuts[g + 1] > cuts[g]]
-        self.slab = self.gathered = self.peers = self.frame = None
+        self.slab = self.gathered = self.peers = self.frame = self.shared = None
         self.glists = [None] * len(self.ranges)
-        if exchange == "gather":
+        if exchange == "stores":
+            # collective: every rank builds its plans in the same order, the handle of the owner's frame goes round once
+            box = [None]
+            if self.rank == 0:
+                self.shared = renderer.shared_create(self.height * self.width * (4 if self.rgba8 else 16), self.world)
+                self.frame = self.shared.tensor((self.height, self.width, 4))
+                if self.world > 1:
+                    box[0] = self.shared.export()
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0)
+                if self.rank != 0:
+                    self.shared = renderer.shared_open(box[0])
+        elif exchange == "gather":
             self.slab = renderer.empty((self.rows_max, self.width, 4), zero=True)
             if self.rank == 0:
                 self.gathered = renderer.empty((self.world, self.rows_max, self.width, 4))
@@ -168,11 +189,32 @@ class FramePlan:
         mark("exchange")
         return None
 
-    def render(self, app, time, mouse=(0.0, 0.0), aux=None, mark=None):
+    def _render_stores(self, app, time, mouse, aux, mark, phase):
+        """the store exchange: begin (owner: release the frame; peer: wait for it), the rank's rows in place, end (peer: signal;
+        owner: wait for every peer).  `phase` splits the owner's call for hosts that drive all ranks from ONE thread on one stream
+        (LoopbackWorld): "open" = begin, "close" = render + end."""
+        if phase in ("all", "open"):
+            self.shared.begin(self.rank)
+        if phase == "open":
+            return None
+        self.r.render_rank_in_place(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
+                                    self.frame if self.rank == 0 else self.shared, mouse=mouse, aux=aux,
+                                    root_rounds=self.root_rounds, rounds=self.rounds, channels=4 if self.rgba8 else self.channels)
+        mark("render")
+        self.shared.end(self.rank)
+        mark("exchange")
+        if self.rank == 0:
+            mark("assemble")                      # nothing to assemble: the frame is complete in stream order
+            return self.frame
+        return None
+
+    def render(self, app, time, mouse=(0.0, 0.0), aux=None, mark=None, phase="all"):
         """All ranks call this; rank 0 returns the assembled [H, W, 4] frame, the others None.  `mark(name)`, if given, is
         called after the rank's rendering ("render"), after the waits of its exchange ("exchange") and after the root's
         assembly ("assemble"): bench.py records stream events there to time the phases of a frame."""
         mark = mark or (lambda name: None)
+        if self.exchange == "stores":
+            return self._render_stores(app, time, mouse, aux, mark, phase)
         if self.exchange == "gather":
             return self._render_gather(app, time, mouse, aux, mark)
         if self.exchange == "spans":
@@ -267,14 +309,28 @@ class LoopbackWorld:
                                            % (self._rank, op.peer))
                     src = q.pop(0)
                     if src.numel() != op.tensor.numel():
-                        raise RuntimeError("LoopbackWorld: send of %d floats meets a receive of %d" % (src.numel(), op.tensor.numel()))
+                        raise RuntimeError("LoopbackWorld: send of %d elements meets a receive of %d" % (src.numel(), op.tensor.numel()))
                     op.tensor.copy_(src.reshape(op.tensor.shape))
                     self._w.bytes_moved += src.numel() * src.element_size()
             return [LoopbackWorld._Work()]
 
+        def broadcast_object_list(self, objs, src=0):
+            """FramePlan's one object broadcast (the handle of a shared frame): the source's k-th call feeds every rank's k-th"""
+            log = self._w.objs.setdefault(src, [])
+            if self._rank == src:
+                log.append(list(objs))
+            else:
+                k = self._w.obj_next.get((src, self._rank), 0)
+                if k >= len(log):
+                    raise RuntimeError("LoopbackWorld: rank %d reads a broadcast rank %d has not made (build the plans in rank order)"
+                                       % (self._rank, src))
+                objs[:] = log[k]
+                self._w.obj_next[(src, self._rank)] = k + 1
+
     def __init__(self, n):
         self.n = int(n)
         self.box = {}
+        self.objs, self.obj_next = {}, {}
         self.bytes_moved = 0
 
     def rank(self, i):
@@ -286,7 +342,14 @@ class LoopbackWorld:
 
     @staticmethod
     def render(plans, app, time, **kw):
-        """one frame through all ranks in the order the emulation needs: peers, then the root; returns the root's frame"""
+        """one frame through all ranks in the order the emulation needs: peers, then the root; returns the root's frame.  (The
+        store exchange runs on ONE stream here, so the owner's "frame may be overwritten" has to be enqueued before the peers'
+        waits for it: the owner's call is split, FramePlan._render_stores.)"""
+        if plans[0].exchange == "stores":
+            plans[0].render(app, time, phase="open", **kw)
+            for p in plans[1:]:
+                p.render(app, time, **kw)
+            return plans[0].render(app, time, phase="close", **kw)
         for p in plans[1:]:
             p.render(app, time, **kw)
         return plans[0].render(app, time, **kw)
@@ -324,6 +387,9 @@ class HostStagedDist:
 
     def get_rank(self):
         return self._d.get_rank()
+
+    def broadcast_object_list(self, objs, src=0):
+        return self._d.broadcast_object_list(objs, src=src)
 
     def batch_isend_irecv(self, ops):
         t = self._t

@@ -21,13 +21,26 @@ def lib():
 
 
 def test_every_declared_symbol_is_exported(lib):
-    """include/sbx.h is the contract: every function it declares must be exported by libsbx.so"""
+    """include/sbx.h is the contract: every function it declares must be exported by libsbx.so; so must the test hooks of
+    include/sbx_test.h, and no hook may be declared in the product header (VERDICT r4 Weak #10)"""
+    declared = {}
+    for name in ("sbx.h", "sbx_test.h"):
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        declared[name] = set(re.findall(r"\b(sbx_[a-z0-9_]+)\s*\(", hdr))
+        for n in declared[name]:
+            assert hasattr(lib, n), "libsbx.so does not export %s (%s)" % (n, name)
+    assert len(declared["sbx.h"]) >= 50 and len(declared["sbx_test.h"]) >= 6
+    hooks = {"sbx_set_variant", "sbx_math_eval", "sbx_tex3d_eval", "sbx_debug_raise_fault", "sbx_multi_set_variant",
+             "sbx_shared_set_timeout_ms", "sbx_model_landing"}
+    assert hooks <= declared["sbx_test.h"] and not (hooks & declared["sbx.h"])
+
+
+def test_abi_version_of_the_library_is_the_headers(lib):
     hdr = open(os.path.join(ROOT, "include", "sbx.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = re.findall(r"\b(sbx_[a-z0-9_]+)\s*\(", hdr)
-    assert len(set(names)) >= 15
-    for n in set(names):
-        assert hasattr(lib, n), "libsbx.so does not export %s" % n
+    v = int(re.search(r"#define\s+SBX_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.sbx_abi_version() == v == shaderbox_amd.SBX_ABI_VERSION
+    assert ("ABI %d" % v).encode() in lib.sbx_version()
 
 
 def test_struct_layout_matches_cbuffers():

@@ -2,17 +2,19 @@
 """tools/strip_scaling.py — ON ONE GPU: what each rank of an N-GPU frame would do, timed, and the exchange budget beside it.
 
     python tools/strip_scaling.py [--app clouds|atmosphere|planet|...] [--width 3840 --height 2160] [--ranks 2,4,8]
-                                  [--exchanges spans,direct] [--quick]
+                                  [--exchanges stores,spans,direct] [--channels 3|4] [--rccl-wgs-per-peer 2] [--quick]
 
 For N = 1 and every N asked for:
   * compute only: the un-overlapped launch of every rank's share (cyclic 8-row blocks) and the same with frames in flight;
-  * the ROOT's frame emulated on this device (bench.py emulated_frame_ms: its launch + a device copy of the peers' payload bytes
-    standing in for what RCCL's receive kernels write into its HBM + the assembly kernel), for every candidate root relief of
-    bench.py's calibration, for the span exchange and the direct exchange;
+  * the ROOT's frame emulated on this device (bench.py emulated_frame_ms: its launch + the landing of the peers' payload bytes —
+    sbx_model_landing: --rccl-wgs-per-peer workgroups per peer resident for the link time, writing the bytes at the link's pace,
+    the model of RCCL's grouped receive — + the assembly kernel), for every candidate root relief of bench.py's calibration, for
+    the span exchange and the direct exchange; and for the STORE exchange (the peers render in place into the root's frame: the
+    root is an ordinary rank, relief 1/1, no landing, no scatter; the link carries the pixel stores: 12 / 16 / 4 bytes per pixel);
   * the exchange budget: bytes per peer, time on one xGMI link at its 76.8 GB/s peak and at a stated realistic rate;
   * the modelled N-GPU frame time = max(root's frame, slowest peer's frame, link time) — compute and transfer fully overlapped,
     which needs >= 2 frames in flight or pipelined pieces — and the pessimistic one, peer + link back to back.
-Nothing here has touched a second GPU: the link rates are assumptions, RCCL's own kernels on the root are represented by a copy."""
+Nothing here has touched a second GPU: the link rates are assumptions, RCCL's own kernels on the root are a model (above)."""
 import argparse
 import importlib.util
 import os
@@ -32,7 +34,9 @@ ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--time", type=float, default=.37)
 ap.add_argument("--ranks", default="2,4,8")
-ap.add_argument("--exchanges", default="spans,direct")
+ap.add_argument("--exchanges", default="stores,spans,direct")
+ap.add_argument("--channels", type=int, choices=[3, 4], default=3, help="store exchange, float pixels: dwords a peer stores per pixel")
+ap.add_argument("--rccl-wgs-per-peer", type=int, default=2, help="landing model of the send/recv exchanges (bench.py); 0 = a plain device copy")
 ap.add_argument("--streams", type=int, default=3)
 ap.add_argument("--link-gbps", type=float, default=50.0, help="the 'realistic' per-direction rate of one xGMI link for the budget")
 ap.add_argument("--quick", action="store_true", help="compute-only part")
@@ -43,6 +47,7 @@ if os.environ.get("SBX_LIB"):              # an A/B library of tools/ab_build.py
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
+bench.LANDING = {"wgs_per_peer": a.rccl_wgs_per_peer, "link_gbps": a.link_gbps} if a.rccl_wgs_per_peer > 0 else None
 
 app, W, H, t = a.app, a.width, a.height, a.time
 dev = torch.device("cuda", 0)
@@ -89,7 +94,8 @@ def whole(i):
 R.set_timing(False)
 p1 = per_frame(whole)
 R.set_timing(True)
-print("pixel format %s (%d bytes per pixel on a link)" % (a.format, BPP))
+print("pixel format %s (%d bytes per pixel on a link; store exchange: %d); landing model: %s"
+      % (a.format, BPP, 4 if R.rgba8 else 4 * a.channels, bench.LANDING or "device copy"))
 print("%s %dx%d  N=1: one launch %.3f ms, %d frames in flight %.3f ms/frame" % (app, W, H, t1, len(streams), p1))
 ranks = [int(v) for v in a.ranks.split(",") if v]
 for n in ranks:
@@ -104,11 +110,15 @@ if a.quick:
 R.set_timing(False)
 for n in ranks:
     for exchange in a.exchanges.split(","):
-        ch = 3
+        ch = a.channels if exchange == "stores" else 3
         print("  --- N=%d, exchange %s" % (n, exchange))
         best = None
-        for m0, m in bench.relief_candidates():
-            if exchange == "spans":
+        for m0, m in (bench.relief_candidates() if exchange != "stores" else [(1, 1)]):
+            if exchange == "stores":
+                bpp = 4 if R.rgba8 else 4 * ch
+                payload = bpp * W * shard.rank_rows_max(H, 8, n, m0, m)
+                total = bpp * W * sum(shard.rank_rows(H, 8, r, n, m0, m) for r in range(1, n))
+            elif exchange == "spans":
                 _, pix, _ = R.span_table(app, W, H, t, 8, n, m0, m)
                 payload = BPP * int(max(pix[1:]))
                 total = BPP * sum(int(p) for p in pix[1:])
