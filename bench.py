@@ -585,14 +585,7 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
             return None
 
     def per_frame(fn, k=24):
-        for i in range(6):
-            fn(i)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(k):
-            fn(i)
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) * 1e3 / k
+        return timed_loop(torch, dev, fn, k)
     out_cfgs, status = [], 0
     cfgs = [(app, W, H)] + ([] if args.no_other_configs or app != "clouds" else DIST_OTHER_CONFIGS)
     for a, w, h in cfgs:
@@ -810,8 +803,18 @@ class GpuSampler:
         import threading
         self.period = period_s
         self.clk, self.pw = [], []
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        self.dpm = cards[index] if index < len(cards) else None
+        # the card of HIP device `index` by its PCI address: a host shows every GPU (and their partitions) under /sys/class/drm,
+        # this process is given one of them, and card0 is somebody else's as often as not
+        self.pci = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            self.pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:                                  # noqa: BLE001  (no such attributes: nothing is sampled)
+            pass
+        cards = [c for c in glob.glob("/sys/class/drm/card[0-9]*/device")
+                 if self.pci and os.path.realpath(c).lower().endswith(self.pci) and os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+        self.dpm = os.path.join(cards[0], "pp_dpm_sclk") if cards else None
         base = os.path.dirname(self.dpm) if self.dpm else None
         hw = sorted(glob.glob(os.path.join(base, "hwmon", "hwmon*"))) if base else []
         self.freq = next((os.path.join(h, "freq1_input") for h in hw if os.path.exists(os.path.join(h, "freq1_input"))), None)
@@ -861,7 +864,7 @@ class GpuSampler:
 
     def summary(self):
         return {"sclk_mhz": self._stat(self.clk, 0), "power_w": self._stat(self.pw, 1),
-                "source": "sysfs: %s, %s" % (self.freq or self.dpm, self.power)}
+                "source": "sysfs of PCI device %s: %s, %s" % (self.pci, self.freq or self.dpm, self.power)}
 
 
 def sustained(torch, dev, step, ns, pixels, seconds, value, serial):
@@ -1231,14 +1234,7 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
         frames = [torch.empty((H, W, 4), dtype=getattr(R, "pixel_dtype", torch.float32), device=dev) for _ in range(nb)]
 
         def per_frame(fn, k=18):
-            for i in range(4):
-                fn(i)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for i in range(k):
-                fn(i)
-            torch.cuda.synchronize(dev)
-            return (time.perf_counter() - t0) * 1e3 / k
+            return timed_loop(torch, dev, fn, k, min_ms=25.0)
 
         best = None
         for m0, m in relief_candidates():
@@ -1264,6 +1260,27 @@ def land(R, torch, dst, src, peers):
         R.model_landing(src, dst, n, LANDING["wgs_per_peer"] * peers, us)
     else:
         dst.view(-1)[:src.numel()].copy_(src.view(-1))
+
+
+def timed_loop(torch, dev, fn, k=24, min_ms=60.0):
+    """ms per call of fn(i) with the calls in flight: a first batch of k sizes a second one that lasts >= min_ms and is timed with ONE
+    synchronisation at its end.  (Round 4 timed k = 24 calls whatever they were: 24 eighth-frames are 7 ms, of which the ramp-in and
+    the drain of the pipeline — the last launches finish on an emptying chip — are 3-4 %; the same loop over different ranks' eighths
+    for 0.6 s gives 0.279 ms per launch where the 24-call window read 0.293-0.302, tools/launch_granularity.py.)"""
+    for i in range(6):
+        fn(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(k):
+        fn(i)
+    torch.cuda.synchronize(dev)
+    est = (time.perf_counter() - t0) * 1e3 / k
+    n = max(k, min(4000, int(min_ms / max(est, 1e-3)) + 1))
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(i)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) * 1e3 / n
 
 
 def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0, m, exchange, ch, per_frame):

@@ -366,8 +366,10 @@ enum { SBX_MULTI_EXCHANGE_SLABS = 0, SBX_MULTI_EXCHANGE_BLOCKS = 1,
        SBX_MULTI_EXCHANGE_SPANS = 2 /* the span exchange above: packed spans only, rank 0 renders the rest (sbx_render_span_*) */,
        SBX_MULTI_EXCHANGE_PEER_STORES = 3 /* no RCCL, no slabs: every rank renders its row-blocks in place into rank 0's frame through
                                              peer access — the exchange is the render kernels' own float4 stores over xGMI (16 B per
-                                             pixel), rank 0 lands and scatters nothing.  UNMEASURED on more than one device; kept for the
-                                             first multi-GPU run to compare (SBX_ERR_UNSUPPORTED without peer access) */ };
+                                             pixel), rank 0 lands and scatters nothing.  UNMEASURED on more than one device: across distinct
+                                             devices it returns SBX_ERR_UNSUPPORTED unless the environment has SBX_ENABLE_PEER_STORES=1
+                                             (also without peer access).  The validated form of the same idea, with explicit ordering
+                                             flags and across processes, is the store exchange sbx_shared_* above */ };
 int sbx_multi_set_exchange(sbx_multi* m, int mode);
 void sbx_multi_destroy(sbx_multi* m);
 int sbx_multi_ranks(const sbx_multi* m);

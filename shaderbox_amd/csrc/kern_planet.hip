@@ -86,7 +86,13 @@ __device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_
 #ifndef PL_BATCH_DETAIL
 #define PL_BATCH_DETAIL 2   // the 7-octave detail maps of the hit shading (6 per hit pixel)
 #endif
-template <int OCT, int MODE, int START, bool XI = false>
+#ifndef PL_SPEC
+#define PL_SPEC 1           // the hash pass of a lone pending cell also hashes the rest of the 2 x 2 x 2 block ahead of the march
+#endif                      // (sbx_hashcache.h hc_insert SPEC; the SKIP kernels only)
+#ifndef PL_TB2
+#define PL_TB2 3            // table of octave k of terrain_map's SECOND fBm: (PL_TB2 + k) & 3 — with 0 its octave k shares table k with
+#endif                      // the first fBm's octave k (another lattice), and the two evict each other's cells on every slot clash
+template <int OCT, int MODE, int START, bool XI = false, int TB = 0>
 __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacunarity, float& H, float gain, float& t, bool on, int lane) {
     constexpr int B = (OCT == 7) ? PL_BATCH_DETAIL : PL_BATCH;
 #if PL_ROLL_DETAIL
@@ -99,8 +105,8 @@ __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacuna
             const int base = START + b * B;
             v3 p[B]; int tab[B]; float nz[B];
 #pragma unroll
-            for (int i = 0; i < B; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
-            coop_noise_n<B, XI>(S, p, tab, on, lane, nz);
+            for (int i = 0; i < B; ++i) { p[i] = q; tab[i] = (TB + base + i) & 3; q = q * lacunarity; }
+            coop_noise_n<B, XI, XI && PL_SPEC>(S, p, tab, on, lane, nz);
 #pragma unroll
             for (int i = 0; i < B; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         }
@@ -108,8 +114,8 @@ __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacuna
         if (R > 0) {
             v3 p[R > 0 ? R : 1]; int tab[R > 0 ? R : 1]; float nz[R > 0 ? R : 1];
 #pragma unroll
-            for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (START + NB * B + i) & 3; q = q * lacunarity; }
-            coop_noise_n<(R > 0 ? R : 1), XI>(S, p, tab, on, lane, nz);
+            for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (TB + START + NB * B + i) & 3; q = q * lacunarity; }
+            coop_noise_n<(R > 0 ? R : 1), XI, XI && PL_SPEC>(S, p, tab, on, lane, nz);
 #pragma unroll
             for (int i = 0; i < R; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         }
@@ -121,16 +127,16 @@ __device__ __forceinline__ void coop_fbm_range(WaveCache& S, v3& q, float lacuna
         if (base + B <= OCT) {
             v3 p[B]; int tab[B]; float nz[B];
 #pragma unroll
-            for (int i = 0; i < B; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
-            coop_noise_n<B, XI>(S, p, tab, on, lane, nz);
+            for (int i = 0; i < B; ++i) { p[i] = q; tab[i] = (TB + base + i) & 3; q = q * lacunarity; }
+            coop_noise_n<B, XI, XI && PL_SPEC>(S, p, tab, on, lane, nz);
 #pragma unroll
             for (int i = 0; i < B; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         } else {
             constexpr int R = (OCT - START) % B;
             v3 p[R > 0 ? R : 1]; int tab[R > 0 ? R : 1]; float nz[R > 0 ? R : 1];
 #pragma unroll
-            for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (base + i) & 3; q = q * lacunarity; }
-            coop_noise_n<(R > 0 ? R : 1), XI>(S, p, tab, on, lane, nz);
+            for (int i = 0; i < R; ++i) { p[i] = q; tab[i] = (TB + base + i) & 3; q = q * lacunarity; }
+            coop_noise_n<(R > 0 ? R : 1), XI, XI && PL_SPEC>(S, p, tab, on, lane, nz);
 #pragma unroll
             for (int i = 0; i < R; ++i) { t += pl_basis<MODE>(nz[i]) * H; H *= gain; }
         }
@@ -227,12 +233,12 @@ __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lan
     // committing lane of the wave the remaining octaves cannot change n1 = +0 and are not evaluated.
     v3 q = pos * 1.50987f + V3(1.9489f, 2.435f, .5483f);
     float H = .454f, h1 = 0.f;
-    coop_fbm_range<1, 2, 0, SKIP>(S, q, 2.0244f, H, .454f, h1, on, lane);
+    coop_fbm_range<1, 2, 0, SKIP, PL_TB2>(S, q, 2.0244f, H, .454f, h1, on, lane);
     constexpr float TAIL = (OCT == 3) ? .2998f : .3745f;       // sum of .454^k, k = 2..OCT, rounded up (OCT = 3 or 7)
     static_assert(OCT == 3 || OCT == 7, "tail bound tabulated for 3 and 7 octaves");
     float n1 = 0.f;
     if (!SKIP || wave_any(on && !(h1 + TAIL * 1.0001f < .6f))) {
-        coop_fbm_range<OCT, 2, 1, SKIP>(S, q, 2.0244f, H, .454f, h1, on, lane);
+        coop_fbm_range<OCT, 2, 1, SKIP, PL_TB2>(S, q, 2.0244f, H, .454f, h1, on, lane);
         n1 = SMOOTHSTEP_K(.6f, 1.f, h1);
     }
     const float n = n0 + n1;
@@ -287,6 +293,8 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
 // direction, with APP_ATMOSPHERE's sun (setup_scene :177-181, FramePlanet.atm_sun).  The sky is evaluated in the plain statement of
 // the spec (atm_incident_light<false>): view directions are arbitrary here, the domains of k_atmosphere's shortcuts were argued for
 // its own camera.  No reference-held answers: parity unpinned.
+// (Reading the marches' two rotations from LDS at every step, so that their 15 multiply-adds per step have no SGPR source — half rate
+//  on gfx950 — was measured: 5.763 against 5.759 ms, nothing; profiles/r05_log.md.)
 template <bool SKIP, bool ATM = false>
 __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
     __shared__ double etab[ATM ? 32 : 1];
@@ -339,6 +347,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
         float t_pos = 0.f;
         float max_cld = PL_MAX_RAY_DIST;
         bool tm = hit_atm;
+        if (SKIP && PL_SPEC) hc_set_direction(S, mul(F.rot, rd), hit_atm, lane);       // both terrain fBms scale the rotated point by positive factors
         for (int i = 0; i < 120; ++i) {
             if (tm && t > PL_MAX_RAY_DIST) tm = false;           // `if (t > max_ray_dist) break;`
             if (!wave_any(tm)) break;
@@ -366,6 +375,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
             const float t_step = PL_MAX_RAY_DIST / 75.f;
             float tc = 0.f;
             bool cm = hit_atm;
+            if (SKIP && PL_SPEC) hc_set_direction(S, mul(F.rot_cloud, rd), hit_atm, lane);
             for (int i = 0; i < 75; ++i) {
                 if (cm && (tc > max_cld || cloud.alpha >= 1.f)) cm = false;   // `return` of clouds_march
                 if (!wave_any(cm)) break;
@@ -386,6 +396,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
             }
         }
         const bool hitl = hit_atm && (df.x < .005f);              // :349
+        if (SKIP && PL_SPEC) hc_no_direction(S, lane);              // the hit shading samples around a point, not along a ray
         v3 c_hit = V3(0, 0, 0);
         if (wave_any(hitl)) {
 #if PL_PARK && PL_PARK_MARCH && PL_TLAST

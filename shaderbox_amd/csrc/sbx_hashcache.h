@@ -40,11 +40,16 @@ __device__ __forceinline__ bool wave_any(bool x) {
 #ifndef SBX_HC_SLOTS
 #define SBX_HC_SLOTS 64
 #endif
+#ifndef SBX_HC_MAGIC_SLOT
+#define SBX_HC_MAGIC_SLOT 1
+#endif
 constexpr int HC_SLOTS = SBX_HC_SLOTS;
 struct alignas(16) WaveCache {
     float h[4][HC_SLOTS][8];          // corner order: +0,+1,+157,+158,+113,+114,+270,+271
     unsigned tag[4][HC_SLOTS];        // bits of n; 0x7fc00001 (a NaN) = empty
     unsigned ins_tag[8], ins_slot[8]; // cells being inserted in the current pass
+    unsigned spec;                    // hc_insert<., SPEC>: 0, or 8 | sx | sy << 1 | sz << 2 — the signs (1 = negative) of the direction the
+                                      // wave's sample points travel in (see hc_insert)
 #ifdef SBX_CL_STATS
     float stat[8];                    // census build only (tools/clouds_census.py): slow calls, passes, cells, re-lookups,
                                       // main samples past the first / second stage, Lipschitz-skipped steps
@@ -53,11 +58,42 @@ struct alignas(16) WaveCache {
 
 // miss path, one octave: the lanes in `need` lack their cell.  Leaders (one per distinct slot) are
 // elected with ballot/readlane, up to 8 cells per pass; lane (r, c) evaluates corner c of pending cell r.
-template <bool B40 = false>
+// SPEC (the marches of APP_PLANET): a pass costs the wave the same instructions whether one cell is pending or eight — lane (r, c)
+// hashes corner c of cell r, and with ONE pending cell 56 of the 64 lanes idle through the binary64 sin.  When the wave has said
+// which way its sample points travel (WaveCache.spec: a march along a ray enters, next, one of the cells of the 2 x 2 x 2 block
+// AHEAD of the current one), the seven idle rows hash the seven other cells of that block — those not in the table yet — in the same
+// pass.  What a table holds never changes what a lookup returns (every entry is hash1 of its own lattice index, whoever put it
+// there), only how often the next lookups miss; an evicted cell is hashed again if it is wanted again.  The eight cells of a block
+// fall into eight different slots for HC_SLOTS >= 32 (offsets +-1, +-157, +-113 and their sums are distinct mod 32).
+template <bool B40 = false, bool SPEC = false>
 __device__ __forceinline__ void hc_insert(WaveCache& S, int k, unsigned nbits, int slot, bool need, int lane) {
     const int corner = lane & 7;
     const float off = (corner & 1 ? 1.0f : 0.0f) + (corner & 2 ? 157.0f : 0.0f) + (corner & 4 ? 113.0f : 0.0f);
     unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+    if (SPEC && HC_SLOTS >= 32) {
+        const unsigned sp = (unsigned)__builtin_amdgcn_readfirstlane((int)S.spec);
+        if (sp && m) {
+            const int leader = __ffsll((long long)m) - 1;
+            const unsigned n0 = (unsigned)__builtin_amdgcn_readlane((int)nbits, leader);
+            const int s0 = __builtin_amdgcn_readlane(slot, leader);
+            if ((m & ~__builtin_amdgcn_ballot_w64(slot == s0)) == 0) {       // one pending cell (wave-uniform): rows 1..7 are free
+                const int r = lane >> 3;
+                const float dx = (sp & 1u) ? -1.0f : 1.0f, dy = (sp & 2u) ? -157.0f : 157.0f, dz = (sp & 4u) ? -113.0f : 113.0f;
+                const float nr = u2f(n0) + ((r & 1 ? dx : 0.0f) + (r & 2 ? dy : 0.0f) + (r & 4 ? dz : 0.0f));
+                const int sr = (int)nr & (HC_SLOTS - 1);
+                const bool present = r != 0 && S.tag[k][sr] == f2u(nr);
+                __builtin_amdgcn_wave_barrier();
+                if (!present) {
+                    S.h[k][sr][corner] = hash1_b<B40>(nr + off);
+                    if (corner == 0) S.tag[k][sr] = f2u(nr);
+                }
+                __builtin_amdgcn_wave_barrier();
+                return;
+            }
+        }
+    }
+    // (Filling the free rows also when SEVERAL cells are pending — lanes on both sides of a cell face — was built and measured:
+    //  k_planet 7680x4320 5.77 -> 5.91 ms; the bookkeeping in this loop costs more than the few passes it saves.  profiles/r05_log.md)
     while (m) {
         int cnt = 0;
         while (m && cnt < 8) {
@@ -105,7 +141,7 @@ inline hipError_t hc_bind_fault_word(unsigned* p) { return hipMemcpyToSymbol(HIP
 #define SBX_HC_SLOW_INLINE __forceinline__
 #endif
 // B40: the caller has shown |n| <= 2^40 for every lattice index it can produce (hash1_b)
-template <bool B40 = false>
+template <bool B40 = false, bool SPEC = false>
 __device__ SBX_HC_SLOW_INLINE H8 hc_slow(WaveCache& S, int k, unsigned nbits, int slot, bool active, int lane) {
     H8 r;
     r.lo = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -122,7 +158,7 @@ __device__ SBX_HC_SLOW_INLINE H8 hc_slow(WaveCache& S, int k, unsigned nbits, in
             need = false;
         }
         if (!wave_any(need)) break;
-        hc_insert<B40>(S, k, nbits, slot, need, lane);
+        hc_insert<B40, SPEC>(S, k, nbits, slot, need, lane);
     }
 #ifndef SBX_HC_FAULT
 #define SBX_HC_FAULT 1
@@ -147,6 +183,22 @@ __device__ __forceinline__ float hc_blend(float4 lo, float4 hi, float fx, float 
 // initialise the calling wave's table (all tags empty)
 __device__ __forceinline__ void hc_init(WaveCache& S, int lane) {
     for (int i = lane; i < 4 * HC_SLOTS; i += 64) (&S.tag[0][0])[i] = 0x7fc00001u;
+    if (lane == 0) S.spec = 0u;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Tell hc_insert<., SPEC> which way the wave's sample points travel: `d` = the direction in lattice space (any positive scale) of
+// the first lane in `on`; on == none or d == 0 switches the speculation off.
+__device__ __forceinline__ void hc_set_direction(WaveCache& S, v3 d, bool on, int lane) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+    unsigned bits = 8u | (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+    const int first = m ? __ffsll((long long)m) - 1 : 0;
+    bits = (unsigned)__builtin_amdgcn_readlane((int)bits, first);
+    if (lane == 0) S.spec = m ? bits : 0u;
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void hc_no_direction(WaveCache& S, int lane) {
+    if (lane == 0) S.spec = 0u;
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -159,7 +211,8 @@ __device__ __forceinline__ void hc_init(WaveCache& S, int lane) {
 // XI ("exact integers"): the caller guarantees lattice coordinates so small that n = px + 157 py + 113 pz is an integer below
 // 2^24 at every step (APP_PLANET: |p| <= 145 in the finest octave).  Both products are then exact, the reference's
 // RN(RN(px + RN(157 py)) + RN(113 pz)) has no rounding at all, and two fmas return the same integer.
-template <int N, bool XI = false>
+// SPEC: hc_insert's forward-block speculation (the caller sets WaveCache.spec around its marches).
+template <int N, bool XI = false, bool SPEC = false>
 __device__ __forceinline__ void coop_noise_n(WaveCache& S, const v3 (&p)[N], const int (&tab)[N], bool active, int lane,
                                              float (&out)[N]) {
     static_assert(N >= 1 && N <= 4, "one table per evaluation: at most four per batch");
@@ -177,7 +230,9 @@ __device__ __forceinline__ void coop_noise_n(WaveCache& S, const v3 (&p)[N], con
         fz[i] = az * az * tm2_(az);
         const float n = XI ? __builtin_fmaf(113.0f, pz, __builtin_fmaf(py, 157.0f, px)) : px + py * 157.0f + 113.0f * pz;
         nbits[i] = f2u(n);
-        slot[i] = (int)n & (HC_SLOTS - 1);
+        // XI: n is an integer below 2^22 in magnitude, so the low bits of RN(n + 1.5 * 2^23) ARE n's low bits (two's complement, as
+        // (int)n & mask): one full-rate add instead of the half-rate conversion
+        slot[i] = (XI && SBX_HC_MAGIC_SLOT) ? (int)(f2u(n + 12582912.0f) & (unsigned)(HC_SLOTS - 1)) : ((int)n & (HC_SLOTS - 1));
         ne[i] = (S.tag[tab[i]][slot[i]] != nbits[i]);
         miss |= ne[i];
     }
@@ -193,7 +248,7 @@ __device__ __forceinline__ void coop_noise_n(WaveCache& S, const v3 (&p)[N], con
         for (int i = 0; i < N; ++i) {
             H8 h;
             if (wave_any(active && ne[i])) {
-                h = hc_slow<XI>(S, tab[i], nbits[i], slot[i], active, lane);       // XI: indices below 2^24
+                h = hc_slow<XI, SPEC>(S, tab[i], nbits[i], slot[i], active, lane);       // XI: indices below 2^24
             } else {
                 h.lo = *reinterpret_cast<const float4*>(&S.h[tab[i]][slot[i]][0]);
                 h.hi = *reinterpret_cast<const float4*>(&S.h[tab[i]][slot[i]][4]);

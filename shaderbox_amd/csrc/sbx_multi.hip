@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -112,6 +113,11 @@ struct sbx_multi {
     unsigned calls = 0;
     hipEvent_t start[kInFlight] = {};
     bool recv_recorded[kInFlight] = {false, false};       // root.recv_done[k] has been recorded at least once
+    // the span exchange's slab sizes: sbx_span_table is host code that probes the app's early-exit tests tile by tile (14 ms for an
+    // 8K ATMOSPHERE frame at 8 ranks against ~0.5 ms of GPU time per frame), and its result depends on (app, u_res,
+    // u_mouse, split) only — computed once per such key, not once per frame
+    std::vector<uint32_t> span_key;
+    std::vector<int64_t> span_pix;
     std::string err;
 };
 
@@ -286,6 +292,15 @@ int sbx_multi_set_exchange(sbx_multi* m, int mode) {
         return mfail(m, SBX_ERR_ARG, "unknown exchange mode");
     if (mode == SBX_MULTI_EXCHANGE_PEER_STORES && !m->peer_stores_ok)
         return mfail(m, SBX_ERR_UNSUPPORTED, "peer stores need every rank's device to have peer access to rank 0's");
+    if (mode == SBX_MULTI_EXCHANGE_PEER_STORES && m->use_rccl) {
+        // distinct devices: this form has never run on more than one GPU (no such box was available to any round), and within one
+        // process it orders a slot's reuse through the caller's stream only.  It stays available for the first multi-GPU run, but a
+        // host has to ask for it twice; the multi-process form with explicit flags is sbx_shared_* (include/sbx.h).
+        const char* en = std::getenv("SBX_ENABLE_PEER_STORES");
+        if (!en || en[0] != '1')
+            return mfail(m, SBX_ERR_UNSUPPORTED, "peer stores across distinct devices are unvalidated: set SBX_ENABLE_PEER_STORES=1 to use them "
+                                                  "(or use the store exchange of sbx_shared_*)");
+    }
     m->exchange = mode;
     return SBX_OK;
 }
@@ -357,9 +372,18 @@ static int render_spans(sbx_multi* m, int app, const sbx_uniforms* uni, const vo
     Rank& root = m->ranks[0];
     hipError_t e;
     const size_t epp = m->out_format == SBX_FORMAT_RGBA8 ? 1 : 3;      // 32-bit words per pixel of a span slab
-    std::vector<int64_t> pix(n, 0);
-    const int nb = sbx_span_table(app, uni, aux, br, n, m0, mr, nullptr, pix.data(), nullptr);
-    if (nb < 0) return mfail(m, nb, "bad span table arguments (app, u_res or split)");
+    std::vector<uint32_t> key(10, 0u);
+    key[0] = (uint32_t)app; key[1] = (uint32_t)br; key[2] = (uint32_t)n; key[3] = (uint32_t)m0; key[4] = (uint32_t)mr;
+    std::memcpy(&key[5], uni->u_res, 8);
+    std::memcpy(&key[7], uni->u_mouse, 8);
+    if (key != m->span_key || (int)m->span_pix.size() != n) {
+        std::vector<int64_t> fresh(n, 0);
+        const int nb = sbx_span_table(app, uni, aux, br, n, m0, mr, nullptr, fresh.data(), nullptr);
+        if (nb < 0) return mfail(m, nb, "bad span table arguments (app, u_res or split)");
+        m->span_pix = fresh;
+        m->span_key = key;
+    }
+    const std::vector<int64_t>& pix = m->span_pix;
     int64_t stride = 0;
     for (int i = 1; i < n; ++i) stride = pix[i] > stride ? pix[i] : stride;
     stride = (stride + 63) / 64 * 64;

@@ -14,6 +14,11 @@
 //     word 0             release: the owner's frame counter — frame q of this object may be overwritten once release >= q
 //     word 16 * r        done[r]: peer r's frame counter — its rows of frame q are in place once done[r] >= q
 // Every side counts its own frames (begin increments), so no sequence number crosses the API.
+//
+// Where the flag kernels run: ALL FOUR on the caller's stream.  Moving the two sets (which never spin) to a side stream behind an
+// event, so that the render stream carries [wait][render] instead of [wait][render][set], was measured and is SLOWER — an event
+// record plus a cross-stream wait per frame cost more than a one-thread kernel in line (eighth-frames of an 8-rank CLOUDS split:
+// 0.304 -> 0.355 ms per frame, profiles/r05_log.md).
 #include "../../include/sbx.h"
 #include "../../include/sbx_test.h"
 #include "sbx_device.h"

@@ -121,7 +121,9 @@ class FramePlan:
     # -- the span exchange ------------------------------------------------------------------------------------
     def _span_layout(self, app, time, mouse, aux):
         """(Re)build buffers and point-to-point descriptors for the span table of (app, mouse): the table depends on the camera
-        and the split only, so an animation keeps one layout."""
+        and the split only, so an animation keeps one layout.  (That is not a property this code hopes for: the library CACHES the
+        device table under exactly (app, u_res, u_mouse, split) — csrc/sbx_capi.hip span_table_device — so the table the kernels
+        read for a later u_time or aux block IS the one this layout was sized from.)"""
         key = (str(app), float(mouse[0]), float(mouse[1]))
         if self._span_key == key:
             return

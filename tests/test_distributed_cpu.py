@@ -39,14 +39,26 @@ class OracleRenderer:
         return slab
 
     def render_rank_in_place(self, app, width, height, time, block_rows, rank, nranks, frame, mouse=(0.0, 0.0), aux=None,
-                             root_rounds=1, rounds=1):
+                             root_rounds=1, rounds=1, channels=4):
         from oracle.oracle import APP_IDS
         from shaderbox_amd import shard
+        if isinstance(frame, CpuSharedFrame):                       # the store exchange: a peer writes into the owner's frame
+            frame = frame.tensor((height, width, 4), torch.uint8 if self.rgba8 else torch.float32)
         rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)
         if rows:
-            img = self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2)
-            frame[rows] = self.px(img)
+            img = self.px(self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2))
+            if channels == 3 and not self.rgba8:
+                frame[rows, :, :3] = img[..., :3]                   # sbx_render_split_in_place_rgb: alpha is left as it is
+            else:
+                frame[rows] = img
         return frame
+
+    # -- the store exchange (include/sbx.h sbx_shared_*): a file-backed stand-in with the same protocol ------------
+    def shared_create(self, nbytes, nranks):
+        return CpuSharedFrame.create(nbytes, nranks, self.rgba8)
+
+    def shared_open(self, handle):
+        return CpuSharedFrame.open(handle)
 
     def assemble_peers(self, peers, width, height, block_rows, nranks, frame, root_rounds=1, rounds=1):
         from shaderbox_amd import shard          # mirror of k_assemble_peers (kern_util.hip)
@@ -117,6 +129,72 @@ class OracleRenderer:
         return out
 
 
+class CpuSharedFrame:
+    """CPU stand-in of sbx_shared for the gloo tests: the frame and the flag page live in a file under /dev/shm that every rank
+    maps; begin / end run the library's protocol on the HOST (owner: publish the frame counter / wait for every peer's; peer: wait
+    for the owner's / publish its own), so FramePlan's schedule, its handle broadcast and its channels are what is tested."""
+    FLAG_WORDS = 1024
+
+    def __init__(self, path, nbytes, nranks, owner):
+        self.path, self.nbytes, self.nranks, self.owner = path, int(nbytes), int(nranks), owner
+        self.mm = np.memmap(path, dtype=np.uint8, mode="r+", shape=(self.nbytes + 4 * self.FLAG_WORDS,))
+        self.flags = self.mm[self.nbytes:].view(np.uint32)
+        self.seq = 0
+
+    @classmethod
+    def create(cls, nbytes, nranks, rgba8):
+        import tempfile
+        fd, path = tempfile.mkstemp(prefix="sbx_cpu_shared_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        os.ftruncate(fd, int(nbytes) + 4 * cls.FLAG_WORDS)
+        os.close(fd)
+        s = cls(path, nbytes, nranks, True)
+        s.rgba8 = bool(rgba8)
+        if not rgba8:
+            s.mm[:s.nbytes].view(np.float32).reshape(-1, 4)[:] = (0.0, 0.0, 0.0, 1.0)      # as sbx_shared_create: alpha comes with the frame
+        return s
+
+    @classmethod
+    def open(cls, handle):
+        path, nbytes, nranks = handle
+        return cls(path, nbytes, nranks, False)
+
+    def export(self):
+        return (self.path, self.nbytes, self.nranks)
+
+    def tensor(self, shape, dtype=None):
+        a = self.mm[:self.nbytes]
+        if dtype is None:
+            dtype = torch.uint8 if getattr(self, "rgba8", False) else torch.float32
+        a = a if dtype == torch.uint8 else a.view(np.float32)
+        return torch.from_numpy(a[:int(np.prod(shape))].reshape(shape))
+
+    def _wait(self, words, what):
+        import time as _t
+        t0 = _t.time()
+        while any(int(np.int32(self.flags[w] - np.uint32(self.seq))) < 0 for w in words):
+            if _t.time() - t0 > 120:
+                raise RuntimeError("CpuSharedFrame: no signal (%s)" % what)
+            _t.sleep(.001)
+
+    def begin(self, rank):
+        self.seq += 1
+        if rank == 0:
+            self.flags[0] = self.seq
+        else:
+            self._wait([0], "the owner's go")
+
+    def end(self, rank):
+        if rank == 0:
+            self._wait([16 * r for r in range(1, self.nranks)], "the peers' rows")
+        else:
+            self.mm.flush()
+            self.flags[16 * rank] = self.seq
+
+    def close(self):
+        if self.owner and os.path.exists(self.path):
+            os.unlink(self.path)
+
+
 def pack_unorm8(img):
     """numpy statement of the Direct3D float -> UNORM8 rule (sbx_pack_unorm8 / store_rgba's RGBA8 mode): NaN and v <= 0 -> 0,
     v > 1 -> 255, else trunc(v * 255 + .5) in binary32"""
@@ -136,14 +214,16 @@ def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1,
                      exchange=exchange, channels=channels)
     frame = None
     for _ in range(2):                       # buffers are reused across frames
-        if rank == 0:
+        if rank == 0 and exchange != "stores":
             plan.frame.fill_(7 if rgba8 else -7.0)           # every pixel of the frame must be written again
         frame = plan.render(app, t)
     if rank == 0:
-        np.save(result_path, frame.numpy())
+        np.save(result_path, np.array(frame.numpy()))
     else:
         assert frame is None
     dist.barrier()
+    if exchange == "stores" and rank == 0:
+        plan.shared.close()
     dist.destroy_process_group()
 
 
@@ -218,6 +298,23 @@ def test_rgba8_exchange_assembles_the_packed_frame(tmp_path, oracle, world, app,
     got = np.load(path)
     ref = pack_unorm8(oracle.render(APP_IDS[app], w, h, 0.37))
     assert got.dtype == np.uint8 and got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("world,app,w,h,br,relief,channels,rgba8", [(2, "clouds", 96, 54, 8, (1, 1), 3, False), (3, "egg", 64, 45, 4, (1, 2), 4, False),
+                                                                    (3, "raytracer", 64, 50, 5, (0, 1), 3, False), (2, "egg", 64, 45, 8, (1, 1), 3, True)])
+def test_store_exchange_schedule_over_gloo(tmp_path, oracle, world, app, w, h, br, relief, channels, rgba8):
+    """exchange='stores' (the peers write their row-blocks IN PLACE into the owner's frame, FramePlan._render_stores): the handle
+    broadcast, the begin / end protocol of every rank and the 3-channel stores (alpha untouched) over gloo with a file-backed
+    stand-in for sbx_shared == the single-process frame, two frames in a row"""
+    from oracle.oracle import APP_IDS
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, 1, path, relief, "stores", channels, rgba8), nprocs=world, join=True)
+    got = np.load(path)
+    ref = oracle.render(APP_IDS[app], w, h, 0.37)
+    if rgba8:
+        assert got.dtype == np.uint8 and np.array_equal(got, pack_unorm8(ref))
+    else:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
 def test_span_table_is_a_consistent_layout():

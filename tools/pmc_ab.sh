@@ -7,12 +7,13 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_ab
 mkdir -p $OUT
 APP=${SBX_AB_APP:-clouds}; W=${SBX_AB_W:-3840}; H=${SBX_AB_H:-2160}
+# SBX_AB_GROUPS="ctr ctr;ctr ctr": counter groups of this run instead of the three below (one rocprofv3 pass each)
 for name in "$@"; do
   echo "=== $name"
   i=0
-  for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE" \
-             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
-             "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_LDS"; do
+  DEFAULT_GROUPS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA;SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_LDS"
+  IFS=';' read -ra GROUPS_ARR <<< "${SBX_AB_GROUPS:-$DEFAULT_GROUPS}"
+  for grp in "${GROUPS_ARR[@]}"; do
     i=$((i+1))
     rm -rf $OUT/$name.$i
     rocprofv3 --kernel-trace -f csv --pmc $grp -d $OUT/$name.$i -o pmc -- python tools/ab_time.py --app $APP --width $W --height $H --reps 4 $name > $OUT/$name.$i.log 2>&1
