@@ -91,6 +91,7 @@ NOMINAL_CLOCK_HZ = 2.4e9
 LANES_PER_SIMD_CYCLE = 32           # a SIMD-32 retires half a wave64 instruction per cycle
 PEAK_LANEOPS_NOMINAL_T = N_SIMD * LANES_PER_SIMD_CYCLE * NOMINAL_CLOCK_HZ / 1e12     # 78.6 T lane-ops/s
 PMC_ROUND = "r04"
+SIDE_STREAMS = []                   # Landing's streams (created once, right after the render streams)
 LANDING = {"wgs_per_peer": 2, "link_gbps": 50.0}     # how the emulated root lands the peers' payloads (main() sets it from the flags)
 COLL_DEV = None                     # device of the small bookkeeping collectives (set in main: the GPU under RCCL, the CPU under gloo)                   # committed per-launch counters: profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json
 # the other BASELINE.json configs that fit one GPU: (app, W, H) — C2, C3, C5 (both apps)
@@ -168,9 +169,10 @@ def main():
     ap.add_argument("--gather-groups", default="auto",
                     help="N>1: issue the one exchange in this many pipelined pieces ('auto': one per ~12 MB of a peer's payload, "
                          "so a 4K slab goes out whole and an 8K one in 3 pieces; 1 = one plain exchange)")
-    ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather", "stores"], default="auto",
-                    help="N>1 (engine dist): 'auto' (default) = try 'stores', 'spans' and 'direct' on the ranks at hand (a few pipelined frames "
-                         "each) and run the fastest; 'stores' = the peers map the root's frame (HIP IPC) and render their row-blocks IN PLACE "
+    ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather", "stores", "span_stores"], default="auto",
+                    help="N>1 (engine dist): 'auto' (default) = try 'stores', 'span_stores', 'spans' and 'direct' on the ranks at hand (a few "
+                         "pipelined frames each) and run the fastest; 'span_stores' = 'stores' with only the SPANS of the peers' row-blocks "
+                         "stored in place, the root renders the rest (fewer bytes on the links: 30 instead of 50 MB per peer at 7680x4320); 'stores' = the peers map the root's frame (HIP IPC) and render their row-blocks IN PLACE "
                          "into it: the exchange is their own pixel stores over xGMI (12 bytes per pixel with --channels 3), the root lands, "
                          "receives and scatters nothing (distributed.py, include/sbx.h sbx_shared_*); 'spans' = only the expensive interval of every row-block is dealt to the peers and "
                          "sent, the root renders the rest in place (distributed.py; config 5's 49.8 MB per peer become 29.7 MB); "
@@ -287,6 +289,11 @@ def main():
     for st in streams:                                  # a HIP stream's hardware queue is created on its first submission
         with torch.cuda.stream(st):
             R.render(app, 64, 36, t)
+    if args.emulate_ranks > 1 or use_dist:              # the emulated root's landing streams, on the queues after the render streams'
+        for _ in range(max(2, ns)):
+            SIDE_STREAMS.append(torch.cuda.Stream(device=dev))
+            with torch.cuda.stream(SIDE_STREAMS[-1]):
+                R.render(app, 64, 36, t)
     if dist is not None:                                # the first RCCL transfer sets up the peer links
         tiny = torch.zeros(4, device=COLL_DEV)
         dist.gather(tiny, [torch.zeros(4, device=COLL_DEV) for _ in range(world)] if rank == 0 else None, dst=0)
@@ -436,7 +443,7 @@ def auto_groups(spec, payload_bytes_per_peer):
 def rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, exchange):
     """pixels the launch(es) of `rank` render per frame"""
     from shaderbox_amd import shard
-    if exchange != "spans" or world == 1:
+    if exchange not in ("spans", "span_stores") or world == 1:
         return shard.rank_rows(H, br, rank, world, relief[0], relief[1]) * W
     table, pix, _ = R.span_table(app, W, H, t, br, world, relief[0], relief[1])
     if rank > 0:
@@ -468,8 +475,8 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, exchange, args.channels)
         payload = 0
         if world > 1:
-            if exchange == "spans":
-                payload = 12 * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
+            if exchange in ("spans", "span_stores"):
+                payload = (16 if (exchange == "span_stores" and args.channels == 4) else 12) * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
             else:
                 payload = (12 if (exchange in ("direct", "stores") and args.channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
         groups = auto_groups(args.gather_groups, payload)
@@ -491,7 +498,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         relief, payload, groups, plans = prepare(exchange)
     else:
         trials, best = {}, None
-        for ex in ("stores", "spans", "direct"):
+        for ex in ("stores", "span_stores", "spans", "direct"):
             cand = prepare(ex)
             cplans = cand[3]
             for i in range(ns + 1):
@@ -537,9 +544,11 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     frame0 = plans[0].frame
     scratch = None
     for _ in range(min(max(steps, 3), 8)):
-        if exchange == "spans":
+        if exchange in ("spans", "span_stores") and world > 1:
             if rank == 0:
                 R.render_span_root(app, W, H, t, br, world, frame0, root_rounds=relief[0], rounds=relief[1])
+            elif exchange == "span_stores":             # (in place into the owner's frame: the same pixels it holds already)
+                R.render_span_peer_in_place(app, W, H, t, br, rank, world, plans[0].shared, root_rounds=relief[0], rounds=relief[1], channels=args.channels)
             else:
                 R.render_span_peer(app, W, H, t, br, rank, world, 0, 1 << 30, plans[0].slab, root_rounds=relief[0], rounds=relief[1])
         else:
@@ -599,15 +608,15 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
         # 'auto': both exchange forms are modelled, the faster one is reported (what the ranks of a real node decide by trying both)
         pick = None
         tried = {}
-        for ex in (("stores", "spans", "direct") if args.exchange == "auto" else (args.exchange,)):
+        for ex in (("stores", "span_stores", "spans", "direct") if args.exchange == "auto" else (args.exchange,)):
             relief = choose_relief(args.root_rounds, R, OneRank, torch, dev, a, w, h, t, br, n, 0, streams, ex, args.channels)
-            ch = (args.channels if ex == "stores" else 3) if ex != "gather" else 4
+            ch = (args.channels if ex in ("stores", "span_stores") else 3) if ex != "gather" else 4
             R.set_timing(False)
             ranks_ms = [emulated_frame_ms(R, torch, dev, streams, frames, a, w, h, t, br, n, r, relief[0], relief[1], ex, ch, per_frame)
                         for r in range(n)]
-            if ex == "spans":
+            if ex in ("spans", "span_stores"):
                 pix = R.span_table(a, w, h, t, br, n, relief[0], relief[1])[1]
-                payload = (4 if R.rgba8 else 12) * int(max(pix[1:]))
+                payload = (4 if R.rgba8 else (16 if (ex == "span_stores" and ch == 4) else 12)) * int(max(pix[1:]))
             else:
                 payload = (4 if R.rgba8 else (12 if ch == 3 else 16)) * w * shard.rank_rows_max(h, br, n, *relief)
             link_peak, link_real = payload / 76.8e9 * 1e3, payload / (args.link_gbps * 1e9) * 1e3
@@ -676,6 +685,9 @@ def dist_line(res, args, app, W, H, t, world):
             "gather": "1 RCCL gather of RGBA slabs",
             "stores": "the peers' own %d-byte pixel stores into the root's frame, mapped through HIP IPC (no RCCL call, no landing area, "
                       "no scatter; two flag kernels per rank and frame)" % (12 if args.channels == 3 else 16),
+            "span_stores": "the peers' own %d-byte pixel stores of the SPANS of their row-blocks into the root's frame, mapped through HIP IPC "
+                           "(the root renders its blocks and everything outside the spans; no RCCL call, no landing area, no scatter)"
+                           % (12 if args.channels == 3 else 16),
             "spans": "1 grouped RCCL send/recv of the peers' packed 3-channel SPANS (the root renders its blocks and everything "
                      "outside the spans in place)"}[res["exchange"]]
     if args.backend != "nccl":
@@ -688,7 +700,7 @@ def dist_line(res, args, app, W, H, t, world):
                        "frames_in_flight": ns,
                        "parallelism": "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + %s (in %d pipelined "
                                       "pieces)%s" % (args.block_rows, world, relief[0], relief[1], exch, res["groups"],
-                                                     "" if res["exchange"] == "stores" else " + assemble")},
+                                                     "" if res["exchange"] in ("stores", "span_stores") else " + assemble")},
             "backend": "RCCL" if args.backend == "nccl" else "gloo with host-staged transfers (TEST form: ranks may share a GPU, nothing here "
                                                                 "says anything about xGMI)",
             "exchange": {"kind": res["exchange"], "chosen": "measured on these ranks: ms per pipelined frame %s" % res["exchange_trials_ms"]
@@ -871,21 +883,34 @@ def sustained(torch, dev, step, ns, pixels, seconds, value, serial):
     """what the chip SUSTAINS: the timed region's loop (frames_in_flight launches overlapping) kept up for `seconds`, outside the
     timed region, with the shader clock and the board power sampled beside it.  `value` is K frames after a short warm-up; this is
     thousands of frames at whatever clock the power limit allows."""
-    n, t0 = 0, time.perf_counter()
-    with GpuSampler(dev.index or 0) as smp:
+    sampler = GpuSampler(dev.index or 0)                 # (finds the device's sysfs entries: tens of ms of host work, before the clock starts)
+    for i in range(2 * ns):
+        step(i)
+    torch.cuda.synchronize(dev)
+    n, t0, marks = 0, time.perf_counter(), []
+    with sampler as smp:
         while time.perf_counter() - t0 < seconds:
             for i in range(8 * ns):
                 step(i)
             torch.cuda.synchronize(dev)
             n += 8 * ns
+            marks.append((time.perf_counter() - t0, n))
         dt = time.perf_counter() - t0
     ms = dt * 1e3 / n
     v = pixels / (ms * 1e-3) / 1e6
+
+    def part(lo, hi):                                    # Mpixels/s of the batches that ended in [lo, hi] seconds
+        inside = [(t, k) for t, k in marks if lo <= t <= hi]
+        if len(inside) < 2:
+            return None
+        return round(pixels * (inside[-1][1] - inside[0][1]) / (inside[-1][0] - inside[0][0]) / 1e6, 3)
     out = {"value": round(v, 3), "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "frames": n, "seconds": round(dt, 3),
-           "frames_in_flight": ns, "value_over_sustained": round(value / v, 4), "value_serial_over_sustained": round(serial / v, 4),
-           "what": "the timed loop (same launches, same streams) held for %.1f s after the timed region; sclk / power sampled every 20 ms "
-                   "from sysfs.  value_over_sustained within +-3 %% = the K-frame window measured the steady state; above = it caught a "
-                   "boost the power limit does not sustain" % seconds}
+           "frames_in_flight": ns, "first_half": part(0, dt / 2), "second_half": part(dt / 2, dt),
+           "value_over_sustained": round(value / v, 4), "value_serial_over_sustained": round(serial / v, 4),
+           "what": "the timed loop (same launches, same streams) held for %.1f s after the timed region, one synchronisation per %d frames; "
+                   "sclk / power of THIS device (by PCI address) sampled every 20 ms from sysfs.  first_half / second_half: the rate is not "
+                   "flat over seconds — boxes differ in how long the board takes to settle at its power level (profiles/r05_clock_probe.txt) — "
+                   "so `value` (K frames after the pre-roll) may sit a few per cent above or below this" % (seconds, 8 * ns)}
     out.update(smp.summary())
     return out
 
@@ -917,8 +942,18 @@ def parity(gpu, ref, nrows):
             "max_abs_diff": float(d.max()), "mismatching_pixels": int(bits.any(axis=-1).sum()), "tolerance": 1e-4}
 
 
-def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_rows=0, pmc_mode="off"):
+def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_rows=0, pmc_mode="off", precision="exact"):
     """pipelined frames (as the headline) + un-overlapped kernel time of one config"""
+    if precision != "exact":
+        R.set_precision(precision)
+        try:
+            out = time_config(R, torch, dev, streams, app, W, H, t, steps, warmup, check_rows, "off")
+        finally:
+            R.set_precision("exact")
+        out["workload"] += " — OPT-IN TOLERANCE TIER SBX_PRECISION_1E4 (include/sbx.h: binary32 exp2 instead of the math spec's exp; within 1e-4 per channel, NOT bit-exact; never part of `value`)"
+        out["precision"] = "1e-4"
+        out["roofline"] = None
+        return out
     ns = len(streams)
     frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(ns)]
 
@@ -983,7 +1018,10 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
 
 
 def other_configs(R, torch, dev, streams, t, check_rows=16, pmc_mode="auto"):
-    return [time_config(R, torch, dev, streams, a, w, h, t, check_rows=check_rows, pmc_mode=pmc_mode) for a, w, h in OTHER_CONFIGS]
+    out = [time_config(R, torch, dev, streams, a, w, h, t, check_rows=check_rows, pmc_mode=pmc_mode) for a, w, h in OTHER_CONFIGS]
+    # the labelled tolerance tier of APP_ATMOSPHERE, after the exact configs and never instead of one
+    out.append(time_config(R, torch, dev, streams, "atmosphere", 7680, 4320, t, check_rows=check_rows, precision="1e-4"))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -1228,7 +1266,7 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
         return (1, 1)                                   # the root does nothing for the others: the plain split, nothing to calibrate
     pick = torch.zeros(2, dtype=torch.int64, device=COLL_DEV or dev)
     if rank == 0:
-        ch = channels if exchange == "direct" else (3 if exchange == "spans" else 4)
+        ch = channels if exchange in ("direct", "span_stores") else (3 if exchange == "spans" else 4)
         st = streams                                    # the loop's own streams (no extra hardware queues)
         nb = max(2, len(st))
         frames = [torch.empty((H, W, 4), dtype=getattr(R, "pixel_dtype", torch.float32), device=dev) for _ in range(nb)]
@@ -1249,17 +1287,42 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
     return (int(pick[0].item()), int(pick[1].item()))
 
 
-def land(R, torch, dst, src, peers):
-    """the peers' payloads arriving in the root's HBM.  With LANDING set: sbx_model_landing — `wgs_per_peer` workgroups per peer
-    stay resident for as long as ONE peer's payload needs on its link (the peers arrive in parallel over their own links) and
-    write all the bytes at that pace: the CUs and the HBM writes of RCCL's grouped receive.  Without: a device copy at HBM speed
-    (round 4's stand-in, which holds the whole chip for a few microseconds instead of a few CUs for the link time)."""
-    n = src.numel() * src.element_size()
-    if LANDING and n % 16 == 0 and n > 0 and peers > 0:
-        us = n / peers / (LANDING["link_gbps"] * 1e9) * 1e6
-        R.model_landing(src, dst, n, LANDING["wgs_per_peer"] * peers, us)
-    else:
-        dst.view(-1)[:src.numel()].copy_(src.view(-1))
+class Landing:
+    """The peers' payloads arriving in the emulated root's HBM, BESIDE the root's own render as on a real node (FramePlan posts the
+    grouped receive before the root's launch; RCCL runs it on its own stream).  begin(): fork a side stream off the frame's stream
+    and start the landing there; end(): the frame's stream waits for it (what work.wait() does) before the scatter.
+    With LANDING set the landing is sbx_model_landing — `wgs_per_peer` workgroups per peer stay resident for as long as ONE peer's
+    payload needs on its link (the peers arrive in parallel over their own links) and write all the bytes at that pace: the CUs and
+    the HBM writes of RCCL's receive kernels.  Without: a device copy at HBM speed (round 4's stand-in, which holds the whole chip
+    for a few microseconds instead of a few CUs for the link time)."""
+
+    def __init__(self, R, torch, dev, nslots):
+        self.R, self.t = R, torch
+        # the side streams are made ONCE per process: HIP deals streams onto a few hardware queues in creation order, and a fresh set
+        # per figure lands on other queues every time — some of them a render stream's, whose launches then wait behind a landing
+        # kernel that is resident for the link time (the root's figures of one sweep came out bimodal, 1.45 / 2.4 ms)
+        while len(SIDE_STREAMS) < nslots:
+            SIDE_STREAMS.append(torch.cuda.Stream(device=dev))
+        self.side = SIDE_STREAMS[:nslots]
+        self.ev0 = [torch.cuda.Event() for _ in range(nslots)]
+        self.ev1 = [torch.cuda.Event() for _ in range(nslots)]
+
+    def begin(self, slot, dst, src, peers):
+        t = self.t
+        main = t.cuda.current_stream()
+        self.ev0[slot].record(main)
+        self.side[slot].wait_event(self.ev0[slot])
+        with t.cuda.stream(self.side[slot]):
+            n = src.numel() * src.element_size()
+            if LANDING and n % 16 == 0 and n > 0 and peers > 0:
+                us = n / peers / (LANDING["link_gbps"] * 1e9) * 1e6
+                self.R.model_landing(src, dst, n, LANDING["wgs_per_peer"] * peers, us)
+            else:
+                dst.view(-1)[:src.numel()].copy_(src.view(-1))
+            self.ev1[slot].record(self.side[slot])
+
+    def end(self, slot):
+        self.t.cuda.current_stream().wait_event(self.ev1[slot])
 
 
 def timed_loop(torch, dev, fn, k=24, min_ms=60.0):
@@ -1285,8 +1348,8 @@ def timed_loop(torch, dev, fn, k=24, min_ms=60.0):
 
 def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0, m, exchange, ch, per_frame):
     """ms per frame of rank `r`'s part of a `world`-rank frame, ALL of it on this one device with the launches in flight on the
-    streams `st`: a peer = its launch; the root = its launch + the landing of the peers' payloads in its HBM (`land`: a model of
-    RCCL's receive kernels) + the assembly kernel; under the store exchange the root is an ordinary rank (its launch and the two
+    streams `st`: a peer = its launch; the root = its launch BESIDE the landing of the peers' payloads in its HBM (`Landing`: a model
+    of RCCL's receive kernels on their own stream) + the assembly kernel behind both; under the store exchange the root is an ordinary rank (its launch and the two
     flag kernels), and so is a peer (which renders in place into a frame on this device).  Used by the relief calibration on
     rank 0, by --emulate-ranks and by tools/strip_scaling.py; it knows nothing about the links."""
     from shaderbox_amd import shard
@@ -1295,6 +1358,32 @@ def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0,
     epp = 4 if pdt == torch.uint8 else 3                    # buffer elements per pixel of a span slab
     if pdt == torch.uint8:
         ch = 4
+    if exchange == "span_stores":
+        owners = [R.shared_create(H * W * (4 if pdt == torch.uint8 else 16), 1 if r == 0 else 2) for _ in range(nb)]
+        peers = [R.shared_open(o.export()) for o in owners] if r > 0 else []
+        views = [o.tensor((H, W, 4)) for o in owners]
+
+        def one(i):
+            with torch.cuda.stream(st[i % len(st)]):
+                o = owners[i % nb]
+                o.begin(0)
+                if r == 0:
+                    R.render_span_root(app, W, H, t, br, world, views[i % nb], root_rounds=m0, rounds=m)
+                    o.end(0)
+                else:
+                    p = peers[i % nb]
+                    p.begin(1)
+                    R.render_span_peer_in_place(app, W, H, t, br, r, world, p, root_rounds=m0, rounds=m, channels=ch)
+                    p.end(1)
+        try:
+            return per_frame(one)
+        finally:
+            torch.cuda.synchronize(dev)
+            del views
+            for p in peers:
+                p.close()
+            for o in owners:
+                o.close()
     if exchange == "stores":
         # one shared frame per stream, as FramePlan keeps them; a peer is driven together with its owner's "go" (one more flag kernel
         # than a real peer launches: on the pessimistic side)
@@ -1339,10 +1428,13 @@ def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0,
         land_el = max((world - 1) * max(stride, 1) * epp, tot_el)
         lands = [torch.zeros((land_el,), dtype=pdt, device=dev) for _ in range(nb)]
 
+        ld = Landing(R, torch, dev, nb)
+
         def root(i):
             with torch.cuda.stream(st[i % len(st)]):
+                ld.begin(i % nb, lands[i % nb], src, world - 1)
                 R.render_span_root(app, W, H, t, br, world, frames[i % nb], root_rounds=m0, rounds=m)
-                land(R, torch, lands[i % nb], src, world - 1)
+                ld.end(i % nb)
                 R.assemble_spans(app, W, H, t, br, world, lands[i % nb], stride, frames[i % nb], root_rounds=m0, rounds=m)
         return per_frame(root)
     rmax = shard.rank_rows_max(H, br, world, m0, m)
@@ -1355,17 +1447,20 @@ def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0,
     src = torch.zeros((world - 1, rmax, W, ch), dtype=pdt, device=dev)
     lands = [torch.zeros((world, rmax, W, ch), dtype=pdt, device=dev) for _ in range(nb)]
 
+    ld = Landing(R, torch, dev, nb)
+
     def root(i):
         with torch.cuda.stream(st[i % len(st)]):
             g, f = lands[i % nb], frames[i % nb]
+            ld.begin(i % nb, g[1:], src, world - 1)
             if exchange == "direct":
                 R.render_rank_in_place(app, W, H, t, br, 0, world, f, root_rounds=m0, rounds=m)
-                land(R, torch, g[1:], src, world - 1)
+                ld.end(i % nb)
                 R.assemble_peers(g[1:], W, H, br, world, f, root_rounds=m0, rounds=m)
             else:
                 R.render_rank_rows(app, W, H, t, br, 0, world, 0, rmax, slabs[i % nb], root_rounds=m0, rounds=m)
                 g[0].copy_(slabs[i % nb])
-                land(R, torch, g[1:], src, world - 1)
+                ld.end(i % nb)
                 R.assemble(g, W, H, br, world, out=f, root_rounds=m0, rounds=m)
     return per_frame(root)
 

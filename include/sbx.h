@@ -279,6 +279,12 @@ void sbx_shared_close(sbx_shared* s);
 float* sbx_shared_frame(sbx_shared* s);
 int sbx_shared_frame_begin(sbx_shared* s, int rank, void* stream);
 int sbx_shared_frame_end(sbx_shared* s, int rank, void* stream);
+/* The store exchange with SPANS (the two ideas together, for frames whose pixel stores would bind a link: 7680x4320 in float
+ * pixels): a peer renders only the spans of its row-blocks (sbx_span_table) — in place, into the owner's mapped frame, `channels` = 3
+ * or 4 dwords per float pixel — and the owner renders its own blocks and everything outside the spans with sbx_render_span_root.
+ * No slab, no landing area, no scatter; the links carry the expensive pixels only (29.7 instead of 49.8 MB per peer at 7680x4320). */
+int sbx_render_span_peer_in_place(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                                  int nranks, int root_rounds, int rounds, int channels, float* frame, void* stream);
 /* sbx_render_split_in_place writing only R, G, B of every float4 pixel (three dwords at a 16-byte stride); under
  * SBX_FORMAT_RGBA8 it is sbx_render_split_in_place. */
 int sbx_render_split_in_place_rgb(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
@@ -303,6 +309,16 @@ int sbx_pack_unorm8(sbx_ctx* ctx, int width, int rows, const float* rgba, unsign
  * return float colours. */
 enum { SBX_FORMAT_RGBA32F = 0, SBX_FORMAT_RGBA8 = 1 };
 int sbx_set_output_format(sbx_ctx* ctx, int format);
+
+/* PRECISION TIER of the frame-granular and per-pixel entry points (default SBX_PRECISION_EXACT: every pixel bit-identical to the
+ * CPU oracle of this repository).  SBX_PRECISION_1E4 is a labelled, opt-in tolerance tier for SBX_APP_ATMOSPHERE only (every other
+ * app ignores it and stays exact): BASELINE.json's bar is 1e-4 per float channel against the C++ reference, not bit-equality, and
+ * APP_ATMOSPHERE (src/app_atmosphere.h:50-160: 336 exp per in-dome pixel, no threshold that amplifies a rounding difference) meets
+ * it with the hardware's binary32 exp2 in place of the math spec's binary64 table form — about half the frame time.  Max |diff|
+ * against the oracle over every pixel of the 7680x4320 frame and over a sweep of sun positions is asserted in the tests.
+ * Not offered for APP_CLOUDS / APP_PLANET: their coverage and density edges turn a 1-ulp difference into 1e-3 pixels. */
+enum { SBX_PRECISION_EXACT = 0, SBX_PRECISION_1E4 = 1 };
+int sbx_set_precision(sbx_ctx* ctx, int precision);
 
 /* Counters of a context since its creation (or the last sbx_reset_stats): what a host or a test reads to see what its calls
  * turned into.  render_launches = render-kernel launches enqueued by any entry point; main_image_hits = sbx_main_image calls

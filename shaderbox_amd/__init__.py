@@ -171,6 +171,7 @@ def load_library(path=None):
     lib.sbx_last_error.argtypes = [vp]
     lib.sbx_last_error.restype = ctypes.c_char_p
     lib.sbx_version.restype = ctypes.c_char_p
+    lib.sbx_set_precision.argtypes = [vp, ci]
     lib.sbx_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     lib.sbx_reset_stats.argtypes = [vp]
     # the store exchange (include/sbx.h sbx_shared_*)
@@ -184,6 +185,7 @@ def load_library(path=None):
     lib.sbx_shared_frame_begin.argtypes = [vp, ci, vp]
     lib.sbx_shared_frame_end.argtypes = [vp, ci, vp]
     lib.sbx_render_split_in_place_rgb.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, fp, vp]
+    lib.sbx_render_span_peer_in_place.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, ci, fp, vp]
     # include/sbx_test.h (test hooks and the landing model of the scaling tools)
     lib.sbx_shared_set_timeout_ms.argtypes = [vp, ci]
     lib.sbx_model_landing.argtypes = [vp, vp, vp, ctypes.c_size_t, ci, ctypes.c_float, vp]
@@ -355,6 +357,11 @@ class Renderer:
         self._check(self.lib.sbx_set_output_format(self.ctx, code))
         self.pixel_dtype = self.torch.uint8 if code == SBX_FORMAT_RGBA8 else self.torch.float32
 
+    def set_precision(self, tier):
+        """'exact' (default: bit-identical to the oracle) or '1e-4' (include/sbx.h SBX_PRECISION_1E4: APP_ATMOSPHERE with the hardware's
+        binary32 exp2, within 1e-4 per channel of the exact frame; every other app ignores it)"""
+        self._check(self.lib.sbx_set_precision(self.ctx, {"exact": 0, "1e-4": 1}[tier]))
+
     @property
     def rgba8(self):
         return self.pixel_dtype == self.torch.uint8
@@ -471,6 +478,17 @@ class Renderer:
         fn = self.lib.sbx_render_split_in_place_rgb if int(channels) == 3 else self.lib.sbx_render_split_in_place
         self._check(fn(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, rank, nranks, root_rounds, rounds,
                        ctypes.c_void_p(ptr), self._stream()))
+        return frame
+
+    def render_span_peer_in_place(self, app, width, height, time, block_rows, rank, nranks, frame, mouse=(0.0, 0.0), aux=None,
+                                  root_rounds=1, rounds=1, channels=4):
+        """The spans of peer `rank`'s row-blocks at their place in the owner's full-size frame (a SharedFrame, or a tensor of this
+        device): sbx_render_span_peer_in_place, the store exchange with spans."""
+        u = self.uniforms(width, height, time, mouse)
+        ptr = frame.ptr if isinstance(frame, SharedFrame) else frame.data_ptr()
+        self._check(self.lib.sbx_render_span_peer_in_place(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, rank, nranks,
+                                                           root_rounds, rounds, 4 if self.rgba8 else int(channels), ctypes.c_void_p(ptr),
+                                                           self._stream()))
         return frame
 
     # -- the store exchange (include/sbx.h sbx_shared_*) --------------------------------------------------------

@@ -17,7 +17,7 @@ namespace sbx {
 #ifndef ATM_MIN_WAVES
 #define ATM_MIN_WAVES 6     // (the max-ILP strategy of this source, build.py, takes what registers it is given: 147 for the plain kernel without a bound)
 #endif
-template <bool FIN>
+template <bool FIN, int PREC = 0>
 __global__ void __launch_bounds__(64 * ATM_TX, ATM_MIN_WAVES) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
     constexpr bool T64 = FIN && ATM_EXP_REG && ATM_EXP64 && !ATM_EXP4K;
     __shared__ double etab[32];
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(64 * ATM_TX, ATM_MIN_WAVES) k_atmosphere(Frame
     const v3 rd = V3(sin_(theta) * cos_(phi), cos_(theta), sin_(theta) * sin_(phi));
     const v3 ro = V3(0, ATM_EARTH_R + 1.f, 0);
 
-    const v3 col = atm_incident_light<FIN>(ro, rd, F.sun_dir, etab, etab64);
+    const v3 col = atm_incident_light<FIN, PREC>(ro, rd, F.sun_dir, etab, etab64);
     store_rgba(M, out, px.idx, to_srgb(col));
 }
 
@@ -61,7 +61,7 @@ void launch_exp4k_eval(const float* a, float* out, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_exp4k_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, out, n);
 }
 
-void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s) {
+void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s, int precision) {
     // FIN: camera and sun direction are finite numbers (they are for every finite u_res / u_time)
     const float chk[] = {F.cam.res_x, F.cam.res_y, F.cam.aspect_x, F.cam.fov, F.sun_dir.x, F.sun_dir.y, F.sun_dir.z,
                          F.cam.fwd.x, F.cam.fwd.y, F.cam.fwd.z, F.cam.up.x, F.cam.up.y, F.cam.up.z, F.cam.right.x, F.cam.right.y, F.cam.right.z};
@@ -70,7 +70,8 @@ void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hi
 #if ATM_NO_FIN
     fin = false;
 #endif
-    if (fin) hipLaunchKernelGGL(k_atmosphere<true>, (grid_for<8, ATM_TX>(M)), dim3(64 * ATM_TX), 0, s, F, M, out);
+    if (fin && precision == 1) hipLaunchKernelGGL((k_atmosphere<true, 1>), (grid_for<8, ATM_TX>(M)), dim3(64 * ATM_TX), 0, s, F, M, out);   // the tolerance tier
+    else if (fin) hipLaunchKernelGGL(k_atmosphere<true>, (grid_for<8, ATM_TX>(M)), dim3(64 * ATM_TX), 0, s, F, M, out);
     else hipLaunchKernelGGL(k_atmosphere<false>, (grid_for<8, ATM_TX>(M)), dim3(64 * ATM_TX), 0, s, F, M, out);
 }
 

@@ -30,6 +30,7 @@ struct sbx_ctx {
     bool timing = false;
     int variant = 0;
     int out_format = 0;                    // sbx_set_output_format: 0 float pixels, 1 R8G8B8A8_UNORM words
+    int precision = 0;                     // sbx_set_precision: 0 bit-exact (default), 1 = SBX_PRECISION_1E4 (APP_ATMOSPHERE only)
     int sdf_roots = 0;                     // sbx_set_variant 2 / 3: the SDF kernels' square-root witness test build / IEEE roots
     // APP_CLOUDS y tables: CLOUDS_YTAB_RING slots for eager launches + CLOUDS_YTAB_CAPTURE slots that only launches
     // recorded into a stream capture use (a captured graph bakes the slot pointer in, so eager rebuilds must never
@@ -647,7 +648,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
                                                     (ctx->tex_bounds_valid && !capturing) ? ctx->tex_bounds : nullptr); break;
     case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, sdf_variant); break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s, ctx->variant == 1 ? 1 : ctx->sdf_roots); break;
-    case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s); break;
+    case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s, ctx->precision); break;
     case SBX_APP_SDF_AO: {
         sbx_aux_sdf_ao A;
         if (aux) A = *(const sbx_aux_sdf_ao*)aux; else sbx_aux_sdf_ao_defaults(&A);
@@ -1145,6 +1146,25 @@ extern "C" int sbx_render_span_peer(sbx_ctx* ctx, int app, const sbx_uniforms* u
     RowMap M{mw, H, 0, block_rows, nranks, rank, r1 - r0, r0, root_rounds, rounds, 0, out_rgb(ctx, 1), nullptr, 0, dev, 1};
     return render_mapped(ctx, app, uni, aux, M, rgb, stream);
 }
+extern "C" int sbx_render_span_peer_in_place(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int rank,
+                                             int nranks, int root_rounds, int rounds, int channels, float* frame, void* stream) {
+    int W, H;
+    int rc = check_common(ctx, uni, frame, W, H);
+    if (rc != SBX_OK) return rc;
+    if (rank < 1 || rank >= nranks) return fail(ctx, SBX_ERR_ARG, "sbx_render_span_peer_in_place is for ranks 1 .. nranks-1");
+    if (channels != 3 && channels != 4) return fail(ctx, SBX_ERR_ARG, "channels must be 3 or 4");
+    const int rows = sbx_split_rank_rows(H, block_rows, rank, nranks, root_rounds, rounds);
+    if (rows < 0) return fail(ctx, SBX_ERR_ARG, "bad rank split");
+    if (rows == 0) return SBX_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
+    const int4* dev = nullptr; int mw = 0;
+    rc = span_table_device(ctx, app, uni, aux, block_rows, nranks, root_rounds, rounds, (hipStream_t)stream, &dev, &mw, nullptr);
+    if (rc != SBX_OK) return rc;
+    if (mw <= 0) return SBX_OK;                                    // every span of the peers is empty
+    RowMap M{W, H, 0, block_rows, nranks, rank, rows, 0, root_rounds, rounds, 1, out_rgb(ctx, channels == 3 ? 3 : 0), nullptr, 0, dev, 3};
+    return render_mapped(ctx, app, uni, aux, M, frame, stream);
+}
 extern "C" int sbx_render_span_root(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, int block_rows, int nranks,
                                     int root_rounds, int rounds, float* frame, void* stream) {
     int W, H;
@@ -1285,6 +1305,23 @@ int sbx_set_output_format(sbx_ctx* ctx, int format) {
     if (!ctx) return SBX_ERR_ARG;
     if (format != SBX_FORMAT_RGBA32F && format != SBX_FORMAT_RGBA8) return fail(ctx, SBX_ERR_ARG, "unknown output format");
     ctx->out_format = format;
+    return SBX_OK;
+}
+int sbx_set_precision(sbx_ctx* ctx, int precision) {
+    if (!ctx) return SBX_ERR_ARG;
+    if (precision != SBX_PRECISION_EXACT && precision != SBX_PRECISION_1E4) return fail(ctx, SBX_ERR_ARG, "unknown precision tier");
+    ctx->precision = precision;
+    {   // frames cached by sbx_main_image were rendered in the other tier
+        std::lock_guard<std::mutex> g(ctx->mi_lock);
+        for (auto& en : ctx->mi) {
+            const uint64_t g0 = en.gen.load(std::memory_order_relaxed);
+            en.gen.store(g0 + 1, std::memory_order_relaxed);
+            std::atomic_thread_fence(std::memory_order_release);
+            for (auto& w : en.key) w.store(0xffffffffu, std::memory_order_relaxed);
+            en.used = false;
+            en.gen.store(g0 + 2, std::memory_order_release);
+        }
+    }
     return SBX_OK;
 }
 int sbx_set_variant(sbx_ctx* ctx, int variant) {

@@ -61,6 +61,9 @@ __device__ __forceinline__ Pixel pixel_of(const RowMap& M, int tid, int bx, int 
             p.x += T.x;
             p.valid = p.valid && p.x < T.y;
             p.idx = (size_t)T.z + (size_t)(yc - g * M.block_rows) * (size_t)(T.y - T.x) + (size_t)(p.x - T.x);
+        } else if (M.span_mode == 3) {                       // a peer of the store exchange: its spans, at their place in the owner's frame
+            p.valid = p.valid && p.x >= T.x && p.x < T.y;
+            p.idx = (size_t)p.y * M.width + p.x;
         } else {
             p.valid = p.valid && (T.w == 0 || p.x < T.x || p.x >= T.y);
             p.idx = (size_t)p.y * M.width + p.x;
@@ -122,7 +125,7 @@ void launch_extract_r(const float* rgba, float* r, size_t n, hipStream_t s);
 void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out, size_t n, hipStream_t s);
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s, int variant);
-void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s);
+void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s, int precision = 0);
 void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, hipStream_t s);

@@ -45,6 +45,9 @@ struct RowMap {
     //                 its block's span and lands at slab pixel off + row_in_block * (x1 - x0) + (x - x0);
     //   span_mode 2 (the owner of the frame, in place over the WHOLE frame): a pixel is rendered iff its block is rank 0's
     //                 or it lies OUTSIDE its block's span.
+    //   span_mode 3 (a peer of the store exchange, sbx_render_span_peer_in_place): the launch covers the rank's rows at the frame's
+    //                 full width; a pixel is rendered iff it lies in its block's span and lands at its GLOBAL position of the owner's
+    //                 full-size frame (waves outside the span exit at once).
     // Either way every pixel is computed by the same kernel from its global coordinates: the spans decide who renders a
     // pixel, never what it looks like.
     const int4* span;

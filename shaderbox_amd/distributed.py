@@ -38,6 +38,9 @@ Two forms of that one exchange (`exchange=`):
   root, no scatter pass: the root is an ordinary rank.  Two flag kernels per frame and rank order it (owner: "frame may be
   overwritten" / wait for every peer's "rows in place"; peer: wait / signal).  Still exactly one exchange step, and since every
   pixel is written by the app's full kernel from its global coordinates the frame is bit-identical to one launch.
+* "span_stores": both ideas together, for frames whose pixel stores would bind a link (7680x4320 in float pixels: 50 MB per peer):
+  a peer stores only the SPANS of its row-blocks in place (`sbx_render_span_peer_in_place`), the owner renders its blocks and
+  everything outside the spans (`sbx_render_span_root`): 30 MB per peer, no landing, no scatter.
 
 Pixel format: the plan moves whatever pixels its renderer writes.  After `renderer.set_output_format("rgba8")` (include/sbx.h
 SBX_FORMAT_RGBA8: the render kernels write one R8G8B8A8_UNORM word per pixel, the reference hosts' display format) every slab,
@@ -55,8 +58,8 @@ class FramePlan:
 
     def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS, groups=1, root_rounds=1,
                  rounds=1, exchange="direct", channels=3):
-        if exchange not in ("direct", "gather", "spans", "stores"):
-            raise ValueError("exchange must be 'direct', 'gather', 'spans' or 'stores'")
+        if exchange not in ("direct", "gather", "spans", "stores", "span_stores"):
+            raise ValueError("exchange must be 'direct', 'gather', 'spans', 'stores' or 'span_stores'")
         if exchange == "spans":
             channels = 3
         if exchange == "gather":
@@ -81,7 +84,7 @@ class FramePlan:
         self.ranges = [(cuts[g], cuts[g + 1]) for g in range(groups) if cuts[g + 1] > cuts[g]]
         self.slab = self.gathered = self.peers = self.frame = self.shared = None
         self.glists = [None] * len(self.ranges)
-        if exchange == "stores":
+        if exchange in ("stores", "span_stores"):
             # collective: every rank builds its plans in the same order, the handle of the owner's frame goes round once
             box = [None]
             if self.rank == 0:
@@ -199,9 +202,21 @@ class FramePlan:
             self.shared.begin(self.rank)
         if phase == "open":
             return None
-        self.r.render_rank_in_place(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
-                                    self.frame if self.rank == 0 else self.shared, mouse=mouse, aux=aux,
-                                    root_rounds=self.root_rounds, rounds=self.rounds, channels=4 if self.rgba8 else self.channels)
+        ch = 4 if self.rgba8 else self.channels
+        if self.exchange == "span_stores" and self.world > 1:
+            # with spans: a peer stores only the expensive interval of each of its row-blocks, the owner renders its own blocks and
+            # everything outside the spans (one launch over the frame; those pixels leave mainImage through an early exit)
+            if self.rank == 0:
+                self.r.render_span_root(app, self.width, self.height, time, self.block_rows, self.world, self.frame, mouse=mouse,
+                                        aux=aux, root_rounds=self.root_rounds, rounds=self.rounds)
+            else:
+                self.r.render_span_peer_in_place(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
+                                                 self.shared, mouse=mouse, aux=aux, root_rounds=self.root_rounds, rounds=self.rounds,
+                                                 channels=ch)
+        else:
+            self.r.render_rank_in_place(app, self.width, self.height, time, self.block_rows, self.rank, self.world,
+                                        self.frame if self.rank == 0 else self.shared, mouse=mouse, aux=aux,
+                                        root_rounds=self.root_rounds, rounds=self.rounds, channels=ch)
         mark("render")
         self.shared.end(self.rank)
         mark("exchange")
@@ -215,7 +230,7 @@ class FramePlan:
         called after the rank's rendering ("render"), after the waits of its exchange ("exchange") and after the root's
         assembly ("assemble"): bench.py records stream events there to time the phases of a frame."""
         mark = mark or (lambda name: None)
-        if self.exchange == "stores":
+        if self.exchange in ("stores", "span_stores"):
             return self._render_stores(app, time, mouse, aux, mark, phase)
         if self.exchange == "gather":
             return self._render_gather(app, time, mouse, aux, mark)
@@ -347,7 +362,7 @@ class LoopbackWorld:
         """one frame through all ranks in the order the emulation needs: peers, then the root; returns the root's frame.  (The
         store exchange runs on ONE stream here, so the owner's "frame may be overwritten" has to be enqueued before the peers'
         waits for it: the owner's call is split, FramePlan._render_stores.)"""
-        if plans[0].exchange == "stores":
+        if plans[0].exchange in ("stores", "span_stores"):
             plans[0].render(app, time, phase="open", **kw)
             for p in plans[1:]:
                 p.render(app, time, **kw)

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes long, opt-in with SBX_SLOW_TESTS=1 (tests/test_variant_matrix.py)")
 
 
 @pytest.fixture(scope="session")

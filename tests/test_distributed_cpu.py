@@ -93,6 +93,24 @@ class OracleRenderer:
                 slab[at * e:(at + x1 - x0) * e] = img[k, x0:x1, :e].reshape(-1)
         return slab
 
+    def render_span_peer_in_place(self, app, width, height, time, block_rows, rank, nranks, frame, mouse=(0.0, 0.0), aux=None,
+                                  root_rounds=1, rounds=1, channels=4):
+        """mirror of sbx_render_span_peer_in_place: the spans of the rank's row-blocks at their place in the owner's frame"""
+        from oracle.oracle import APP_IDS
+        from shaderbox_amd import shard
+        if isinstance(frame, CpuSharedFrame):
+            frame = frame.tensor((height, width, 4), torch.uint8 if self.rgba8 else torch.float32)
+        table, _, _ = self.span_table(app, width, height, time, block_rows, nranks, root_rounds, rounds, mouse, aux)
+        rows = [y for y in shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)
+                if table[y // block_rows][1] > table[y // block_rows][0]]
+        if rows:
+            img = self.px(self.o.render_rows(APP_IDS[app], width, height, time, rows, mouse=mouse, aux=aux, threads=2))
+            c = 4 if (self.rgba8 or channels == 4) else 3
+            for k, y in enumerate(rows):
+                x0, x1 = int(table[y // block_rows][0]), int(table[y // block_rows][1])
+                frame[y, x0:x1, :c] = img[k, x0:x1, :c]
+        return frame
+
     def render_span_root(self, app, width, height, time, block_rows, nranks, frame, mouse=(0.0, 0.0), aux=None, root_rounds=1,
                          rounds=1):
         from oracle.oracle import APP_IDS
@@ -214,7 +232,7 @@ def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1,
                      exchange=exchange, channels=channels)
     frame = None
     for _ in range(2):                       # buffers are reused across frames
-        if rank == 0 and exchange != "stores":
+        if rank == 0 and exchange not in ("stores", "span_stores"):
             plan.frame.fill_(7 if rgba8 else -7.0)           # every pixel of the frame must be written again
         frame = plan.render(app, t)
     if rank == 0:
@@ -222,7 +240,7 @@ def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1,
     else:
         assert frame is None
     dist.barrier()
-    if exchange == "stores" and rank == 0:
+    if exchange in ("stores", "span_stores") and rank == 0:
         plan.shared.close()
     dist.destroy_process_group()
 
@@ -315,6 +333,19 @@ def test_store_exchange_schedule_over_gloo(tmp_path, oracle, world, app, w, h, b
         assert got.dtype == np.uint8 and np.array_equal(got, pack_unorm8(ref))
     else:
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,app,w,h,br,relief,channels", [(2, "atmosphere", 448, 252, 8, (1, 1), 3), (3, "clouds", 128, 72, 4, (1, 2), 4),
+                                                              (2, "egg", 64, 45, 8, (1, 1), 3)])
+def test_span_store_exchange_schedule_over_gloo(tmp_path, oracle, world, app, w, h, br, relief, channels):
+    """exchange='span_stores': the store exchange with only the spans of the peers' row-blocks stored (partial spans, empty spans,
+    an app without a span model) over gloo with the file-backed stand-in == the single-process frame"""
+    from oracle.oracle import APP_IDS
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, 1, path, relief, "span_stores", channels, False), nprocs=world, join=True)
+    got = np.load(path)
+    ref = oracle.render(APP_IDS[app], w, h, 0.37)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
 def test_span_table_is_a_consistent_layout():

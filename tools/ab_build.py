@@ -3,7 +3,7 @@
 other objects of the normal build.
 
     python tools/ab_build.py name1:kern_clouds.hip:-DFOO=1,-DBAR name2:kern_planet.hip:-DX ...
-    python tools/ab_build.py --all-variants        # every non-default setting of kern_clouds.hip's CL_* switches, one at a time
+    python tools/ab_build.py --all-variants        # every non-default setting of kern_clouds.hip's CL_* and kern_planet.hip's PL_* switches, one at a time
 -> build/ab/libsbx_<name>.so   (build/ is git-ignored but travels with gpurun); time them with tools/ab_time.py, check them
 with tools/sweep_clouds_variants.py (same bits as the per-lane kernel on random frames).
 
@@ -25,6 +25,11 @@ CLOUDS_VARIANTS = [("CL_PARK", 0), ("CL_LIPSKIP", 0), ("CL_LIPSKIP2", 0), ("CL_E
                    ("CL_MIN_WAVES_YZ", 4), ("CL_YZ_MARCH", 0), ("CL_MIN_WAVES", 5), ("CL_EXP64", 0), ("CL_EXP_SMALL", 0),
                    ("CL_EXP_SMALL_ASM", 0), ("CL_YZ_SM", 0), ("CL_DIV3", 0), ("CL_EXP4K", 0), ("CL_TOP_FIRST", "true"),
                    ("CL_PRESCALE", 0)]
+
+
+# kern_planet.hip / sbx_hashcache.h as k_planet uses it.  Not listed: PL_MIN_WAVES, PL_TW, PL_BATCH* (shapes and sizes).
+PLANET_VARIANTS = [("PL_SPEC", 0), ("PL_TB2", 0), ("SBX_HC_MAGIC_SLOT", 0), ("PL_DIV3", 0), ("PL_MED3", 0), ("PL_EXP4K", 0),
+                   ("PL_SQRT_RS", 0), ("PL_SQRT_N", 0), ("PL_PARK", 0), ("PL_TLAST", 0), ("PL_ROLL_DETAIL", 0)]
 
 
 def build_one(spec):
@@ -57,6 +62,12 @@ def main():
             if v is None:
                 continue
             specs.append("v_%s_%s:kern_clouds.hip:-D%s=%s" % (k.lower(), v, k, v))
+        psrc = open(os.path.join(b.CSRC, "kern_planet.hip")).read() + open(os.path.join(b.CSRC, "sbx_hashcache.h")).read()
+        for k, v in PLANET_VARIANTS:
+            if ("#ifndef %s\n" % k) not in psrc and ("#ifndef %s " % k) not in psrc:
+                print("(switch %s no longer exists)" % k)
+                continue
+            specs.append("v_pl_%s_%s:kern_planet.hip:-D%s=%s" % (k.lower(), v, k, v))
     failed = 0
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         for msg in ex.map(build_one, specs):

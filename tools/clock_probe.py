@@ -47,8 +47,9 @@ for name in a.libs.split(","):
         torch.cuda.synchronize()
         time.sleep(1.0)                                           # let the clocks fall back to idle
         marks = []                                                # (seconds since start, frames done)
+        sampler = bench.GpuSampler(0)                             # (its sysfs search is host work: before the clock starts)
         n, t0 = 0, time.perf_counter()
-        with bench.GpuSampler(0) as smp:
+        with sampler as smp:
             while time.perf_counter() - t0 < a.seconds:
                 for i in range(2 * a.streams):
                     step(i)

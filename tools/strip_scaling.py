@@ -35,7 +35,7 @@ ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--time", type=float, default=.37)
 ap.add_argument("--ranks", default="2,4,8")
-ap.add_argument("--exchanges", default="stores,spans,direct")
+ap.add_argument("--exchanges", default="stores,span_stores,spans,direct")
 ap.add_argument("--channels", type=int, choices=[3, 4], default=3, help="store exchange, float pixels: dwords a peer stores per pixel")
 ap.add_argument("--rccl-wgs-per-peer", type=int, default=2, help="landing model of the send/recv exchanges (bench.py); 0 = a plain device copy")
 ap.add_argument("--streams", type=int, default=3)
@@ -59,6 +59,10 @@ R.set_timing(True)
 streams = [torch.cuda.Stream() for _ in range(a.streams)]   # created once: HIP maps streams onto a few hardware queues
 for s in streams:
     with torch.cuda.stream(s):
+        R.render(app, 64, 36, t)
+for _ in streams:                            # the emulated root's landing streams (bench.Landing), on the hardware queues after these
+    bench.SIDE_STREAMS.append(torch.cuda.Stream())
+    with torch.cuda.stream(bench.SIDE_STREAMS[-1]):
         R.render(app, 64, 36, t)
 torch.cuda.synchronize()
 
@@ -104,7 +108,7 @@ if a.quick:
 R.set_timing(False)
 for n in ranks:
     for exchange in a.exchanges.split(","):
-        ch = a.channels if exchange == "stores" else 3
+        ch = a.channels if exchange in ("stores", "span_stores") else 3
         print("  --- N=%d, exchange %s" % (n, exchange))
         best = None
         for m0, m in (bench.relief_candidates() if exchange != "stores" else [(1, 1)]):
@@ -112,10 +116,11 @@ for n in ranks:
                 bpp = 4 if R.rgba8 else 4 * ch
                 payload = bpp * W * shard.rank_rows_max(H, 8, n, m0, m)
                 total = bpp * W * sum(shard.rank_rows(H, 8, r, n, m0, m) for r in range(1, n))
-            elif exchange == "spans":
+            elif exchange in ("spans", "span_stores"):
+                bpp = BPP if exchange == "spans" or R.rgba8 else 4 * ch
                 _, pix, _ = R.span_table(app, W, H, t, 8, n, m0, m)
-                payload = BPP * int(max(pix[1:]))
-                total = BPP * sum(int(p) for p in pix[1:])
+                payload = bpp * int(max(pix[1:]))
+                total = bpp * sum(int(p) for p in pix[1:])
             else:
                 payload = BPP * W * shard.rank_rows_max(H, 8, n, m0, m)
                 total = BPP * W * sum(shard.rank_rows(H, 8, r, n, m0, m) for r in range(1, n))

@@ -14,10 +14,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def one_planet(path, N):
+    """the same for APP_PLANET (libraries named libsbx_v_pl_*): default kernel == plain kernel on random (time, mouse, size) frames,
+    NaN == NaN (app_planet.h:270-273 makes NaN pixels)"""
+    import numpy as np
+    import torch
+    import shaderbox_amd
+    if path != "base":
+        shaderbox_amd.LIB_PATH = path
+    R = shaderbox_amd.Renderer(0)
+    rng = np.random.default_rng(321)
+    bad = 0
+    for i in range(N):
+        t = float(rng.uniform(0, 60)) if i % 3 else float(rng.uniform(0, 3))
+        mouse = (float(rng.uniform(0, 600)), float(rng.uniform(0, 300))) if i % 2 else (0.0, 0.0)
+        W, H = [(640, 360), (333, 187), (1280, 200)][i % 3]
+        app = "planet_atmosphere" if i % 9 == 8 else "planet"
+        R.set_variant(0); a = R.render(app, W, H, t, mouse=mouse).clone()
+        R.set_variant(1); b = R.render(app, W, H, t, mouse=mouse)
+        same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+        if not bool(same.all()):
+            bad += 1
+    R.set_variant(0)
+    print("%-44s frames %d, with a differing pixel: %d%s" % (os.path.basename(path) + " (planet)", N, bad, "" if bad == 0 else "   <-- DIFFERENT"))
+
+
 def one(path, N):
     import numpy as np
     import torch
     import shaderbox_amd
+    if "libsbx_v_pl_" in os.path.basename(path):
+        return one_planet(path, max(20, N // 3))
     if path != "base":
         shaderbox_amd.LIB_PATH = path
     R = shaderbox_amd.Renderer(0)
@@ -55,10 +82,16 @@ if __name__ == "__main__":
     if "--one" in args:
         one(args[args.index("--one") + 1], N)
         sys.exit(0)
+    if "--one-planet" in args:
+        one_planet(args[args.index("--one-planet") + 1], N)
+        sys.exit(0)
     names = [a for a in args if not a.startswith("--") and not a.isdigit()]
     paths = ["base"] + [os.path.join(ROOT, "build", "ab", "libsbx_%s.so" % n) for n in names]
     if "--all" in args:
         paths += sorted(glob.glob(os.path.join(ROOT, "build", "ab", "libsbx_v_*.so")))
+    if "--all" in args:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-planet", "base", "--frames", str(max(20, N // 3))], capture_output=True, text=True)
+        print(([l for l in r.stdout.splitlines() if "frames" in l] or ["base (planet) FAILED: " + r.stderr[-300:]])[-1])
     for p in paths:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", p, "--frames", str(N)], capture_output=True, text=True)
         out = [l for l in r.stdout.splitlines() if "frames" in l]
