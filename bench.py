@@ -908,9 +908,9 @@ def sustained(torch, dev, step, ns, pixels, seconds, value, serial):
            "frames_in_flight": ns, "first_half": part(0, dt / 2), "second_half": part(dt / 2, dt),
            "value_over_sustained": round(value / v, 4), "value_serial_over_sustained": round(serial / v, 4),
            "what": "the timed loop (same launches, same streams) held for %.1f s after the timed region, one synchronisation per %d frames; "
-                   "sclk / power of THIS device (by PCI address) sampled every 20 ms from sysfs.  first_half / second_half: the rate is not "
-                   "flat over seconds — boxes differ in how long the board takes to settle at its power level (profiles/r05_clock_probe.txt) — "
-                   "so `value` (K frames after the pre-roll) may sit a few per cent above or below this" % (seconds, 8 * ns)}
+                   "sclk / power of THIS device (by PCI address) sampled every 20 ms from sysfs; first_half / second_half show whether "
+                   "the rate drifts over seconds.  `value` (K frames after the pre-roll) within a per cent of this = the short window "
+                   "measured the steady state" % (seconds, 8 * ns)}
     out.update(smp.summary())
     return out
 

@@ -9,7 +9,8 @@ import shaderbox_amd
 
 R = shaderbox_amd.Renderer(0)
 R.set_timing(True)
-CASES = [("clouds", 3840, 2160), ("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320)]
+CASES = [("clouds", 3840, 2160), ("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320),
+         ("planet_atmosphere", 7680, 4320)]      # (the last: config 5's labelled composite, k_planet<., ATM> — VERDICT r4 Weak #8: it had no counters)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 for _ in range(20):                      # clocks up before the first case
     R.render("clouds", 3840, 2160, 0.37)
