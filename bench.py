@@ -90,7 +90,7 @@ VALU_ISSUE_CYCLES = 2.0             # wave64 VALU instruction on a SIMD-32 (MI35
 NOMINAL_CLOCK_HZ = 2.4e9
 LANES_PER_SIMD_CYCLE = 32           # a SIMD-32 retires half a wave64 instruction per cycle
 PEAK_LANEOPS_NOMINAL_T = N_SIMD * LANES_PER_SIMD_CYCLE * NOMINAL_CLOCK_HZ / 1e12     # 78.6 T lane-ops/s
-PMC_ROUND = "r04"
+PMC_ROUND = "r05"
 SIDE_STREAMS = []                   # Landing's streams (created once, right after the render streams)
 LANDING = {"wgs_per_peer": 2, "link_gbps": 50.0}     # how the emulated root lands the peers' payloads (main() sets it from the flags)
 COLL_DEV = None                     # device of the small bookkeeping collectives (set in main: the GPU under RCCL, the CPU under gloo)                   # committed per-launch counters: profiles/<PMC_ROUND>_pmc_<app>_<W>x<H>.json
@@ -498,26 +498,71 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         relief, payload, groups, plans = prepare(exchange)
     else:
         trials, best = {}, None
+
+        def agreed(ok):                                  # every rank's verdict on a step of a trial: all of them, or none
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=COLL_DEV or dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
         for ex in ("stores", "span_stores", "spans", "direct"):
-            cand = prepare(ex)
+            # A form that cannot be set up on these devices (the store exchange needs HIP IPC and peer mapping), that faults, or
+            # whose frame differs from one launch is DROPPED, on every rank alike, and the line says so: the trial must never
+            # take the run down with it.
+            cand, why = None, None
+            try:
+                cand = prepare(ex)
+            except Exception as e:                       # noqa: BLE001
+                why = "set-up failed on rank %d: %s: %s" % (rank, type(e).__name__, str(e)[:200])
+            if not agreed(cand is not None):
+                trials[ex] = "unavailable (%s)" % (why or "set-up failed on another rank")
+                cand = None
+                torch.cuda.empty_cache()
+                continue
             cplans = cand[3]
-            for i in range(ns + 1):
-                with torch.cuda.stream(streams[i % ns]):
-                    cplans[i % ns].render(app, t)
-            sync()
-            t0 = time.perf_counter()
-            ktrial = 8
-            for i in range(ktrial):
-                with torch.cuda.stream(streams[i % ns]):
-                    cplans[i % ns].render(app, t)
-            sync()
-            dt = torch.tensor([(time.perf_counter() - t0) * 1e3 / ktrial], dtype=torch.float64, device=COLL_DEV or dev)
+            ms, why = None, None
+            try:
+                for i in range(ns + 1):
+                    with torch.cuda.stream(streams[i % ns]):
+                        cplans[i % ns].render(app, t)
+                sync()
+                if rank == 0:                            # the trial's own frame against one launch, bit for bit
+                    whole = R.render(app, W, H, t)
+                    got = cplans[ns % ns].frame
+                    torch.cuda.synchronize(dev)
+                    if bool((got.view(torch.int32) != whole.view(torch.int32)).any().item()):
+                        why = "its frame differs from a one-launch render"
+                    del whole
+                if R.fault_status() != 0:
+                    why = "a wait of the exchange timed out (fault word)"
+                if why is None:
+                    t0 = time.perf_counter()
+                    ktrial = 8
+                    for i in range(ktrial):
+                        with torch.cuda.stream(streams[i % ns]):
+                            cplans[i % ns].render(app, t)
+                    sync()
+                    ms = (time.perf_counter() - t0) * 1e3 / ktrial
+            except Exception as e:                       # noqa: BLE001
+                why = "%s: %s" % (type(e).__name__, str(e)[:200])
+            if not agreed(why is None):
+                trials[ex] = "dropped (%s)" % (why or "failed on another rank")
+                try:
+                    torch.cuda.synchronize(dev)
+                    if R.fault_status() != 0:
+                        R.clear_fault()
+                except Exception:                        # noqa: BLE001
+                    pass
+                del cand, cplans
+                torch.cuda.empty_cache()
+                continue
+            dt = torch.tensor([ms], dtype=torch.float64, device=COLL_DEV or dev)
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             trials[ex] = round(float(dt.item()), 4)
             if best is None or trials[ex] < best[0]:
                 best = (trials[ex], ex, cand)
             del cand, cplans
             torch.cuda.empty_cache()
+        if best is None:
+            raise SystemExit("no exchange form could be set up on these ranks: %s" % trials)
         exchange = best[1]
         relief, payload, groups, plans = best[2]
         best = None

@@ -88,12 +88,20 @@ class FramePlan:
             # collective: every rank builds its plans in the same order, the handle of the owner's frame goes round once
             box = [None]
             if self.rank == 0:
-                self.shared = renderer.shared_create(self.height * self.width * (4 if self.rgba8 else 16), self.world)
-                self.frame = self.shared.tensor((self.height, self.width, 4))
-                if self.world > 1:
-                    box[0] = self.shared.export()
+                try:
+                    self.shared = renderer.shared_create(self.height * self.width * (4 if self.rgba8 else 16), self.world)
+                    self.frame = self.shared.tensor((self.height, self.width, 4))
+                    if self.world > 1:
+                        box[0] = self.shared.export()
+                except Exception as e:                                   # noqa: BLE001
+                    # the peers are about to enter the broadcast: tell them instead of leaving them there
+                    box[0] = ("error", "%s: %s" % (type(e).__name__, e))
+                    if self.world <= 1:
+                        raise
             if self.world > 1:
                 dist.broadcast_object_list(box, src=0)
+                if isinstance(box[0], tuple) and box[0] and box[0][0] == "error":
+                    raise RuntimeError("FramePlan(exchange=%r): rank 0 could not create or export the shared frame: %s" % (exchange, box[0][1]))
                 if self.rank != 0:
                     self.shared = renderer.shared_open(box[0])
         elif exchange == "gather":

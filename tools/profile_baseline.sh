@@ -13,6 +13,7 @@ cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 S=$OUT/apps_pmc.txt
+if [ "${SBX_PROFILE_ONLY_TRACE:-0}" != "1" ]; then
 echo "# python tools/time_baseline.py (unprofiled, HIP events, median of 8 serial launches)" > $S
 python tools/time_baseline.py >> $S 2>$OUT/time.log
 echo "# rocprofv3 --kernel-trace --stats -- python tools/time_baseline.py" >> $S
@@ -30,12 +31,13 @@ for pass in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS
   echo "# rocprofv3 --kernel-trace --pmc $pass -- python tools/time_baseline.py 4   (full-frame dispatches only)" >> $S
   if [ -n "$f" ]; then python tools/pmc_summary.py "$f" --largest-grid >> $S; else echo "(no counters; see $tag.log)" >> $S; tail -3 $OUT/$tag.log >> $S; fi
 done
+fi
 # 3) the headline with three and with one frame in flight: launch intervals of k_clouds
 T=$OUT/streams3_trace.txt
 : > $T
 for ns in 3 1; do
-  rocprofv3 --kernel-trace --stats -f csv -d $OUT/bench_s$ns -o t -- python bench.py --steps 20 --warmup 5 --streams $ns --no-cpu-baseline --pmc off --no-other-configs > $OUT/bench_s$ns.log 2>&1
-  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --streams $ns --no-cpu-baseline --pmc off --no-other-configs" >> $T
+  rocprofv3 --kernel-trace --stats -f csv -d $OUT/bench_s$ns -o t -- python bench.py --steps 20 --warmup 5 --streams $ns --no-cpu-baseline --pmc off --no-other-configs --sustained-seconds 0 > $OUT/bench_s$ns.log 2>&1
+  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --streams $ns --no-cpu-baseline --pmc off --no-other-configs --sustained-seconds 0" >> $T
   tail -1 $OUT/bench_s$ns.log | cut -c1-600 >> $T
   find $OUT/bench_s$ns -name '*kernel_stats.csv' | head -1 | xargs -r head -4 >> $T
   f=$(find $OUT/bench_s$ns -name '*kernel_trace.csv' | head -1)
@@ -43,5 +45,5 @@ for ns in 3 1; do
 done
 find $OUT -name '*.csv' -size +1M -delete
 find $OUT -name '*.db' -delete
-cat $S | head -150
+[ -f $S ] && cat $S | head -150
 cat $T
