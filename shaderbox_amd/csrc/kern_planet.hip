@@ -78,7 +78,7 @@ __device__ __forceinline__ float pl_fbm_from(const float (&nz)[OCT], float init_
 // fBm over the cached noise: octaves START..OCT-1 are fetched in cooperative batches of <= 4 (register budget) and
 // added to (t, H, q) in octave order exactly as fbm.h:6 (t += basis * H; p *= lacunarity; H *= gain)
 #ifndef PL_BATCH
-#define PL_BATCH 2          // octaves fetched per cooperative batch: 4 at a time (round 1) peaked at 32 hash registers and spilled
+#define PL_BATCH 3          // octaves fetched per cooperative batch: 4 at a time (round 1) peaked at 32 hash registers and spilled; 3 (round 5): 91 VGPRs, no scratch, -0.5 % against 2
 #endif
 #ifndef PL_ROLL_DETAIL
 #define PL_ROLL_DETAIL 1
@@ -243,6 +243,116 @@ __device__ __forceinline__ v2 terrain_map(WaveCache& S, v3 pos, bool on, int lan
     }
     const float n = n0 + n1;
     return V2(pl_length<SKIP>(pos) - 1.f - n * PL_MAX_HEIGHT, PL_DIVK(n, PL_MAX_HEIGHT));
+}
+
+
+// ---- the central differences of sdf_terrain_normal (:201-212) as PAIRS --------------------------------------------------------
+// The six detail maps of a hit pixel are three pairs pos + d, pos - d with d along one axis (e = .001): the two points of a pair
+// have two coordinates in common — bit for bit, and so all the way down both fBms (the same multiplications of the same numbers) —
+// and lie in the same lattice cell except where the 0.002 between them straddles a cell face.  A pair is therefore evaluated
+// together: per octave the floor / fraction / smoothstep weight of the two common axes ONCE, ONE lookup where the cells coincide,
+// and of the trilinear blend (x, then y, then z: noise_iq.h:20-23) everything below the differing axis once — nothing shared for an
+// x pair, the four x-mixes for a y pair, the x- and y-mixes for a z pair.  Lanes whose pair straddles a face get the second point's
+// own lookup and blend behind a wave-wide test.  Every value is computed by the reference's operations on the reference's operands;
+// only the duplicates are gone.  (pos.c + 0 and pos.c - 0 are pos.c unless it is a zero: a wave with a zero coordinate takes the
+// unpaired path.)
+#ifndef PL_PAIRS
+#define PL_PAIRS 1
+#endif
+template <bool XI, bool SPEC>
+__device__ __forceinline__ H8 pl_lookup(WaveCache& S, int tab, unsigned nbits, int slot, bool active, int lane) {
+    H8 h;
+    if (wave_any(active && S.tag[tab][slot] != nbits)) {
+        h = hc_slow<XI, SPEC>(S, tab, nbits, slot, active, lane);
+    } else {
+        h.lo = *reinterpret_cast<const float4*>(&S.h[tab][slot][0]);
+        h.hi = *reinterpret_cast<const float4*>(&S.h[tab][slot][4]);
+    }
+    return h;
+}
+// one octave: qa = the pair's first point, qb_ax = the second point's coordinate on axis AX (its other two are qa's)
+template <int AX, bool XI>
+__device__ __forceinline__ void pl_noise_pair(WaveCache& S, v3 qa, float qb_ax, int tab, bool on, int lane, float& na, float& nb) {
+    const float px = floor_(qa.x), py = floor_(qa.y), pz = floor_(qa.z);
+    const float ax = qa.x - px, ay = qa.y - py, az = qa.z - pz;
+    const float fx = ax * ax * tm2_(ax), fy = ay * ay * tm2_(ay), fz = az * az * tm2_(az);
+    const float pb = floor_(qb_ax), ab = qb_ax - pb, fb = ab * ab * tm2_(ab);
+    const float bx = AX == 0 ? pb : px, by = AX == 1 ? pb : py, bz = AX == 2 ? pb : pz;
+    const float n_a = XI ? __builtin_fmaf(113.0f, pz, __builtin_fmaf(py, 157.0f, px)) : px + py * 157.0f + 113.0f * pz;
+    const float n_b = XI ? __builtin_fmaf(113.0f, bz, __builtin_fmaf(by, 157.0f, bx)) : bx + by * 157.0f + 113.0f * bz;
+    const unsigned ka = f2u(n_a), kb = f2u(n_b);
+    const int sa = (XI && SBX_HC_MAGIC_SLOT) ? (int)(f2u(n_a + 12582912.0f) & (unsigned)(HC_SLOTS - 1)) : ((int)n_a & (HC_SLOTS - 1));
+    const H8 h = pl_lookup<XI, false>(S, tab, ka, sa, on, lane);
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz, gb = 1.0f - fb;
+    // the first point, and of the second whatever does not depend on the differing axis (hc_blend's operations, its order)
+    if (AX == 0) {
+        na = hc_blend(h.lo, h.hi, fx, fy, fz);
+        nb = hc_blend(h.lo, h.hi, fb, fy, fz);
+    } else {
+        const float a = h.lo.x * gx + h.lo.y * fx, b = h.lo.z * gx + h.lo.w * fx;
+        const float c = h.hi.x * gx + h.hi.y * fx, d = h.hi.z * gx + h.hi.w * fx;
+        if (AX == 1) {
+            na = (a * gy + b * fy) * gz + (c * gy + d * fy) * fz;
+            nb = (a * gb + b * fb) * gz + (c * gb + d * fb) * fz;
+        } else {
+            const float m = a * gy + b * fy, n = c * gy + d * fy;
+            na = m * gz + n * fz;
+            nb = m * gb + n * fb;
+        }
+    }
+    // lanes whose two points lie in different cells: the second point's own cell
+    const bool other = ka != kb;
+    if (wave_any(on && other)) {
+        const int sb = (XI && SBX_HC_MAGIC_SLOT) ? (int)(f2u(n_b + 12582912.0f) & (unsigned)(HC_SLOTS - 1)) : ((int)n_b & (HC_SLOTS - 1));
+        const H8 g = pl_lookup<XI, false>(S, tab, kb, sb, on && other, lane);
+        const float v = hc_blend(g.lo, g.hi, AX == 0 ? fb : fx, AX == 1 ? fb : fy, AX == 2 ? fb : fz);
+        if (other) nb = v;
+    }
+}
+// octaves START .. OCT-1 of an fBm for both points of a pair: t += basis(noise) * H; p *= lacunarity; H *= gain   (fbm.h:6)
+template <int OCT, int MODE, int START, int AX, bool XI, int TB>
+__device__ __forceinline__ void pl_fbm_pair(WaveCache& S, v3& qa, float& qb_ax, float lacunarity, float& H, float gain, float& ta, float& tb,
+                                            bool on, int lane) {
+#pragma unroll 1
+    for (int k = START; k < OCT; ++k) {
+        float na, nb;
+        pl_noise_pair<AX, XI>(S, qa, qb_ax, (TB + k) & 3, on, lane, na, nb);
+        ta += pl_basis<MODE>(na) * H;
+        tb += pl_basis<MODE>(nb) * H;
+        qa = qa * lacunarity;
+        qb_ax = qb_ax * lacunarity;
+        H *= gain;
+    }
+}
+// sdf_terrain_map_detail(pos + d).x - sdf_terrain_map_detail(pos - d).x with d = e along axis AX   (:188-199, :201-212)
+template <int AX, bool SKIP>
+__device__ __forceinline__ float terrain_detail_difference(WaveCache& S, v3 pos, float e, bool on, int lane) {
+    // the two points: pos.c + e and pos.c - e on axis AX; pos.c + 0 = pos.c - 0 = pos.c on the others (no zero coordinates here)
+    const float ca = (AX == 0 ? pos.x : AX == 1 ? pos.y : pos.z) + e, cb = (AX == 0 ? pos.x : AX == 1 ? pos.y : pos.z) - e;
+    const v3 pa = V3(AX == 0 ? ca : pos.x, AX == 1 ? ca : pos.y, AX == 2 ? ca : pos.z);
+    const v3 pb = V3(AX == 0 ? cb : pos.x, AX == 1 ? cb : pos.y, AX == 2 ? cb : pos.z);
+    // first fBm: fbm(pos * 2.0987, 2.0244, .454, .454), 7 octaves of noise
+    v3 q = pa * 2.0987f;
+    float qb = cb * 2.0987f;
+    float H = .454f, h0a = 0.f, h0b = 0.f;
+    pl_fbm_pair<7, 0, 0, AX, SKIP, 0>(S, q, qb, 2.0244f, H, .454f, h0a, h0b, on, lane);
+    const float n0a = SMOOTHSTEP_K(.35f, 1.f, h0a), n0b = SMOOTHSTEP_K(.35f, 1.f, h0b);
+    // second fBm (ridged): pos * 1.50987 + (1.9489, 2.435, .5483); the tail bound of terrain_map for both points
+    const v3 off = V3(1.9489f, 2.435f, .5483f);
+    q = pa * 1.50987f + off;
+    qb = cb * 1.50987f + (AX == 0 ? off.x : AX == 1 ? off.y : off.z);
+    H = .454f;
+    float h1a = 0.f, h1b = 0.f;
+    pl_fbm_pair<1, 2, 0, AX, SKIP, PL_TB2>(S, q, qb, 2.0244f, H, .454f, h1a, h1b, on, lane);
+    float n1a = 0.f, n1b = 0.f;
+    if (!SKIP || wave_any(on && !(h1a + .3745f * 1.0001f < .6f && h1b + .3745f * 1.0001f < .6f))) {
+        pl_fbm_pair<7, 2, 1, AX, SKIP, PL_TB2>(S, q, qb, 2.0244f, H, .454f, h1a, h1b, on, lane);
+        n1a = SMOOTHSTEP_K(.6f, 1.f, h1a);
+        n1b = SMOOTHSTEP_K(.6f, 1.f, h1b);
+    }
+    const float va = pl_length<SKIP>(pa) - 1.f - (n0a + n1a) * PL_MAX_HEIGHT;
+    const float vb = pl_length<SKIP>(pb) - 1.f - (n0b + n1b) * PL_MAX_HEIGHT;
+    return va - vb;
 }
 
 __device__ __forceinline__ v3 setup_lights(v3 L, v3 normal) {                          // :217-236
@@ -417,6 +527,16 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
             pk[3 * 64] = pos.x; pk[4 * 64] = pos.y; pk[5 * 64] = pos.z; pk[6 * 64] = h;
             pk[1 * 64] = cloud.radiance; pk[2 * 64] = cloud.alpha;
             asm volatile("" ::: "memory");
+            // (a zero coordinate of the hit point: pos.c + 0 and pos.c - 0 then differ in the sign of their zero — the unpaired path)
+            const bool pairs = SKIP && PL_PAIRS && !wave_any(hitl && (pk[3 * 64] == 0.f || pk[4 * 64] == 0.f || pk[5 * 64] == 0.f));
+            if (pairs) {
+                pk[7 * 64] = terrain_detail_difference<0, SKIP>(S, V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]), e, hitl, lane);
+                asm volatile("" ::: "memory");
+                pk[8 * 64] = terrain_detail_difference<1, SKIP>(S, V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]), e, hitl, lane);
+                asm volatile("" ::: "memory");
+                pk[9 * 64] = terrain_detail_difference<2, SKIP>(S, V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]), e, hitl, lane);
+                asm volatile("" ::: "memory");
+            } else {
 #pragma unroll 1
             for (int ax = 0; ax < 3; ++ax) {                       // one code copy for the three central differences
                 const v3 d = V3(ax == 0 ? e : 0.f, ax == 1 ? e : 0.f, ax == 2 ? e : 0.f);
@@ -425,6 +545,7 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
                 const float vb = terrain_map<7, SKIP>(S, V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]) - d, hitl, lane).x;
                 pk[(7 + ax) * 64] = va - vb;
                 asm volatile("" ::: "memory");
+            }
             }
             pos = V3(pk[3 * 64], pk[4 * 64], pk[5 * 64]);
             h = pk[6 * 64];

@@ -27,12 +27,15 @@ for c in range(n_cases):
     m = int(rng.integers(1, 6))
     m0 = int(rng.integers(0, m + 1))
     groups = int(rng.integers(1, 5))
-    exchange = str(rng.choice(["spans", "spans", "spans", "direct"]))
+    exchange = str(rng.choice(["spans", "spans", "direct", "stores", "stores", "span_stores", "span_stores"]))
+    channels = int(rng.choice([3, 4]))
     t = float(rng.uniform(0, 30))
     mouse = (float(rng.uniform(0, 6.3)), 0.0) if app.startswith("clouds") and c % 2 else (0.0, 0.0)
     world = LoopbackWorld(n)
-    plans = world.plans(R, w, h, block_rows=br, groups=groups, root_rounds=m0, rounds=m, exchange=exchange)
+    plans = world.plans(R, w, h, block_rows=br, groups=groups, root_rounds=m0, rounds=m, exchange=exchange, channels=channels)
     plans[0].frame.fill_(-7.0)
+    if exchange in ("stores", "span_stores") and channels == 3:
+        plans[0].frame[..., 3] = 1.0              # the alpha a three-dword store leaves alone (it comes with the shared frame)
     got = LoopbackWorld.render(plans, app, t, mouse=mouse)
     ref = R.render(app, w, h, t, mouse=mouse)
     same = (got.view(torch.int32) == ref.view(torch.int32)) | (torch.isnan(got) & torch.isnan(ref))
@@ -48,6 +51,11 @@ for c in range(n_cases):
     if not (ok and ok2):
         bad += 1
         print("MISMATCH", app, w, h, n, br, (m0, m), groups, exchange, t, mouse, "frame" if not ok else "points")
+    if exchange in ("stores", "span_stores"):
+        torch.cuda.synchronize()
+        for p in plans[1:]:
+            p.shared.close()
+        plans[0].shared.close()
     del plans, world, got, ref
 # the library's own multi-GPU path (sbx_multi_*, all ranks on device 0: copies instead of RCCL), every exchange form
 mbad, mcases = 0, 0
