@@ -1038,7 +1038,23 @@ extern "C" int sbx_span_table(int app, const sbx_uniforms* uni, const void* aux,
     const int ntiles = (W + SPAN_ALIGN - 1) / SPAN_ALIGN;
     const SpanProbe P = span_probe(app, *uni, aux);
     std::vector<int> x0(nblocks, 0), x1(nblocks, W);
+    // The intervals depend on (app, u_res, u_mouse, block_rows) — not on the split — and finding them is the expensive part (tile by
+    // tile, nine probes each, a 16-step march per ATMOSPHERE probe: 14 ms for the 8K dome), while a host asks for the same
+    // frame's table once per candidate relief and once per rank context: the last few results are kept, process-wide.
+    struct Intervals { std::vector<uint32_t> key; std::vector<int> x0, x1; };
+    static std::mutex cache_lock;
+    static std::vector<Intervals> cache;
+    std::vector<uint32_t> key(6, 0u);
+    key[0] = (uint32_t)app; key[1] = (uint32_t)block_rows;
+    std::memcpy(&key[2], uni->u_res, 8);
+    std::memcpy(&key[4], uni->u_mouse, 8);
+    bool cached = false;
     if (P.model) {
+        std::lock_guard<std::mutex> g(cache_lock);
+        for (const Intervals& c : cache)
+            if (c.key == key && (int)c.x0.size() == nblocks) { x0 = c.x0; x1 = c.x1; cached = true; break; }
+    }
+    if (P.model && !cached) {
         // the heavy part of a row-block is taken to be ONE interval of tiles (a disc, a horizon): scan inwards from both ends
         for (int g = 0; g < nblocks; ++g) {
             const int ya = g * block_rows, yb = std::min(H, ya + block_rows) - 1;
@@ -1058,6 +1074,9 @@ extern "C" int sbx_span_table(int app, const sbx_uniforms* uni, const void* aux,
             x0[g] = lo * SPAN_ALIGN;
             x1[g] = std::min(W, (hi + 1) * SPAN_ALIGN);
         }
+        std::lock_guard<std::mutex> g(cache_lock);
+        if (cache.size() >= 8) cache.erase(cache.begin());
+        cache.push_back(Intervals{key, x0, x1});
     }
     // owner and slab offset of every block: the ranks' local blocks in slab order (sbx_split_rank_rows' enumeration)
     std::vector<int> owner(nblocks, 0), off(nblocks, 0);

@@ -214,6 +214,16 @@ def test_sixteen_host_threads_share_one_launch(tmp_path):
     assert "launches_by_main_image=1 " in r.stdout and "differing=0 " in r.stdout, r.stdout
 
 
+def test_main_image_under_contention_returns_the_right_frames_pixels():
+    """host/mainimage_stress.cpp: 8 host threads ask one context for random pixels of THREE frames (the context caches two: constant
+    evictions and re-renders under the readers' feet) and the resolution changes half way (pinned buffers retired in mid-run); every
+    colour returned must be the right frame's — the sequence locks of sbx_main_image under the load they exist for"""
+    host = os.path.join(ROOT, "host")
+    subprocess.run(["make", "-s", "-C", host, "mainimage_stress"], check=True)
+    r = subprocess.run([os.path.join(host, "mainimage_stress"), "8", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " wrong=0 errors=0" in r.stdout, r.stdout + r.stderr
+
+
 def test_main_image_keeps_two_frames_and_counts(renderer):
     """the context caches the last TWO distinct frames (two host threads with different uniforms do not evict each other), hits
     cost no launch; the counters say what happened"""
