@@ -721,7 +721,7 @@ def dist_line(res, args, app, W, H, t, world):
     if roofline is not None:
         roofline["rank"] = "slowest (rank %d of the un-overlapped launches %s ms; %d pixels)" % (res["slowest_rank"], res["per_rank_launch_ms"],
                                                                                               res["launch_pixels"])
-        if res["exchange"] == "spans" and world > 1 and roofline.get("frac") is not None:
+        if res["exchange"] in ("spans", "span_stores") and world > 1 and roofline.get("frac") is not None:
             roofline["frac_is"] += ("; NOTE a span launch renders mostly the frame's EXPENSIVE pixels, so the frame-average instruction "
                                     "count per pixel understates its work: read this frac as a lower bound")
     ph = res["phases"]
