@@ -403,11 +403,19 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
 // ATM: the config-5 composite SBX_APP_PLANET_ATMOSPHERE (include/sbx.h; SURVEY.md §8a note: "planet background() replaced by
 // get_incident_light"): wherever APP_PLANET shows its background() (app_planet.h:316-318, 364-366) the pixel shows APP_ATMOSPHERE's
 // sky instead — get_incident_light (app_atmosphere.h:78-160) for a ray from 1 m above the ground (:204-207) along the VIEW
-// direction, with APP_ATMOSPHERE's sun (setup_scene :177-181, FramePlanet.atm_sun).  The sky is evaluated in the plain statement of
-// the spec (atm_incident_light<false>): view directions are arbitrary here, the domains of k_atmosphere's shortcuts were argued for
-// its own camera.  No reference-held answers: parity unpinned.
+// direction, with APP_ATMOSPHERE's sun (setup_scene :177-181, FramePlanet.atm_sun).  No reference-held answers: parity unpinned.
+// The sky runs k_atmosphere's exhaustively-equal forms (atm_incident_light<true>: exp_reg4k_, div3_, sqrt_rs_) in the SKIP kernels
+// (tame frames: finite uniforms) where their domains hold for THIS camera too (round 5): the ray starts at (0, Re + 1, 0) whatever
+// its direction, so every sample lies inside the atmosphere sphere and the exp arguments stay in [-50.1, 5300] (sbx_atmosphere.h);
+// and |s|^2 of a march position cannot be 0 or tiny because the view direction normalize(pc.x, pc.y, 1) has rd.z > 0 — a wave
+// checks rd.z > 1e-15 for its pixels (s.z = rd.z t with t >= 4e5 on a ray that can come near the centre, so |s|^2 >= 1e-19 against
+// sqrt_rs_'s 2^-102) and takes the plain statement of the spec otherwise (fragCoords 1e15 frames below the frame, through the point
+// list).  9.73 -> 8.75 ms came from the planet's own marches; this: see profiles/r05_log.md.
 // (Reading the marches' two rotations from LDS at every step, so that their 15 multiply-adds per step have no SGPR source — half rate
 //  on gfx950 — was measured: 5.763 against 5.759 ms, nothing; profiles/r05_log.md.)
+#ifndef PL_ATM_FIN
+#define PL_ATM_FIN 1
+#endif
 template <bool SKIP, bool ATM = false>
 __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
     __shared__ double etab[ATM ? 32 : 1];
@@ -606,8 +614,11 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
     if (!pxe.valid) return;
     if (ATM) {
         if (cloud_sky || !hit_atm) {
-            const v3 sky = atm_incident_light<false>(V3(0, ATM_EARTH_R + 1.f, 0), rde, F.atm_sun,
-                                                     reinterpret_cast<const double (&)[32]>(etab), nullptr);
+            v3 sky;
+            if (SKIP && PL_ATM_FIN && !wave_any(!(rde.z > 1e-15f)))       // (wave-uniform; a NaN direction takes the plain form)
+                sky = atm_incident_light<true>(V3(0, ATM_EARTH_R + 1.f, 0), rde, F.atm_sun, reinterpret_cast<const double (&)[32]>(etab), nullptr);
+            else
+                sky = atm_incident_light<false>(V3(0, ATM_EARTH_R + 1.f, 0), rde, F.atm_sun, reinterpret_cast<const double (&)[32]>(etab), nullptr);
             col = hit_atm ? abs3(mix3(sky, V3s(sky_r), sky_a)) : sky;
         }
     } else {

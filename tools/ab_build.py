@@ -28,7 +28,7 @@ CLOUDS_VARIANTS = [("CL_PARK", 0), ("CL_LIPSKIP", 0), ("CL_LIPSKIP2", 0), ("CL_E
 
 
 # kern_planet.hip / sbx_hashcache.h as k_planet uses it.  Not listed: PL_MIN_WAVES, PL_TW, PL_BATCH* (shapes and sizes).
-PLANET_VARIANTS = [("PL_PAIRS", 0), ("PL_SPEC", 0), ("PL_TB2", 0), ("SBX_HC_MAGIC_SLOT", 0), ("PL_DIV3", 0), ("PL_MED3", 0), ("PL_EXP4K", 0),
+PLANET_VARIANTS = [("PL_ATM_FIN", 0), ("PL_PAIRS", 0), ("PL_SPEC", 0), ("PL_TB2", 0), ("SBX_HC_MAGIC_SLOT", 0), ("PL_DIV3", 0), ("PL_MED3", 0), ("PL_EXP4K", 0),
                    ("PL_SQRT_RS", 0), ("PL_SQRT_N", 0), ("PL_PARK", 0), ("PL_TLAST", 0), ("PL_ROLL_DETAIL", 0)]
 
 
