@@ -213,3 +213,22 @@ def test_cli_rgba8_writes_the_same_ppm(built, tmp_path):
         assert open(a, "rb").read() == open(b, "rb").read(), (app, extra)
     r = subprocess.run([exe, "--app", "egg", "--res", "32x32", "--rgba8", "--f32", str(tmp_path / "x.f32")], capture_output=True, text=True)
     assert r.returncode == 2 and "--rgba8" in r.stderr
+
+
+def test_bench_gpu_sampler_degrades_to_nothing_without_its_device():
+    """bench.py's sustained leg samples sclk / power of the device it runs on from sysfs, found by PCI address; where there is no such
+    device (this container) or no such file it reports None instead of failing — and never another GPU's numbers"""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    smp = bench.GpuSampler(0, period_s=.01)
+    with smp:
+        time.sleep(.05)
+    s = smp.summary()
+    import torch
+    if not torch.cuda.is_available():
+        assert s["sclk_mhz"] is None and s["power_w"] is None and "None" in s["source"]
+    else:
+        assert s["sclk_mhz"] is None or s["sclk_mhz"]["samples"] >= 1
