@@ -316,3 +316,31 @@ def test_precision_tier_touches_nothing_else(renderer, oracle):
     assert a1 != a0 and max(abs(x - y) for x, y in zip(a1, a0)) <= 1e-4
     with pytest.raises(shaderbox_amd.SbxError):
         renderer._check(renderer.lib.sbx_set_precision(renderer.ctx, 7))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k_raytracer's walls as axis pairs (csrc/kern_raytracer.hip hit_walls)
+# ---------------------------------------------------------------------------------------------------------
+def test_raytracer_axis_pair_walls_equal_the_six_plane_loop(renderer, oracle):
+    """hit_walls — one division per axis, the plane rd points at, candidates in the reference's array order — against the kernel
+    that runs intersect_plane six times from the scene block (variant 3: IEEE forms, generic planes) over camera rotations,
+    sphere positions and sizes with ragged last tiles; a frame that is not finite (u_time inf / NaN moves a sphere's centre there)
+    takes the generic kernel by the host's check and still equals variant 3; three frames against the oracle"""
+    from oracle.oracle import APP_IDS
+    rng = np.random.default_rng(2025)
+    cases = [(640, 360, 0.0, (0.0, 0.0)), (517, 291, 1.25, (517 * 2 / 3.15, 100.0)), (1280, 720, 7.7, (900.0, 300.0))]
+    cases += [(int(rng.integers(96, 900)), int(rng.integers(64, 500)), float(rng.uniform(0, 100)),
+               (float(rng.uniform(1, 900)), float(rng.uniform(1, 500)))) for _ in range(24)]
+    cases += [(320, 180, float("inf"), (0.0, 0.0)), (320, 180, float("nan"), (10.0, 10.0)), (320, 180, 3.0e38, (50.0, 60.0))]
+    try:
+        for i, (w, h, t, mouse) in enumerate(cases):
+            renderer.set_variant(0)
+            a = renderer.render("raytracer", w, h, t, mouse=mouse).clone()
+            renderer.set_variant(3)
+            b = renderer.render("raytracer", w, h, t, mouse=mouse)
+            assert bits_differ(a, b) == 0, (w, h, t, mouse)
+            if i < 3:
+                ref = oracle.render(APP_IDS["raytracer"], w, h, t, mouse=mouse)
+                assert np.array_equal(a.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (w, h, t, mouse)
+    finally:
+        renderer.set_variant(0)
