@@ -964,9 +964,13 @@ def sustained(torch, dev, step, ns, pixels, seconds, value, serial):
 def steady_state(step_done, ns, pixels):
     """The pipeline's rate without its ramp-in and its drain: with ns frames in flight the frames complete in bursts of about
     ns (they share the GPU), the first burst ends at ~ns frame times and the last burst drains on an emptying chip, so the
-    rate is taken between the end of the first burst (frame ns - 1) and the frame ns before the last one."""
+    rate is taken between the end of the first burst (frame ns - 1) and the end of the last burst that finishes at least ns
+    frames before the end — a whole number of bursts (round 5: a window of 14 frames with 3 in flight read 6 % low)."""
     K = len(step_done)
-    i1, i2 = ns - 1, K - 1 - ns
+    i1 = ns - 1
+    i2 = i1 + ns * ((K - 1 - ns - i1) // ns)       # whole bursts only: a window that cuts a burst counts its wait, not its frames
+    if i2 - i1 < 2:
+        i2 = K - 1 - ns                             # too few timed frames for whole bursts: the plain window
     if i2 - i1 < 2:
         return None
     span_ms = step_done[i1].elapsed_time(step_done[i2])
