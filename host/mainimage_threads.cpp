@@ -38,6 +38,22 @@ int main(int argc, char** argv) {
         });
     for (auto& t : th) t.join();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // the same loop again: the frame is cached now, every call is a hit (the first pass's time holds sbx_create, the launch and the copy)
+    const auto h0 = std::chrono::steady_clock::now();
+    th.clear();
+    for (int k = 0; k < T; ++k)
+        th.emplace_back([&, k] {
+            iResolution[0] = (float)W; iResolution[1] = (float)H;
+            iGlobalTime = time;
+            for (int y = k; y < H; y += T)
+                for (int x = 0; x < W; ++x) {
+                    vec4 c;
+                    mainImage(c, vec2{x + .5f, y + .5f});
+                    std::memcpy(&got[((size_t)y * W + x) * 4], &c, 16);
+                }
+        });
+    for (auto& t : th) t.join();
+    const double hit_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
     sbx_ctx* ctx = sbx_host::context().get();
     sbx_stats st{};
     sbx_get_stats(ctx, &st);
@@ -52,8 +68,9 @@ int main(int argc, char** argv) {
     (void)hipFree(dev);
     size_t differing = 0;
     for (size_t i = 0; i < ref.size(); i += 4) differing += std::memcmp(&got[i], &ref[i], 16) != 0;
-    printf("%dx%d threads=%d pixels=%zu launches_by_main_image=%llu frames=%llu hits=%llu points=%llu differing=%zu seconds=%.3f Mpixels_per_s=%.1f\n",
+    printf("%dx%d threads=%d pixels=%zu launches_by_main_image=%llu frames=%llu hits=%llu points=%llu differing=%zu seconds=%.3f Mpixels_per_s=%.1f | second pass (hits only) seconds=%.4f Mpixels_per_s=%.1f ns_per_call_per_thread=%.1f\n",
            W, H, T, (size_t)W * H, (unsigned long long)st.render_launches, (unsigned long long)st.main_image_frames,
-           (unsigned long long)st.main_image_hits, (unsigned long long)st.main_image_points, differing, sec, W * (double)H / sec / 1e6);
-    return (st.render_launches == 1 && st.main_image_frames == 1 && differing == 0 && st.main_image_hits + 1 == (unsigned long long)W * H) ? 0 : 1;
+           (unsigned long long)st.main_image_hits, (unsigned long long)st.main_image_points, differing, sec, W * (double)H / sec / 1e6,
+           hit_sec, W * (double)H / hit_sec / 1e6, hit_sec * 1e9 * T / (W * (double)H));
+    return (st.render_launches == 1 && st.main_image_frames == 1 && differing == 0 && st.main_image_hits + 1 == 2ull * W * H) ? 0 : 1;
 }
