@@ -3,7 +3,7 @@
 other objects of the normal build.
 
     python tools/ab_build.py name1:kern_clouds.hip:-DFOO=1,-DBAR name2:kern_planet.hip:-DX ...
-    python tools/ab_build.py --all-variants        # every non-default setting of kern_clouds.hip's CL_* and kern_planet.hip's PL_* switches, one at a time
+    python tools/ab_build.py --all-variants        # every non-default setting of kern_clouds.hip's CL_*, kern_planet.hip's PL_* and kern_raytracer.hip's RT_* switches, one at a time
 -> build/ab/libsbx_<name>.so   (build/ is git-ignored but travels with gpurun); time them with tools/ab_time.py, check them
 with tools/sweep_clouds_variants.py (same bits as the per-lane kernel on random frames).
 
@@ -30,6 +30,10 @@ CLOUDS_VARIANTS = [("CL_PARK", 0), ("CL_LIPSKIP", 0), ("CL_LIPSKIP2", 0), ("CL_E
 # kern_planet.hip / sbx_hashcache.h as k_planet uses it.  Not listed: PL_MIN_WAVES, PL_TW, PL_BATCH* (shapes and sizes).
 PLANET_VARIANTS = [("PL_ATM_FIN", 0), ("PL_PAIRS", 0), ("PL_SPEC", 0), ("PL_TB2", 0), ("SBX_HC_MAGIC_SLOT", 0), ("PL_DIV3", 0), ("PL_MED3", 0), ("PL_EXP4K", 0),
                    ("PL_SQRT_RS", 0), ("PL_SQRT_N", 0), ("PL_PARK", 0), ("PL_TLAST", 0), ("PL_ROLL_DETAIL", 0)]
+
+
+# kern_raytracer.hip
+RT_VARIANTS = [("RT_AXIS_PLANES", 0), ("RT_WITNESS", 0), ("RT_LDS_FRAME", 0)]
 
 
 def build_one(spec):
@@ -68,6 +72,12 @@ def main():
                 print("(switch %s no longer exists)" % k)
                 continue
             specs.append("v_pl_%s_%s:kern_planet.hip:-D%s=%s" % (k.lower(), v, k, v))
+        rsrc = open(os.path.join(b.CSRC, "kern_raytracer.hip")).read()
+        for k, v in RT_VARIANTS:
+            if ("#ifndef %s\n" % k) not in rsrc and ("#ifndef %s " % k) not in rsrc:
+                print("(switch %s no longer exists)" % k)
+                continue
+            specs.append("v_rt_%s_%s:kern_raytracer.hip:-D%s=%s" % (k.lower(), v, k, v))
     failed = 0
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         for msg in ex.map(build_one, specs):

@@ -39,12 +39,40 @@ def one_planet(path, N):
     print("%-44s frames %d, with a differing pixel: %d%s" % (os.path.basename(path) + " (planet)", N, bad, "" if bad == 0 else "   <-- DIFFERENT"))
 
 
+def one_raytracer(path, N):
+    """APP_RAYTRACER (libraries named libsbx_v_rt_*): the default kernel == the witness's test edge (2) == the IEEE kernel with the six
+    planes from the scene block (3) on random (time, mouse, size) frames"""
+    import numpy as np
+    import torch
+    import shaderbox_amd
+    if path != "base":
+        shaderbox_amd.LIB_PATH = path
+    R = shaderbox_amd.Renderer(0)
+    rng = np.random.default_rng(55)
+    bad = 0
+    for i in range(N):
+        t = float(rng.uniform(0, 100))
+        mouse = (float(rng.uniform(1, 900)), float(rng.uniform(1, 500))) if i % 2 else (0.0, 0.0)
+        W, H = [(640, 360), (333, 187), (1280, 720)][i % 3]
+        fr = []
+        for v in (0, 2, 3):
+            R.set_variant(v)
+            fr.append(R.render("raytracer", W, H, t, mouse=mouse).clone())
+        same = (fr[0].view(torch.int32) == fr[1].view(torch.int32)) & (fr[0].view(torch.int32) == fr[2].view(torch.int32))
+        if not bool(same.all()):
+            bad += 1
+    R.set_variant(0)
+    print("%-44s frames %d, with a differing pixel: %d%s" % (os.path.basename(path) + " (raytracer)", N, bad, "" if bad == 0 else "   <-- DIFFERENT"))
+
+
 def one(path, N):
     import numpy as np
     import torch
     import shaderbox_amd
     if "libsbx_v_pl_" in os.path.basename(path):
         return one_planet(path, max(20, N // 3))
+    if "libsbx_v_rt_" in os.path.basename(path):
+        return one_raytracer(path, max(20, N // 3))
     if path != "base":
         shaderbox_amd.LIB_PATH = path
     R = shaderbox_amd.Renderer(0)
@@ -85,6 +113,9 @@ if __name__ == "__main__":
     if "--one-planet" in args:
         one_planet(args[args.index("--one-planet") + 1], N)
         sys.exit(0)
+    if "--one-raytracer" in args:
+        one_raytracer(args[args.index("--one-raytracer") + 1], N)
+        sys.exit(0)
     names = [a for a in args if not a.startswith("--") and not a.isdigit()]
     paths = ["base"] + [os.path.join(ROOT, "build", "ab", "libsbx_%s.so" % n) for n in names]
     if "--all" in args:
@@ -92,6 +123,8 @@ if __name__ == "__main__":
     if "--all" in args:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-planet", "base", "--frames", str(max(20, N // 3))], capture_output=True, text=True)
         print(([l for l in r.stdout.splitlines() if "frames" in l] or ["base (planet) FAILED: " + r.stderr[-300:]])[-1])
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-raytracer", "base", "--frames", str(max(20, N // 3))], capture_output=True, text=True)
+        print(([l for l in r.stdout.splitlines() if "frames" in l] or ["base (raytracer) FAILED: " + r.stderr[-300:]])[-1])
     for p in paths:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", p, "--frames", str(N)], capture_output=True, text=True)
         out = [l for l in r.stdout.splitlines() if "frames" in l]
