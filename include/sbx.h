@@ -145,6 +145,17 @@ void sbx_destroy(sbx_ctx* ctx);
  * This is the replacement of "for every pixel: mainImage(fragColor, fragCoord)". */
 int sbx_render_rows(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
                     int y0, int y1, float* rgba, void* stream);
+/* The same rows for a host that owns a HOST framebuffer (SURVEY.md 8b "Entry signature": rgba_device_or_host; the reference's
+ * harness loops mainImage over a host surface, src/main.h:6-53): `rgba_host` is host memory for row y0, 4-byte aligned, in the
+ * context's output format (16 or 4 bytes per pixel).  The rows are rendered into a staging buffer of the context, behind whatever
+ * `stream` holds, and copied out; returns when all pixels are in `rgba_host`.  Pinned memory (hipHostMalloc / hipHostRegister): up to
+ * sixteen strips, each copied at the link's rate while the next ones render (CLOUDS 4K 3.55 ms for a 2.7 ms kernel at these clocks
+ * + 2.3 ms of copy; an 8K frame 10 ms for 9.3 ms of copy).
+ * Pageable memory: one strip, one synchronous copy.  Not capturable; one caller per context.
+ * (sbx_render_rows itself accepts any DEVICE-ACCESSIBLE pointer: handed pinned host memory, the kernel's own stores cross PCIe —
+ * no staging, one launch; profiles/r05_host_boundary.txt has both.) */
+int sbx_render_rows_host(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux,
+                         int y0, int y1, void* rgba_host, void* stream);
 
 /* The reference's own per-pixel entry, for hosts that keep their pixel loop:
  *     void mainImage(out vec4 fragColor, in vec2 fragCoord)            src/main.h:6-9

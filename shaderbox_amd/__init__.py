@@ -119,6 +119,7 @@ def load_library(path=None):
     lib.sbx_destroy.argtypes = [vp]
     lib.sbx_destroy.restype = None
     lib.sbx_render_rows.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, fp, vp]
+    lib.sbx_render_rows_host.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, vp, vp]
     lib.sbx_render_rank.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, fp, vp]
     lib.sbx_pack_unorm8.argtypes = [vp, ci, ci, fp, vp, ci, vp]
     lib.sbx_set_output_format.argtypes = [vp, ci]
@@ -390,6 +391,24 @@ class Renderer:
         self._check(self.lib.sbx_render_rows(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), y0, y1,
                                              ctypes.c_void_p(buf.data_ptr()), self._stream()))
         return buf
+
+    def render_to_host(self, app, width, height, time, out, mouse=(0.0, 0.0), aux=None, rows=None):
+        """sbx_render_rows_host: rows [y0, y1) (default: the whole frame) into HOST memory `out` — a C-contiguous numpy array or CPU
+        torch tensor (pinned or not) of rows x width x 4 float32 (uint8 with the RGBA8 format); returns `out` when the pixels are
+        there (strips are copied out while the next ones render)."""
+        y0, y1 = (0, int(height)) if rows is None else (int(rows[0]), int(rows[1]))
+        u = self.uniforms(width, height, time, mouse)
+        n = max(y1 - y0, 0) * int(width) * 4
+        if hasattr(out, "data_ptr"):
+            assert not out.is_cuda and out.is_contiguous() and out.numel() >= n and out.dtype == (self.torch.uint8 if self.rgba8 else self.torch.float32)
+            ptr = out.data_ptr()
+        else:
+            import numpy as np
+            assert out.flags["C_CONTIGUOUS"] and out.size >= n and out.dtype == (np.uint8 if self.rgba8 else np.float32)
+            ptr = out.ctypes.data
+        self._check(self.lib.sbx_render_rows_host(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), y0, y1,
+                                                  ctypes.c_void_p(ptr), self._stream()))
+        return out
 
     def render_rank(self, app, width, height, time, block_rows, rank, nranks, mouse=(0.0, 0.0), aux=None, out=None,
                     root_rounds=1, rounds=1):

@@ -344,3 +344,55 @@ def test_raytracer_axis_pair_walls_equal_the_six_plane_loop(renderer, oracle):
                 assert np.array_equal(a.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (w, h, t, mouse)
     finally:
         renderer.set_variant(0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host framebuffers (include/sbx.h sbx_render_rows_host; SURVEY.md 8b "rgba_device_or_host")
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("app,w,h,rows", [("clouds", 640, 360, None), ("egg", 333, 517, None), ("raytracer", 1280, 720, (100, 613)),
+                                          ("atmosphere", 500, 255, (3, 4)), ("planet", 300, 1031, None)])
+def test_render_rows_into_host_memory_equals_the_device_frame(renderer, app, w, h, rows):
+    """sbx_render_rows_host — strips rendered into the context's staging buffer and copied out while the next one renders — into
+    pageable (numpy) and pinned (torch) host memory: the same bits as sbx_render_rows' device frame; odd sizes, row ranges that are
+    not multiples of the strip height, one-row strips"""
+    import torch
+    dev = renderer.render(app, w, h, 0.37, rows=rows).cpu()
+    n = dev.shape[0]
+    pageable = np.full((n, w, 4), -7.0, dtype=np.float32)
+    renderer.render_to_host(app, w, h, 0.37, pageable, rows=rows)
+    pinned = torch.full((n, w, 4), -7.0, dtype=torch.float32).pin_memory()
+    renderer.render_to_host(app, w, h, 0.37, pinned, rows=rows)
+    assert np.array_equal(pageable.view(np.uint32), dev.numpy().view(np.uint32))
+    assert bits_differ(pinned, dev) == 0
+    # an unaligned host pointer (4-byte aligned only) is fine for a host frame
+    raw = np.zeros(n * w * 4 + 1, dtype=np.float32)
+    renderer.render_to_host(app, w, h, 0.37, raw[1:], rows=rows)
+    assert np.array_equal(raw[1:].view(np.uint32).reshape(n, w, 4), dev.numpy().view(np.uint32))
+
+
+def test_render_rows_into_host_memory_rgba8_and_errors(renderer):
+    import shaderbox_amd
+    import torch
+    r8 = shaderbox_amd.Renderer(0)
+    try:
+        r8.set_output_format("rgba8")
+        dev = r8.render("clouds", 640, 360, 1.5).cpu()
+        host = np.zeros((360, 640, 4), dtype=np.uint8)
+        r8.render_to_host("clouds", 640, 360, 1.5, host)
+        assert np.array_equal(host, dev.numpy())
+    finally:
+        r8.close()
+    with pytest.raises(shaderbox_amd.SbxError):
+        renderer.render_to_host("clouds", 64, 36, 0.0, np.zeros((36, 64, 4), dtype=np.float32), rows=(10, 40))
+    u = renderer.uniforms(64, 36, 0.0)
+    import ctypes
+    assert renderer.lib.sbx_render_rows_host(renderer.ctx, 1, ctypes.byref(u), None, 0, 36, None, None) == shaderbox_amd.SBX_ERR_ARG
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    host = torch.zeros((36, 64, 4)).pin_memory()
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        rc = renderer.lib.sbx_render_rows_host(renderer.ctx, 1, ctypes.byref(u), None, 0, 36, ctypes.c_void_p(host.data_ptr()),
+                                               ctypes.c_void_p(s.cuda_stream))
+        g.capture_end()
+    assert rc == shaderbox_amd.SBX_ERR_ARG and b"captured" in renderer.lib.sbx_last_error(renderer.ctx)

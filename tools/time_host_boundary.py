@@ -6,6 +6,7 @@ frame left in HBM (the C ABI's sbx_render* write device memory); this is the PCI
 
     python tools/time_host_boundary.py [--configs clouds:3840x2160,...] [--reps 6]"""
 import argparse
+import ctypes
 import os
 import sys
 import time
@@ -51,12 +52,35 @@ for cfg in a.configs.split(","):
         host.copy_(frame, non_blocking=True)
         torch.cuda.synchronize()
         c.append((time.perf_counter() - t0) * 1e3)
+    h, hp = [], []
+    pageable = torch.empty((H, W, 4), dtype=torch.float32)
+    for _ in range(6):                                            # sbx_render_rows_host: strips copied out while the next ones render
+        t0 = time.perf_counter()
+        R.render_to_host(app, W, H, .37, host)
+        h.append((time.perf_counter() - t0) * 1e3)
+    for _ in range(3):
+        t0 = time.perf_counter()
+        R.render_to_host(app, W, H, .37, pageable)
+        hp.append((time.perf_counter() - t0) * 1e3)
+    z = []
+    u = R.uniforms(W, H, .37)
+    for _ in range(6):                                            # sbx_render_rows handed the pinned frame: the kernel's stores cross PCIe
+        t0 = time.perf_counter()
+        R._check(R.lib.sbx_render_rows(R.ctx, shaderbox_amd.app_id(app), ctypes.byref(u), None, 0, H, ctypes.c_void_p(host.data_ptr()), None))
+        torch.cuda.synchronize()
+        z.append((time.perf_counter() - t0) * 1e3)
+    z.sort()
+    zm = z[len(z) // 2]
+    h.sort(); hp.sort()
+    hm, hpm = h[len(h) // 2], hp[len(hp) // 2]
     miss.sort(); k.sort(); c.sort()
     m, km, cm = miss[len(miss) // 2], k[len(k) // 2], c[len(c) // 2]
     mb = W * H * 16 / 1e6
     print("%-10s %dx%d  sbx_main_image miss (launch + %.0f MB to pinned host) %.3f ms = %.0f Mpixels/s host-visible | kernel alone %.3f ms "
-          "(%.0f Mpixels/s) | copy alone %.3f ms (%.1f GB/s) | hit %.2f us per call through ctypes"
-          % (app, W, H, mb, m, W * H / m / 1e3, km, W * H / km / 1e3, cm, mb / cm, hit_us))
-    del frame, host
+          "(%.0f Mpixels/s) | copy alone %.3f ms (%.1f GB/s) | hit %.2f us per call through ctypes | "
+          "sbx_render_rows_host into pinned memory %.3f ms = %.0f Mpixels/s, into pageable memory %.3f ms = %.0f Mpixels/s | "
+          "sbx_render_rows storing straight into the pinned frame %.3f ms"
+          % (app, W, H, mb, m, W * H / m / 1e3, km, W * H / km / 1e3, cm, mb / cm, hit_us, hm, W * H / hm / 1e3, hpm, W * H / hpm / 1e3, zm))
+    del frame, host, pageable
     torch.cuda.empty_cache()
 R.close()
