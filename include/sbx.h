@@ -163,7 +163,7 @@ int sbx_render_rows_host(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
  * by u_res (main.h:40) and never snaps or clamps it — and so is this call:
  *   - fragCoord = the centre (x + .5, y + .5) of a pixel of the frame (y = 0 at the bottom row) and u_res whole numbers: the
  *     first call for a given (app, uniforms, aux) renders the whole frame on the GPU with one launch and brings it to pinned
- *     host memory with one asynchronous copy; later calls read their pixel from it;
+ *     host memory — the kernel's own stores cross PCIe, no copy follows it; later calls read their pixel from it;
  *   - ANY other fragCoord (off-centre: a supersampling host; outside the frame; a fractional u_res): evaluated exactly at that
  *     coordinate by a one-point launch (sbx_main_image_batch with n = 1) — never another pixel's sample.
  * Safe to call from several host threads on one context (serialised inside); hosts with many samples per frame should use

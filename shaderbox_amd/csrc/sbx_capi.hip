@@ -85,8 +85,6 @@ struct sbx_ctx {
     };
     MiEntry mi[MI_FRAMES];
     uint64_t mi_clock = 0;
-    float* mi_dev = nullptr;
-    size_t mi_floats = 0;
     std::vector<float*> mi_retired;              // pinned buffers outgrown by a larger frame: a reader may still be inside one, so
                                                  // they outlive the resize (the oldest goes when eight are waiting; all at destroy)
     // sbx_get_stats; the hit counter is striped over cache lines (it is bumped once per pixel by every host thread)
@@ -476,7 +474,6 @@ void sbx_destroy(sbx_ctx* ctx) {
     if (ctx->ytab) (void)hipFree(ctx->ytab);
     if (ctx->ytab_big) (void)hipFree(ctx->ytab_big);
     if (ctx->have_ytab_big_event) (void)hipEventDestroy(ctx->ytab_big_ready);
-    if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
     for (auto& en : ctx->mi) if (en.host.load()) (void)hipHostFree(en.host.load());
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_dev) (void)hipFree(ctx->pt_dev);
@@ -934,12 +931,6 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
     std::atomic_thread_fence(std::memory_order_release);
     for (auto& w : en->key) w.store(0xffffffffu, std::memory_order_relaxed);     // (no frame has app = -1)
     en->used = false;
-    if (n > ctx->mi_floats) {
-        if (ctx->mi_dev) (void)hipFree(ctx->mi_dev);
-        ctx->mi_dev = nullptr; ctx->mi_floats = 0;
-        if ((e = hipMalloc((void**)&ctx->mi_dev, n * sizeof(float))) != hipSuccess) { en->gen.store(g0 + 2, std::memory_order_release); return fail(ctx, SBX_ERR_HIP, "hipMalloc", e); }
-        ctx->mi_floats = n;
-    }
     if (n > en->cap_floats) {
         float* fresh = nullptr;
         if ((e = hipHostMalloc((void**)&fresh, n * sizeof(float), hipHostMallocDefault)) != hipSuccess) { en->gen.store(g0 + 2, std::memory_order_release); return fail(ctx, SBX_ERR_HIP, "hipHostMalloc", e); }
@@ -951,13 +942,15 @@ int sbx_main_image(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* a
         en->cap_floats = n;
     }
     float* host = en->host.load(std::memory_order_relaxed);
-    const int rc = render_rows(ctx, app, uni, aux, 0, H, ctx->mi_dev, nullptr, true);     // (the cache holds float pixels whatever the context's output format)
+    // The kernel stores STRAIGHT into the pinned frame (hipHostMalloc memory is device-accessible at its host address): one launch,
+    // no device copy of the frame, no transfer behind it — the stores cross PCIe while the rest of the frame is computed (CLOUDS 4K
+    // 3.6 ms against 5.1 for launch + copy, PLANET 8K 12.2 against 15.8; profiles/r05_host_boundary.txt).  (The cache holds float
+    // pixels whatever the context's output format.)
+    const int rc = render_rows(ctx, app, uni, aux, 0, H, host, nullptr, true);
     if (rc != SBX_OK) { en->gen.store(g0 + 2, std::memory_order_release); return rc; }
-    // pinned destination: one DMA transfer at the link's rate behind the kernel, then one wait
-    if ((e = hipMemcpyAsync(host, ctx->mi_dev, n * sizeof(float), hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
-        (e = hipStreamSynchronize(nullptr)) != hipSuccess) {
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) {
         en->gen.store(g0 + 2, std::memory_order_release);
-        return fail(ctx, SBX_ERR_HIP, "frame copy", e);
+        return fail(ctx, SBX_ERR_HIP, "frame render", e);
     }
     ctx->st_frames.fetch_add(1, std::memory_order_relaxed);
     for (int i = 0; i < sbx_ctx::MI_KEY_WORDS; ++i) en->key[i].store(key[i], std::memory_order_relaxed);

@@ -205,7 +205,7 @@ def test_model_landing_copies_at_the_stated_pace(renderer):
 # ---------------------------------------------------------------------------------------------------------
 def test_sixteen_host_threads_share_one_launch(tmp_path):
     """host/mainimage_threads.cpp: 16 threads loop mainImage() over disjoint rows of one 1920x1080 frame through
-    include/sbx_mainimage.hpp; the program itself asserts ONE render launch, ONE frame copy, 2 W*H - 1 cache hits over its two passes (the second one
+    include/sbx_mainimage.hpp; the program itself asserts ONE render launch, ONE cached frame, 2 W*H - 1 cache hits over its two passes (the second one
     times the hits alone) and bit-equality with sbx_render_rows"""
     host = os.path.join(ROOT, "host")
     subprocess.run(["make", "-s", "-C", host, "mainimage_threads", "APP=-DAPP_EGG"], check=True)

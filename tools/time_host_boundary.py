@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The HOST-visible rate of the per-pixel drop-in (run on the GPU box): what sbx_main_image costs when the frame is not cached — one
-launch plus one asynchronous copy of the whole RGBA32F frame into pinned host memory (16 B/pixel over PCIe) — for the BASELINE
+launch whose stores go straight into the cache's pinned host frame (16 B/pixel over PCIe; until round 5: launch + copy) — for the BASELINE
 frames, beside the kernel alone and beside a plain device-to-pinned copy of the same bytes.  bench.py's `value` is measured with the
 frame left in HBM (the C ABI's sbx_render* write device memory); this is the PCIe-inclusive figure DESIGN.md §1 quotes.
 
@@ -76,7 +76,7 @@ for cfg in a.configs.split(","):
     miss.sort(); k.sort(); c.sort()
     m, km, cm = miss[len(miss) // 2], k[len(k) // 2], c[len(c) // 2]
     mb = W * H * 16 / 1e6
-    print("%-10s %dx%d  sbx_main_image miss (launch + %.0f MB to pinned host) %.3f ms = %.0f Mpixels/s host-visible | kernel alone %.3f ms "
+    print("%-10s %dx%d  sbx_main_image miss (one launch storing %.0f MB into the pinned frame) %.3f ms = %.0f Mpixels/s host-visible | kernel alone %.3f ms "
           "(%.0f Mpixels/s) | copy alone %.3f ms (%.1f GB/s) | hit %.2f us per call through ctypes | "
           "sbx_render_rows_host into pinned memory %.3f ms = %.0f Mpixels/s, into pageable memory %.3f ms = %.0f Mpixels/s | "
           "sbx_render_rows storing straight into the pinned frame %.3f ms"
