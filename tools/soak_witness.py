@@ -2,7 +2,7 @@
 """Run on the GPU box: the recorded-domain kernels (csrc/sbx_witness.h: EGG, SDF_AO, VINYL, VINYL_GPU, RAYTRACER) against the SAME
 kernels with the IEEE forms only (sbx_set_variant 3) on N random (u_time, u_mouse) frames at 3840x2160 and at an odd size whose
 centre column has fragCoord.x == u_res.x / 2 (a zero component in the primary direction: the record fires there) — every pixel,
-bit for bit.     python tools/soak_witness.py [frames per app = 200]"""
+bit for bit.     python tools/soak_witness.py [frames per app = 200] [app,app,...]"""
 import sys
 
 import numpy as np
@@ -15,7 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(2024)
 R = shaderbox_amd.Renderer(0)
 total_bad = 0
-for app in ("egg", "raytracer", "sdf_ao", "vinyl", "vinyl_gpu"):
+for app in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("egg", "raytracer", "sdf_ao", "vinyl", "vinyl_gpu")):
     bad = 0
     pixels = 0
     for i in range(n):
