@@ -91,8 +91,8 @@ struct sbx_ctx {
     struct alignas(64) Stripe { std::atomic<uint64_t> n{0}; };
     Stripe st_hits[16];
     std::atomic<uint64_t> st_launches{0}, st_frames{0}, st_points{0};
-    // sbx_main_image_batch / off-centre sbx_main_image: staging of a point list (device: 2 + 4 floats per point; host: pinned)
-    float* pt_dev = nullptr;
+    // sbx_main_image_batch / off-centre sbx_main_image: pinned staging of a point list (4 + 2 floats per point), read and written by
+    // the kernel where it lies
     float* pt_host = nullptr;
     size_t pt_cap = 0;
     // sbx_render_rows_host: device staging of a host frame, the stream its strips are copied out on, one event per strip
@@ -476,7 +476,6 @@ void sbx_destroy(sbx_ctx* ctx) {
     if (ctx->have_ytab_big_event) (void)hipEventDestroy(ctx->ytab_big_ready);
     for (auto& en : ctx->mi) if (en.host.load()) (void)hipHostFree(en.host.load());
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
-    if (ctx->pt_dev) (void)hipFree(ctx->pt_dev);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
     if (ctx->hs_dev) (void)hipFree(ctx->hs_dev);
     if (ctx->hs_copy) (void)hipStreamDestroy(ctx->hs_copy);
@@ -809,11 +808,9 @@ static int stage_points(sbx_ctx* ctx, size_t n) {
     if (n <= ctx->pt_cap) return SBX_OK;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
-    if (ctx->pt_dev) (void)hipFree(ctx->pt_dev);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
-    ctx->pt_dev = nullptr; ctx->pt_host = nullptr; ctx->pt_cap = 0;
+    ctx->pt_host = nullptr; ctx->pt_cap = 0;
     const size_t cap = n < 1024 ? 1024 : n;
-    if ((e = hipMalloc((void**)&ctx->pt_dev, cap * 6 * sizeof(float))) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc", e);
     if ((e = hipHostMalloc((void**)&ctx->pt_host, cap * 6 * sizeof(float), hipHostMallocDefault)) != hipSuccess)
         return fail(ctx, SBX_ERR_HIP, "hipHostMalloc", e);
     ctx->pt_cap = cap;
@@ -825,17 +822,14 @@ static int main_image_points(sbx_ctx* ctx, int app, const sbx_uniforms* uni, con
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
     int rc = stage_points(ctx, n);
     if (rc != SBX_OK) return rc;
-    // layout of both staging buffers: the n colours (16-byte aligned) first, then the n coordinates
+    // The pinned staging buffer is device-accessible at its host address: the kernel reads the coordinates from it and stores the
+    // colours into it — one launch, one wait, no transfer before or after (round 5; until then H2D copy + launch + D2H copy).
+    // Layout: the n colours (16-byte aligned) first, then the n coordinates.
     float* hcol = ctx->pt_host; float* hfrag = ctx->pt_host + 4 * ctx->pt_cap;
-    float* dcol = ctx->pt_dev;  float* dfrag = ctx->pt_dev + 4 * ctx->pt_cap;
     std::memcpy(hfrag, frag, n * 2 * sizeof(float));
-    if ((e = hipMemcpyAsync(dfrag, hfrag, n * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr)) != hipSuccess)
-        return fail(ctx, SBX_ERR_HIP, "hipMemcpyAsync", e);
-    rc = sbx_render_points(ctx, app, uni, aux, n, dfrag, dcol, nullptr);
+    rc = sbx_render_points(ctx, app, uni, aux, n, hfrag, hcol, nullptr);
     if (rc != SBX_OK) return rc;
-    if ((e = hipMemcpyAsync(hcol, dcol, n * 4 * sizeof(float), hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
-        (e = hipStreamSynchronize(nullptr)) != hipSuccess)
-        return fail(ctx, SBX_ERR_HIP, "point list copy", e);
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "point list launch", e);
     std::memcpy(colors, hcol, n * 4 * sizeof(float));
     return SBX_OK;
 }
