@@ -470,18 +470,19 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def prepare(exchange):
+    def prepare(exchange, channels=None):
         """relief (calibrated on rank 0 for THIS exchange), payload, pieces and the ranks' plans"""
-        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, exchange, args.channels)
+        channels = args.channels if channels is None else channels
+        relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, exchange, channels)
         payload = 0
         if world > 1:
             if exchange in ("spans", "span_stores"):
-                payload = (16 if (exchange == "span_stores" and args.channels == 4) else 12) * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
+                payload = (16 if (exchange == "span_stores" and channels == 4) else 12) * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
             else:
-                payload = (12 if (exchange in ("direct", "stores") and args.channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
+                payload = (12 if (exchange in ("direct", "stores") and channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
         groups = auto_groups(args.gather_groups, payload)
         plans = [FramePlan(R, fdist, W, H, br, groups=groups, root_rounds=relief[0], rounds=relief[1], exchange=exchange,
-                           channels=args.channels) for _ in range(ns)]
+                           channels=channels) for _ in range(ns)]
         return relief, payload, groups, plans
 
     # `--exchange auto` (default): the store exchange costs the root nothing but puts every pixel store on a link; the span exchange
@@ -503,17 +504,21 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=COLL_DEV or dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return bool(flag.item())
-        for ex in ("stores", "span_stores", "spans", "direct"):
+        # The store forms are tried with 12-byte stores (R, G, B of every float4 pixel: fewest bytes) AND with whole 16-byte pixels:
+        # a link may take partial-line stores far below its rate — PCIe does, 11.9 against 51.8 GB/s (tools/time_link_stores.py,
+        # profiles/r05_link_stores.txt) — and then the 16-byte form wins although it carries a third more.
+        for ex, ch in (("stores", 3), ("stores", 4), ("span_stores", 3), ("span_stores", 4), ("spans", None), ("direct", None)):
+            name = ex if ch in (None, 3) else ex + "_16B"
             # A form that cannot be set up on these devices (the store exchange needs HIP IPC and peer mapping), that faults, or
             # whose frame differs from one launch is DROPPED, on every rank alike, and the line says so: the trial must never
             # take the run down with it.
             cand, why = None, None
             try:
-                cand = prepare(ex)
+                cand = prepare(ex, ch)
             except Exception as e:                       # noqa: BLE001
                 why = "set-up failed on rank %d: %s: %s" % (rank, type(e).__name__, str(e)[:200])
             if not agreed(cand is not None):
-                trials[ex] = "unavailable (%s)" % (why or "set-up failed on another rank")
+                trials[name] = "unavailable (%s)" % (why or "set-up failed on another rank")
                 cand = None
                 torch.cuda.empty_cache()
                 continue
@@ -545,7 +550,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
             except Exception as e:                       # noqa: BLE001
                 why = "%s: %s" % (type(e).__name__, str(e)[:200])
             if not agreed(why is None):
-                trials[ex] = "dropped (%s)" % (why or "failed on another rank")
+                trials[name] = "dropped (%s)" % (why or "failed on another rank")
                 try:
                     torch.cuda.synchronize(dev)
                     if R.fault_status() != 0:
@@ -557,15 +562,17 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
                 continue
             dt = torch.tensor([ms], dtype=torch.float64, device=COLL_DEV or dev)
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            trials[ex] = round(float(dt.item()), 4)
-            if best is None or trials[ex] < best[0]:
-                best = (trials[ex], ex, cand)
+            trials[name] = round(float(dt.item()), 4)
+            if best is None or trials[name] < best[0]:
+                best = (trials[name], ex, cand, ch)
             del cand, cplans
             torch.cuda.empty_cache()
         if best is None:
             raise SystemExit("no exchange form could be set up on these ranks: %s" % trials)
         exchange = best[1]
         relief, payload, groups, plans = best[2]
+        if best[3] is not None:
+            args.channels = best[3]                      # (what the rest of the run and the line's text say)
         best = None
 
     def step(i=0):

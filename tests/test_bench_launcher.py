@@ -135,7 +135,7 @@ def test_bench_whole_multi_rank_program_on_one_gpu(n, exchange):
     assert line["n_gpus"] == n and "gloo" in line["backend"]
     if exchange == "auto":                 # every form tried on the ranks (the store exchange through HIP IPC between the processes), the fastest runs
         assert line["exchange"]["kind"] in ("stores", "span_stores", "spans", "direct") and "measured on these ranks" in line["exchange"]["chosen"]
-        assert all(k in line["exchange"]["chosen"] for k in ("stores", "span_stores", "spans", "direct"))
+        assert all(k in line["exchange"]["chosen"] for k in ("stores", "stores_16B", "span_stores", "span_stores_16B", "spans", "direct"))
     else:
         assert line["exchange"]["kind"] == exchange
     assert line["parity"]["mismatching_pixels"] == 0 and line["parity"]["rows"] == 540
