@@ -499,6 +499,15 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         relief, payload, groups, plans = prepare(exchange)
     else:
         trials, best = {}, None
+        # the clocks first (VERDICT r4 Weak #6: ~25 ms of launches until DVFS holds its clock) — or the form tried first pays for the
+        # ramp: 4.8 against 2.5 ms per frame for the same work in a 2-process run on one GPU
+        t_pre = time.perf_counter()
+        scratch_pre = R.empty((H, W, 4))
+        while (time.perf_counter() - t_pre) * 1e3 < max(args.preroll_ms, 40.0):
+            for _ in range(4):
+                R.render(app, W, H, t, out=scratch_pre)
+            torch.cuda.synchronize(dev)
+        del scratch_pre
 
         def agreed(ok):                                  # every rank's verdict on a step of a trial: all of them, or none
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=COLL_DEV or dev)
@@ -507,8 +516,14 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         # The store forms are tried with 12-byte stores (R, G, B of every float4 pixel: fewest bytes) AND with whole 16-byte pixels:
         # a link may take partial-line stores far below its rate — PCIe does, 11.9 against 51.8 GB/s (tools/time_link_stores.py,
         # profiles/r05_link_stores.txt) — and then the 16-byte form wins although it carries a third more.
-        for ex, ch in (("stores", 3), ("stores", 4), ("span_stores", 3), ("span_stores", 4), ("spans", None), ("direct", None)):
+        # (The form tried FIRST reads slow whatever it is — 4.7-11.5 ms per frame against 2.5 for the same work one trial later, in
+        # 2-process runs on one GPU, pre-roll or not: first use of the mappings and of two processes' queues — so the first form is
+        # tried twice and its first reading is thrown away.)
+        for k_trial, (ex, ch) in enumerate((("stores", 3), ("stores", 3), ("stores", 4), ("span_stores", 3), ("span_stores", 4), ("spans", None),
+                                            ("direct", None))):
             name = ex if ch in (None, 3) else ex + "_16B"
+            if k_trial == 0:
+                name = "(first trial, discarded) " + name
             # A form that cannot be set up on these devices (the store exchange needs HIP IPC and peer mapping), that faults, or
             # whose frame differs from one launch is DROPPED, on every rank alike, and the line says so: the trial must never
             # take the run down with it.
@@ -563,7 +578,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
             dt = torch.tensor([ms], dtype=torch.float64, device=COLL_DEV or dev)
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             trials[name] = round(float(dt.item()), 4)
-            if best is None or trials[name] < best[0]:
+            if k_trial > 0 and (best is None or trials[name] < best[0]):
                 best = (trials[name], ex, cand, ch)
             del cand, cplans
             torch.cuda.empty_cache()
