@@ -117,6 +117,10 @@ def test_bench_emulated_ranks_on_one_gpu():
     e = line["emulated"][0]
     assert e["parity"]["mismatching_pixels"] == 0 and len(e["per_rank_ms"]) == 4 and e["modelled_speedup"] > 1.0
     assert e["bytes_moved_per_frame"] > 0 and e["bound"] in ("link", "root", "peer compute")
+    # the store forms are modelled with 12- and with 16-byte pixels; the best form WITHOUT partial-pixel stores is named beside the pick
+    assert all(k in e["exchanges_tried"] for k in ("stores", "stores_16B", "span_stores", "span_stores_16B", "spans", "direct"))
+    wp = e["without_partial_pixel_stores"]
+    assert wp["exchange"] in ("stores_16B", "span_stores_16B", "spans", "direct") and wp["modelled_speedup"] <= e["modelled_speedup"] + 1e-9
 
 
 @pytest.mark.gpu
