@@ -169,12 +169,12 @@ def main():
     ap.add_argument("--gather-groups", default="auto",
                     help="N>1: issue the one exchange in this many pipelined pieces ('auto': one per ~12 MB of a peer's payload, "
                          "so a 4K slab goes out whole and an 8K one in 3 pieces; 1 = one plain exchange)")
-    ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather", "stores", "span_stores"], default="auto",
-                    help="N>1 (engine dist): 'auto' (default) = try 'stores', 'span_stores', 'spans' and 'direct' on the ranks at hand (a few "
+    ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather", "stores", "span_stores", "packed_stores"], default="auto",
+                    help="N>1 (engine dist): 'auto' (default) = try 'stores' and 'span_stores' (12- and 16-byte pixels), 'packed_stores', 'spans' and 'direct' on the ranks at hand (a few "
                          "pipelined frames each) and run the fastest; 'span_stores' = 'stores' with only the SPANS of the peers' row-blocks "
                          "stored in place, the root renders the rest (fewer bytes on the links: 30 instead of 50 MB per peer at 7680x4320); 'stores' = the peers map the root's frame (HIP IPC) and render their row-blocks IN PLACE "
                          "into it: the exchange is their own pixel stores over xGMI (12 bytes per pixel with --channels 3), the root lands, "
-                         "receives and scatters nothing (distributed.py, include/sbx.h sbx_shared_*); 'spans' = only the expensive interval of every row-block is dealt to the peers and "
+                         "receives and scatters nothing (distributed.py, include/sbx.h sbx_shared_*); 'packed_stores' = the span exchange with the peers' own stores as transport: packed spans (12 contiguous bytes per pixel) straight into the root's mapped landing area, the root scatters; 'spans' = only the expensive interval of every row-block is dealt to the peers and "
                          "sent, the root renders the rest in place (distributed.py; config 5's 49.8 MB per peer become 29.7 MB); "
                          "'direct' = the root renders its blocks in place and receives the peers' whole slabs by ONE grouped "
                          "send/recv; 'gather' = dist.gather of equal RGBA slabs + assembly of all of them (round 1)")
@@ -443,7 +443,7 @@ def auto_groups(spec, payload_bytes_per_peer):
 def rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, exchange):
     """pixels the launch(es) of `rank` render per frame"""
     from shaderbox_amd import shard
-    if exchange not in ("spans", "span_stores") or world == 1:
+    if exchange not in ("spans", "span_stores", "packed_stores") or world == 1:
         return shard.rank_rows(H, br, rank, world, relief[0], relief[1]) * W
     table, pix, _ = R.span_table(app, W, H, t, br, world, relief[0], relief[1])
     if rank > 0:
@@ -476,7 +476,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, exchange, channels)
         payload = 0
         if world > 1:
-            if exchange in ("spans", "span_stores"):
+            if exchange in ("spans", "span_stores", "packed_stores"):
                 payload = (16 if (exchange == "span_stores" and channels == 4) else 12) * int(max(R.span_table(app, W, H, t, br, world, relief[0], relief[1])[1][1:]))
             else:
                 payload = (12 if (exchange in ("direct", "stores") and channels == 3) else 16) * W * shard.rank_rows_max(H, br, world, *relief)
@@ -519,8 +519,8 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         # (The form tried FIRST reads slow whatever it is — 4.7-11.5 ms per frame against 2.5 for the same work one trial later, in
         # 2-process runs on one GPU, pre-roll or not: first use of the mappings and of two processes' queues — so the first form is
         # tried twice and its first reading is thrown away.)
-        for k_trial, (ex, ch) in enumerate((("stores", 3), ("stores", 3), ("stores", 4), ("span_stores", 3), ("span_stores", 4), ("spans", None),
-                                            ("direct", None))):
+        for k_trial, (ex, ch) in enumerate((("stores", 3), ("stores", 3), ("stores", 4), ("span_stores", 3), ("span_stores", 4), ("packed_stores", None),
+                                            ("spans", None), ("direct", None))):
             name = ex if ch in (None, 3) else ex + "_16B"
             if k_trial == 0:
                 name = "(first trial, discarded) " + name
@@ -612,7 +612,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     frame0 = plans[0].frame
     scratch = None
     for _ in range(min(max(steps, 3), 8)):
-        if exchange in ("spans", "span_stores") and world > 1:
+        if exchange in ("spans", "span_stores", "packed_stores") and world > 1:
             if rank == 0:
                 R.render_span_root(app, W, H, t, br, world, frame0, root_rounds=relief[0], rounds=relief[1])
             elif exchange == "span_stores":             # (in place into the owner's frame: the same pixels it holds already)
@@ -678,7 +678,7 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
         tried = {}
         # (the store forms with 12- and with 16-byte pixels, as the ranks of a node try them: a link that takes partial-pixel stores
         # below its rate — PCIe does, profiles/r05_link_stores.txt — makes the 16-byte reading the one that counts)
-        forms = ((("stores", 3), ("stores", 4), ("span_stores", 3), ("span_stores", 4), ("spans", None), ("direct", None))
+        forms = ((("stores", 3), ("stores", 4), ("span_stores", 3), ("span_stores", 4), ("packed_stores", None), ("spans", None), ("direct", None))
                  if args.exchange == "auto" else ((args.exchange, None),))
         pick16 = None
         for ex, chx in forms:
@@ -688,7 +688,7 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
             R.set_timing(False)
             ranks_ms = [emulated_frame_ms(R, torch, dev, streams, frames, a, w, h, t, br, n, r, relief[0], relief[1], ex, ch, per_frame)
                         for r in range(n)]
-            if ex in ("spans", "span_stores"):
+            if ex in ("spans", "span_stores", "packed_stores"):
                 pix = R.span_table(a, w, h, t, br, n, relief[0], relief[1])[1]
                 payload = (4 if R.rgba8 else (16 if (ex == "span_stores" and ch == 4) else 12)) * int(max(pix[1:]))
             else:
@@ -758,7 +758,7 @@ def dist_line(res, args, app, W, H, t, world):
     if roofline is not None:
         roofline["rank"] = "slowest (rank %d of the un-overlapped launches %s ms; %d pixels)" % (res["slowest_rank"], res["per_rank_launch_ms"],
                                                                                               res["launch_pixels"])
-        if res["exchange"] in ("spans", "span_stores") and world > 1 and roofline.get("frac") is not None:
+        if res["exchange"] in ("spans", "span_stores", "packed_stores") and world > 1 and roofline.get("frac") is not None:
             roofline["frac_is"] += ("; NOTE a span launch renders mostly the frame's EXPENSIVE pixels, so the frame-average instruction "
                                     "count per pixel understates its work: read this frac as a lower bound")
     ph = res["phases"]
@@ -770,6 +770,9 @@ def dist_line(res, args, app, W, H, t, world):
             "span_stores": "the peers' own %d-byte pixel stores of the SPANS of their row-blocks into the root's frame, mapped through HIP IPC "
                            "(the root renders its blocks and everything outside the spans; no RCCL call, no landing area, no scatter)"
                            % (12 if args.channels == 3 else 16),
+            "packed_stores": "the peers' own stores of the packed 3-channel SPANS of their row-blocks (12 contiguous bytes per pixel) straight "
+                             "into the root's landing area, mapped through HIP IPC; the root renders its blocks and everything outside the "
+                             "spans, then scatters (no RCCL call, no receive kernels on the root)",
             "spans": "1 grouped RCCL send/recv of the peers' packed 3-channel SPANS (the root renders its blocks and everything "
                      "outside the spans in place)"}[res["exchange"]]
     if args.backend != "nccl":
@@ -1352,7 +1355,7 @@ def choose_relief(spec, R, dist, torch, dev, app, W, H, t, br, world, rank, stre
         return (1, 1)                                   # the root does nothing for the others: the plain split, nothing to calibrate
     pick = torch.zeros(2, dtype=torch.int64, device=COLL_DEV or dev)
     if rank == 0:
-        ch = channels if exchange in ("direct", "span_stores") else (3 if exchange == "spans" else 4)
+        ch = channels if exchange in ("direct", "span_stores") else (3 if exchange in ("spans", "packed_stores") else 4)
         st = streams                                    # the loop's own streams (no extra hardware queues)
         nb = max(2, len(st))
         frames = [torch.empty((H, W, 4), dtype=getattr(R, "pixel_dtype", torch.float32), device=dev) for _ in range(nb)]
@@ -1488,6 +1491,38 @@ def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0,
                     p = peers[i % nb]
                     p.begin(1)
                     R.render_rank_in_place(app, W, H, t, br, r, world, p, root_rounds=m0, rounds=m, channels=ch)
+                    p.end(1)
+        try:
+            return per_frame(one)
+        finally:
+            torch.cuda.synchronize(dev)
+            del views
+            for p in peers:
+                p.close()
+            for o in owners:
+                o.close()
+    if exchange == "packed_stores":
+        # the span exchange with the peers' stores as its transport: no landing kernels on the root, the scatter stays
+        _, pix, _ = R.span_table(app, W, H, t, br, world, m0, m)
+        stride = (int(max(pix[1:])) + 63) // 64 * 64
+        land_el = max(world - 1, 1) * max(stride, 1) * epp
+        owners = [R.shared_create(land_el * (1 if pdt == torch.uint8 else 4), 1 if r == 0 else 2) for _ in range(nb)]
+        peers = [R.shared_open(o.export()) for o in owners] if r > 0 else []
+        views = [o.tensor((land_el,)) for o in owners]
+
+        def one(i):
+            with torch.cuda.stream(st[i % len(st)]):
+                o = owners[i % nb]
+                o.begin(0)
+                if r == 0:
+                    R.render_span_root(app, W, H, t, br, world, frames[i % nb], root_rounds=m0, rounds=m)
+                    o.end(0)
+                    R.assemble_spans(app, W, H, t, br, world, views[i % nb], stride, frames[i % nb], root_rounds=m0, rounds=m)
+                else:
+                    p = peers[i % nb]
+                    p.begin(1)
+                    R.render_span_peer(app, W, H, t, br, r, world, 0, 1 << 30, (p, (r - 1) * stride * epp * (1 if pdt == torch.uint8 else 4)),
+                                       root_rounds=m0, rounds=m)
                     p.end(1)
         try:
             return per_frame(one)

@@ -550,10 +550,13 @@ class Renderer:
         device buffer of >= 3 * rank_pixels[rank] floats: the table's offsets are absolute within it; 'rgba8': 4 bytes per
         pixel of a flat uint8 buffer)."""
         u = self.uniforms(width, height, time, mouse)
-        assert self._is_pixels(slab)
+        if isinstance(slab, tuple):                       # (SharedFrame, byte offset): the rank's slab inside the owner's mapped landing area
+            ptr = slab[0].ptr + int(slab[1])
+        else:
+            assert self._is_pixels(slab)
+            ptr = slab.data_ptr()
         self._check(self.lib.sbx_render_span_peer(self.ctx, app_id(app), ctypes.byref(u), self._auxp(aux), block_rows, rank, nranks,
-                                                  root_rounds, rounds, int(r0), int(r1), ctypes.c_void_p(slab.data_ptr()),
-                                                  self._stream()))
+                                                  root_rounds, rounds, int(r0), int(r1), ctypes.c_void_p(ptr), self._stream()))
         return slab
 
     def render_span_root(self, app, width, height, time, block_rows, nranks, frame, mouse=(0.0, 0.0), aux=None, root_rounds=1,

@@ -41,6 +41,11 @@ Two forms of that one exchange (`exchange=`):
 * "span_stores": both ideas together, for frames whose pixel stores would bind a link (7680x4320 in float pixels: 50 MB per peer):
   a peer stores only the SPANS of its row-blocks in place (`sbx_render_span_peer_in_place`), the owner renders its blocks and
   everything outside the spans (`sbx_render_span_root`): 30 MB per peer, no landing, no scatter.
+* "packed_stores": the span exchange with the peers' own stores as its transport.  Storing R, G, B into 16-byte pixels leaves a hole
+  in every pixel, and a link may take such partial stores far below its rate (PCIe: 11.9 against 52 GB/s, profiles/r05_link_stores.txt);
+  a PACKED 3-float slab has no holes (52 GB/s on the same link).  So the owner's LANDING AREA is the shared object: a peer renders its
+  packed spans straight into its stretch of it (`sbx_render_span_peer` on the mapped pointer), the owner waits for the signals and
+  scatters (`sbx_assemble_spans`).  12 contiguous bytes per pixel on the link, no RCCL call, no receive kernels on the owner.
 
 Pixel format: the plan moves whatever pixels its renderer writes.  After `renderer.set_output_format("rgba8")` (include/sbx.h
 SBX_FORMAT_RGBA8: the render kernels write one R8G8B8A8_UNORM word per pixel, the reference hosts' display format) every slab,
@@ -58,9 +63,9 @@ class FramePlan:
 
     def __init__(self, renderer, dist, width, height, block_rows=shard.DEFAULT_BLOCK_ROWS, groups=1, root_rounds=1,
                  rounds=1, exchange="direct", channels=3):
-        if exchange not in ("direct", "gather", "spans", "stores", "span_stores"):
-            raise ValueError("exchange must be 'direct', 'gather', 'spans', 'stores' or 'span_stores'")
-        if exchange == "spans":
+        if exchange not in ("direct", "gather", "spans", "stores", "span_stores", "packed_stores"):
+            raise ValueError("exchange must be 'direct', 'gather', 'spans', 'stores', 'span_stores' or 'packed_stores'")
+        if exchange in ("spans", "packed_stores"):
             channels = 3
         if exchange == "gather":
             channels = 4
@@ -110,7 +115,7 @@ class FramePlan:
                 self.gathered = renderer.empty((self.world, self.rows_max, self.width, 4))
                 self.glists = [[self.gathered[i, a:b] for i in range(self.world)] for a, b in self.ranges]
                 self.frame = renderer.empty((self.height, self.width, 4))
-        elif exchange == "spans":
+        elif exchange in ("spans", "packed_stores"):
             if self.rank == 0:
                 self.frame = renderer.empty((self.height, self.width, 4))
             self._span_key = None        # buffers and descriptors depend on the app's span table: built at the first render
@@ -154,6 +159,34 @@ class FramePlan:
             return at(min(lo, len(blocks))), at(min(hi, len(blocks)))
         d = self.dist
         self.p2p = []
+        if self.exchange == "packed_stores":
+            # the landing area lives in a shared object of the library: the owner creates and exports it, every peer maps it and
+            # will render its packed spans straight into its own stretch of it (collective, like the plan's construction)
+            if self.shared is not None:
+                self.shared.close()
+                self.shared = None
+            total = max(self.world - 1, 1) * max(self.span_stride, 1) * self.span_epp
+            nbytes = total * (1 if self.rgba8 else 4)
+            box = [None]
+            if self.rank == 0:
+                try:
+                    self.shared = self.r.shared_create(nbytes, self.world)
+                    self.peers = self.shared.tensor((total,))
+                    if self.world > 1:
+                        box[0] = self.shared.export()
+                except Exception as e:                                   # noqa: BLE001
+                    box[0] = ("error", "%s: %s" % (type(e).__name__, e))
+                    if self.world <= 1:
+                        raise
+            if self.world > 1:
+                d.broadcast_object_list(box, src=0)
+                if isinstance(box[0], tuple) and box[0] and box[0][0] == "error":
+                    raise RuntimeError("FramePlan(exchange='packed_stores'): rank 0 could not create or export the landing area: %s" % (box[0][1],))
+                if self.rank != 0:
+                    self.shared = self.r.shared_open(box[0])
+                    self.slab = (self.shared, (self.rank - 1) * self.span_stride * self.span_epp * (1 if self.rgba8 else 4))
+            self._span_key = key
+            return
         if self.rank == 0:
             self.peers = self.r.empty((max(self.world - 1, 1) * max(self.span_stride, 1) * self.span_epp,), zero=True)
             for a, b in self.ranges:
@@ -233,6 +266,35 @@ class FramePlan:
             return self.frame
         return None
 
+    def _render_packed_stores(self, app, time, mouse, aux, mark, phase):
+        """the span exchange with the peers' own stores as its transport: a peer renders its packed spans (12 contiguous bytes per
+        pixel: whole lines on the link, unlike 12-byte stores into 16-byte pixels) straight into its stretch of the owner's landing
+        area; the owner renders its blocks and everything outside the spans, waits for the peers' signals and scatters.  No RCCL
+        call and no receive kernels on the owner; one scatter pass more than "span_stores"."""
+        self._span_layout(app, time, mouse, aux)
+        if phase in ("all", "open"):
+            self.shared.begin(self.rank)
+        if phase == "open":
+            return None
+        if self.rank == 0:
+            self.r.render_span_root(app, self.width, self.height, time, self.block_rows, self.world, self.frame, mouse=mouse,
+                                    aux=aux, root_rounds=self.root_rounds, rounds=self.rounds)
+            mark("render")
+            self.shared.end(0)                         # every peer's spans are in the landing area
+            mark("exchange")
+            if self.world > 1:
+                self.r.assemble_spans(app, self.width, self.height, time, self.block_rows, self.world, self.peers,
+                                      self.span_stride, self.frame, mouse=mouse, aux=aux, root_rounds=self.root_rounds,
+                                      rounds=self.rounds)
+            mark("assemble")
+            return self.frame
+        self.r.render_span_peer(app, self.width, self.height, time, self.block_rows, self.rank, self.world, 0, 1 << 30, self.slab,
+                                mouse=mouse, aux=aux, root_rounds=self.root_rounds, rounds=self.rounds)
+        mark("render")
+        self.shared.end(self.rank)
+        mark("exchange")
+        return None
+
     def render(self, app, time, mouse=(0.0, 0.0), aux=None, mark=None, phase="all"):
         """All ranks call this; rank 0 returns the assembled [H, W, 4] frame, the others None.  `mark(name)`, if given, is
         called after the rank's rendering ("render"), after the waits of its exchange ("exchange") and after the root's
@@ -240,6 +302,8 @@ class FramePlan:
         mark = mark or (lambda name: None)
         if self.exchange in ("stores", "span_stores"):
             return self._render_stores(app, time, mouse, aux, mark, phase)
+        if self.exchange == "packed_stores":
+            return self._render_packed_stores(app, time, mouse, aux, mark, phase)
         if self.exchange == "gather":
             return self._render_gather(app, time, mouse, aux, mark)
         if self.exchange == "spans":
@@ -370,7 +434,7 @@ class LoopbackWorld:
         """one frame through all ranks in the order the emulation needs: peers, then the root; returns the root's frame.  (The
         store exchange runs on ONE stream here, so the owner's "frame may be overwritten" has to be enqueued before the peers'
         waits for it: the owner's call is split, FramePlan._render_stores.)"""
-        if plans[0].exchange in ("stores", "span_stores"):
+        if plans[0].exchange in ("stores", "span_stores", "packed_stores"):
             plans[0].render(app, time, phase="open", **kw)
             for p in plans[1:]:
                 p.render(app, time, **kw)

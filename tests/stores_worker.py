@@ -3,7 +3,8 @@ over gloo, rank 0 exports its frames (hipIpcGetMemHandle), the others map them (
 in place — FramePlan(exchange="stores") exactly as bench.py --gpus N drives it, several frames in flight.  Rank 0 compares every
 frame with one launch and writes a JSON verdict.
 
-    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/stores_worker.py out.json app W H channels fmt nframes
+    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/stores_worker.py out.json app W H channels fmt nframes [exchange]
+(exchange: stores (default), span_stores or packed_stores — the last one shares the owner's LANDING AREA instead of its frame)
 """
 import json
 import os
@@ -15,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out, app, W, H, channels, fmt, nframes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7])
+    exchange = sys.argv[8] if len(sys.argv) > 8 else "stores"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
@@ -29,7 +31,7 @@ def main():
     ns = 2
     streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
     hd = HostStagedDist(dist, torch)
-    plans = [FramePlan(R, hd, W, H, 8, exchange="stores", channels=channels) for _ in range(ns)]
+    plans = [FramePlan(R, hd, W, H, 8, exchange=exchange, channels=channels) for _ in range(ns)]
     times = [0.37 + .5 * i for i in range(nframes)]
     bad, frames = [], []
     for i, t in enumerate(times):
@@ -49,7 +51,7 @@ def main():
         json.dump({"mismatching_pixels": bad, "fault": R.fault_status(), "world": world}, open(out, "w"))
     dist.barrier()
     for p in plans[::-1]:
-        if rank != 0:
+        if rank != 0 and p.shared is not None:
             p.shared.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -118,13 +118,13 @@ def test_bench_emulated_ranks_on_one_gpu():
     assert e["parity"]["mismatching_pixels"] == 0 and len(e["per_rank_ms"]) == 4 and e["modelled_speedup"] > 1.0
     assert e["bytes_moved_per_frame"] > 0 and e["bound"] in ("link", "root", "peer compute")
     # the store forms are modelled with 12- and with 16-byte pixels; the best form WITHOUT partial-pixel stores is named beside the pick
-    assert all(k in e["exchanges_tried"] for k in ("stores", "stores_16B", "span_stores", "span_stores_16B", "spans", "direct"))
+    assert all(k in e["exchanges_tried"] for k in ("stores", "stores_16B", "span_stores", "span_stores_16B", "packed_stores", "spans", "direct"))
     wp = e["without_partial_pixel_stores"]
-    assert wp["exchange"] in ("stores_16B", "span_stores_16B", "spans", "direct") and wp["modelled_speedup"] <= e["modelled_speedup"] + 1e-9
+    assert wp["exchange"] in ("stores_16B", "span_stores_16B", "packed_stores", "spans", "direct") and wp["modelled_speedup"] <= e["modelled_speedup"] + 1e-9
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,exchange", [(2, "spans"), (3, "direct"), (2, "auto"), (3, "stores"), (2, "span_stores")])
+@pytest.mark.parametrize("n,exchange", [(2, "spans"), (3, "direct"), (2, "auto"), (3, "stores"), (2, "span_stores"), (3, "packed_stores")])
 def test_bench_whole_multi_rank_program_on_one_gpu(n, exchange):
     """`bench.py --gpus N --backend gloo`: N real processes (self-launched ranks, rendezvous, the relief calibration and its broadcast,
     FramePlan's schedule with its pieces, the all_gathers of the per-rank figures, config 5 at 7680x4320 through the same schedule,
@@ -138,8 +138,8 @@ def test_bench_whole_multi_rank_program_on_one_gpu(n, exchange):
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == n and "gloo" in line["backend"]
     if exchange == "auto":                 # every form tried on the ranks (the store exchange through HIP IPC between the processes), the fastest runs
-        assert line["exchange"]["kind"] in ("stores", "span_stores", "spans", "direct") and "measured on these ranks" in line["exchange"]["chosen"]
-        assert all(k in line["exchange"]["chosen"] for k in ("stores", "stores_16B", "span_stores", "span_stores_16B", "spans", "direct"))
+        assert line["exchange"]["kind"] in ("stores", "span_stores", "packed_stores", "spans", "direct") and "measured on these ranks" in line["exchange"]["chosen"]
+        assert all(k in line["exchange"]["chosen"] for k in ("stores", "stores_16B", "span_stores", "span_stores_16B", "packed_stores", "spans", "direct"))
     else:
         assert line["exchange"]["kind"] == exchange
     assert line["parity"]["mismatching_pixels"] == 0 and line["parity"]["rows"] == 540

@@ -81,6 +81,10 @@ class OracleRenderer:
         from oracle.oracle import APP_IDS
         from shaderbox_amd import shard
         table, _, _ = self.span_table(app, width, height, time, block_rows, nranks, root_rounds, rounds, mouse, aux)
+        if isinstance(slab, tuple):                  # (shared landing area, byte offset): the packed_stores exchange
+            sh, off = slab
+            item = 1 if self.rgba8 else 4
+            slab = sh.tensor((sh.nbytes // item,), torch.uint8 if self.rgba8 else torch.float32)[int(off) // item:]
         rows = shard.rank_row_indices(height, block_rows, rank, nranks, root_rounds, rounds)[r0:r1]
         rows = [y for y in rows if table[y // block_rows][1] > table[y // block_rows][0]]
         if rows:
@@ -240,7 +244,7 @@ def _worker(rank, world, port, app, w, h, t, br, groups, result_path, relief=(1,
     else:
         assert frame is None
     dist.barrier()
-    if exchange in ("stores", "span_stores") and rank == 0:
+    if exchange in ("stores", "span_stores", "packed_stores") and rank == 0:
         plan.shared.close()
     dist.destroy_process_group()
 
@@ -346,6 +350,23 @@ def test_span_store_exchange_schedule_over_gloo(tmp_path, oracle, world, app, w,
     got = np.load(path)
     ref = oracle.render(APP_IDS[app], w, h, 0.37)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,app,w,h,br,relief,rgba8", [(2, "atmosphere", 448, 252, 8, (1, 1), False), (3, "clouds", 128, 72, 4, (1, 2), False),
+                                                           (2, "egg", 64, 45, 8, (1, 1), True)])
+def test_packed_store_exchange_schedule_over_gloo(tmp_path, oracle, world, app, w, h, br, relief, rgba8):
+    """exchange='packed_stores': the span exchange whose transport is the peers' own stores — every peer renders its packed spans
+    into its stretch of the owner's landing area (the shared object, created and broadcast at the first frame), the owner waits
+    for the signals and scatters — over gloo with the file-backed stand-in == the single-process frame (float and RGBA8 pixels)"""
+    from oracle.oracle import APP_IDS
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), app, w, h, 0.37, br, 1, path, relief, "packed_stores", 3, rgba8), nprocs=world, join=True)
+    got = np.load(path)
+    ref = oracle.render(APP_IDS[app], w, h, 0.37)
+    if rgba8:
+        assert got.dtype == np.uint8 and np.array_equal(got, pack_unorm8(ref))
+    else:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
 def test_span_table_is_a_consistent_layout():

@@ -183,6 +183,67 @@ def test_store_exchange_between_processes_through_hip_ipc(tmp_path, world, app, 
     assert v["world"] == world and v["fault"] == 0 and v["mismatching_pixels"] == [0] * 5, v
 
 
+@pytest.mark.parametrize("app,w,h,n,relief,fmt", [("atmosphere", 448, 252, 3, (1, 2), "rgba32f"), ("planet", 448, 96, 5, (2, 3), "rgba32f"),
+                                                   ("clouds", 640, 360, 8, (1, 1), "rgba32f"), ("egg", 200, 99, 2, (1, 1), "rgba32f"),
+                                                   ("clouds", 640, 360, 4, (1, 1), "rgba8"), ("atmosphere", 7680, 4320, 8, (4, 5), "rgba32f")])
+def test_packed_store_exchange_loopback_equals_one_launch(app, w, h, n, relief, fmt):
+    """exchange='packed_stores': every peer renders its PACKED spans (12 contiguous bytes per pixel, 4 with RGBA8) straight into its
+    stretch of the owner's landing area — the shared object —, the owner renders the rest, waits for the signals and scatters: equal
+    to one launch bit for bit; partial / empty spans, apps without a span model, relief, the 8-rank 7680x4320 frame of config 5;
+    no byte moves through the world's send / receive"""
+    import shaderbox_amd
+    import torch
+    from shaderbox_amd.distributed import LoopbackWorld
+    R = shaderbox_amd.Renderer(0)
+    try:
+        R.set_output_format(fmt)
+        world = LoopbackWorld(n)
+        plans = world.plans(R, w, h, block_rows=8, root_rounds=relief[0], rounds=relief[1], exchange="packed_stores")
+        for t in (0.37, 2.5):
+            plans[0].frame.fill_(5 if fmt == "rgba8" else -3.0)
+            got = LoopbackWorld.render(plans, app, t)
+            ref = R.render(app, w, h, t)
+            torch.cuda.synchronize()
+            if fmt == "rgba8":
+                assert bool((got == ref).all()), (app, t)
+            else:
+                nan = torch.isnan(got) & torch.isnan(ref)
+                assert int(((got.view(torch.int32) != ref.view(torch.int32)) & ~nan).any(dim=-1).sum().item()) == 0, (app, t)
+            del ref
+        assert world.bytes_moved == 0 and R.fault_status() == 0
+        for p in plans[1:]:
+            p.shared.close()
+        plans[0].shared.close()
+    finally:
+        R.close()
+
+
+@pytest.mark.parametrize("world,app,w,h,fmt", [(2, "clouds", 640, 360, "rgba32f"), (3, "atmosphere", 448, 252, "rgba32f"), (2, "clouds", 320, 180, "rgba8")])
+def test_packed_store_exchange_between_processes_through_hip_ipc(tmp_path, world, app, w, h, fmt):
+    """SEPARATE processes on this box's one GPU: rank 0 exports its LANDING AREAS (built with the span layout at the first frame, the
+    handle broadcast inside render), the peers map them and store their packed spans there, rank 0 scatters; two frames in flight,
+    five frames, every frame equal to one launch"""
+    out = str(tmp_path / "verdict.json")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "stores_worker.py"), out, app, str(w), str(h),
+                                       "3", fmt, "5", "packed_stores"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
+    v = json.load(open(out))
+    assert v["world"] == world and v["fault"] == 0 and v["mismatching_pixels"] == [0] * 5, v
+
+
 def test_model_landing_copies_at_the_stated_pace(renderer):
     """sbx_test.h sbx_model_landing (the scaling tools' stand-in for RCCL's receive kernels): the bytes arrive, and the kernel
     stays resident for the stated time"""

@@ -27,7 +27,7 @@ for c in range(n_cases):
     m = int(rng.integers(1, 6))
     m0 = int(rng.integers(0, m + 1))
     groups = int(rng.integers(1, 5))
-    exchange = str(rng.choice(["spans", "spans", "direct", "stores", "stores", "span_stores", "span_stores"]))
+    exchange = str(rng.choice(["spans", "spans", "direct", "stores", "stores", "span_stores", "span_stores", "packed_stores", "packed_stores"]))
     channels = int(rng.choice([3, 4]))
     t = float(rng.uniform(0, 30))
     mouse = (float(rng.uniform(0, 6.3)), 0.0) if app.startswith("clouds") and c % 2 else (0.0, 0.0)
@@ -51,11 +51,13 @@ for c in range(n_cases):
     if not (ok and ok2):
         bad += 1
         print("MISMATCH", app, w, h, n, br, (m0, m), groups, exchange, t, mouse, "frame" if not ok else "points")
-    if exchange in ("stores", "span_stores"):
+    if exchange in ("stores", "span_stores", "packed_stores"):
         torch.cuda.synchronize()
         for p in plans[1:]:
-            p.shared.close()
-        plans[0].shared.close()
+            if p.shared is not None:
+                p.shared.close()
+        if plans[0].shared is not None:
+            plans[0].shared.close()
     del plans, world, got, ref
 # the library's own multi-GPU path (sbx_multi_*, all ranks on device 0: copies instead of RCCL), every exchange form
 mbad, mcases = 0, 0

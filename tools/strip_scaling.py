@@ -35,7 +35,7 @@ ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--time", type=float, default=.37)
 ap.add_argument("--ranks", default="2,4,8")
-ap.add_argument("--exchanges", default="stores,span_stores,spans,direct")
+ap.add_argument("--exchanges", default="stores,span_stores,packed_stores,spans,direct")
 ap.add_argument("--channels", type=int, choices=[3, 4], default=3, help="store exchange, float pixels: dwords a peer stores per pixel")
 ap.add_argument("--rccl-wgs-per-peer", type=int, default=2, help="landing model of the send/recv exchanges (bench.py); 0 = a plain device copy")
 ap.add_argument("--streams", type=int, default=3)
@@ -116,8 +116,8 @@ for n in ranks:
                 bpp = 4 if R.rgba8 else 4 * ch
                 payload = bpp * W * shard.rank_rows_max(H, 8, n, m0, m)
                 total = bpp * W * sum(shard.rank_rows(H, 8, r, n, m0, m) for r in range(1, n))
-            elif exchange in ("spans", "span_stores"):
-                bpp = BPP if exchange == "spans" or R.rgba8 else 4 * ch
+            elif exchange in ("spans", "span_stores", "packed_stores"):
+                bpp = BPP if exchange in ("spans", "packed_stores") or R.rgba8 else 4 * ch
                 _, pix, _ = R.span_table(app, W, H, t, 8, n, m0, m)
                 payload = bpp * int(max(pix[1:]))
                 total = bpp * sum(int(p) for p in pix[1:])

@@ -55,14 +55,23 @@ for app, W, H in (("raytracer", 3840, 2160), ("egg", 1920, 1080), ("clouds", 384
     host[..., 3] = 1.0
     p12 = med(lambda: go(R, f3, host.data_ptr()))
     same12 = bool((host[..., :3].contiguous().view(torch.int32) == ref[..., :3].contiguous().view(torch.int32)).all())
+    # the PACKED 3-float slab of the send / receive forms (sbx_render_split_rgb, rank 0 of 1: the whole frame, 12 bytes per pixel
+    # with no holes): the same 12 bytes per lane, but a wave's stores cover whole lines
+    hostp = torch.zeros((H, W, 3), dtype=torch.float32).pin_memory()
+    fp = R.lib.sbx_render_split_rgb
+
+    def gop(ptr):
+        R._check(fp(R.ctx, app_id(app), ctypes.byref(u), None, 8, 0, 1, 1, 1, 0, H, ctypes.c_void_p(ptr), None))
+    pp = med(lambda: gop(hostp.data_ptr()))
+    samep = bool((hostp.view(torch.int32) == ref[..., :3].contiguous().view(torch.int32)).all())
     p4 = med(lambda: go(R8, R8.lib.sbx_render_split_in_place, host8.data_ptr()))
     same4 = bool((host8 == hbm8.cpu()).all())
     c = med(lambda: host.copy_(hbm, non_blocking=True))
     px = W * H
     print("%-10s %dx%d | into HBM: 16 B %.3f ms, 12 B %.3f, 4 B %.3f | into pinned host memory over PCIe: 16 B pixels %.3f ms (%.1f GB/s), "
-          "12 B stores at a 16 B stride %.3f ms (%.1f GB/s of pixel bytes), RGBA8 %.3f ms (%.1f GB/s) | DMA copy of the float frame %.3f ms "
+          "12 B stores at a 16 B stride %.3f ms (%.1f GB/s of pixel bytes), PACKED 12 B pixels (3-float slab) %.3f ms (%.1f GB/s), RGBA8 %.3f ms (%.1f GB/s) | DMA copy of the float frame %.3f ms "
           "(%.1f GB/s) | same bits: %s %s %s"
-          % (app, W, H, k, k3, k8, p16, px * 16 / p16 / 1e6, p12, px * 12 / p12 / 1e6, p4, px * 4 / p4 / 1e6, c, px * 16 / c / 1e6,
-             same16, same12, same4))
-    del host, host8, hbm, hbm8
+          % (app, W, H, k, k3, k8, p16, px * 16 / p16 / 1e6, p12, px * 12 / p12 / 1e6, pp, px * 12 / pp / 1e6, p4, px * 4 / p4 / 1e6, c, px * 16 / c / 1e6,
+             "%s %s %s" % (same16, same12, samep), "", same4))
+    del host, host8, hbm, hbm8, hostp
     torch.cuda.empty_cache()
