@@ -472,7 +472,9 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
 
     def prepare(exchange, channels=None):
         """relief (calibrated on rank 0 for THIS exchange), payload, pieces and the ranks' plans"""
-        channels = args.channels if channels is None else channels
+        if not hasattr(args, "channels_asked"):
+            args.channels_asked = args.channels          # (auto overwrites args.channels with what it chose: later configs start from the flag again)
+        channels = args.channels_asked if channels is None else channels
         relief = choose_relief(args.root_rounds, R, dist, torch, dev, app, W, H, t, br, world, rank, streams, exchange, channels)
         payload = 0
         if world > 1:
@@ -586,8 +588,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
             raise SystemExit("no exchange form could be set up on these ranks: %s" % trials)
         exchange = best[1]
         relief, payload, groups, plans = best[2]
-        if best[3] is not None:
-            args.channels = best[3]                      # (what the rest of the run and the line's text say)
+        args.channels = best[3] if best[3] is not None else args.channels_asked     # (what the rest of the run and the line's text say)
         best = None
 
     def step(i=0):
