@@ -598,6 +598,23 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     for i in range(ns):                                 # builds the span layout, touches every buffer (page mapping)
         step(i)
     sync()
+    # pre-roll, as at N = 1: frames until --preroll-ms have passed on rank 0 (every rank runs the same count) — the clocks, and the
+    # first use of a form's mappings (a form asked for with --exchange has had no trial: its first frames read 2-4x slow)
+    npre = torch.zeros(1, dtype=torch.int64, device=COLL_DEV or dev)
+    if rank == 0:
+        t_pre, k_pre = time.perf_counter(), 0
+        for i in range(ns):
+            step(i)
+        torch.cuda.synchronize(dev)
+        one = max((time.perf_counter() - t_pre) / ns, 1e-5)
+        npre[0] = max(0, min(400, int(args.preroll_ms * 1e-3 / one) - ns))
+    else:
+        for i in range(ns):
+            step(i)
+    dist.broadcast(npre, src=0)
+    for i in range(int(npre.item())):
+        step(i)
+    sync()
     for i in range(warmup):
         step(i)
     sync()
