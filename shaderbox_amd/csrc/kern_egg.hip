@@ -16,8 +16,23 @@
 #ifndef EGG_TW
 #define EGG_TW 16          // wave tile EGG_TW x 64/EGG_TW pixels (profiles/r01_tile_shapes.txt)
 #endif
+#ifndef EGG_COOP
+#define EGG_COOP 1         // the four waves of a workgroup finish its LONG rays together, one part of sdf() each (see egg_coop_finish)
+#endif
 #ifndef EGG_TX
-#define EGG_TX 1           // waves per workgroup: 1 (4: the same single launch, 7 % slower with frames in flight at 1080p, 3 % at 4K)
+#define EGG_TX (EGG_COOP ? 4 : 1)   // waves per workgroup.  Without the cooperative finish: 1 (4: the same single launch, 7 % slower with
+#endif                     // frames in flight at 1080p, 3 % at 4K)
+#ifndef EGG_COOP_K0
+#define EGG_COOP_K0 8      // trace steps before a workgroup first counts its rays still marching
+#endif
+#ifndef EGG_COOP_DK
+#define EGG_COOP_DK 4      // ... and between later counts
+#endif
+#ifndef EGG_MIN_WAVES
+#define EGG_MIN_WAVES 7    // waves per SIMD the register allocation is held to: the kernel needs all 7 to fill the pipes (5: -8 % throughput)
+#endif
+#ifndef EGG_COOP_PRIO
+#define EGG_COOP_PRIO 0    // s_setprio of the waves inside the cooperative finish (0: unchanged)
 #endif
 
 namespace sbx {
@@ -156,60 +171,206 @@ __device__ __forceinline__ void hot_first_tile(const HotRect& R, int gx, int& bx
     bx = c - (c / gx) * gx;
 }
 
+// One ray of render_scene's trace loop (:190-231) as state that a loop can leave and another can resume.  The trace only FINDS the
+// hit; what the reference does inside the loop at the hit (`:205-228`: depth, the 20-step shadow march of ground pixels, the flat
+// colours, `break`) runs after the loop, once per wave with all of its hit lanes, instead of once per distinct hit iteration of the
+// wave with the few lanes that hit in that iteration.  Per lane the same operations on the same values in the same order.
+// 1920x1080: 0.54 -> 0.27 ms.  (Trace and shadow march as ONE loop around one copy of the sdf — lanes with a ground hit start their
+// shadow march while neighbours still trace — is slower: 0.283 vs 0.273 ms, 4K 0.68 vs 0.64; the per-lane phase logic costs more
+// than the shorter waves save.)
+struct EggRay { float t; bool done, hit; int mat; v3 hp; int steps; };
+
+// trace steps [i0, i1) of the lanes not done yet
+template <bool CULL, class W>
+__device__ __forceinline__ void egg_trace_steps(const FrameEgg& F, v3 ro, v3 rd, EggRay& r, int i0, int i1, W& w) {
+    if (r.done) return;
+    for (int i = i0; i < i1; ++i) {                         // render_scene :190-231
+        if (EGG_PRIO_STEP > 0 && i == EGG_PRIO_STEP) __builtin_amdgcn_s_setprio(EGG_PRIO);   // a long wave: ahead of the short ones on its SIMD
+        const v3 p = ro + rd * r.t;
+        const D2 d = egg_sdf<CULL>(F, p, w);
+        if (r.t > 15.f) { r.done = true; break; }
+        if (d.d < 0.001f) { r.hit = true; r.mat = (int)d.m; r.hp = p; r.done = true; break; }
+        r.t += d.d;
+#ifdef SBX_EGG_STATS
+        ++r.steps;
+#endif
+    }
+}
+
+// THE COOPERATIVE FINISH (round 6).  One wave issues at most one VALU instruction per ~5 cycles whatever its instruction-level
+// parallelism (profiles/r02_ubench_issue.txt, W = 1), so a ray that grazes the egg's legs for all 80 steps — ~600 instructions of
+// sdf() per step with nothing left to cull — costs its wave 80 x 1.2 us however few of its lanes still march, and one launch cannot
+// end before that wave (profiles/r04_egg_lone_wave.txt: 0.09-0.13 ms ALONE on the chip; the census of round 4: a 125 us tail with
+// < 7 % of the wave slots in use).  A step cannot start before the previous one's distance is known; what CAN run in parallel is
+// the union inside one step.  So a workgroup is four waves (a 64 x 4 pixel strip), and once at most 64 of its 256 rays are still
+// marching (counted after EGG_COOP_K0 steps and every EGG_COOP_DK after that, one LDS word per wave and a barrier), those rays are
+// packed into the 64 lanes of EVERY wave and each wave evaluates ONE part of the union for all of them —
+//     wave 0: left leg     wave 1: right leg     wave 2: the egg (three spheres, two smooth-mins)     wave 3: wheel and both feet
+// — writes its distances to LDS, and after one barrier all four fold the five values with op_add2 in sdf()'s own order (:140-143;
+// a strict `<`, so a tie keeps the reference's winner) and advance their identical copies of the rays.  A step costs the slowest
+// part (a Bezier tube, ~210 instructions) plus ~60 for the point, the exchange and the fold, instead of the whole union.
+// Same bits: every member is evaluated by the same expressions on the same point (-ffp-contract=off: an expression's value does not
+// depend on which wave computes it); a part skipped because it is far (bezier_far, egg_far: the culls of egg_sdf, against the
+// ground's distance, which bounds the union from above) enters as a value that cannot win, as in egg_sdf.  Steps on which every
+// ray left is far from everything but the ground (egg_far) skip the exchange altogether — the four waves decide that from the
+// same numbers, so they agree without talking.
+struct EggCoopLds {
+    int cnt[2][4];              // rays still marching, per wave; two sets: a fast wave may write the next count while a slow one reads
+    float rd[3][64], t[64];     // the packed rays: direction and distance marched
+    float part[2][5][64];       // left leg, right leg, egg, feet, wheel; two sets, by exchange parity, for the same reason
+    float res[4][64];           // hit | material << 1 | steps << 8, hit point
+};
+
+template <bool CULL, class W>
+__device__ __forceinline__ void egg_coop_finish(const FrameEgg& F, v3 ro, v3 rd, EggRay& r, int i0, bool live, unsigned long long mask,
+                                                int base, int S, EggCoopLds& L, W& w) {
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // (an SGPR: the compiler cannot know it is uniform)
+    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    if (live) { L.rd[0][slot] = rd.x; L.rd[1][slot] = rd.y; L.rd[2][slot] = rd.z; L.t[slot] = r.t; }
+    __syncthreads();
+    const bool active = lane < S;
+    const v3 crd = V3(L.rd[0][lane], L.rd[1][lane], L.rd[2][lane]);          // (lanes >= S: stale words of a ray never advanced)
+    EggRay c;
+    c.t = L.t[lane]; c.done = !active; c.hit = false; c.mat = 0; c.hp = V3(0, 0, 0); c.steps = 0;
+    const float inf = u2f(0x7f800000u), thick = .05f;
+    const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
+    if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(EGG_COOP_PRIO);
+    int ex = 0;
+    for (int i = i0; i < 80; ++i) {
+        if (__builtin_amdgcn_ballot_w64(!c.done) == 0ull) break;             // the same word in all four waves
+        const v3 P = ro + crd * c.t;
+        const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};       // sd_plane :136-138
+        D2 d = ground;
+        const bool need = !c.done && !(CULL && egg_far(F, P, ground.d));
+        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {                     // ... and so is this one
+            const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                // :40-41
+            float (*part)[64] = L.part[ex & 1];
+            if (need) {                   // (a lane that is done or far evaluates nothing: it must not record a root either)
+                if (wave == 0) {                                             // :102-118.  (Two copies of the tube rather than one with a
+                    const bool far = CULL && __builtin_amdgcn_ballot_w64(!bezier_far(F.leg_l, p, thick, ground.d)) == 0ull;   // selected
+                    part[0][lane] = far ? inf : sd_bezier_x(F.leg_l, p, thick, w);                  // frame: the select of 18 kernel
+                } else if (wave == 1) {                                                            // arguments lands in VGPRs and spills)
+                    const bool far = CULL && __builtin_amdgcn_ballot_w64(!bezier_far(F.leg_r, p, thick, ground.d)) == 0ull;
+                    part[1][lane] = far ? inf : sd_bezier_x(F.leg_r, p, thick, w);
+                } else if (wave == 2) {                                      // :47-53
+                    const float egg_y = 0.65f;
+                    const float egg_m = w.length(p - V3(0, egg_y, 0)) - 0.475f;
+                    const float egg_b = w.length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
+                    const float egg_t = w.length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
+                    const float egg_1 = op_blend(egg_m, egg_b, .5f);
+                    part[2][lane] = op_blend(egg_1, egg_t, .5f);
+                } else {                                                     // :120-134
+                    const D2 left_foot = {sd_cylinder0<false>(F.foot_l, p + F.left_foot, thick, w), mat_egg};
+                    const D2 right_foot = {sd_cylinder0<false>(F.foot_r, p + F.right_foot, thick, w), mat_egg};
+                    part[3][lane] = op_add2(left_foot, right_foot).d;
+                    const v3 pw = p + V3(0, 1.2f, 0);
+                    part[4][lane] = w.length(V2(w.length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f;   // sd_torus sdf.h:75-83
+                }
+            }
+            __syncthreads();
+            if (need) {
+                const D2 feet = {part[3][lane], mat_egg}, bike = {part[4][lane], mat_bike}, egg = {part[2][lane], mat_egg};
+                const D2 _1 = op_add2(feet, bike);                           // :140-143
+                const D2 _2 = op_add2(egg, _1);
+                const D2 legs = op_add2(D2{part[0][lane], mat_egg}, D2{part[1][lane], mat_egg});
+                const D2 _3 = op_add2(legs, _2);
+                d = op_add2(ground, _3);
+            }
+            ++ex;
+        }
+        if (!c.done) {
+            if (c.t > 15.f) c.done = true;
+            else if (d.d < 0.001f) { c.hit = true; c.mat = (int)d.m; c.hp = P; c.done = true; }
+            else { c.t += d.d; ++c.steps; }
+        }
+    }
+    if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(0);
+    if (wave == 0 && active) {
+        L.res[0][lane] = u2f((c.hit ? 1u : 0u) | ((unsigned)c.mat << 1) | ((unsigned)c.steps << 8));
+        L.res[1][lane] = c.hp.x; L.res[2][lane] = c.hp.y; L.res[3][lane] = c.hp.z;
+    }
+    __syncthreads();
+    if (live) {
+        const unsigned k = f2u(L.res[0][slot]);
+        r.hit = (k & 1u) != 0u; r.mat = (int)((k >> 1) & 0x7fu); r.steps += (int)(k >> 8);
+        r.hp = V3(L.res[1][slot], L.res[2][slot], L.res[3][slot]);
+    }
+    r.done = true;
+}
+
 #ifndef EGG_WITNESS
 #define EGG_WITNESS 1      // five-instruction square roots with a recorded domain (sbx_sdf.h Wit): 0 = the IEEE roots only
 #endif
 
-// One pixel up to (colour, depth) — render_scene :190-231 — with the roots of witness `w`
+// One pixel up to (colour, depth) — render_scene :190-231 — with the roots of witness `w`.  `coop` (the same in every thread of the
+// workgroup): count the marching rays and finish the last <= 64 together; every thread of the workgroup must then be here.
 template <bool CULL, class W>
-__device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, W& w, v3& color, float& depth, int& st_trace, int& st_shadow) {
+__device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, bool valid, bool coop, EggCoopLds& L, W& w, v3& color, float& depth,
+                                          int& st_trace, int& st_shadow) {
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc, w);
     depth = -1e8f;                                          // :188, fresh per pixel
     color = V3(.1f, .1f, .7f);                              // background :9-12
-    st_trace = 0; st_shadow = 0;
-    float t = 0.f;
-    // The trace only FINDS the hit; what the reference does inside the loop at the hit (`:205-228`: depth, the 20-step shadow
-    // march of ground pixels, the flat colours, `break`) runs after the loop, once per wave with all of its hit lanes, instead of
-    // once per distinct hit iteration of the wave with the few lanes that hit in that iteration.  Per lane the same operations
-    // on the same values in the same order.  1920x1080: 0.54 -> 0.27 ms.  (Trace and shadow march as ONE loop around one copy of
-    // the sdf — lanes with a ground hit start their shadow march while neighbours still trace —
-    // is slower: 0.283 vs 0.273 ms, 4K 0.68 vs 0.64; the per-lane phase logic costs more than the shorter waves save.)
-    bool hit = false;
-    int mat = 0;
-    v3 hp = V3(0, 0, 0);
-    for (int i = 0; i < 80; ++i) {                          // render_scene :190-231
-        if (EGG_PRIO_STEP > 0 && i == EGG_PRIO_STEP) __builtin_amdgcn_s_setprio(EGG_PRIO);   // a long wave: ahead of the short ones on its SIMD
-        const v3 p = ro + rd * t;
-        const D2 d = egg_sdf<CULL>(F, p, w);
-        if (t > 15.f) break;
-        if (d.d < 0.001f) { hit = true; mat = (int)d.m; hp = p; break; }
-        t += d.d;
-#ifdef SBX_EGG_STATS
-        ++st_trace;
-#endif
+    EggRay r;
+    r.t = 0.f; r.done = !valid; r.hit = false; r.mat = 0; r.hp = V3(0, 0, 0); r.steps = 0;
+    if (!(EGG_COOP && coop)) {
+        egg_trace_steps<CULL>(F, ro, rd, r, 0, 80, w);
+    } else {
+        const int lane = (int)threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        int i = 0, iend = EGG_COOP_K0, set = 0;
+        for (;;) {                                          // every condition below is the same in all four waves
+            egg_trace_steps<CULL>(F, ro, rd, r, i, iend, w);
+            i = iend;
+            if (i >= 80) break;
+            const bool live = !r.done;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+            if (lane == 0) L.cnt[set][wave] = __popcll(mask);
+            __syncthreads();
+            // (read into SGPRs: the compiler cannot know that an LDS word is the same in every lane, and a branch it takes for
+            // divergent is a masked region that a wave may walk through with no lane active — barriers and all)
+            const int c0 = __builtin_amdgcn_readfirstlane(L.cnt[set][0]), c1 = __builtin_amdgcn_readfirstlane(L.cnt[set][1]);
+            const int c2 = __builtin_amdgcn_readfirstlane(L.cnt[set][2]), c3 = __builtin_amdgcn_readfirstlane(L.cnt[set][3]);
+            set ^= 1;
+            const int S = c0 + c1 + c2 + c3;
+            if (S == 0) break;
+            if (S <= 64) {
+                const int base = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+                egg_coop_finish<CULL>(F, ro, rd, r, i, live, mask, base, S, L, w);
+                break;
+            }
+            iend = i + EGG_COOP_DK < 80 ? i + EGG_COOP_DK : 80;
+        }
     }
 #ifdef SBX_EGG_STATS
-    if (hit && mat == 3) st_shadow = 1;
+    st_trace = r.steps;
+    st_shadow = (r.hit && r.mat == 3) ? 1 : 0;
 #endif
-    if (hit) {
-        if (mat == 1 || mat == 2) depth = fmax_(depth, hp.z);
+    if (r.hit) {
+        if (r.mat == 1 || r.mat == 2) depth = fmax_(depth, r.hp.z);
         float s = 1.f;
-        if (mat == 3) {
+        if (r.mat == 3) {
             const v3 sh_dir = V3(0, 1, 1);
-            s = egg_shadowmarch<CULL>(F, hp + sh_dir * 0.05f, sh_dir, w);
+            s = egg_shadowmarch<CULL>(F, r.hp + sh_dir * 0.05f, sh_dir, w);
         }
         v3 base = V3(1, 1, 1);                              // illuminate :29-35
-        if (mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
-        else if (mat == 1) base = V3(0.9f, 0.95f, 0.95f);
-        else if (mat == 2) base = V3(.2f, .2f, .2f);
+        if (r.mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
+        else if (r.mat == 1) base = V3(0.9f, 0.95f, 0.95f);
+        else if (r.mat == 2) base = V3(.2f, .2f, .2f);
         color = base * s;
     }
 }
 
+// Where the cooperative finish is worth its barriers: workgroups with a pixel under the projection of the sphere around everything
+// but the ground (in point_cam units: the same extents as the hot rectangle, egg_extents below) — only there can a ray graze
+// anything.  Elsewhere the four waves of a workgroup never meet.  all = 1: no usable projection (the camera is inside the sphere):
+// every workgroup counts.
+struct CoopBox { float x0, x1, y0, y1; int all; };
+
 // WIT: 0 = IEEE roots; 1 = witnessed roots (the shipped form); 2 = the same with the witness's lower edge at 1.0, so that waves
 // near any primitive's axis DO record and re-run (sbx_set_variant 2: the test of the re-run path — same frame required)
 template <bool CULL, int WIT>
-__global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float* __restrict__ out, HotRect hot) {
+__global__ void __launch_bounds__(64 * EGG_TX, EGG_MIN_WAVES) k_egg(FrameEgg F, RowMap M, float* __restrict__ out, HotRect hot, CoopBox box) {
 #ifdef SBX_EGG_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();      // census build (tools/egg_census.py): 100 MHz counter
 #endif
@@ -225,25 +386,33 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
         asm volatile("" : "+v"(F.foot_ml.x), "+v"(F.foot_ml.y), "+v"(F.foot_ml.z), "+v"(F.foot_mr.x), "+v"(F.foot_mr.y), "+v"(F.foot_mr.z));
 #endif
     }
+    __shared__ EggCoopLds L;
     int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     if (EGG_HOT_FIRST && hot.w > 0) hot_first_tile(hot, (int)gridDim.x, bx, by);          // wave-uniform
     const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
-    if (!px.valid) return;
+    if (!EGG_COOP && !px.valid) return;
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
+    bool coop = false;
+    if (EGG_COOP)           // (an invalid pixel stays: its wave's barriers need it.  It never marches and never stores.)
+        coop = __syncthreads_or(px.valid && (box.all || (pc.x >= box.x0 && pc.x <= box.x1 && pc.y >= box.y0 && pc.y <= box.y1))) != 0;
     float depth;
     v3 color;
     if (WIT != 0) {
         Wit<true> w;
         if (WIT == 2) w.lo = 0x3F800000u;
-        egg_pixel<CULL>(F, pc, w, color, depth, st_trace, st_shadow);
-        if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {      // some lane took a root outside the proved interval: the IEEE forms
+        egg_pixel<CULL>(F, pc, px.valid, coop, L, w, color, depth, st_trace, st_shadow);
+        // some lane took a root outside the proved interval: the IEEE forms.  (With the cooperative finish a wave's roots may have been
+        // another wave's rays: the workgroup re-runs together.)
+        const bool again = coop ? __syncthreads_or(w.bad) != 0 : __builtin_amdgcn_ballot_w64(w.bad) != 0ull;
+        if (again) {
             Wit<false> w0;
-            egg_pixel<CULL>(F, pc, w0, color, depth, st_trace, st_shadow);
+            egg_pixel<CULL>(F, pc, px.valid, coop, L, w0, color, depth, st_trace, st_shadow);
         }
     } else {
         Wit<false> w0;
-        egg_pixel<CULL>(F, pc, w0, color, depth, st_trace, st_shadow);
+        egg_pixel<CULL>(F, pc, px.valid, coop, L, w0, color, depth, st_trace, st_shadow);
     }
+    if (EGG_COOP && !px.valid) return;
     // bars overlay :233-251
     const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);
     const float depth_factor = 1.f - step_(1.f, depth);
@@ -262,7 +431,7 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
         o4.x = __uint_as_float((unsigned)(st_t0 & 0xffffffffu));
         o4.y = __uint_as_float((unsigned)(st_t1 - st_t0));
         o4.z = __uint_as_float((unsigned)mx | ((unsigned)nsh << 8) | ((xcc & 0xfu) << 16) | ((hwid & 0xffffu) << 20));
-        o4.w = __uint_as_float(hwid);
+        o4.w = __uint_as_float((unsigned)st_trace | ((unsigned)st_shadow << 8));      // per LANE: its own trace steps, shadow march or not
         reinterpret_cast<float4*>(out)[px.idx] = o4;
         return;
     }
@@ -270,18 +439,15 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     store_rgba(M, out, px.idx, to_srgb(color));
 }
 
-// The tiles under the projection of the sphere (F.oc, F.orad) around everything but the ground (sdf()'s p space: P = rot_y^T (p +
-// (0, .5, 3.5))), for a launch that covers whole rows of the frame from row M.y0 (a contiguous strip; other maps: plain order).
-// A hint about cost: off by any amount it only changes the order in which the same workgroups run.
-static HotRect egg_hot_rect(const FrameEgg& F, const RowMap& M, dim3 grid) {
-    HotRect none{0, 0, 0, 0};
-    if (!EGG_HOT_FIRST || M.nranks != 1 || M.frag || M.span_mode || M.r0 != 0) return none;
+// The projection of the sphere (F.oc, F.orad) around everything but the ground (sdf()'s p space: P = rot_y^T (p + (0, .5, 3.5))) in
+// point_cam units: x = X / Z and y = Y / Z over the sphere.  false: the camera is inside or beside the sphere.
+static bool egg_extents(const FrameEgg& F, float& pxa, float& pxb, float& pya, float& pyb) {
     const v3 c = mul(transpose(F.rot_y), F.oc + V3(0, 0.5f, 3.5f));
     const v3 v = c - F.cam.eye;
     const float depth = dot(v, F.cam.fwd), r = F.orad;
-    if (!(depth > r * 1.05f)) return none;                               // the camera is inside or beside the sphere
-    // extent of x = X / Z over the sphere: the planes through the eye that contain the camera's up axis and touch the sphere — in
-    // the (right, fwd) plane the sphere is a circle of radius r at (vx, depth), the tangents from the origin are at phi +- asin(r / d)
+    if (!(depth > r * 1.05f)) return false;
+    // the planes through the eye that contain the camera's up axis and touch the sphere — in the (right, fwd) plane the sphere is a
+    // circle of radius r at (vx, depth), the tangents from the origin are at phi +- asin(r / d)
     const float vx = dot(v, F.cam.right), vy = dot(v, F.cam.up);
     auto extent = [&](float side, float& lo, float& hi) {
         const float d = sqrt_(side * side + depth * depth);
@@ -289,9 +455,18 @@ static HotRect egg_hot_rect(const FrameEgg& F, const RowMap& M, dim3 grid) {
         const float a = std::max(phi - al, -1.5f), b = std::min(phi + al, 1.5f);
         lo = std::tan(a); hi = std::tan(b);
     };
-    float pxa, pxb, pya, pyb;
     extent(vx, pxa, pxb);
     extent(vy, pya, pyb);
+    return pxa == pxa && pxb == pxb && pya == pya && pyb == pyb;
+}
+
+// The tiles under that projection, for a launch that covers whole rows of the frame from row M.y0 (a contiguous strip; other maps:
+// plain order).  A hint about cost: off by any amount it only changes the order in which the same workgroups run.
+static HotRect egg_hot_rect(const FrameEgg& F, const RowMap& M, dim3 grid) {
+    HotRect none{0, 0, 0, 0};
+    if (!EGG_HOT_FIRST || M.nranks != 1 || M.frag || M.span_mode || M.r0 != 0) return none;
+    float pxa, pxb, pya, pyb;
+    if (!egg_extents(F, pxa, pxb, pya, pyb)) return none;
     // point_cam = ((2 ndc - 1) * aspect * fov, (2 ndc - 1) * fov)  ->  pixel = ndc * res
     const float sx = F.cam.aspect_x * F.cam.fov, sy = F.cam.fov;
     auto pix = [](float pc, float scale, float res) { return (pc / scale + 1.f) * .5f * res; };
@@ -309,11 +484,13 @@ static HotRect egg_hot_rect(const FrameEgg& F, const RowMap& M, dim3 grid) {
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant) {
     const dim3 grid = grid_for<EGG_TW, EGG_TX>(M);
     const HotRect hot = egg_hot_rect(F, M, grid);
+    CoopBox box{0.f, 0.f, 0.f, 0.f, 1};
+    if (egg_extents(F, box.x0, box.x1, box.y0, box.y1)) box.all = 0;
     static const int pad = []() { const char* e = std::getenv("SBX_DEBUG_LDS_PAD"); return e ? std::atoi(e) : EGG_LDS_PAD; }();
-    if (variant == 1) hipLaunchKernelGGL((k_egg<false, 0>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
-    else if (variant == 2) hipLaunchKernelGGL((k_egg<true, 2>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
-    else if (variant == 3) hipLaunchKernelGGL((k_egg<true, 0>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
-    else hipLaunchKernelGGL((k_egg<true, EGG_WITNESS>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot);
+    if (variant == 1) hipLaunchKernelGGL((k_egg<false, 0>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot, box);
+    else if (variant == 2) hipLaunchKernelGGL((k_egg<true, 2>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot, box);
+    else if (variant == 3) hipLaunchKernelGGL((k_egg<true, 0>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot, box);
+    else hipLaunchKernelGGL((k_egg<true, EGG_WITNESS>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot, box);
 }
 
 }  // namespace sbx
