@@ -28,9 +28,10 @@
 #ifndef EGG_COOP_DK
 #define EGG_COOP_DK 4      // ... and between later counts
 #endif
-#ifndef EGG_MIN_WAVES
-#define EGG_MIN_WAVES 7    // waves per SIMD the register allocation is held to: the kernel needs all 7 to fill the pipes (5: -8 % throughput)
-#endif
+#ifndef EGG_NUM_VGPR
+#define EGG_NUM_VGPR 72    // 7 waves per SIMD: the kernel needs all 7 to fill the pipes (5: -8 % throughput).  As amdgpu_num_vgpr, not as
+#endif                     // __launch_bounds__' second argument: that one also takes 12 SGPRs away (94 instead of 106), and this kernel
+                           // keeps ~100 frame constants in SGPRs — with 94 the trace loop reloads 136 of them per step through v_readlane
 #ifndef EGG_COOP_PRIO
 #define EGG_COOP_PRIO 0    // s_setprio of the waves inside the cooperative finish (0: unchanged)
 #endif
@@ -178,7 +179,7 @@ __device__ __forceinline__ void hot_first_tile(const HotRect& R, int gx, int& bx
 // 1920x1080: 0.54 -> 0.27 ms.  (Trace and shadow march as ONE loop around one copy of the sdf — lanes with a ground hit start their
 // shadow march while neighbours still trace — is slower: 0.283 vs 0.273 ms, 4K 0.68 vs 0.64; the per-lane phase logic costs more
 // than the shorter waves save.)
-struct EggRay { float t; bool done, hit; int mat; v3 hp; int steps; };
+struct EggRay { float t; bool done, hit; int mat; v3 hp; int steps; int id; };
 
 // trace steps [i0, i1) of the lanes not done yet
 template <bool CULL, class W>
@@ -188,6 +189,9 @@ __device__ __forceinline__ void egg_trace_steps(const FrameEgg& F, v3 ro, v3 rd,
         if (EGG_PRIO_STEP > 0 && i == EGG_PRIO_STEP) __builtin_amdgcn_s_setprio(EGG_PRIO);   // a long wave: ahead of the short ones on its SIMD
         const v3 p = ro + rd * r.t;
         const D2 d = egg_sdf<CULL>(F, p, w);
+#ifdef SBX_EGG_DEBUG
+        if (r.id == SBX_EGG_DEBUG) printf("normal step %d t %.9g -> d %.9g m %g\n", i, r.t, d.d, d.m);
+#endif
         if (r.t > 15.f) { r.done = true; break; }
         if (d.d < 0.001f) { r.hit = true; r.mat = (int)d.m; r.hp = p; r.done = true; break; }
         r.t += d.d;
@@ -219,6 +223,9 @@ struct EggCoopLds {
     float rd[3][64], t[64];     // the packed rays: direction and distance marched
     float part[2][5][64];       // left leg, right leg, egg, feet, wheel; two sets, by exchange parity, for the same reason
     float res[4][64];           // hit | material << 1 | steps << 8, hit point
+#ifdef SBX_EGG_DEBUG
+    int id[64];
+#endif
 };
 
 template <bool CULL, class W>
@@ -228,11 +235,14 @@ __device__ __forceinline__ void egg_coop_finish(const FrameEgg& F, v3 ro, v3 rd,
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // (an SGPR: the compiler cannot know it is uniform)
     const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
     if (live) { L.rd[0][slot] = rd.x; L.rd[1][slot] = rd.y; L.rd[2][slot] = rd.z; L.t[slot] = r.t; }
+#ifdef SBX_EGG_DEBUG
+    if (live) L.id[slot] = r.id;
+#endif
     __syncthreads();
     const bool active = lane < S;
     const v3 crd = V3(L.rd[0][lane], L.rd[1][lane], L.rd[2][lane]);          // (lanes >= S: stale words of a ray never advanced)
     EggRay c;
-    c.t = L.t[lane]; c.done = !active; c.hit = false; c.mat = 0; c.hp = V3(0, 0, 0); c.steps = 0;
+    c.t = L.t[lane]; c.done = !active; c.hit = false; c.mat = 0; c.steps = 0;       // (c.hp: after the loop, from c.t — registers)
     const float inf = u2f(0x7f800000u), thick = .05f;
     const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
     if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(EGG_COOP_PRIO);
@@ -247,26 +257,32 @@ __device__ __forceinline__ void egg_coop_finish(const FrameEgg& F, v3 ro, v3 rd,
             const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                // :40-41
             float (*part)[64] = L.part[ex & 1];
             if (need) {                   // (a lane that is done or far evaluates nothing: it must not record a root either)
+                // One store after the chain, at an address that does not depend on the branch taken: with a store in every branch
+                // hipcc (ROCm 7.2) sinks them into one store whose address is a phi, and the structurised code of the LAST branch
+                // never sets that address register (seen in the listing: wave 3 stored the wheel's distance through a stale s22;
+                // every pixel whose ray met the cooperative finish came out as a wheel hit).
+                float val;
                 if (wave == 0) {                                             // :102-118.  (Two copies of the tube rather than one with a
                     const bool far = CULL && __builtin_amdgcn_ballot_w64(!bezier_far(F.leg_l, p, thick, ground.d)) == 0ull;   // selected
-                    part[0][lane] = far ? inf : sd_bezier_x(F.leg_l, p, thick, w);                  // frame: the select of 18 kernel
+                    val = far ? inf : sd_bezier_x(F.leg_l, p, thick, w);                            // frame: the select of 18 kernel
                 } else if (wave == 1) {                                                            // arguments lands in VGPRs and spills)
                     const bool far = CULL && __builtin_amdgcn_ballot_w64(!bezier_far(F.leg_r, p, thick, ground.d)) == 0ull;
-                    part[1][lane] = far ? inf : sd_bezier_x(F.leg_r, p, thick, w);
+                    val = far ? inf : sd_bezier_x(F.leg_r, p, thick, w);
                 } else if (wave == 2) {                                      // :47-53
                     const float egg_y = 0.65f;
                     const float egg_m = w.length(p - V3(0, egg_y, 0)) - 0.475f;
                     const float egg_b = w.length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
                     const float egg_t = w.length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
                     const float egg_1 = op_blend(egg_m, egg_b, .5f);
-                    part[2][lane] = op_blend(egg_1, egg_t, .5f);
+                    val = op_blend(egg_1, egg_t, .5f);
                 } else {                                                     // :120-134
                     const D2 left_foot = {sd_cylinder0<false>(F.foot_l, p + F.left_foot, thick, w), mat_egg};
                     const D2 right_foot = {sd_cylinder0<false>(F.foot_r, p + F.right_foot, thick, w), mat_egg};
                     part[3][lane] = op_add2(left_foot, right_foot).d;
                     const v3 pw = p + V3(0, 1.2f, 0);
-                    part[4][lane] = w.length(V2(w.length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f;   // sd_torus sdf.h:75-83
+                    val = w.length(V2(w.length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f;             // sd_torus sdf.h:75-83
                 }
+                part[wave + (wave == 3)][lane] = val;
             }
             __syncthreads();
             if (need) {
@@ -279,16 +295,28 @@ __device__ __forceinline__ void egg_coop_finish(const FrameEgg& F, v3 ro, v3 rd,
             }
             ++ex;
         }
+#ifdef SBX_EGG_DEBUG
+        if (!c.done && L.id[lane] == SBX_EGG_DEBUG)
+            printf("coop wave %d lane %d of %d step %d t %.9g ground %.9g need %d ex %d parts %.9g %.9g %.9g %.9g %.9g -> d %.9g m %g\n", wave, lane, S, i,
+                   c.t, ground.d, (int)need, ex, L.part[(ex - 1) & 1][0][lane], L.part[(ex - 1) & 1][1][lane], L.part[(ex - 1) & 1][2][lane],
+                   L.part[(ex - 1) & 1][3][lane], L.part[(ex - 1) & 1][4][lane], d.d, d.m);
+#endif
         if (!c.done) {
             if (c.t > 15.f) c.done = true;
-            else if (d.d < 0.001f) { c.hit = true; c.mat = (int)d.m; c.hp = P; c.done = true; }
-            else { c.t += d.d; ++c.steps; }
+            else if (d.d < 0.001f) { c.hit = true; c.mat = (int)d.m; c.done = true; }      // (c.t stays: the hit point is ro + crd * c.t)
+            else {
+                c.t += d.d;
+#ifdef SBX_EGG_STATS
+                ++c.steps;
+#endif
+            }
         }
     }
     if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(0);
     if (wave == 0 && active) {
+        const v3 hp = ro + crd * c.t;                                        // = P of the step that hit (c.t was not advanced)
         L.res[0][lane] = u2f((c.hit ? 1u : 0u) | ((unsigned)c.mat << 1) | ((unsigned)c.steps << 8));
-        L.res[1][lane] = c.hp.x; L.res[2][lane] = c.hp.y; L.res[3][lane] = c.hp.z;
+        L.res[1][lane] = hp.x; L.res[2][lane] = hp.y; L.res[3][lane] = hp.z;
     }
     __syncthreads();
     if (live) {
@@ -307,12 +335,12 @@ __device__ __forceinline__ void egg_coop_finish(const FrameEgg& F, v3 ro, v3 rd,
 // workgroup): count the marching rays and finish the last <= 64 together; every thread of the workgroup must then be here.
 template <bool CULL, class W>
 __device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, bool valid, bool coop, EggCoopLds& L, W& w, v3& color, float& depth,
-                                          int& st_trace, int& st_shadow) {
+                                          int& st_trace, int& st_shadow, int id = 0) {
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc, w);
     depth = -1e8f;                                          // :188, fresh per pixel
     color = V3(.1f, .1f, .7f);                              // background :9-12
     EggRay r;
-    r.t = 0.f; r.done = !valid; r.hit = false; r.mat = 0; r.hp = V3(0, 0, 0); r.steps = 0;
+    r.t = 0.f; r.done = !valid; r.hit = false; r.mat = 0; r.hp = V3(0, 0, 0); r.steps = 0; r.id = id;
     if (!(EGG_COOP && coop)) {
         egg_trace_steps<CULL>(F, ro, rd, r, 0, 80, w);
     } else {
@@ -370,7 +398,7 @@ struct CoopBox { float x0, x1, y0, y1; int all; };
 // WIT: 0 = IEEE roots; 1 = witnessed roots (the shipped form); 2 = the same with the witness's lower edge at 1.0, so that waves
 // near any primitive's axis DO record and re-run (sbx_set_variant 2: the test of the re-run path — same frame required)
 template <bool CULL, int WIT>
-__global__ void __launch_bounds__(64 * EGG_TX, EGG_MIN_WAVES) k_egg(FrameEgg F, RowMap M, float* __restrict__ out, HotRect hot, CoopBox box) {
+__global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float* __restrict__ out, HotRect hot, CoopBox box) {
 #ifdef SBX_EGG_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();      // census build (tools/egg_census.py): 100 MHz counter
 #endif
@@ -389,30 +417,39 @@ __global__ void __launch_bounds__(64 * EGG_TX, EGG_MIN_WAVES) k_egg(FrameEgg F, 
     __shared__ EggCoopLds L;
     int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     if (EGG_HOT_FIRST && hot.w > 0) hot_first_tile(hot, (int)gridDim.x, bx, by);          // wave-uniform
-    const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
-    if (!EGG_COOP && !px.valid) return;
-    const v2 pc = point_cam(F.cam, px.fx, px.fy);
+    const Pixel px0 = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
+    if (!EGG_COOP && !px0.valid) return;
+    const v2 pc0 = point_cam(F.cam, px0.fx, px0.fy);
     bool coop = false;
     if (EGG_COOP)           // (an invalid pixel stays: its wave's barriers need it.  It never marches and never stores.)
-        coop = __syncthreads_or(px.valid && (box.all || (pc.x >= box.x0 && pc.x <= box.x1 && pc.y >= box.y0 && pc.y <= box.y1))) != 0;
+        coop = __syncthreads_or(px0.valid && (box.all || (pc0.x >= box.x0 && pc0.x <= box.x1 && pc0.y >= box.y0 && pc0.y <= box.y1))) != 0;
+#ifdef EGG_COOP_NEVER      // A/B: the four-wave workgroup and all of its code, but no workgroup ever counts
+    coop = false;
+#endif
     float depth;
     v3 color;
     if (WIT != 0) {
         Wit<true> w;
         if (WIT == 2) w.lo = 0x3F800000u;
-        egg_pixel<CULL>(F, pc, px.valid, coop, L, w, color, depth, st_trace, st_shadow);
+        egg_pixel<CULL>(F, pc0, px0.valid, coop, L, w, color, depth, st_trace, st_shadow, px0.x | (px0.y << 16));
         // some lane took a root outside the proved interval: the IEEE forms.  (With the cooperative finish a wave's roots may have been
         // another wave's rays: the workgroup re-runs together.)
         const bool again = coop ? __syncthreads_or(w.bad) != 0 : __builtin_amdgcn_ballot_w64(w.bad) != 0ull;
         if (again) {
             Wit<false> w0;
-            egg_pixel<CULL>(F, pc, px.valid, coop, L, w0, color, depth, st_trace, st_shadow);
+            egg_pixel<CULL>(F, pc0, px0.valid, coop, L, w0, color, depth, st_trace, st_shadow, px0.x | (px0.y << 16));
         }
     } else {
         Wit<false> w0;
-        egg_pixel<CULL>(F, pc, px.valid, coop, L, w0, color, depth, st_trace, st_shadow);
+        egg_pixel<CULL>(F, pc0, px0.valid, coop, L, w0, color, depth, st_trace, st_shadow, px0.x | (px0.y << 16));
     }
+    // The pixel's place and point_cam again, from a thread id the compiler cannot recognise: kept across the march they are six
+    // VGPRs the whole pixel long, and the march is what needs registers
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, tid, bx, by, (int)gridDim.y);
     if (EGG_COOP && !px.valid) return;
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     // bars overlay :233-251
     const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);
     const float depth_factor = 1.f - step_(1.f, depth);

@@ -1,0 +1,12 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch, shaderbox_amd as sa
+sa.LIB_PATH = os.path.join(ROOT, "build", "ab", "libsbx_%s.so" % sys.argv[1])
+r = sa.Renderer(0)
+r.set_variant(3)
+out = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda")
+a = r.render("egg", 1920, 1080, 0.37, out=out)
+torch.cuda.synchronize()
+x, y = int(sys.argv[2]), int(sys.argv[3])
+print("pixel", x, y, a[y, x].cpu().numpy())
