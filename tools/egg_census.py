@@ -23,7 +23,8 @@ import numpy as np
 import torch
 import shaderbox_amd as sa
 
-sa.LIB_PATH = os.path.join(ROOT, "build", "ab", "libsbx_eggstats%s.so" % ("_plain" if "--plain" in sys.argv else ""))
+_lib = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--lib=")]          # --lib=name: build/ab/libsbx_<name>.so (a census build)
+sa.LIB_PATH = os.path.join(ROOT, "build", "ab", "libsbx_%s.so" % (_lib[0] if _lib else "eggstats" + ("_plain" if "--plain" in sys.argv else "")))
 print("# %s" % ("rows dealt bottom to top (EGG_HOT_FIRST=0)" if "--plain" in sys.argv else "hot-first dispatch (the shipped order)"))
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 W, H = (int(args[0]), int(args[1])) if len(args) >= 2 else (1920, 1080)
