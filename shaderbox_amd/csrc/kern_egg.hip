@@ -17,23 +17,25 @@
 #define EGG_TW 16          // wave tile EGG_TW x 64/EGG_TW pixels (profiles/r01_tile_shapes.txt)
 #endif
 #ifndef EGG_COOP
-#define EGG_COOP 1         // the four waves of a workgroup finish its LONG rays together, one part of sdf() each (see egg_coop_finish)
+#define EGG_COOP 1         // long, expensive rays leave their wave for a queue that four-wave FINISHER workgroups serve (see below)
 #endif
 #ifndef EGG_TX
-#define EGG_TX (EGG_COOP ? 4 : 1)   // waves per workgroup.  Without the cooperative finish: 1 (4: the same single launch, 7 % slower with
-#endif                     // frames in flight at 1080p, 3 % at 4K)
-#ifndef EGG_COOP_K0
-#define EGG_COOP_K0 8      // trace steps before a workgroup first counts its rays still marching
+#define EGG_TX 1           // waves per workgroup: 1 (4: the same single launch, 7 % slower with frames in flight at 1080p, 3 % at 4K;
+#endif                     // census round 6: 4500 instead of 5900 waves resident — a workgroup's slots come back all at once)
+#ifndef EGG_COOP_K1
+#define EGG_COOP_K1 32     // trace steps before a wave first offers rays to the queue
 #endif
 #ifndef EGG_COOP_DK
-#define EGG_COOP_DK 4      // ... and between later counts
+#define EGG_COOP_DK 4      // ... and between later offers
 #endif
-#ifndef EGG_NUM_VGPR
-#define EGG_NUM_VGPR 72    // 7 waves per SIMD: the kernel needs all 7 to fill the pipes (5: -8 % throughput).  As amdgpu_num_vgpr, not as
-#endif                     // __launch_bounds__' second argument: that one also takes 12 SGPRs away (94 instead of 106), and this kernel
-                           // keeps ~100 frame constants in SGPRs — with 94 the trace loop reloads 136 of them per step through v_readlane
+#ifndef EGG_COOP_NF
+#define EGG_COOP_NF 64     // finisher workgroups (four waves each) of one launch
+#endif
 #ifndef EGG_COOP_PRIO
-#define EGG_COOP_PRIO 0    // s_setprio of the waves inside the cooperative finish (0: unchanged)
+#define EGG_COOP_PRIO 0    // s_setprio of the finisher's waves (0: unchanged)
+#endif
+#ifndef EGG_Q_CAP
+#define EGG_Q_CAP 65536    // rays one launch's queue holds (32 B each); a wave that finds it full keeps its rays
 #endif
 
 namespace sbx {
@@ -179,7 +181,7 @@ __device__ __forceinline__ void hot_first_tile(const HotRect& R, int gx, int& bx
 // 1920x1080: 0.54 -> 0.27 ms.  (Trace and shadow march as ONE loop around one copy of the sdf — lanes with a ground hit start their
 // shadow march while neighbours still trace — is slower: 0.283 vs 0.273 ms, 4K 0.68 vs 0.64; the per-lane phase logic costs more
 // than the shorter waves save.)
-struct EggRay { float t; bool done, hit; int mat; v3 hp; int steps; int id; };
+struct EggRay { float t; bool done, hit; int mat; v3 hp; int steps; };
 
 // trace steps [i0, i1) of the lanes not done yet
 template <bool CULL, class W>
@@ -189,9 +191,6 @@ __device__ __forceinline__ void egg_trace_steps(const FrameEgg& F, v3 ro, v3 rd,
         if (EGG_PRIO_STEP > 0 && i == EGG_PRIO_STEP) __builtin_amdgcn_s_setprio(EGG_PRIO);   // a long wave: ahead of the short ones on its SIMD
         const v3 p = ro + rd * r.t;
         const D2 d = egg_sdf<CULL>(F, p, w);
-#ifdef SBX_EGG_DEBUG
-        if (r.id == SBX_EGG_DEBUG) printf("normal step %d t %.9g -> d %.9g m %g\n", i, r.t, d.d, d.m);
-#endif
         if (r.t > 15.f) { r.done = true; break; }
         if (d.d < 0.001f) { r.hit = true; r.mat = (int)d.m; r.hp = p; r.done = true; break; }
         r.t += d.d;
@@ -201,174 +200,90 @@ __device__ __forceinline__ void egg_trace_steps(const FrameEgg& F, v3 ro, v3 rd,
     }
 }
 
-// THE COOPERATIVE FINISH (round 6).  One wave issues at most one VALU instruction per ~5 cycles whatever its instruction-level
-// parallelism (profiles/r02_ubench_issue.txt, W = 1), so a ray that grazes the egg's legs for all 80 steps — ~600 instructions of
-// sdf() per step with nothing left to cull — costs its wave 80 x 1.2 us however few of its lanes still march, and one launch cannot
-// end before that wave (profiles/r04_egg_lone_wave.txt: 0.09-0.13 ms ALONE on the chip; the census of round 4: a 125 us tail with
-// < 7 % of the wave slots in use).  A step cannot start before the previous one's distance is known; what CAN run in parallel is
-// the union inside one step.  So a workgroup is four waves (a 64 x 4 pixel strip), and once at most 64 of its 256 rays are still
-// marching (counted after EGG_COOP_K0 steps and every EGG_COOP_DK after that, one LDS word per wave and a barrier), those rays are
-// packed into the 64 lanes of EVERY wave and each wave evaluates ONE part of the union for all of them —
-//     wave 0: left leg     wave 1: right leg     wave 2: the egg (three spheres, two smooth-mins)     wave 3: wheel and both feet
-// — writes its distances to LDS, and after one barrier all four fold the five values with op_add2 in sdf()'s own order (:140-143;
-// a strict `<`, so a tie keeps the reference's winner) and advance their identical copies of the rays.  A step costs the slowest
-// part (a Bezier tube, ~210 instructions) plus ~60 for the point, the exchange and the fold, instead of the whole union.
-// Same bits: every member is evaluated by the same expressions on the same point (-ffp-contract=off: an expression's value does not
-// depend on which wave computes it); a part skipped because it is far (bezier_far, egg_far: the culls of egg_sdf, against the
-// ground's distance, which bounds the union from above) enters as a value that cannot win, as in egg_sdf.  Steps on which every
-// ray left is far from everything but the ground (egg_far) skip the exchange altogether — the four waves decide that from the
-// same numbers, so they agree without talking.
-struct EggCoopLds {
-    int cnt[2][4];              // rays still marching, per wave; two sets: a fast wave may write the next count while a slow one reads
-    float rd[3][64], t[64];     // the packed rays: direction and distance marched
-    float part[2][5][64];       // left leg, right leg, egg, feet, wheel; two sets, by exchange parity, for the same reason
-    float res[4][64];           // hit | material << 1 | steps << 8, hit point
-#ifdef SBX_EGG_DEBUG
-    int id[64];
-#endif
+// THE FINISHERS (round 6).  One wave issues at most one VALU instruction per ~5 cycles whatever its instruction-level parallelism
+// (profiles/r02_ubench_issue.txt, W = 1), so a ray that grazes the egg's legs for all 80 steps — ~600 instructions of sdf() per step
+// with nothing left to cull — costs its wave 80 x 1.2 us however few of its lanes still march, and one launch cannot end before that
+// wave (profiles/r04_egg_lone_wave.txt: 0.09-0.13 ms ALONE on the chip; the census: the chip is full for 120 us and then runs a
+// 100 us tail with < 7 % of the wave slots in use).  A step cannot start before the previous one's distance is known; what CAN run
+// in parallel is the union inside one step.  So:
+//   * a wave of k_egg that is still marching after EGG_COOP_K1 steps hands those of its rays that are near the scene (not egg_far:
+//     the others take ~28 instructions a step) to a QUEUE in device memory — fragCoord, distance marched, step count, pixel index,
+//     32 bytes a ray — and goes on without them;
+//   * k_egg_finish, a second launch that runs BESIDE k_egg (its own stream, forked from and joined to the caller's), is EGG_COOP_NF
+//     workgroups of FOUR waves.  A workgroup claims 64 queue slots, waits for their rays, and each of its waves evaluates ONE part
+//     of the union for all 64 —
+//         wave 0: left leg     wave 1: right leg     wave 2: the egg (three spheres, two smooth-mins)     wave 3: wheel and both feet
+//     — writes its distances to LDS, and after one barrier all four fold the five values with op_add2 in sdf()'s own order
+//     (:140-143; a strict `<`, so a tie keeps the reference's winner) and advance their identical copies of the rays: a step costs
+//     the slowest part (a Bezier tube, ~210 instructions) plus ~60 for the point, the exchange and the fold, and it serves 64 rays,
+//     where the wave that handed them over paid the whole union for a handful.  The same for the shadow march of those that land on
+//     the ground; then the colours, the bars, the store — the rest of the pixel, by the same functions.
+// Same bits: a ray's state crosses the queue exactly (its direction is recomputed from fragCoord by the function that computed it);
+// every member is evaluated by the same expressions on the same point (-ffp-contract=off: an expression's value does not depend on
+// which wave computes it); a part skipped because it is far (bezier_far, egg_far: the culls of egg_sdf, against the ground's
+// distance, which bounds the union from above) enters as a value that cannot win, as in egg_sdf.  Steps on which every ray left is
+// far from everything but the ground skip the exchange altogether — the four waves decide that from the same numbers, so they
+// agree without talking.
+// (Round 6 first built the cooperation INSIDE k_egg — four-wave workgroups, the last <= 64 rays of a workgroup finished by its own
+// waves.  Bit-exact, and the longest wave fell from 190 to 140 us, but workgroups of four give their wave slots back all at once:
+// 4500 instead of 5900 waves resident, the chip-full phase 120 -> 150 us, one launch 0.216 against 0.215 ms.
+// profiles/r06_egg_design1.txt.)
+struct EggRec { float fx, fy, t; unsigned i; unsigned long long idx; unsigned tag, pad; };     // tag == the launch's sequence number: written
+struct EggQueue {
+    unsigned reserve, head, done, out, pad[12];     // slots handed out to producers / claimed by finishers; producer waves finished; finishers gone
+    EggRec rec[EGG_Q_CAP];
 };
+struct EggQArg { EggQueue* q; unsigned seq, expected; int nf; };     // q == nullptr: no queue (plain kernel)
 
-template <bool CULL, class W>
-__device__ __forceinline__ void egg_coop_finish(const FrameEgg& F, v3 ro, v3 rd, EggRay& r, int i0, bool live, unsigned long long mask,
-                                                int base, int S, EggCoopLds& L, W& w) {
+__device__ __forceinline__ unsigned egg_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// A wave offers the rays in `want` (all lanes of the wave are here).  true: they are in the queue and no longer this wave's.
+__device__ __forceinline__ bool egg_export(const EggQArg& A, unsigned long long want, bool mine, float fx, float fy, float t, int i, size_t idx) {
+    const int n = __popcll(want);
     const int lane = (int)threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // (an SGPR: the compiler cannot know it is uniform)
-    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-    if (live) { L.rd[0][slot] = rd.x; L.rd[1][slot] = rd.y; L.rd[2][slot] = rd.z; L.t[slot] = r.t; }
-#ifdef SBX_EGG_DEBUG
-    if (live) L.id[slot] = r.id;
-#endif
-    __syncthreads();
-    const bool active = lane < S;
-    const v3 crd = V3(L.rd[0][lane], L.rd[1][lane], L.rd[2][lane]);          // (lanes >= S: stale words of a ray never advanced)
-    EggRay c;
-    c.t = L.t[lane]; c.done = !active; c.hit = false; c.mat = 0; c.steps = 0;       // (c.hp: after the loop, from c.t — registers)
-    const float inf = u2f(0x7f800000u), thick = .05f;
-    const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
-    if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(EGG_COOP_PRIO);
-    int ex = 0;
-    for (int i = i0; i < 80; ++i) {
-        if (__builtin_amdgcn_ballot_w64(!c.done) == 0ull) break;             // the same word in all four waves
-        const v3 P = ro + crd * c.t;
-        const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};       // sd_plane :136-138
-        D2 d = ground;
-        const bool need = !c.done && !(CULL && egg_far(F, P, ground.d));
-        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {                     // ... and so is this one
-            const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                // :40-41
-            float (*part)[64] = L.part[ex & 1];
-            if (need) {                   // (a lane that is done or far evaluates nothing: it must not record a root either)
-                // One store after the chain, at an address that does not depend on the branch taken: with a store in every branch
-                // hipcc (ROCm 7.2) sinks them into one store whose address is a phi, and the structurised code of the LAST branch
-                // never sets that address register (seen in the listing: wave 3 stored the wheel's distance through a stale s22;
-                // every pixel whose ray met the cooperative finish came out as a wheel hit).
-                float val;
-                if (wave == 0) {                                             // :102-118.  (Two copies of the tube rather than one with a
-                    const bool far = CULL && __builtin_amdgcn_ballot_w64(!bezier_far(F.leg_l, p, thick, ground.d)) == 0ull;   // selected
-                    val = far ? inf : sd_bezier_x(F.leg_l, p, thick, w);                            // frame: the select of 18 kernel
-                } else if (wave == 1) {                                                            // arguments lands in VGPRs and spills)
-                    const bool far = CULL && __builtin_amdgcn_ballot_w64(!bezier_far(F.leg_r, p, thick, ground.d)) == 0ull;
-                    val = far ? inf : sd_bezier_x(F.leg_r, p, thick, w);
-                } else if (wave == 2) {                                      // :47-53
-                    const float egg_y = 0.65f;
-                    const float egg_m = w.length(p - V3(0, egg_y, 0)) - 0.475f;
-                    const float egg_b = w.length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
-                    const float egg_t = w.length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
-                    const float egg_1 = op_blend(egg_m, egg_b, .5f);
-                    val = op_blend(egg_1, egg_t, .5f);
-                } else {                                                     // :120-134
-                    const D2 left_foot = {sd_cylinder0<false>(F.foot_l, p + F.left_foot, thick, w), mat_egg};
-                    const D2 right_foot = {sd_cylinder0<false>(F.foot_r, p + F.right_foot, thick, w), mat_egg};
-                    part[3][lane] = op_add2(left_foot, right_foot).d;
-                    const v3 pw = p + V3(0, 1.2f, 0);
-                    val = w.length(V2(w.length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f;             // sd_torus sdf.h:75-83
-                }
-                part[wave + (wave == 3)][lane] = val;
-            }
-            __syncthreads();
-            if (need) {
-                const D2 feet = {part[3][lane], mat_egg}, bike = {part[4][lane], mat_bike}, egg = {part[2][lane], mat_egg};
-                const D2 _1 = op_add2(feet, bike);                           // :140-143
-                const D2 _2 = op_add2(egg, _1);
-                const D2 legs = op_add2(D2{part[0][lane], mat_egg}, D2{part[1][lane], mat_egg});
-                const D2 _3 = op_add2(legs, _2);
-                d = op_add2(ground, _3);
-            }
-            ++ex;
-        }
-#ifdef SBX_EGG_DEBUG
-        if (!c.done && L.id[lane] == SBX_EGG_DEBUG)
-            printf("coop wave %d lane %d of %d step %d t %.9g ground %.9g need %d ex %d parts %.9g %.9g %.9g %.9g %.9g -> d %.9g m %g\n", wave, lane, S, i,
-                   c.t, ground.d, (int)need, ex, L.part[(ex - 1) & 1][0][lane], L.part[(ex - 1) & 1][1][lane], L.part[(ex - 1) & 1][2][lane],
-                   L.part[(ex - 1) & 1][3][lane], L.part[(ex - 1) & 1][4][lane], d.d, d.m);
-#endif
-        if (!c.done) {
-            if (c.t > 15.f) c.done = true;
-            else if (d.d < 0.001f) { c.hit = true; c.mat = (int)d.m; c.done = true; }      // (c.t stays: the hit point is ro + crd * c.t)
-            else {
-                c.t += d.d;
-#ifdef SBX_EGG_STATS
-                ++c.steps;
-#endif
-            }
-        }
-    }
-    if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(0);
-    if (wave == 0 && active) {
-        const v3 hp = ro + crd * c.t;                                        // = P of the step that hit (c.t was not advanced)
-        L.res[0][lane] = u2f((c.hit ? 1u : 0u) | ((unsigned)c.mat << 1) | ((unsigned)c.steps << 8));
-        L.res[1][lane] = hp.x; L.res[2][lane] = hp.y; L.res[3][lane] = hp.z;
-    }
-    __syncthreads();
-    if (live) {
-        const unsigned k = f2u(L.res[0][slot]);
-        r.hit = (k & 1u) != 0u; r.mat = (int)((k >> 1) & 0x7fu); r.steps += (int)(k >> 8);
-        r.hp = V3(L.res[1][slot], L.res[2][slot], L.res[3][slot]);
-    }
-    r.done = true;
+    unsigned pos = 0;
+    if (lane == 0) pos = __hip_atomic_fetch_add(&A.q->reserve, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+    if (pos + (unsigned)n > (unsigned)EGG_Q_CAP) return false;          // full: the slots stay untagged, which a finisher reads as empty
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+    EggRec* r = &A.q->rec[pos + (unsigned)rank];
+    if (mine) { r->fx = fx; r->fy = fy; r->t = t; r->i = (unsigned)i; r->idx = (unsigned long long)idx; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                   // the ray before its tag
+    if (mine) __hip_atomic_store(&r->tag, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
 }
 
 #ifndef EGG_WITNESS
 #define EGG_WITNESS 1      // five-instruction square roots with a recorded domain (sbx_sdf.h Wit): 0 = the IEEE roots only
 #endif
 
-// One pixel up to (colour, depth) — render_scene :190-231 — with the roots of witness `w`.  `coop` (the same in every thread of the
-// workgroup): count the marching rays and finish the last <= 64 together; every thread of the workgroup must then be here.
+// One pixel up to (colour, depth) — render_scene :190-231 — with the roots of witness `w`.  `offer` (wave-uniform): this wave may
+// hand rays to the queue; `gone`: this lane's ray is a finisher's now (it computes nothing more and stores nothing).
 template <bool CULL, class W>
-__device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, bool valid, bool coop, EggCoopLds& L, W& w, v3& color, float& depth,
-                                          int& st_trace, int& st_shadow, int id = 0) {
+__device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, bool valid, bool offer, const EggQArg& A, const Pixel& px, bool& gone,
+                                          W& w, v3& color, float& depth, int& st_trace, int& st_shadow) {
     const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc, w);
     depth = -1e8f;                                          // :188, fresh per pixel
     color = V3(.1f, .1f, .7f);                              // background :9-12
     EggRay r;
-    r.t = 0.f; r.done = !valid; r.hit = false; r.mat = 0; r.hp = V3(0, 0, 0); r.steps = 0; r.id = id;
-    if (!(EGG_COOP && coop)) {
-        egg_trace_steps<CULL>(F, ro, rd, r, 0, 80, w);
-    } else {
-        const int lane = (int)threadIdx.x & 63;
-        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        int i = 0, iend = EGG_COOP_K0, set = 0;
-        for (;;) {                                          // every condition below is the same in all four waves
-            egg_trace_steps<CULL>(F, ro, rd, r, i, iend, w);
-            i = iend;
-            if (i >= 80) break;
-            const bool live = !r.done;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
-            if (lane == 0) L.cnt[set][wave] = __popcll(mask);
-            __syncthreads();
-            // (read into SGPRs: the compiler cannot know that an LDS word is the same in every lane, and a branch it takes for
-            // divergent is a masked region that a wave may walk through with no lane active — barriers and all)
-            const int c0 = __builtin_amdgcn_readfirstlane(L.cnt[set][0]), c1 = __builtin_amdgcn_readfirstlane(L.cnt[set][1]);
-            const int c2 = __builtin_amdgcn_readfirstlane(L.cnt[set][2]), c3 = __builtin_amdgcn_readfirstlane(L.cnt[set][3]);
-            set ^= 1;
-            const int S = c0 + c1 + c2 + c3;
-            if (S == 0) break;
-            if (S <= 64) {
-                const int base = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
-                egg_coop_finish<CULL>(F, ro, rd, r, i, live, mask, base, S, L, w);
-                break;
-            }
-            iend = i + EGG_COOP_DK < 80 ? i + EGG_COOP_DK : 80;
+    r.t = 0.f; r.done = !valid || gone; r.hit = false; r.mat = 0; r.hp = V3(0, 0, 0); r.steps = 0;
+    // ONE copy of the trace loop (each is a copy of sdf(), ~4.5 KB of a 64 KB instruction cache): a wave that may not offer runs its
+    // 80 steps in one go, one that may stops after EGG_COOP_K1 and then every EGG_COOP_DK
+    int i = 0, iend = (EGG_COOP && offer) ? EGG_COOP_K1 : 80;
+#pragma clang loop unroll(disable)
+    for (;;) {                                              // (wave-uniform conditions)
+        egg_trace_steps<CULL>(F, ro, rd, r, i, iend, w);
+        i = iend;
+        if (i >= 80 || __builtin_amdgcn_ballot_w64(!r.done) == 0ull) break;
+        // near the scene, hence expensive, hence worth a finisher's lane.  A wave in which ANY lane has taken a root outside the
+        // witness's interval keeps its rays: it is going to run again with the IEEE roots (k_egg), from the start.
+        const v3 P = ro + rd * r.t;
+        const bool want = !r.done && !egg_far(F, P, dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f));
+        const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
+        if (wm != 0ull && __builtin_amdgcn_ballot_w64(w.bad) == 0ull && egg_export(A, wm, want, px.fx, px.fy, r.t, i, px.idx)) {
+            if (want) { gone = true; r.done = true; }
         }
+        iend = i + EGG_COOP_DK < 80 ? i + EGG_COOP_DK : 80;
     }
 #ifdef SBX_EGG_STATS
     st_trace = r.steps;
@@ -389,16 +304,17 @@ __device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, bool valid, 
     }
 }
 
-// Where the cooperative finish is worth its barriers: workgroups with a pixel under the projection of the sphere around everything
-// but the ground (in point_cam units: the same extents as the hot rectangle, egg_extents below) — only there can a ray graze
-// anything.  Elsewhere the four waves of a workgroup never meet.  all = 1: no usable projection (the camera is inside the sphere):
-// every workgroup counts.
-struct CoopBox { float x0, x1, y0, y1; int all; };
+// bars overlay :233-251
+__device__ __forceinline__ v3 egg_bars(v3 color, float pcx, float depth) {
+    const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pcx) - 0.6f)) - 0.05f);
+    const float depth_factor = 1.f - step_(1.f, depth);
+    return abs3(mix3(color, V3(.6f, .6f, .6f), bar_factor * depth_factor));
+}
 
 // WIT: 0 = IEEE roots; 1 = witnessed roots (the shipped form); 2 = the same with the witness's lower edge at 1.0, so that waves
 // near any primitive's axis DO record and re-run (sbx_set_variant 2: the test of the re-run path — same frame required)
 template <bool CULL, int WIT>
-__global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float* __restrict__ out, HotRect hot, CoopBox box) {
+__global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float* __restrict__ out, HotRect hot, EggQArg A) {
 #ifdef SBX_EGG_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();      // census build (tools/egg_census.py): 100 MHz counter
 #endif
@@ -414,46 +330,35 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
         asm volatile("" : "+v"(F.foot_ml.x), "+v"(F.foot_ml.y), "+v"(F.foot_ml.z), "+v"(F.foot_mr.x), "+v"(F.foot_mr.y), "+v"(F.foot_mr.z));
 #endif
     }
-    __shared__ EggCoopLds L;
     int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    // The waves that may hand rays over are those of the hot rectangle — the first hot.w * hot.h workgroups — and the finishers
+    // count exactly those home (A.expected): every one of them reports below, whatever its pixels did.
+    const bool offer = EGG_COOP && A.q != nullptr && by * (int)gridDim.x + bx < hot.w * hot.h;
     if (EGG_HOT_FIRST && hot.w > 0) hot_first_tile(hot, (int)gridDim.x, bx, by);          // wave-uniform
-    const Pixel px0 = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
-    if (!EGG_COOP && !px0.valid) return;
-    const v2 pc0 = point_cam(F.cam, px0.fx, px0.fy);
-    bool coop = false;
-    if (EGG_COOP)           // (an invalid pixel stays: its wave's barriers need it.  It never marches and never stores.)
-        coop = __syncthreads_or(px0.valid && (box.all || (pc0.x >= box.x0 && pc0.x <= box.x1 && pc0.y >= box.y0 && pc0.y <= box.y1))) != 0;
-#ifdef EGG_COOP_NEVER      // A/B: the four-wave workgroup and all of its code, but no workgroup ever counts
-    coop = false;
-#endif
+    const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
+    if (!(EGG_COOP && offer) && !px.valid) return;           // (an offering wave keeps its invalid lanes: lane 0 reports for the wave)
+    const v2 pc = point_cam(F.cam, px.fx, px.fy);
     float depth;
     v3 color;
+    bool gone = false;
     if (WIT != 0) {
         Wit<true> w;
         if (WIT == 2) w.lo = 0x3F800000u;
-        egg_pixel<CULL>(F, pc0, px0.valid, coop, L, w, color, depth, st_trace, st_shadow, px0.x | (px0.y << 16));
-        // some lane took a root outside the proved interval: the IEEE forms.  (With the cooperative finish a wave's roots may have been
-        // another wave's rays: the workgroup re-runs together.)
-        const bool again = coop ? __syncthreads_or(w.bad) != 0 : __builtin_amdgcn_ballot_w64(w.bad) != 0ull;
-        if (again) {
-            Wit<false> w0;
-            egg_pixel<CULL>(F, pc0, px0.valid, coop, L, w0, color, depth, st_trace, st_shadow, px0.x | (px0.y << 16));
+        egg_pixel<CULL>(F, pc, px.valid, offer, A, px, gone, w, color, depth, st_trace, st_shadow);
+        if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull) {      // some lane took a root outside the proved interval: the IEEE forms
+            Wit<false> w0;                                     // (rays handed over before that were exact, and stay handed over)
+            egg_pixel<CULL>(F, pc, px.valid, offer, A, px, gone, w0, color, depth, st_trace, st_shadow);
         }
     } else {
         Wit<false> w0;
-        egg_pixel<CULL>(F, pc0, px0.valid, coop, L, w0, color, depth, st_trace, st_shadow, px0.x | (px0.y << 16));
+        egg_pixel<CULL>(F, pc, px.valid, offer, A, px, gone, w0, color, depth, st_trace, st_shadow);
     }
-    // The pixel's place and point_cam again, from a thread id the compiler cannot recognise: kept across the march they are six
-    // VGPRs the whole pixel long, and the march is what needs registers
-    int tid = (int)threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, tid, bx, by, (int)gridDim.y);
-    if (EGG_COOP && !px.valid) return;
-    const v2 pc = point_cam(F.cam, px.fx, px.fy);
-    // bars overlay :233-251
-    const float bar_factor = 1.0f - smoothstep_(0.0f, 0.01f, abs_((abs_(pc.x) - 0.6f)) - 0.05f);
-    const float depth_factor = 1.f - step_(1.f, depth);
-    color = abs3(mix3(color, V3(.6f, .6f, .6f), bar_factor * depth_factor));
+    if (EGG_COOP && offer) {                                   // this wave hands over nothing more
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (((int)threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&A.q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!px.valid) return;
+    }
+    color = egg_bars(color, pc.x, depth);
 #ifdef SBX_EGG_STATS
     {   // lane 0 of the wave: start / end time, the wave's longest trace, lanes that ran a shadow march, the wave's place
         int mx = st_trace;
@@ -468,12 +373,216 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
         o4.x = __uint_as_float((unsigned)(st_t0 & 0xffffffffu));
         o4.y = __uint_as_float((unsigned)(st_t1 - st_t0));
         o4.z = __uint_as_float((unsigned)mx | ((unsigned)nsh << 8) | ((xcc & 0xfu) << 16) | ((hwid & 0xffffu) << 20));
-        o4.w = __uint_as_float((unsigned)st_trace | ((unsigned)st_shadow << 8));      // per LANE: its own trace steps, shadow march or not
+        o4.w = __uint_as_float((unsigned)st_trace | ((unsigned)st_shadow << 8) | (gone ? 0x10000u : 0u));   // per LANE: trace steps, shadow march, handed over
         reinterpret_cast<float4*>(out)[px.idx] = o4;
         return;
     }
 #endif
+    if (gone) return;
     store_rgba(M, out, px.idx, to_srgb(color));
+}
+
+// ---- the finishers ---------------------------------------------------------------------------------------------------------
+struct EggCoopLds {
+    float part[2][5][64];       // left leg, right leg, egg, feet, wheel; two sets, by exchange parity: a fast wave may write the next
+                                // exchange while a slow one still reads this one (the barrier of the exchange between orders the reuse)
+    float fx[64], fy[64], t[64];
+    unsigned i[64];
+    unsigned long long idx[64];
+    unsigned start, n, last, bad, timeout;
+};
+
+// sdf(P) of the lanes in `on`, by the four waves of the workgroup together: every wave calls this with the SAME P and on
+template <bool CULL, class W>
+__device__ __forceinline__ D2 egg_coop_sdf(const FrameEgg& F, v3 P, bool on, int wave, int lane, EggCoopLds& L, int& ex, W& w) {
+    const float inf = u2f(0x7f800000u), thick = .05f;
+    const float mat_egg = 1.f, mat_bike = 2.f, mat_ground = 3.f;              // :17-20
+    const D2 ground = {dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f), mat_ground};           // sd_plane :136-138
+    D2 d = ground;
+    const bool need = on && !(CULL && egg_far(F, P, ground.d));
+    if (__builtin_amdgcn_ballot_w64(need) != 0ull) {                         // the same word in all four waves
+        const v3 p = mul(F.rot_y, P) - V3(0, 0.5f, 3.5f);                    // :40-41
+        float (*part)[64] = L.part[ex & 1];
+        if (need) {                       // (a lane that is off or far evaluates nothing: it must not record a root either)
+            // One store after the chain, at an address that does not depend on the branch taken: with a store in every branch hipcc
+            // (ROCm 7.2) sinks them into one store whose address is a phi, and the structurised code of the LAST branch never sets
+            // that address register (seen in the listing: wave 3 stored the wheel's distance through a stale s22; every ray that
+            // met the cooperation came out as a wheel hit).
+            float val;
+            if (wave == 0) {                                                 // :102-118.  (Two copies of the tube rather than one with a
+                const bool far = CULL && __builtin_amdgcn_ballot_w64(!bezier_far(F.leg_l, p, thick, ground.d)) == 0ull;   // selected
+                val = far ? inf : sd_bezier_x(F.leg_l, p, thick, w);                                // frame: the select of 18 kernel
+            } else if (wave == 1) {                                                                // arguments lands in VGPRs and spills)
+                const bool far = CULL && __builtin_amdgcn_ballot_w64(!bezier_far(F.leg_r, p, thick, ground.d)) == 0ull;
+                val = far ? inf : sd_bezier_x(F.leg_r, p, thick, w);
+            } else if (wave == 2) {                                          // :47-53
+                const float egg_y = 0.65f;
+                const float egg_m = w.length(p - V3(0, egg_y, 0)) - 0.475f;
+                const float egg_b = w.length(p - V3(0, egg_y - 0.45f, 0)) - 0.25f;
+                const float egg_t = w.length(p - V3(0, egg_y + 0.45f, 0)) - 0.25f;
+                const float egg_1 = op_blend(egg_m, egg_b, .5f);
+                val = op_blend(egg_1, egg_t, .5f);
+            } else {                                                         // :120-134
+                const D2 left_foot = {sd_cylinder0<false>(F.foot_l, p + F.left_foot, thick, w), mat_egg};
+                const D2 right_foot = {sd_cylinder0<false>(F.foot_r, p + F.right_foot, thick, w), mat_egg};
+                part[3][lane] = op_add2(left_foot, right_foot).d;
+                const v3 pw = p + V3(0, 1.2f, 0);
+                val = w.length(V2(w.length(V2(pw.x, pw.y)) - 1.f, pw.z)) - .03f;                 // sd_torus sdf.h:75-83
+            }
+            part[wave + (wave == 3)][lane] = val;
+        }
+        __syncthreads();
+        if (need) {
+            const D2 feet = {part[3][lane], mat_egg}, bike = {part[4][lane], mat_bike}, egg = {part[2][lane], mat_egg};
+            const D2 _1 = op_add2(feet, bike);                               // :140-143
+            const D2 _2 = op_add2(egg, _1);
+            const D2 legs = op_add2(D2{part[0][lane], mat_egg}, D2{part[1][lane], mat_egg});
+            const D2 _3 = op_add2(legs, _2);
+            d = op_add2(ground, _3);
+        }
+        ++ex;
+    }
+    return d;
+}
+
+// The rest of 64 queued pixels, by the four waves together (each holds the same copy; wave 0 stores).  false: a root outside the
+// witness's interval was taken somewhere — nothing was stored, run again with the IEEE roots.
+template <bool CULL, class W>
+__device__ __forceinline__ bool egg_finish_batch(const FrameEgg& F, const RowMap& M, float* __restrict__ out, int n, int wave, int lane,
+                                                 EggCoopLds& L, W& w) {
+    const bool active = lane < n;
+    const float fx = active ? L.fx[lane] : .5f, fy = active ? L.fy[lane] : .5f;
+    const v2 pc = point_cam(F.cam, fx, fy);
+    const v3 ro = F.cam.eye, rd = primary_dir(F.cam, pc, w);                 // the producer's functions on the producer's numbers
+    float t = active ? L.t[lane] : 0.f;
+    int i = active ? (int)L.i[lane] : 80;
+    bool done = !active, hit = false;
+    int mat = 0, ex = 0;
+    while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {                     // render_scene :190-231 from step i on
+        const v3 P = ro + rd * t;
+        const D2 d = egg_coop_sdf<CULL>(F, P, !done, wave, lane, L, ex, w);
+        if (!done) {
+            if (t > 15.f) done = true;
+            else if (d.d < 0.001f) { hit = true; mat = (int)d.m; done = true; }   // (t stays: the hit point is ro + rd * t)
+            else { t += d.d; if (++i >= 80) done = true; }
+        }
+    }
+    float depth = -1e8f;
+    v3 color = V3(.1f, .1f, .7f);
+    const v3 hp = ro + rd * t;
+    float s = 1.f;
+    {   // shadowmarch :161-186 of the pixels that landed on the ground
+        const v3 sh_dir = V3(0, 1, 1), so = hp + sh_dir * 0.05f;
+        bool sdone = !(hit && mat == 3);
+        float st = 0.f, umbra = 1.f;
+        for (int k = 0; k < 20; ++k) {
+            if (__builtin_amdgcn_ballot_w64(!sdone) == 0ull) break;
+            const v3 P = so + sh_dir * st;
+            const D2 d = egg_coop_sdf<CULL>(F, P, !sdone, wave, lane, L, ex, w);
+            if (!sdone) {
+                if (st > 10.f) sdone = true;
+                else if (d.d < 0.001f) { umbra = 0.1f; sdone = true; }
+                else { st += d.d; umbra = fmin_(umbra, 15.f * d.d / st); }
+            }
+        }
+        if (hit && mat == 3) s = umbra;
+    }
+    if (hit) {
+        if (mat == 1 || mat == 2) depth = fmax_(depth, hp.z);
+        v3 base = V3(1, 1, 1);                              // illuminate :29-35
+        if (mat == 3) base = V3(13.f / 255.f, 104.f / 255.f, 0.f / 255.f);
+        else if (mat == 1) base = V3(0.9f, 0.95f, 0.95f);
+        else if (mat == 2) base = V3(.2f, .2f, .2f);
+        color = base * s;
+    }
+    if (W::fast) {                                          // one verdict for the workgroup
+        if (__builtin_amdgcn_ballot_w64(w.bad) != 0ull && lane == 0) L.bad = 1u;
+        __syncthreads();
+        const bool bad = __builtin_amdgcn_readfirstlane((int)L.bad) != 0;
+        __syncthreads();
+        if (bad) return false;
+    }
+    color = egg_bars(color, pc.x, depth);
+#ifndef SBX_EGG_STATS                                       // (the census build's frame holds k_egg's per-wave records instead)
+    if (wave == 0 && active) store_rgba(M, out, (size_t)L.idx[lane], to_srgb(color));
+#endif
+    return true;
+}
+
+#ifndef EGG_FIN_POLLS
+#define EGG_FIN_POLLS (1 << 22)     // polls (~0.5 us each) after which a finisher gives up on the producers: seconds, never reached by a
+#endif                              // launch that runs; then the fault word is raised (the frame is incomplete) instead of a hang
+__device__ unsigned* g_egg_fault = nullptr;
+
+template <bool CULL, int WIT>
+__global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float* __restrict__ out, EggQArg A) {
+    __shared__ EggCoopLds L;
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // (an SGPR: the compiler cannot know it is uniform)
+    if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(EGG_COOP_PRIO);
+    if (threadIdx.x == 0) { L.bad = 0u; L.timeout = 0u; }
+    for (;;) {
+        if (threadIdx.x == 0) L.start = __hip_atomic_fetch_add(&A.q->head, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned start = (unsigned)__builtin_amdgcn_readfirstlane((int)L.start);
+        if (wave == 0) {
+            // lane j waits for slot start + j: tagged with this launch's number = a ray; still untagged when every producer wave
+            // has reported (their tags were released before their reports) = empty, and so is every later slot
+            const unsigned slot = start + (unsigned)lane;
+            const EggRec* r = &A.q->rec[slot < (unsigned)EGG_Q_CAP ? slot : 0u];
+            bool have = false, empty = slot >= (unsigned)EGG_Q_CAP;
+            int polls = 0;
+            while (__builtin_amdgcn_ballot_w64(!have && !empty) != 0ull) {
+                if (!have && !empty) {
+                    if (egg_ld(&r->tag) == A.seq) have = true;
+                    else if (egg_ld(&A.q->done) >= A.expected) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        if (egg_ld(&r->tag) == A.seq) have = true; else empty = true;
+                    }
+                }
+                if (++polls > EGG_FIN_POLLS) { empty = true; if (lane == 0) L.timeout = 1u; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(have);
+            if (have) {
+                const int k = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                L.fx[k] = r->fx; L.fy[k] = r->fy; L.t[k] = r->t; L.i[k] = r->i; L.idx[k] = r->idx;
+            }
+            if (lane == 0) { L.n = (unsigned)__popcll(hm); L.last = __builtin_amdgcn_ballot_w64(empty) != 0ull ? 1u : 0u; }
+        }
+        __syncthreads();
+        const int n = __builtin_amdgcn_readfirstlane((int)L.n);
+        const bool last = __builtin_amdgcn_readfirstlane((int)L.last) != 0;
+        if (n > 0) {
+            bool ok = false;
+            if (WIT != 0) {
+                Wit<true> w;
+                if (WIT == 2) w.lo = 0x3F800000u;
+                ok = egg_finish_batch<CULL>(F, M, out, n, wave, lane, L, w);
+                if (!ok && threadIdx.x == 0) L.bad = 0u;
+            }
+            if (!ok) {
+                __syncthreads();
+                Wit<false> w0;
+                egg_finish_batch<CULL>(F, M, out, n, wave, lane, L, w0);
+            }
+        }
+        if (last) break;
+        __syncthreads();                                    // (the batch's LDS words before the next claim overwrites them)
+    }
+    if (threadIdx.x == 0) {
+        if (L.timeout && g_egg_fault) __hip_atomic_store(g_egg_fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the last finisher out leaves the counters as the next launch on this queue expects them (tags need no reset: the next
+        // launch carries another number)
+        const unsigned gone = __hip_atomic_fetch_add(&A.q->out, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone + 1u == (unsigned)A.nf) {
+            __hip_atomic_store(&A.q->reserve, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&A.q->head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&A.q->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&A.q->out, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // The projection of the sphere (F.oc, F.orad) around everything but the ground (sdf()'s p space: P = rot_y^T (p + (0, .5, 3.5))) in
@@ -498,7 +607,8 @@ static bool egg_extents(const FrameEgg& F, float& pxa, float& pxb, float& pya, f
 }
 
 // The tiles under that projection, for a launch that covers whole rows of the frame from row M.y0 (a contiguous strip; other maps:
-// plain order).  A hint about cost: off by any amount it only changes the order in which the same workgroups run.
+// plain order).  A hint about cost: off by any amount it only changes the order in which the same workgroups run (and which waves
+// may hand rays to the finishers).
 static HotRect egg_hot_rect(const FrameEgg& F, const RowMap& M, dim3 grid) {
     HotRect none{0, 0, 0, 0};
     if (!EGG_HOT_FIRST || M.nranks != 1 || M.frag || M.span_mode || M.r0 != 0) return none;
@@ -518,16 +628,82 @@ static HotRect egg_hot_rect(const FrameEgg& F, const RowMap& M, dim3 grid) {
     return HotRect{x0, y0, x1 - x0, y1 - y0};
 }
 
-void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant) {
+// ---- the launch's side: queues, the finishers' streams, the events that fork and join them -------------------------------------
+// One EggSide per context (sbx_capi.hip), made on first use.  A launch takes the next of EGG_SIDE_RING queues and the next of the
+// side streams; a queue is reused only behind the event of the launch that used it last (both of the new launch's streams wait on
+// it: nothing on the host blocks).
+constexpr int EGG_SIDE_RING = 8, EGG_SIDE_STREAMS = 4;
+struct EggSide {
+    EggQueue* q[EGG_SIDE_RING] = {};
+    unsigned seq[EGG_SIDE_RING] = {};
+    hipEvent_t used[EGG_SIDE_RING] = {};
+    bool was_used[EGG_SIDE_RING] = {};
+    hipStream_t side[EGG_SIDE_STREAMS] = {};
+    hipEvent_t fork[EGG_SIDE_RING] = {};
+    unsigned next = 0;
+    bool ok = false;
+};
+void* egg_side_create() {
+    EggSide* S = new EggSide;
+    bool ok = true;
+    for (int k = 0; k < EGG_SIDE_RING && ok; ++k) {
+        ok = hipMalloc((void**)&S->q[k], sizeof(EggQueue)) == hipSuccess && hipMemset(S->q[k], 0, sizeof(EggQueue)) == hipSuccess &&
+             hipEventCreateWithFlags(&S->used[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&S->fork[k], hipEventDisableTiming) == hipSuccess;
+    }
+    for (int k = 0; k < EGG_SIDE_STREAMS && ok; ++k) ok = hipStreamCreateWithFlags(&S->side[k], hipStreamNonBlocking) == hipSuccess;
+    if (ok) ok = hipDeviceSynchronize() == hipSuccess;       // the zeroed counters, before any stream's first launch
+    S->ok = ok;
+    if (!ok) (void)hipGetLastError();
+    return S;
+}
+void egg_side_destroy(void* p) {
+    EggSide* S = static_cast<EggSide*>(p);
+    if (!S) return;
+    for (int k = 0; k < EGG_SIDE_RING; ++k) {
+        if (S->q[k]) (void)hipFree(S->q[k]);
+        if (S->used[k]) (void)hipEventDestroy(S->used[k]);
+        if (S->fork[k]) (void)hipEventDestroy(S->fork[k]);
+    }
+    for (auto& st : S->side) if (st) (void)hipStreamDestroy(st);
+    delete S;
+}
+hipError_t bind_fault_egg(unsigned* word) { return hipMemcpyToSymbol(HIP_SYMBOL(g_egg_fault), &word, sizeof(word)); }
+
+template <bool CULL, int WIT>
+static void launch_egg_t(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, dim3 grid, HotRect hot, size_t pad, EggSide* S) {
+    EggQArg A{nullptr, 0u, 0u, 0};
+    const int nhot = hot.w * hot.h;
+    if (!EGG_COOP || !S || !S->ok || nhot <= 0) {
+        hipLaunchKernelGGL((k_egg<CULL, WIT>), grid, dim3(64 * EGG_TX), pad, s, F, M, out, hot, A);
+        return;
+    }
+    const int k = (int)(S->next++ % EGG_SIDE_RING);
+    hipStream_t side = S->side[k % EGG_SIDE_STREAMS];
+    if (++S->seq[k] == 0u) ++S->seq[k];                      // (0 is the tag of a slot never written)
+    A.q = S->q[k]; A.seq = S->seq[k]; A.expected = (unsigned)nhot * EGG_TX; A.nf = EGG_COOP_NF;
+    if (S->was_used[k]) { (void)hipStreamWaitEvent(s, S->used[k], 0); (void)hipStreamWaitEvent(side, S->used[k], 0); }
+    // fork: the finishers start where the caller's stream stands; k_egg FIRST — should both streams share a hardware queue, the
+    // finishers then run behind it (late, but they never wait for a kernel that is queued behind them)
+    (void)hipEventRecord(S->fork[k], s);
+    hipLaunchKernelGGL((k_egg<CULL, WIT>), grid, dim3(64 * EGG_TX), pad, s, F, M, out, hot, A);
+    (void)hipStreamWaitEvent(side, S->fork[k], 0);
+    hipLaunchKernelGGL((k_egg_finish<CULL, WIT>), dim3(EGG_COOP_NF), dim3(256), 0, side, F, M, out, A);
+    (void)hipEventRecord(S->used[k], side);
+    (void)hipStreamWaitEvent(s, S->used[k], 0);              // join
+    S->was_used[k] = true;
+}
+
+// side: the context's EggSide, or nullptr (a stream being captured, a launch that must stay one kernel): the plain kernel
+void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant, void* side) {
     const dim3 grid = grid_for<EGG_TW, EGG_TX>(M);
     const HotRect hot = egg_hot_rect(F, M, grid);
-    CoopBox box{0.f, 0.f, 0.f, 0.f, 1};
-    if (egg_extents(F, box.x0, box.x1, box.y0, box.y1)) box.all = 0;
+    EggSide* S = static_cast<EggSide*>(side);
     static const int pad = []() { const char* e = std::getenv("SBX_DEBUG_LDS_PAD"); return e ? std::atoi(e) : EGG_LDS_PAD; }();
-    if (variant == 1) hipLaunchKernelGGL((k_egg<false, 0>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot, box);
-    else if (variant == 2) hipLaunchKernelGGL((k_egg<true, 2>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot, box);
-    else if (variant == 3) hipLaunchKernelGGL((k_egg<true, 0>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot, box);
-    else hipLaunchKernelGGL((k_egg<true, EGG_WITNESS>), grid, dim3(64 * EGG_TX), (size_t)pad, s, F, M, out, hot, box);
+    if (variant == 1) launch_egg_t<false, 0>(F, M, out, s, grid, hot, (size_t)pad, S);
+    else if (variant == 2) launch_egg_t<true, 2>(F, M, out, s, grid, hot, (size_t)pad, S);
+    else if (variant == 3) launch_egg_t<true, 0>(F, M, out, s, grid, hot, (size_t)pad, S);
+    else launch_egg_t<true, EGG_WITNESS>(F, M, out, s, grid, hot, (size_t)pad, S);
 }
 
 }  // namespace sbx

@@ -107,6 +107,7 @@ struct sbx_ctx {
     struct SpanSlot { std::vector<int> key; std::vector<int> table; int4* dev = nullptr; int max_w = 0; size_t cap = 0; };
     SpanSlot span_slots[4];
     unsigned span_next = 0;
+    void* egg_side = nullptr;        // kern_egg.hip EggSide: queues, streams and events of APP_EGG's finisher launches
     std::string err;
 };
 
@@ -125,7 +126,8 @@ static int bind_fault_word(int device) {
     }
     unsigned* dev = nullptr;
     if (hipHostGetDevicePointer((void**)&dev, g_fault_word[device], 0) != hipSuccess) return SBX_ERR_HIP;
-    if (bind_fault_clouds(dev) != hipSuccess || bind_fault_clouds_ue4(dev) != hipSuccess || bind_fault_planet(dev) != hipSuccess)
+    if (bind_fault_clouds(dev) != hipSuccess || bind_fault_clouds_ue4(dev) != hipSuccess || bind_fault_planet(dev) != hipSuccess ||
+        bind_fault_egg(dev) != hipSuccess)
         return SBX_ERR_HIP;
     return SBX_OK;
 }
@@ -477,6 +479,7 @@ void sbx_destroy(sbx_ctx* ctx) {
     for (auto& en : ctx->mi) if (en.host.load()) (void)hipHostFree(en.host.load());
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
+    egg_side_destroy(ctx->egg_side);
     if (ctx->hs_dev) (void)hipFree(ctx->hs_dev);
     if (ctx->hs_copy) (void)hipStreamDestroy(ctx->hs_copy);
     for (auto& st : ctx->hs_render) if (st) (void)hipStreamDestroy(st);
@@ -599,7 +602,12 @@ static unsigned device_fault_code(const sbx_ctx* ctx) {
     return w ? *(volatile const unsigned*)w : 0u;
 }
 static bool device_fault(const sbx_ctx* ctx) { return device_fault_code(ctx) != 0u; }
-static const char* fault_text(const sbx_ctx* ctx) { return device_fault_code(ctx) == 2u ? kFaultTextWait : kFaultText; }
+static const char* kFaultTextEgg = "a finisher of an APP_EGG launch on this device gave up waiting for the launch's own waves (kern_egg.hip "
+                                   "k_egg_finish): the frame is incomplete; re-render after sbx_clear_fault";
+static const char* fault_text(const sbx_ctx* ctx) {
+    const unsigned c = device_fault_code(ctx);
+    return c == 2u ? kFaultTextWait : c == 3u ? kFaultTextEgg : kFaultText;
+}
 
 // Domain of the margin-based culls of EGG / SDF_AO / VINYL (bounding spheres and boxes around members placed by rotations) and
 // of PLANET's |o|^2 band test (a rotation preserves the norm): their proofs take the frame's rotations to BE rotations.  The
@@ -654,7 +662,12 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
                                                     // a captured launch is replayed later, possibly over volumes re-bound in place with
                                                     // other texel ranges: no bounds baked into a graph (the plain exp_ / IEEE divide)
                                                     (ctx->tex_bounds_valid && !capturing) ? ctx->tex_bounds : nullptr); break;
-    case SBX_APP_EGG: launch_egg(build_egg(*uni), M, rgba, s, sdf_variant); break;
+    case SBX_APP_EGG:
+        // the finishers' queues and streams, on first use; a stream being captured gets the plain kernel (a graph would bake a queue
+        // and its sequence number in)
+        if (!ctx->egg_side && !capturing) ctx->egg_side = egg_side_create();
+        launch_egg(build_egg(*uni), M, rgba, s, sdf_variant, capturing ? nullptr : ctx->egg_side);
+        break;
     case SBX_APP_RAYTRACER: launch_raytracer(build_raytracer(*uni), M, rgba, s, ctx->variant == 1 ? 1 : ctx->sdf_roots); break;
     case SBX_APP_ATMOSPHERE: launch_atmosphere(build_atmosphere(*uni), M, rgba, s, ctx->precision); break;
     case SBX_APP_SDF_AO: {
@@ -1599,7 +1612,7 @@ int sbx_debug_raise_fault(sbx_ctx* ctx, void* stream) {
 
 const char* sbx_last_error(sbx_ctx* ctx) {
     if (!ctx) return "no context";
-    if (device_fault(ctx) && ctx->err.find("hash cache") == std::string::npos) { ctx->err += ctx->err.empty() ? "" : "; "; ctx->err += kFaultText; }
+    if (device_fault(ctx) && ctx->err.find(fault_text(ctx)) == std::string::npos) { ctx->err += ctx->err.empty() ? "" : "; "; ctx->err += fault_text(ctx); }
     return ctx->err.c_str();
 }
 const char* sbx_version(void) { return "libsbx 0.2 (gfx950, ABI 2)"; }

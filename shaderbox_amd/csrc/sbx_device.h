@@ -123,7 +123,10 @@ void launch_minmax_r(const float* r, size_t n, unsigned* res, hipStream_t s);
 float minmax_key_to_float(unsigned k);
 void launch_extract_r(const float* rgba, float* r, size_t n, hipStream_t s);
 void launch_tex3d_eval(int size, const float* rgba, const float* xyz, float* out, size_t n, hipStream_t s);
-void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant);
+void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant, void* side);   // side: egg_side_create() or nullptr
+void* egg_side_create();
+void egg_side_destroy(void* side);
+hipError_t bind_fault_egg(unsigned* word);
 void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s, int variant);
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s, int precision = 0);
 void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant);
