@@ -228,14 +228,32 @@ __device__ __forceinline__ void egg_trace_steps(const FrameEgg& F, v3 ro, v3 rd,
 // waves.  Bit-exact, and the longest wave fell from 190 to 140 us, but workgroups of four give their wave slots back all at once:
 // 4500 instead of 5900 waves resident, the chip-full phase 120 -> 150 us, one launch 0.216 against 0.215 ms.
 // profiles/r06_egg_design1.txt.)
-struct EggRec { float fx, fy, t; unsigned i; unsigned long long idx; unsigned tag, pad; };     // tag == the launch's sequence number: written
-struct EggQueue {
-    unsigned reserve, head, done, out, pad[12];     // slots handed out to producers / claimed by finishers; producer waves finished; finishers gone
+struct EggRec { unsigned fx, fy, t, i, idx_lo, idx_hi, tag, pad; };      // (floats as their bits) tag == the launch's sequence number: a ray
+constexpr int EGG_Q_SHARDS = 64;                    // the producer waves' reports are spread over this many words, one per 128-byte line:
+struct EggQueue {                                   // one word takes ~88 atomics per microsecond, a launch reports 6000 times
+    unsigned reserve, pad0[31];                     // slots handed out to producers
+    unsigned head, out, pad[30];                    // slots claimed by finishers; finishers gone (pad: the census build's sums)
+    unsigned done[EGG_Q_SHARDS][32];                // producer waves finished, [shard][0]
     EggRec rec[EGG_Q_CAP];
 };
 struct EggQArg { EggQueue* q; unsigned seq, expected; int nf; };     // q == nullptr: no queue (plain kernel)
 
+// The queue's words cross between compute units (and XCDs, whose L2s do not snoop each other) WITHOUT fences: an agent-scope release
+// is a write-back of the whole L2 and an acquire an invalidate of it — six thousand reporting waves doing that took k_egg from 0.20 to
+// 0.31 ms.  Instead every queue word is written and read by agent-scope relaxed atomics (write-through / cache-bypassing `sc1`
+// accesses), and the ORDER a reader relies on is made by the writer waiting for its stores' acknowledgements (s_waitcnt vmcnt(0))
+// before it issues the word that announces them: a ray's words, wait, its tag, wait, the wave's report.
 __device__ __forceinline__ unsigned egg_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void egg_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void egg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// producer waves that have reported, summed over the shards by the 64 lanes of a wave
+__device__ __forceinline__ unsigned egg_reported(const EggQArg& A, int lane) {
+    unsigned v = egg_ld(&A.q->done[lane % EGG_Q_SHARDS][0]);
+    if (lane >= EGG_Q_SHARDS) v = 0u;
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o);
+    return v;
+}
 
 // A wave offers the rays in `want` (all lanes of the wave are here).  true: they are in the queue and no longer this wave's.
 __device__ __forceinline__ bool egg_export(const EggQArg& A, unsigned long long want, bool mine, float fx, float fy, float t, int i, size_t idx) {
@@ -247,9 +265,13 @@ __device__ __forceinline__ bool egg_export(const EggQArg& A, unsigned long long 
     if (pos + (unsigned)n > (unsigned)EGG_Q_CAP) return false;          // full: the slots stay untagged, which a finisher reads as empty
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
     EggRec* r = &A.q->rec[pos + (unsigned)rank];
-    if (mine) { r->fx = fx; r->fy = fy; r->t = t; r->i = (unsigned)i; r->idx = (unsigned long long)idx; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                   // the ray before its tag
-    if (mine) __hip_atomic_store(&r->tag, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (mine) {
+        egg_st(&r->fx, f2u(fx)); egg_st(&r->fy, f2u(fy)); egg_st(&r->t, f2u(t)); egg_st(&r->i, (unsigned)i);
+        egg_st(&r->idx_lo, (unsigned)idx); egg_st(&r->idx_hi, (unsigned)((unsigned long long)idx >> 32));
+    }
+    egg_drain();                                                         // the ray before its tag
+    if (mine) egg_st(&r->tag, A.seq);
+    egg_drain();                                                         // ... and the tag before this wave's report
     return true;
 }
 
@@ -353,9 +375,11 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
         Wit<false> w0;
         egg_pixel<CULL>(F, pc, px.valid, offer, A, px, gone, w0, color, depth, st_trace, st_shadow);
     }
-    if (EGG_COOP && offer) {                                   // this wave hands over nothing more
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (((int)threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&A.q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (EGG_COOP && offer) {                                   // this wave hands over nothing more (its tags are acknowledged: egg_export)
+#ifndef EGG_DBG_NOREPORT
+        if (((int)threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_add(&A.q->done[(blockIdx.y * gridDim.x + blockIdx.x) % EGG_Q_SHARDS][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         if (!px.valid) return;
     }
     color = egg_bars(color, pc.x, depth);
@@ -522,6 +546,9 @@ __global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float*
     if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(EGG_COOP_PRIO);
     if (threadIdx.x == 0) { L.bad = 0u; L.timeout = 0u; }
     for (;;) {
+#ifdef SBX_EGG_STATS
+        const unsigned long long st_c0 = __builtin_amdgcn_s_memrealtime();
+#endif
         if (threadIdx.x == 0) L.start = __hip_atomic_fetch_add(&A.q->head, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned start = (unsigned)__builtin_amdgcn_readfirstlane((int)L.start);
@@ -529,31 +556,50 @@ __global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float*
             // lane j waits for slot start + j: tagged with this launch's number = a ray; still untagged when every producer wave
             // has reported (their tags were released before their reports) = empty, and so is every later slot
             const unsigned slot = start + (unsigned)lane;
-            const EggRec* r = &A.q->rec[slot < (unsigned)EGG_Q_CAP ? slot : 0u];
+            EggRec* r = &A.q->rec[slot < (unsigned)EGG_Q_CAP ? slot : 0u];
             bool have = false, empty = slot >= (unsigned)EGG_Q_CAP;
             int polls = 0;
+            // ONE lane looks, about once a microsecond, at two words — slots handed out so far, producer waves reported — until the
+            // window has a ray coming or can have none; only then do the 64 lanes look at their tags.  (All lanes of all finishers
+            // polling tags and the report word took the L2 channel of that line away from the reports themselves: k_egg 0.20 -> 0.27 ms.)
+            bool all_reported = false;
+            for (;;) {
+                unsigned res = 0;
+                if (lane == 0) res = egg_ld(&A.q->reserve);
+                res = (unsigned)__builtin_amdgcn_readfirstlane((int)res);
+                all_reported = egg_reported(A, lane) >= A.expected;
+                if (res > start || all_reported) break;
+                if (++polls > EGG_FIN_POLLS) { if (lane == 0) L.timeout = 1u; break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (L.timeout) empty = true;
             while (__builtin_amdgcn_ballot_w64(!have && !empty) != 0ull) {
                 if (!have && !empty) {
                     if (egg_ld(&r->tag) == A.seq) have = true;
-                    else if (egg_ld(&A.q->done) >= A.expected) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        if (egg_ld(&r->tag) == A.seq) have = true; else empty = true;
+                    else if (all_reported) {                             // (read BEFORE this look at the tag: a report follows its wave's tags)
+                        empty = true;
                     }
                 }
+                if (__builtin_amdgcn_ballot_w64(!have && !empty) == 0ull) break;
+                const bool rep = egg_reported(A, lane) >= A.expected;
+                if (rep && !all_reported) { all_reported = true; continue; }   // one more look at the tags, now final
                 if (++polls > EGG_FIN_POLLS) { empty = true; if (lane == 0) L.timeout = 1u; }
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(8);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const unsigned long long hm = __builtin_amdgcn_ballot_w64(have);
             if (have) {
                 const int k = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-                L.fx[k] = r->fx; L.fy[k] = r->fy; L.t[k] = r->t; L.i[k] = r->i; L.idx[k] = r->idx;
+                L.fx[k] = u2f(egg_ld(&r->fx)); L.fy[k] = u2f(egg_ld(&r->fy)); L.t[k] = u2f(egg_ld(&r->t)); L.i[k] = egg_ld(&r->i);
+                L.idx[k] = (unsigned long long)egg_ld(&r->idx_lo) | ((unsigned long long)egg_ld(&r->idx_hi) << 32);
             }
             if (lane == 0) { L.n = (unsigned)__popcll(hm); L.last = __builtin_amdgcn_ballot_w64(empty) != 0ull ? 1u : 0u; }
         }
         __syncthreads();
         const int n = __builtin_amdgcn_readfirstlane((int)L.n);
         const bool last = __builtin_amdgcn_readfirstlane((int)L.last) != 0;
+#ifdef SBX_EGG_STATS
+        const unsigned long long st_b0 = __builtin_amdgcn_s_memrealtime();
+#endif
         if (n > 0) {
             bool ok = false;
             if (WIT != 0) {
@@ -568,6 +614,14 @@ __global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float*
                 egg_finish_batch<CULL>(F, M, out, n, wave, lane, L, w0);
             }
         }
+#ifdef SBX_EGG_STATS
+        if (threadIdx.x == 0 && n > 0) {
+            __hip_atomic_fetch_add(&A.q->pad[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&A.q->pad[1], (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&A.q->pad[2], (unsigned)(__builtin_amdgcn_s_memrealtime() - st_b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&A.q->pad[3], (unsigned)(st_b0 - st_c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
         if (last) break;
         __syncthreads();                                    // (the batch's LDS words before the next claim overwrites them)
     }
@@ -575,12 +629,17 @@ __global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float*
         if (L.timeout && g_egg_fault) __hip_atomic_store(g_egg_fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // the last finisher out leaves the counters as the next launch on this queue expects them (tags need no reset: the next
         // launch carries another number)
-        const unsigned gone = __hip_atomic_fetch_add(&A.q->out, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned gone = __hip_atomic_fetch_add(&A.q->out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (after this group's last claim returned)
         if (gone + 1u == (unsigned)A.nf) {
+#ifdef SBX_EGG_STATS
+            printf("finishers: %u batches, %u rays (queue reserve %u), %.1f us in batches, %.1f us waiting for rays (sums over %d workgroups)\n",
+                   egg_ld(&A.q->pad[0]), egg_ld(&A.q->pad[1]), egg_ld(&A.q->reserve), egg_ld(&A.q->pad[2]) * .01, egg_ld(&A.q->pad[3]) * .01, A.nf);
+            for (int k = 0; k < 4; ++k) egg_st(&A.q->pad[k], 0u);
+#endif
             __hip_atomic_store(&A.q->reserve, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&A.q->head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&A.q->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&A.q->out, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < EGG_Q_SHARDS; ++k) egg_st(&A.q->done[k][0], 0u);
+            __hip_atomic_store(&A.q->out, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -687,6 +746,9 @@ static void launch_egg_t(const FrameEgg& F, const RowMap& M, float* out, hipStre
     // finishers then run behind it (late, but they never wait for a kernel that is queued behind them)
     (void)hipEventRecord(S->fork[k], s);
     hipLaunchKernelGGL((k_egg<CULL, WIT>), grid, dim3(64 * EGG_TX), pad, s, F, M, out, hot, A);
+#ifdef EGG_DBG_NOFIN
+    return;
+#endif
     (void)hipStreamWaitEvent(side, S->fork[k], 0);
     hipLaunchKernelGGL((k_egg_finish<CULL, WIT>), dim3(EGG_COOP_NF), dim3(256), 0, side, F, M, out, A);
     (void)hipEventRecord(S->used[k], side);
