@@ -17,8 +17,9 @@
 #define EGG_TW 16          // wave tile EGG_TW x 64/EGG_TW pixels (profiles/r01_tile_shapes.txt)
 #endif
 #ifndef EGG_COOP
-#define EGG_COOP 1         // long, expensive rays leave their wave for a queue that four-wave FINISHER workgroups serve (see below)
-#endif
+#define EGG_COOP 0         // 1: long, expensive rays leave their wave for a queue that four-wave FINISHER workgroups serve (see "THE
+#endif                     // FINISHERS" below).  Bit-exact, measured, and NOT faster on this part: 0.225-0.35 ms against 0.215 for one
+                           // 1920x1080 launch, 0.21-0.24 against 0.136 ms per frame with two in flight (profiles/r06_egg_finishers.txt)
 #ifndef EGG_TX
 #define EGG_TX 1           // waves per workgroup: 1 (4: the same single launch, 7 % slower with frames in flight at 1080p, 3 % at 4K;
 #endif                     // census round 6: 4500 instead of 5900 waves resident — a workgroup's slots come back all at once)
@@ -29,7 +30,16 @@
 #define EGG_COOP_DK 4      // ... and between later offers
 #endif
 #ifndef EGG_COOP_NF
-#define EGG_COOP_NF 64     // finisher workgroups (four waves each) of one launch
+#define EGG_COOP_NF 128    // finisher workgroups (four waves each) of one launch
+#endif
+#ifndef EGG_COOP_DMAX
+#define EGG_COOP_DMAX 1e30f   // a ray is offered only if its last step was shorter than this (a grazing ray's steps are short)
+#endif
+#ifndef EGG_COOP_MINB
+#define EGG_COOP_MINB 32   // a finisher takes fewer rays than this only after EGG_COOP_IDLE looks at a queue that did not grow
+#endif
+#ifndef EGG_COOP_IDLE
+#define EGG_COOP_IDLE 3
 #endif
 #ifndef EGG_COOP_PRIO
 #define EGG_COOP_PRIO 0    // s_setprio of the finisher's waves (0: unchanged)
@@ -181,7 +191,7 @@ __device__ __forceinline__ void hot_first_tile(const HotRect& R, int gx, int& bx
 // 1920x1080: 0.54 -> 0.27 ms.  (Trace and shadow march as ONE loop around one copy of the sdf — lanes with a ground hit start their
 // shadow march while neighbours still trace — is slower: 0.283 vs 0.273 ms, 4K 0.68 vs 0.64; the per-lane phase logic costs more
 // than the shorter waves save.)
-struct EggRay { float t; bool done, hit; int mat; v3 hp; int steps; };
+struct EggRay { float t; bool done, hit; int mat; v3 hp; int steps; float dl; };     // dl: the last step's length
 
 // trace steps [i0, i1) of the lanes not done yet
 template <bool CULL, class W>
@@ -194,6 +204,7 @@ __device__ __forceinline__ void egg_trace_steps(const FrameEgg& F, v3 ro, v3 rd,
         if (r.t > 15.f) { r.done = true; break; }
         if (d.d < 0.001f) { r.hit = true; r.mat = (int)d.m; r.hp = p; r.done = true; break; }
         r.t += d.d;
+        if (EGG_COOP) r.dl = d.d;
 #ifdef SBX_EGG_STATS
         ++r.steps;
 #endif
@@ -232,10 +243,13 @@ struct EggRec { unsigned fx, fy, t, i, idx_lo, idx_hi, tag, pad; };      // (flo
 constexpr int EGG_Q_SHARDS = 64;                    // the producer waves' reports are spread over this many words, one per 128-byte line:
 struct EggQueue {                                   // one word takes ~88 atomics per microsecond, a launch reports 6000 times
     unsigned reserve, pad0[31];                     // slots handed out to producers
+    unsigned commit, pad1[31];                      // rays whose words and tag are written (in any order: a claimed slot may lag, briefly)
     unsigned head, out, pad[30];                    // slots claimed by finishers; finishers gone (pad: the census build's sums)
+    unsigned alldone, pad2[31];                     // shards of `done` that have all their reports: what the finishers poll — ONE word
     unsigned done[EGG_Q_SHARDS][32];                // producer waves finished, [shard][0]
     EggRec rec[EGG_Q_CAP];
 };
+static_assert(!EGG_COOP || EGG_TX == 1, "the finishers count k_egg's offering WAVES as workgroups");
 struct EggQArg { EggQueue* q; unsigned seq, expected; int nf; };     // q == nullptr: no queue (plain kernel)
 
 // The queue's words cross between compute units (and XCDs, whose L2s do not snoop each other) WITHOUT fences: an agent-scope release
@@ -247,12 +261,12 @@ __device__ __forceinline__ unsigned egg_ld(const unsigned* p) { return __hip_ato
 __device__ __forceinline__ void egg_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void egg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// producer waves that have reported, summed over the shards by the 64 lanes of a wave
-__device__ __forceinline__ unsigned egg_reported(const EggQArg& A, int lane) {
-    unsigned v = egg_ld(&A.q->done[lane % EGG_Q_SHARDS][0]);
-    if (lane >= EGG_Q_SHARDS) v = 0u;
-    for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o);
-    return v;
+// have all producer waves reported?  (the last report of a shard counts the shard in `alldone`: one word to look at)
+__device__ __forceinline__ bool egg_all_reported(const EggQArg& A, int lane) {
+    unsigned v = 0;
+    if (lane == 0) v = egg_ld(&A.q->alldone);
+    v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    return v >= (A.expected < (unsigned)EGG_Q_SHARDS ? A.expected : (unsigned)EGG_Q_SHARDS);
 }
 
 // A wave offers the rays in `want` (all lanes of the wave are here).  true: they are in the queue and no longer this wave's.
@@ -271,7 +285,9 @@ __device__ __forceinline__ bool egg_export(const EggQArg& A, unsigned long long 
     }
     egg_drain();                                                         // the ray before its tag
     if (mine) egg_st(&r->tag, A.seq);
-    egg_drain();                                                         // ... and the tag before this wave's report
+    egg_drain();
+    if (lane == 0) __hip_atomic_fetch_add(&A.q->commit, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    egg_drain();                                                         // ... the tags before the count, the count before this wave's report
     return true;
 }
 
@@ -288,7 +304,7 @@ __device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, bool valid, 
     depth = -1e8f;                                          // :188, fresh per pixel
     color = V3(.1f, .1f, .7f);                              // background :9-12
     EggRay r;
-    r.t = 0.f; r.done = !valid || gone; r.hit = false; r.mat = 0; r.hp = V3(0, 0, 0); r.steps = 0;
+    r.t = 0.f; r.done = !valid || gone; r.hit = false; r.mat = 0; r.hp = V3(0, 0, 0); r.steps = 0; r.dl = 0.f;
     // ONE copy of the trace loop (each is a copy of sdf(), ~4.5 KB of a 64 KB instruction cache): a wave that may not offer runs its
     // 80 steps in one go, one that may stops after EGG_COOP_K1 and then every EGG_COOP_DK
     int i = 0, iend = (EGG_COOP && offer) ? EGG_COOP_K1 : 80;
@@ -300,7 +316,7 @@ __device__ __forceinline__ void egg_pixel(const FrameEgg& F, v2 pc, bool valid, 
         // near the scene, hence expensive, hence worth a finisher's lane.  A wave in which ANY lane has taken a root outside the
         // witness's interval keeps its rays: it is going to run again with the IEEE roots (k_egg), from the start.
         const v3 P = ro + rd * r.t;
-        const bool want = !r.done && !egg_far(F, P, dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f));
+        const bool want = !r.done && r.dl < EGG_COOP_DMAX && !egg_far(F, P, dot(V3(0.f, 1.f, 0.f), P) + (1.2f + 0.5f));
         const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
         if (wm != 0ull && __builtin_amdgcn_ballot_w64(w.bad) == 0ull && egg_export(A, wm, want, px.fx, px.fy, r.t, i, px.idx)) {
             if (want) { gone = true; r.done = true; }
@@ -377,8 +393,12 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     }
     if (EGG_COOP && offer) {                                   // this wave hands over nothing more (its tags are acknowledged: egg_export)
 #ifndef EGG_DBG_NOREPORT
-        if (((int)threadIdx.x & 63) == 0)
-            __hip_atomic_fetch_add(&A.q->done[(blockIdx.y * gridDim.x + blockIdx.x) % EGG_Q_SHARDS][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((int)threadIdx.x & 63) == 0) {                    // (the offering waves are workgroups 0 .. expected - 1 of the launch)
+            const unsigned id = blockIdx.y * gridDim.x + blockIdx.x, sh = id % EGG_Q_SHARDS;
+            const unsigned full = A.expected / EGG_Q_SHARDS + (sh < A.expected % EGG_Q_SHARDS ? 1u : 0u);
+            if (__hip_atomic_fetch_add(&A.q->done[sh][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == full)
+                __hip_atomic_fetch_add(&A.q->alldone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #endif
         if (!px.valid) return;
     }
@@ -545,54 +565,70 @@ __global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float*
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // (an SGPR: the compiler cannot know it is uniform)
     if (EGG_COOP_PRIO > 0) __builtin_amdgcn_s_setprio(EGG_COOP_PRIO);
     if (threadIdx.x == 0) { L.bad = 0u; L.timeout = 0u; }
+#ifdef SBX_EGG_STATS
+    const unsigned long long st_g0 = __builtin_amdgcn_s_memrealtime();
+    int st_nb = 0;
+    unsigned long long st_first = 0, st_lastb = 0;
+#endif
     for (;;) {
 #ifdef SBX_EGG_STATS
         const unsigned long long st_c0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (threadIdx.x == 0) L.start = __hip_atomic_fetch_add(&A.q->head, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const unsigned start = (unsigned)__builtin_amdgcn_readfirstlane((int)L.start);
         if (wave == 0) {
-            // lane j waits for slot start + j: tagged with this launch's number = a ray; still untagged when every producer wave
-            // has reported (their tags were released before their reports) = empty, and so is every later slot
-            const unsigned slot = start + (unsigned)lane;
-            EggRec* r = &A.q->rec[slot < (unsigned)EGG_Q_CAP ? slot : 0u];
-            bool have = false, empty = slot >= (unsigned)EGG_Q_CAP;
-            int polls = 0;
-            // ONE lane looks, about once a microsecond, at two words — slots handed out so far, producer waves reported — until the
-            // window has a ray coming or can have none; only then do the 64 lanes look at their tags.  (All lanes of all finishers
-            // polling tags and the report word took the L2 channel of that line away from the reports themselves: k_egg 0.20 -> 0.27 ms.)
-            bool all_reported = false;
+            // CLAIM: rays [h, h + k) of the queue, k <= 64 of those written so far (`commit` counts rays written, in whatever order
+            // their waves got there; `head` is moved by compare-and-swap).  A finisher does not wait for a full 64 unless rays
+            // keep coming: a ray must not sit in the queue while finishers idle — the launch ends with its last ray.  No ray left
+            // and every producer wave reported (a wave's count precedes its report): done.
+            unsigned h = 0, k = 0;
+            int idle = 0, polls = 0;
+            unsigned seen = 0;
             for (;;) {
-                unsigned res = 0;
-                if (lane == 0) res = egg_ld(&A.q->reserve);
-                res = (unsigned)__builtin_amdgcn_readfirstlane((int)res);
-                all_reported = egg_reported(A, lane) >= A.expected;
-                if (res > start || all_reported) break;
-                if (++polls > EGG_FIN_POLLS) { if (lane == 0) L.timeout = 1u; break; }
-                __builtin_amdgcn_s_sleep(32);
-            }
-            if (L.timeout) empty = true;
-            while (__builtin_amdgcn_ballot_w64(!have && !empty) != 0ull) {
-                if (!have && !empty) {
-                    if (egg_ld(&r->tag) == A.seq) have = true;
-                    else if (all_reported) {                             // (read BEFORE this look at the tag: a report follows its wave's tags)
-                        empty = true;
+                unsigned c = 0;
+                if (lane == 0) { h = egg_ld(&A.q->head); c = egg_ld(&A.q->commit); }
+                h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                const unsigned avail = c > h ? c - h : 0u;
+                bool take = avail >= (unsigned)EGG_COOP_MINB;
+                if (!take) {
+                    const bool rep = egg_all_reported(A, lane);               // (read BEFORE the counts are read again)
+                    if (rep) {
+                        if (lane == 0) { h = egg_ld(&A.q->head); c = egg_ld(&A.q->commit); }
+                        h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+                        c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                        if (c <= h) { k = 0; break; }                          // final counts: nothing left
+                        take = true;
+                    } else if (avail > 0u) {
+                        idle = (c == seen) ? idle + 1 : 0;
+                        seen = c;
+                        take = idle >= EGG_COOP_IDLE;
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(!have && !empty) == 0ull) break;
-                const bool rep = egg_reported(A, lane) >= A.expected;
-                if (rep && !all_reported) { all_reported = true; continue; }   // one more look at the tags, now final
-                if (++polls > EGG_FIN_POLLS) { empty = true; if (lane == 0) L.timeout = 1u; }
-                __builtin_amdgcn_s_sleep(8);
+                if (take) {
+                    const unsigned want = (c - h) < 64u ? (c - h) : 64u;
+                    unsigned got = 0;
+                    if (lane == 0) {
+                        unsigned e = h;
+                        got = __hip_atomic_compare_exchange_strong(&A.q->head, &e, h + want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+                    }
+                    if (__builtin_amdgcn_readfirstlane((int)got) != 0) { k = want; break; }
+                    continue;                                               // another finisher moved the head: look again
+                }
+                if (++polls > EGG_FIN_POLLS) { if (lane == 0) L.timeout = 1u; k = 0; break; }
+                __builtin_amdgcn_s_sleep(48);                               // ~1.3 us: 128 finishers looking at three words
             }
-            const unsigned long long hm = __builtin_amdgcn_ballot_w64(have);
-            if (have) {
-                const int k = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-                L.fx[k] = u2f(egg_ld(&r->fx)); L.fy[k] = u2f(egg_ld(&r->fy)); L.t[k] = u2f(egg_ld(&r->t)); L.i[k] = egg_ld(&r->i);
-                L.idx[k] = (unsigned long long)egg_ld(&r->idx_lo) | ((unsigned long long)egg_ld(&r->idx_hi) << 32);
+            // the k rays: a slot's tag may lag its claim by the moment between a producer's count and a slower producer's tag
+            const bool mine = (unsigned)lane < k;
+            EggRec* r = &A.q->rec[(h + (unsigned)lane) % (unsigned)EGG_Q_CAP];
+            bool have = !mine;
+            while (__builtin_amdgcn_ballot_w64(!have) != 0ull) {
+                if (!have && egg_ld(&r->tag) == A.seq) have = true;
+                if (++polls > EGG_FIN_POLLS) { have = true; if (lane == 0) L.timeout = 1u; }
             }
-            if (lane == 0) { L.n = (unsigned)__popcll(hm); L.last = __builtin_amdgcn_ballot_w64(empty) != 0ull ? 1u : 0u; }
+            if (mine) {
+                L.fx[lane] = u2f(egg_ld(&r->fx)); L.fy[lane] = u2f(egg_ld(&r->fy)); L.t[lane] = u2f(egg_ld(&r->t)); L.i[lane] = egg_ld(&r->i);
+                L.idx[lane] = (unsigned long long)egg_ld(&r->idx_lo) | ((unsigned long long)egg_ld(&r->idx_hi) << 32);
+            }
+            if (lane == 0) { L.n = L.timeout ? 0u : k; L.last = (k == 0u) ? 1u : 0u; }
         }
         __syncthreads();
         const int n = __builtin_amdgcn_readfirstlane((int)L.n);
@@ -615,6 +651,7 @@ __global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float*
             }
         }
 #ifdef SBX_EGG_STATS
+        if (n > 0) { if (!st_nb) st_first = st_b0; ++st_nb; st_lastb = __builtin_amdgcn_s_memrealtime(); }
         if (threadIdx.x == 0 && n > 0) {
             __hip_atomic_fetch_add(&A.q->pad[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&A.q->pad[1], (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -625,6 +662,12 @@ __global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float*
         if (last) break;
         __syncthreads();                                    // (the batch's LDS words before the next claim overwrites them)
     }
+#ifdef SBX_EGG_STATS
+    if (threadIdx.x == 0)
+        printf("finisher %3d: start %llu end %llu (%.1f us) batches %d first batch at +%.1f us, last batch done at +%.1f us\n", (int)blockIdx.x, st_g0,
+               __builtin_amdgcn_s_memrealtime(), (__builtin_amdgcn_s_memrealtime() - st_g0) * .01, st_nb, st_nb ? (st_first - st_g0) * .01 : 0.,
+               st_nb ? (st_lastb - st_g0) * .01 : 0.);
+#endif
     if (threadIdx.x == 0) {
         if (L.timeout && g_egg_fault) __hip_atomic_store(g_egg_fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // the last finisher out leaves the counters as the next launch on this queue expects them (tags need no reset: the next
@@ -638,7 +681,9 @@ __global__ void __launch_bounds__(256) k_egg_finish(FrameEgg F, RowMap M, float*
 #endif
             __hip_atomic_store(&A.q->reserve, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&A.q->head, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&A.q->commit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int k = 0; k < EGG_Q_SHARDS; ++k) egg_st(&A.q->done[k][0], 0u);
+            egg_st(&A.q->alldone, 0u);
             __hip_atomic_store(&A.q->out, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -703,6 +748,7 @@ struct EggSide {
     bool ok = false;
 };
 void* egg_side_create() {
+    if (!EGG_COOP) return nullptr;
     EggSide* S = new EggSide;
     bool ok = true;
     for (int k = 0; k < EGG_SIDE_RING && ok; ++k) {
@@ -710,7 +756,12 @@ void* egg_side_create() {
              hipEventCreateWithFlags(&S->used[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&S->fork[k], hipEventDisableTiming) == hipSuccess;
     }
-    for (int k = 0; k < EGG_SIDE_STREAMS && ok; ++k) ok = hipStreamCreateWithFlags(&S->side[k], hipStreamNonBlocking) == hipSuccess;
+    // The side streams have the device's HIGHEST priority: k_egg is launched first and refills every wave slot it frees from its own
+    // 32 400 workgroups; a finisher workgroup needs four free slots on one CU, and at equal priority most of them got theirs only
+    // when k_egg had nothing left to launch (trace: the finishers ended 150 us after k_egg).
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+    for (int k = 0; k < EGG_SIDE_STREAMS && ok; ++k) ok = hipStreamCreateWithPriority(&S->side[k], hipStreamNonBlocking, hi) == hipSuccess;
     if (ok) ok = hipDeviceSynchronize() == hipSuccess;       // the zeroed counters, before any stream's first launch
     S->ok = ok;
     if (!ok) (void)hipGetLastError();
@@ -737,6 +788,7 @@ static void launch_egg_t(const FrameEgg& F, const RowMap& M, float* out, hipStre
         hipLaunchKernelGGL((k_egg<CULL, WIT>), grid, dim3(64 * EGG_TX), pad, s, F, M, out, hot, A);
         return;
     }
+    if constexpr (EGG_COOP != 0) {                           // (the finisher kernels are compiled only into builds that launch them)
     const int k = (int)(S->next++ % EGG_SIDE_RING);
     hipStream_t side = S->side[k % EGG_SIDE_STREAMS];
     if (++S->seq[k] == 0u) ++S->seq[k];                      // (0 is the tag of a slot never written)
@@ -754,6 +806,7 @@ static void launch_egg_t(const FrameEgg& F, const RowMap& M, float* out, hipStre
     (void)hipEventRecord(S->used[k], side);
     (void)hipStreamWaitEvent(s, S->used[k], 0);              // join
     S->was_used[k] = true;
+    }
 }
 
 // side: the context's EggSide, or nullptr (a stream being captured, a launch that must stay one kernel): the plain kernel
