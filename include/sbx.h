@@ -288,6 +288,7 @@ int sbx_shared_export(sbx_shared* s, sbx_shared_handle* handle);
 int sbx_shared_open(sbx_ctx* ctx, const sbx_shared_handle* handle, sbx_shared** out);
 void sbx_shared_close(sbx_shared* s);
 float* sbx_shared_frame(sbx_shared* s);
+size_t sbx_shared_bytes(sbx_shared* s);            /* bytes of the frame (as given to sbx_shared_create), on either side */
 int sbx_shared_frame_begin(sbx_shared* s, int rank, void* stream);
 int sbx_shared_frame_end(sbx_shared* s, int rank, void* stream);
 /* The store exchange with SPANS (the two ideas together, for frames whose pixel stores would bind a link: 7680x4320 in float

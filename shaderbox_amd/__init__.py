@@ -183,6 +183,8 @@ def load_library(path=None):
     lib.sbx_shared_close.restype = None
     lib.sbx_shared_frame.argtypes = [vp]
     lib.sbx_shared_frame.restype = vp
+    lib.sbx_shared_bytes.argtypes = [vp]
+    lib.sbx_shared_bytes.restype = ctypes.c_size_t
     lib.sbx_shared_frame_begin.argtypes = [vp, ci, vp]
     lib.sbx_shared_frame_end.argtypes = [vp, ci, vp]
     lib.sbx_render_split_in_place_rgb.argtypes = [vp, ci, ctypes.POINTER(Uniforms), vp, ci, ci, ci, ci, ci, fp, vp]
@@ -524,8 +526,7 @@ class Renderer:
         ctypes.memmove(ctypes.byref(hd), bytes(handle_bytes), ctypes.sizeof(hd))
         h = ctypes.c_void_p()
         self._check(self.lib.sbx_shared_open(self.ctx, ctypes.byref(hd), ctypes.byref(h)))
-        import struct
-        return SharedFrame(self, h, False, struct.unpack_from("<Q", bytes(handle_bytes), 136)[0])     # (frame_bytes of the handle blob)
+        return SharedFrame(self, h, False, int(self.lib.sbx_shared_bytes(h)))
 
     def model_landing(self, src, dst, nbytes, workgroups, duration_us):
         """include/sbx_test.h sbx_model_landing: the scaling tools' stand-in for RCCL's receive kernels on the frame's owner"""

@@ -250,7 +250,8 @@ void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipS
     for (int i = 0; i < 3; ++i) walls = walls && std::isfinite(F.spheres[i].o.x) && std::isfinite(F.spheres[i].o.y) && std::isfinite(F.spheres[i].o.z) && std::isfinite(F.spheres[i].r);
     const float chk[] = {F.cam.eye.x, F.cam.eye.y, F.cam.eye.z, F.light.x, F.light.y, F.light.z};
     for (float v : chk) walls = walls && std::isfinite(v);
-    if (variant == 2) hipLaunchKernelGGL((k_raytracer<2, RT_AXIS_PLANES != 0>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
+    if (variant == 2 && walls) hipLaunchKernelGGL((k_raytracer<2, true>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);     // (the witness's test build
+    else if (variant == 2) hipLaunchKernelGGL((k_raytracer<2, false>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);         //  keeps hit_walls' domain too)
     else if (variant == 1 || variant == 3) hipLaunchKernelGGL(k_raytracer<0>, grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
     else if (!walls) hipLaunchKernelGGL((k_raytracer<RT_WITNESS, false>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);
     else hipLaunchKernelGGL((k_raytracer<RT_WITNESS, true>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);

@@ -99,6 +99,7 @@ struct sbx_ctx {
     char* hs_dev = nullptr;
     size_t hs_cap = 0;
     hipStream_t hs_copy = nullptr, hs_render[2] = {nullptr, nullptr};
+    bool hs_ready = false;           // every stream and event below exists
     hipEvent_t hs_entry = nullptr;
     hipEvent_t hs_ev[16] = {};
     std::mutex hs_lock;
@@ -749,14 +750,26 @@ int sbx_render_rows_host(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
         if ((e = hipMalloc((void**)&ctx->hs_dev, need)) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipMalloc (host-frame staging)", e);
         ctx->hs_cap = need;
     }
-    if (!ctx->hs_copy) {
+    if (!ctx->hs_ready) {
+        // all of the streams and events, or none: a set-up that stopped half way must not leave the next call a null stream
+        // (the old test was `!hs_copy`, which is set first)
+        auto undo = [&]() {
+            if (ctx->hs_copy) { (void)hipStreamDestroy(ctx->hs_copy); ctx->hs_copy = nullptr; }
+            for (auto& st : ctx->hs_render) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+            if (ctx->hs_entry) { (void)hipEventDestroy(ctx->hs_entry); ctx->hs_entry = nullptr; }
+            for (auto& ev : ctx->hs_ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+        };
+        undo();
         if ((e = hipStreamCreateWithFlags(&ctx->hs_copy, hipStreamNonBlocking)) != hipSuccess ||
             (e = hipStreamCreateWithFlags(&ctx->hs_render[0], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipStreamCreateWithFlags(&ctx->hs_render[1], hipStreamNonBlocking)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&ctx->hs_entry, hipEventDisableTiming)) != hipSuccess)
+            (e = hipEventCreateWithFlags(&ctx->hs_entry, hipEventDisableTiming)) != hipSuccess) {
+            undo();
             return fail(ctx, SBX_ERR_HIP, "hipStreamCreate", e);
+        }
         for (auto& ev : ctx->hs_ev)
-            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipEventCreate", e);
+            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) { undo(); return fail(ctx, SBX_ERR_HIP, "hipEventCreate", e); }
+        ctx->hs_ready = true;
     }
     // Pinned (or registered) memory: the copies are asynchronous, so the frame goes out in strips — whole 64-row bands (a multiple of
     // every kernel's tile height), sixteen at most — rendered alternately on two streams of the context (one strip's tail overlaps the

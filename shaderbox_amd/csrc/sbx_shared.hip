@@ -6,8 +6,10 @@
 // pointer itself inside one process) and its render kernel writes its rows where they belong, over xGMI.  The owner receives
 // nothing, lands nothing, scatters nothing: it is an ordinary rank.
 //
-// Ordering.  Pixel visibility rides on KERNEL BOUNDARIES (the HIP peer-access model): a peer's render kernel ends (system-scope
-// release: its stores have reached the owner's HBM) before its signal kernel starts; the owner's wait kernel ends before the
+// Ordering.  Pixel visibility rides on KERNEL BOUNDARIES (the HIP peer-access model): a peer's render kernel ends before its signal
+// kernel starts, and between the two the stream records an event made with hipEventReleaseToSystem — the boundary of two kernels of
+// one stream by itself promises an AGENT-scope release only, and the signal kernel's own __threadfence_system runs in one wave
+// (no run on two devices has been possible yet, so the release is asked for explicitly rather than assumed); the owner's wait kernel ends before the
 // stream's next kernel starts (system-scope acquire).  The flags only carry the order, and they are polled INSIDE a running kernel,
 // so they live in their own page of FINE-GRAINED device memory (hipDeviceMallocFinegrained: uncached for system-scope atomics on
 // every agent) next to the coarse-grained frame:
@@ -30,7 +32,11 @@ namespace sbx {
 constexpr int FLAG_STRIDE = 16;                  // words between two flags: one 64-byte line each
 constexpr size_t FLAG_BYTES = 4096;
 
-__global__ void k_flag_set(unsigned* flag, unsigned seq) {
+// `abort` (a word of the object's own device, or nullptr): the frame number whose wait gave up on this side.  A side that never saw
+// the frame released must not report its rows as in place: the owner's wait then gives up too, and both sides hold the
+// fault word instead of one of them holding a frame that was overwritten under it.
+__global__ void k_flag_set(unsigned* flag, unsigned seq, const unsigned* abort) {
+    if (abort && *abort == seq) return;
     __threadfence_system();
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -39,7 +45,7 @@ __global__ void k_flag_set(unsigned* flag, unsigned seq) {
 // s_sleep between polls keeps the wave off its SIMD's issue slots; the bound turns a lost peer into a fault word instead of a hung
 // device (wall_clock64 = the constant 100 MHz counter).
 __global__ void __launch_bounds__(64) k_flag_wait(const unsigned* flags, int first, int count, unsigned seq, unsigned* fault,
-                                                   long long timeout_ticks) {
+                                                   long long timeout_ticks, unsigned* abort) {
     const int i = (int)threadIdx.x;
     const long long t0 = wall_clock64();
     bool ok = i >= count;
@@ -51,6 +57,7 @@ __global__ void __launch_bounds__(64) k_flag_wait(const unsigned* flags, int fir
         if (__all(ok)) break;
         if (wall_clock64() - t0 > timeout_ticks) {
             if (i == 0 && fault) __hip_atomic_store(fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (i == 0 && abort) *abort = seq;
             break;
         }
         __builtin_amdgcn_s_sleep(16);
@@ -99,6 +106,7 @@ struct HandleBlob {                              // what sbx_shared_handle.opaqu
     uint64_t frame_ptr, flags_ptr;               // valid in process `pid` only (ranks of one process share the pointers)
     int32_t nranks, device;
     uint32_t magic;
+    uint32_t ipc_ok;                             // the two IPC handles are valid (hipIpcGetMemHandle worked in the exporting process)
 };
 static_assert(sizeof(HandleBlob) <= sizeof(sbx_shared_handle), "handle too small");
 static const uint32_t kMagic = 0x53425853u;      // "SXBS"
@@ -111,10 +119,23 @@ struct sbx_shared {
     unsigned* flags = nullptr;
     size_t frame_bytes = 0;
     int nranks = 1;
+    unsigned* abort = nullptr;                   // device word: the frame whose wait gave up here (k_flag_wait / k_flag_set)
+    hipEvent_t release = nullptr;                // hipEventReleaseToSystem: recorded between a peer's render and its signal
     unsigned seq[64] = {0};                      // per rank driven through this object (one process may drive several)
     long long timeout_ticks = 10000ll * 100000ll;  // 10 s at 100 MHz
     HandleBlob blob{};
 };
+
+static hipError_t shared_extras(sbx_shared* s) {
+    hipError_t e = hipMalloc((void**)&s->abort, 64);
+    if (e == hipSuccess) e = hipMemset(s->abort, 0, 64);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->release, hipEventDisableTiming | hipEventReleaseToSystem);
+    return e;
+}
+static void shared_extras_free(sbx_shared* s) {
+    if (s->abort) (void)hipFree(s->abort);
+    if (s->release) (void)hipEventDestroy(s->release);
+}
 
 extern "C" {
 
@@ -128,9 +149,10 @@ int sbx_shared_create(sbx_ctx* ctx, size_t frame_bytes, int nranks, sbx_shared**
     s->ctx = ctx; s->device = ctx_device(ctx); s->owner = true; s->frame_bytes = frame_bytes; s->nranks = nranks;
     if ((e = hipMalloc((void**)&s->frame, frame_bytes)) != hipSuccess ||
         (e = hipExtMallocWithFlags((void**)&s->flags, FLAG_BYTES, hipDeviceMallocFinegrained)) != hipSuccess ||
-        (e = hipMemset(s->flags, 0, FLAG_BYTES)) != hipSuccess) {
+        (e = hipMemset(s->flags, 0, FLAG_BYTES)) != hipSuccess || (e = shared_extras(s)) != hipSuccess) {
         if (s->frame) (void)hipFree(s->frame);
         if (s->flags) (void)hipFree(s->flags);
+        shared_extras_free(s);
         delete s;
         return ctx_fail(ctx, SBX_ERR_HIP, "sbx_shared_create: allocation", e);
     }
@@ -141,7 +163,7 @@ int sbx_shared_create(sbx_ctx* ctx, size_t frame_bytes, int nranks, sbx_shared**
         (void)hipMemsetAsync(s->frame, 0, frame_bytes, nullptr);
     }
     if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) {
-        (void)hipFree(s->frame); (void)hipFree(s->flags); delete s;
+        (void)hipFree(s->frame); (void)hipFree(s->flags); shared_extras_free(s); delete s;
         return ctx_fail(ctx, SBX_ERR_HIP, "sbx_shared_create: first touch", e);
     }
     HandleBlob& b = s->blob;
@@ -158,8 +180,13 @@ int sbx_shared_export(sbx_shared* s, sbx_shared_handle* handle) {
     if (!s->owner) return ctx_fail(s->ctx, SBX_ERR_ARG, "sbx_shared_export: only the owner exports", hipSuccess);
     hipError_t e = hipSetDevice(s->device);
     if (e != hipSuccess) return ctx_fail(s->ctx, SBX_ERR_HIP, "hipSetDevice", e);
-    if ((e = hipIpcGetMemHandle(&s->blob.frame, s->frame)) != hipSuccess || (e = hipIpcGetMemHandle(&s->blob.flags, s->flags)) != hipSuccess)
-        return ctx_fail(s->ctx, SBX_ERR_HIP, "hipIpcGetMemHandle (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", e);
+    // Ranks of THIS process open the blob by its pointers and never look at the IPC handles: a host without HIP IPC still gets a blob
+    // that works inside the process (ipc_ok = 0 makes sbx_shared_open in another process say why it cannot).
+    s->blob.ipc_ok = 1;
+    if ((e = hipIpcGetMemHandle(&s->blob.frame, s->frame)) != hipSuccess || (e = hipIpcGetMemHandle(&s->blob.flags, s->flags)) != hipSuccess) {
+        (void)hipGetLastError();
+        s->blob.ipc_ok = 0;
+    }
     std::memset(handle, 0, sizeof(*handle));
     std::memcpy(handle->opaque, &s->blob, sizeof(s->blob));
     return SBX_OK;
@@ -189,6 +216,7 @@ int sbx_shared_open(sbx_ctx* ctx, const sbx_shared_handle* handle, sbx_shared** 
         }
     } else {
         void *pf = nullptr, *pg = nullptr;
+        if (!b.ipc_ok) { delete s; return ctx_fail(ctx, SBX_ERR_UNSUPPORTED, "sbx_shared_open: the exporting process could not take HIP IPC handles (is HSA_ENABLE_IPC_MODE_LEGACY=0 set there?)", hipSuccess); }
         if ((e = hipIpcOpenMemHandle(&pf, b.frame, hipIpcMemLazyEnablePeerAccess)) != hipSuccess ||
             (e = hipIpcOpenMemHandle(&pg, b.flags, hipIpcMemLazyEnablePeerAccess)) != hipSuccess) {
             if (pf) (void)hipIpcCloseMemHandle(pf);
@@ -196,6 +224,12 @@ int sbx_shared_open(sbx_ctx* ctx, const sbx_shared_handle* handle, sbx_shared** 
             return ctx_fail(ctx, SBX_ERR_HIP, "hipIpcOpenMemHandle (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", e);
         }
         s->frame = (float*)pf; s->flags = (unsigned*)pg; s->mapped = true;
+    }
+    if ((e = shared_extras(s)) != hipSuccess) {
+        if (s->mapped) { (void)hipIpcCloseMemHandle(s->frame); (void)hipIpcCloseMemHandle(s->flags); }
+        shared_extras_free(s);
+        delete s;
+        return ctx_fail(ctx, SBX_ERR_HIP, "sbx_shared_open: allocation", e);
     }
     *out = s;
     return SBX_OK;
@@ -213,10 +247,12 @@ void sbx_shared_close(sbx_shared* s) {
         (void)hipIpcCloseMemHandle(s->frame);
         (void)hipIpcCloseMemHandle(s->flags);
     }
+    shared_extras_free(s);
     delete s;
 }
 
 float* sbx_shared_frame(sbx_shared* s) { return s ? s->frame : nullptr; }
+size_t sbx_shared_bytes(sbx_shared* s) { return s ? s->frame_bytes : 0; }
 
 int sbx_shared_set_timeout_ms(sbx_shared* s, int ms) {
     if (!s || ms <= 0) return SBX_ERR_ARG;
@@ -238,13 +274,17 @@ int sbx_shared_frame_begin(sbx_shared* s, int rank, void* stream) {
     }
     hipError_t e = hipSetDevice(s->device);
     if (e != hipSuccess) return ctx_fail(s->ctx, SBX_ERR_HIP, "hipSetDevice", e);
-    const unsigned q = ++s->seq[rank];
+    unsigned* fault = fault_word_device(s->device);
+    if (!fault) return ctx_fail(s->ctx, SBX_ERR_HIP, "sbx_shared_frame_begin: the device's fault word is not bound (a wait that gives up could not say so)", hipSuccess);
+    const unsigned q = s->seq[rank] + 1u;
     if (rank == 0)
-        hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, (hipStream_t)stream, s->flags, q);
+        hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, (hipStream_t)stream, s->flags, q, (const unsigned*)nullptr);
     else
-        hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)s->flags, 0, 1, q,
-                           fault_word_device(s->device), s->timeout_ticks);
-    return flag_launch_done(s, "sbx_shared_frame_begin launch");
+        hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)s->flags, 0, 1, q, fault, s->timeout_ticks,
+                           s->abort);
+    const int rc = flag_launch_done(s, "sbx_shared_frame_begin launch");
+    if (rc == SBX_OK) s->seq[rank] = q;                      // (a launch that failed has not started frame q: the counters stay in step)
+    return rc;
 }
 
 int sbx_shared_frame_end(sbx_shared* s, int rank, void* stream) {
@@ -258,9 +298,10 @@ int sbx_shared_frame_end(sbx_shared* s, int rank, void* stream) {
     if (rank == 0) {
         if (s->nranks > 1)
             hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)s->flags, 1, s->nranks - 1, q,
-                               fault_word_device(s->device), s->timeout_ticks);
+                               fault_word_device(s->device), s->timeout_ticks, s->abort);
     } else {
-        hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, (hipStream_t)stream, s->flags + (size_t)rank * FLAG_STRIDE, q);
+        (void)hipEventRecord(s->release, (hipStream_t)stream);            // system-scope release of the render kernel's stores
+        hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, (hipStream_t)stream, s->flags + (size_t)rank * FLAG_STRIDE, q, (const unsigned*)s->abort);
     }
     return flag_launch_done(s, "sbx_shared_frame_end launch");
 }
