@@ -58,6 +58,13 @@ shaderbox_amd.Renderer on GPUs; the CPU tests drive the same code over gloo with
 from . import shard
 
 
+def choose_exchange(*args, **kwargs):
+    """shaderbox_amd.tuning.choose_exchange: the exchange form (and the root's relief, the pieces, the plans) for these ranks, chosen by
+    trying the candidates on them.  Here so that a host finds it beside FramePlan."""
+    from .tuning import choose_exchange as f
+    return f(*args, **kwargs)
+
+
 class FramePlan:
     """Buffers and schedule of one rank for repeated frames of a fixed size."""
 

@@ -24,6 +24,21 @@ class OracleRenderer:
     def empty(self, shape, zero=False):
         return torch.zeros(tuple(shape), dtype=torch.uint8 if self.rgba8 else torch.float32)
 
+    def render(self, app, width, height, time, out=None, mouse=(0.0, 0.0), aux=None):
+        """one launch = the whole frame (what tuning.choose_exchange compares every trial frame with)"""
+        from oracle.oracle import APP_IDS
+        img = self.px(self.o.render(APP_IDS[app], width, height, time, mouse=mouse, aux=aux, threads=2))
+        if out is not None:
+            out.copy_(img)
+            return out
+        return img
+
+    def fault_status(self):
+        return 0
+
+    def clear_fault(self):
+        pass
+
     def px(self, img):
         """the oracle's float RGBA rows as this renderer's pixels"""
         return torch.from_numpy(pack_unorm8(img)) if self.rgba8 else torch.from_numpy(img)
@@ -392,3 +407,57 @@ def test_span_table_is_a_consistent_layout():
         table, pix, _ = shaderbox_amd.span_table(app, w, h, 0.37, 8, 8)
         full = sum(shard.rank_rows(h, 8, r, 8) * w for r in range(1, 8))
         assert lo < sum(int(p) for p in pix[1:]) / full < hi, (app, sum(pix[1:]) / full)
+
+
+def _choose_worker(rank, world, port, app, w, h, t, br, result_path, allow_stores, budget_s):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shaderbox_amd import tuning
+    from shaderbox_amd.distributed import choose_exchange          # where a host finds it: beside FramePlan
+    tuning.CONFIG.coll_dev = torch.device("cpu")
+    choice = choose_exchange(OracleRenderer(), dist, torch, torch.device("cpu"), [None, None], app, w, h, t, world=world, rank=rank,
+                             block_rows=br, root_rounds="1/1", groups="auto", budget_s=budget_s, preroll_ms=0, allow_stores=allow_stores,
+                             trial_frames=2)
+    # the chosen plans are ready to run: one frame at another time, compared by the caller
+    frame = choice.plans[0].render(app, t + .25)
+    if rank == 0:
+        import json
+        np.save(result_path, np.array(frame.numpy()))
+        json.dump({"exchange": choice.exchange, "channels": choice.channels, "relief": list(choice.relief), "groups": choice.groups,
+                   "payload": choice.payload_bytes_per_peer, "trials": choice.trials, "notes": choice.notes},
+                  open(result_path + ".json", "w"))
+    dist.barrier()
+    for pl in choice.plans:
+        if getattr(pl, "shared", None) is not None and rank == 0:
+            pl.shared.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("allow_stores,budget_s", [(False, 600.0), (True, 600.0), (True, 0.0)])
+def test_choose_exchange_over_gloo(tmp_path, oracle, allow_stores, budget_s):
+    """shaderbox_amd.tuning.choose_exchange with world 2: every candidate is set up on both ranks, soaked against one-launch renders of
+    frames at different times, timed; the fastest runs; the store forms are candidates only where allowed (and after the IPC
+    pre-flight); a spent time budget cuts the later candidates and says which (VERDICT r5 #4, #5)"""
+    import json
+    from oracle.oracle import APP_IDS
+    app, w, h, br = "egg", 48, 32, 8
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_choose_worker, args=(2, _free_port(), app, w, h, 0.37, br, path, allow_stores, budget_s), nprocs=2, join=True)
+    rec = json.load(open(path + ".json"))
+    forms = ["spans", "direct"] + (["stores", "stores_16B", "span_stores", "span_stores_16B", "packed_stores"] if allow_stores else [])
+    assert rec["notes"]["candidates"] == forms
+    if budget_s > 0:
+        assert rec["notes"]["cut"] == [] and all(isinstance(rec["trials"][f], float) and rec["trials"][f] > 0 for f in forms)
+        assert "(first trial, discarded) spans" in rec["trials"]
+    else:                                   # no budget: the first candidate (twice: its first reading is discarded) and nothing else
+        assert rec["notes"]["cut"] == forms[1:] and rec["exchange"] == "spans" and set(rec["trials"]) == {"(first trial, discarded) spans", "spans"}
+    best = min((f for f in forms if isinstance(rec["trials"].get(f), float)), key=lambda f: rec["trials"][f])
+    assert form_of(rec["exchange"], rec["channels"]) == best and rec["relief"] == [1, 1] and rec["groups"] >= 1 and rec["payload"] > 0
+    got = np.load(path)
+    ref = oracle.render(APP_IDS[app], w, h, 0.62)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def form_of(exchange, channels):
+    return exchange + ("_16B" if (exchange in ("stores", "span_stores") and channels == 4) else "")

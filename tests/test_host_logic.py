@@ -123,18 +123,29 @@ def test_product_does_not_touch_the_oracle():
                     code = re.sub(r"//[^\n]*", "", code)
                     code = re.sub(r"^\s*#(?!\s*(include|define|if|ifdef|ifndef|else|elif|endif|pragma|undef|error))[^\n]*", "", code, flags=re.M)
                     assert "oracle" not in code.lower(), f
-    bench = open(os.path.join(ROOT, "bench.py")).read()
+    # bench.py is a thin CLI over sbxbench/ and shaderbox_amd/tuning.py: the timed regions live there
+    srcs = {n: open(os.path.join(ROOT, n)).read() for n in ("bench.py", "sbxbench/n1.py", "sbxbench/dist.py", "sbxbench/emulate.py",
+                                                            "sbxbench/cpu.py", "sbxbench/common.py", "sbxbench/pmc.py",
+                                                            "shaderbox_amd/tuning.py")}
+    bench = "\n".join(srcs.values())
     # the timed regions: every `t0 = time.perf_counter()` ... `elapsed = ` / `ms = ` span
-    spans = re.findall(r"t0 = time\.perf_counter\(\)(.*?)(?:(?:elapsed|ms|dt) = |return \(time\.perf_counter\(\) - t0\))", bench, flags=re.S)
+    spans = re.findall(r"t0 = time\.perf_counter\(\)(.*?)(?:(?:elapsed|elapsed_pipe|ms|ms_pipe|dt) = |return \(time\.perf_counter\(\) - t0\))", bench, flags=re.S)
     assert len(spans) >= 6
     timed_with_oracle = [sp for sp in spans if re.search(r"[Oo]racle|\bo\.render", sp)]
     # the only timed spans that run the oracle are the cpu_baseline legs (they time the oracle ITSELF, by definition)
     for sp in timed_with_oracle:
         assert "o.render_rows(" in sp and "R.render" not in sp and "step(" not in sp
-    main_body = bench[bench.index("def main():"):bench.index("def bench_lib(")]
-    t0 = main_body.index("t0 = time.perf_counter()")
-    region = main_body[t0:main_body.index("elapsed = time.perf_counter() - t0")]
-    assert "oracle" not in region.lower() and "step(i)" in region
+    # the oracle is imported by the cpu leg and by the per-config parity rows only
+    for n, txt in srcs.items():
+        if n not in ("sbxbench/cpu.py", "sbxbench/n1.py"):
+            assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), n
+    n1 = srcs["sbxbench/n1.py"]
+    body = n1[n1.index("def bench_n1("):]
+    for start, end in (("t0 = time.perf_counter()\n    for i in range(args.steps):\n        step1(i)", "elapsed = time.perf_counter() - t0"),
+                       ("t0 = time.perf_counter()\n    for i in range(args.steps):\n        step(i)", "elapsed_pipe = time.perf_counter() - t0")):
+        region = body[body.index(start):body.index(end)]
+        assert "oracle" not in region.lower() and "cpu_baseline" not in region
+    assert body.index("elapsed_pipe = time.perf_counter() - t0") < body.index("cpu_baseline(app")
 
 
 def test_app_ids():

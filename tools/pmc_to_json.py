@@ -7,11 +7,13 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 KERNELS = {"clouds": ("k_clouds<", 3840, 2160), "egg": ("k_egg<", 1920, 1080), "raytracer": ("k_raytracer<", 3840, 2160),
            "atmosphere": ("k_atmosphere<", 7680, 4320), "planet": ("k_planet<true, false>", 7680, 4320)}
 WANT = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE", "VALUBusy", "VALUUtilization", "WRITE_SIZE", "FETCH_SIZE",
-        "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_SALU"]
+        "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_SALU",
+        "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT",
+        "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]
 src = os.path.join(ROOT, "profiles", "%s_apps_pmc.txt" % rnd)
 cur, acc = None, {k: {} for k in KERNELS}
 for line in open(src):

@@ -27,7 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import shaderbox_amd  # noqa: E402
-from shaderbox_amd import shard  # noqa: E402
+from shaderbox_amd import shard, tuning  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--app", default="clouds")
@@ -48,7 +48,7 @@ if os.environ.get("SBX_LIB"):              # an A/B library of tools/ab_build.py
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
-bench.LANDING = {"wgs_per_peer": a.rccl_wgs_per_peer, "link_gbps": a.link_gbps} if a.rccl_wgs_per_peer > 0 else None
+tuning.CONFIG.landing = {"wgs_per_peer": a.rccl_wgs_per_peer, "link_gbps": a.link_gbps} if a.rccl_wgs_per_peer > 0 else None
 
 app, W, H, t = a.app, a.width, a.height, a.time
 dev = torch.device("cuda", 0)
@@ -61,8 +61,8 @@ for s in streams:
     with torch.cuda.stream(s):
         R.render(app, 64, 36, t)
 for _ in streams:                            # the emulated root's landing streams (bench.Landing), on the hardware queues after these
-    bench.SIDE_STREAMS.append(torch.cuda.Stream())
-    with torch.cuda.stream(bench.SIDE_STREAMS[-1]):
+    tuning.CONFIG.side_streams.append(torch.cuda.Stream())
+    with torch.cuda.stream(tuning.CONFIG.side_streams[-1]):
         R.render(app, 64, 36, t)
 torch.cuda.synchronize()
 
@@ -93,7 +93,7 @@ R.set_timing(False)
 p1 = per_frame(whole)
 R.set_timing(True)
 print("pixel format %s (%d bytes per pixel on a link; store exchange: %d); landing model: %s"
-      % (a.format, BPP, 4 if R.rgba8 else 4 * a.channels, bench.LANDING or "device copy"))
+      % (a.format, BPP, 4 if R.rgba8 else 4 * a.channels, tuning.CONFIG.landing or "device copy"))
 print("%s %dx%d  N=1: one launch %.3f ms, %d frames in flight %.3f ms/frame" % (app, W, H, t1, len(streams), p1))
 ranks = [int(v) for v in a.ranks.split(",") if v]
 for n in ranks:
