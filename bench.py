@@ -119,11 +119,18 @@ def main():
                     help="N>1: issue the one exchange in this many pipelined pieces ('auto': one per ~12 MB of a peer's payload, "
                          "so a 4K slab goes out whole and an 8K one in 3 pieces; 1 = one plain exchange)")
     ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather", "stores", "span_stores", "packed_stores"], default="auto",
-                    help="N>1 (engine dist): 'auto' (default) = try 'stores' and 'span_stores' (12- and 16-byte pixels), 'packed_stores', 'spans' and 'direct' on the ranks at hand (a few "
-                         "pipelined frames each) and run the fastest; 'span_stores' = 'stores' with only the SPANS of the peers' row-blocks "
-                         "stored in place, the root renders the rest (fewer bytes on the links: 30 instead of 50 MB per peer at 7680x4320); 'stores' = the peers map the root's frame (HIP IPC) and render their row-blocks IN PLACE "
-                         "into it: the exchange is their own pixel stores over xGMI (12 bytes per pixel with --channels 3), the root lands, "
-                         "receives and scatters nothing (distributed.py, include/sbx.h sbx_shared_*); 'packed_stores' = the span exchange with the peers' own stores as transport: packed spans (12 contiguous bytes per pixel) straight into the root's mapped landing area, the root scatters; 'spans' = only the expensive interval of every row-block is dealt to the peers and "
+                    help="N>1 (engine dist): 'auto' (default) = try 'stores' and 'span_stores' (12- and 16-byte pixels), 'packed_stores', "
+                        "'spans' and 'direct' on the ranks at hand (a few "
+                         "pipelined frames each) and run the fastest; 'span_stores' = 'stores' with only the SPANS of the peers' "
+                             "row-blocks "
+                         "stored in place, the root renders the rest (fewer bytes on the links: 30 instead of 50 MB per peer at "
+                             "7680x4320); 'stores' = the peers map the root's frame (HIP IPC) and render their row-blocks IN PLACE "
+                         "into it: the exchange is their own pixel stores over xGMI (12 bytes per pixel with --channels 3), the root "
+                             "lands, "
+                         "receives and scatters nothing (distributed.py, include/sbx.h sbx_shared_*); 'packed_stores' = the span exchange "
+                             "with the peers' own stores as transport: packed spans (12 contiguous bytes per pixel) straight into the "
+                                 "root's mapped landing area, the root scatters; 'spans' = only the expensive interval of every row-block "
+                                     "is dealt to the peers and "
                          "sent, the root renders the rest in place (distributed.py; config 5's 49.8 MB per peer become 29.7 MB); "
                          "'direct' = the root renders its blocks in place and receives the peers' whole slabs by ONE grouped "
                          "send/recv; 'gather' = dist.gather of equal RGBA slabs + assembly of all of them (round 1)")
@@ -152,7 +159,8 @@ def main():
                          "process drives the N GPUs through the library's own multi-GPU path (sbx_multi_*: RCCL send/recv per "
                          "row-block straight into the final rows, no assembly pass); with fewer GPUs than N the ranks share devices")
     ap.add_argument("--lib-exchange", choices=["slabs", "blocks", "spans", "peer_stores"], default="spans",
-                    help="--engine lib: 'spans' (default) = the span exchange inside the library; 'slabs' = one send/receive per peer of its "
+                    help="--engine lib: 'spans' (default) = the span exchange inside the library; 'slabs' = one send/receive per peer of "
+                        "its "
                          "whole 3-channel slab + one scatter kernel on the root; 'blocks' = one send/receive pair per row-block straight "
                          "into the final rows (round 2); 'peer_stores' = every rank stores into rank 0's frame through peer access")
     ap.add_argument("--emulate-ranks", type=int, default=0,
@@ -175,8 +183,10 @@ def main():
                          "device r mod device count), point-to-point transfers are staged through host memory "
                          "(distributed.HostStagedDist) — runs the whole N > 1 program on a 1-GPU box, measures nothing about xGMI")
     ap.add_argument("--preroll-ms", type=float, default=40.0,
-                    help="N = 1: back-to-back frames for at least this long BEFORE the warm-up steps (not steps, not timed): the first ~25 ms "
-                         "of launches after host work run at ramping clocks (profiles/r04_streams3_trace.txt), and 5 warm-up frames are 11 ms")
+                    help="N = 1: back-to-back frames for at least this long BEFORE the warm-up steps (not steps, not timed): the first "
+                        "~25 ms "
+                         "of launches after host work run at ramping clocks (profiles/r04_streams3_trace.txt), and 5 warm-up frames are "
+                             "11 ms")
     ap.add_argument("--sustained-seconds", type=float, default=2.5,
                     help="N = 1: after the timed region, frames back to back for this long with the shader clock and the board power "
                          "sampled beside them -> the `sustained` object (0 = skip)")

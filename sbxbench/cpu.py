@@ -84,9 +84,11 @@ def cpu_baseline(app, W, H, t, stride):
     stride, rows = cpu_rows(H, stride, cores, rows_per_s=len(cal) / max(time.perf_counter() - t0, 1e-6), target_s=8.0)
     ref, dt, value, one, n1, dt1 = _timed_rows(o, APP_IDS[app], W, H, t, rows, cores)
     return ({"value": round(value, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-             "variant": "the restatement over glibc libm (oracle/libsbx_oracle_libm.so: sin / cos / exp / pow / acos / atan2 from <cmath>), "
+             "variant": "the restatement over glibc libm (oracle/libsbx_oracle_libm.so: sin / cos / exp / pow / acos / atan2 from "
+                 "<cmath>), "
                         "g++ -O2 -ffp-contract=off",
-             "sample": "%d of %d rows (every %dth row) of the same %dx%d frame in 64-pixel tiles, %.1f s" % (len(rows), H, stride, W, H, dt),
+             "sample": "%d of %d rows (every %dth row) of the same %dx%d frame in 64-pixel tiles, %.1f "
+                 "s" % (len(rows), H, stride, W, H, dt),
              "affinity": facts["affinity"], "os_cpu_count": facts["os_cpu_count"], "cgroup_cpu_max": facts["cgroup_cpu_max"],
              "cores_is": "threads used = min(scheduler affinity, cgroup CPU quota rounded up)",
              "one_thread": {"value": round(one, 5), "unit": "Mpixels/s", "sample": "%d rows, %.1f s" % (n1, dt1)},

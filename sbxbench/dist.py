@@ -163,10 +163,12 @@ def dist_line(res, args, app, W, H, t, world):
             "gather": "1 RCCL gather of RGBA slabs",
             "stores": "the peers' own %d-byte pixel stores into the root's frame, mapped through HIP IPC (no RCCL call, no landing area, "
                       "no scatter; two flag kernels per rank and frame)" % (12 if args.channels == 3 else 16),
-            "span_stores": "the peers' own %d-byte pixel stores of the SPANS of their row-blocks into the root's frame, mapped through HIP IPC "
+            "span_stores": "the peers' own %d-byte pixel stores of the SPANS of their row-blocks into the root's frame, mapped through "
+                "HIP IPC "
                            "(the root renders its blocks and everything outside the spans; no RCCL call, no landing area, no scatter)"
                            % (12 if args.channels == 3 else 16),
-            "packed_stores": "the peers' own stores of the packed 3-channel SPANS of their row-blocks (12 contiguous bytes per pixel) straight "
+            "packed_stores": "the peers' own stores of the packed 3-channel SPANS of their row-blocks (12 contiguous bytes per pixel) "
+                "straight "
                              "into the root's landing area, mapped through HIP IPC; the root renders its blocks and everything outside the "
                              "spans, then scatters (no RCCL call, no receive kernels on the root)",
             "spans": "1 grouped RCCL send/recv of the peers' packed 3-channel SPANS (the root renders its blocks and everything "
@@ -196,10 +198,12 @@ def dist_line(res, args, app, W, H, t, world):
                        "parallelism": "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + %s (in %d pipelined "
                                       "pieces)%s" % (args.block_rows, world, relief[0], relief[1], exch, res["groups"],
                                                      "" if res["exchange"] in ("stores", "span_stores") else " + assemble")},
-            "backend": "RCCL" if args.backend == "nccl" else "gloo with host-staged transfers (TEST form: ranks may share a GPU, nothing here "
+            "backend": "RCCL" if args.backend == "nccl" else "gloo with host-staged transfers (TEST form: ranks may share a GPU, nothing "
+                "here "
                                                                 "says anything about xGMI)",
             "value_rccl_spans": rccl_value("spans"), "value_rccl_direct": rccl_value("direct"), "rccl": out_rccl,
-            "exchange": {"kind": res["exchange"], "notes": res.get("exchange_notes"), "chosen": "measured on these ranks: ms per pipelined frame %s" % res["exchange_trials_ms"]
+            "exchange": {"kind": res["exchange"], "notes": res.get("exchange_notes"), "chosen": "measured on these ranks: ms per "
+                "pipelined frame %s" % res["exchange_trials_ms"]
                          if res.get("exchange_trials_ms") else "as asked (--exchange)" if args.exchange != "auto" else "one rank: nothing to choose",
                          "bytes_per_peer": res["payload_bytes_per_peer"], "pieces": res["groups"],
                          "link_ms_at_76p8_GBps": round(res["payload_bytes_per_peer"] / 76.8e9 * 1e3, 4),
@@ -285,8 +289,10 @@ def bench_lib(args):
                                         ("%s, %s" % ("RCCL send/recv" if M.uses_rccl else
                                                      "device copies (ranks share devices: emulation, not a scaling number)",
                                                      {"slabs": "one per peer of its whole 3-channel slab + one scatter kernel",
-                                                      "spans": "one per peer of its packed 3-channel spans + one scatter kernel, rank 0 renders the rest",
-                                                      "peer_stores": "none: every rank stores its pixels into rank 0's frame through peer access",
+                                                      "spans": "one per peer of its packed 3-channel spans + one scatter kernel, rank 0 "
+                                                          "renders the rest",
+                                                      "peer_stores": "none: every rank stores its pixels into rank 0's frame through peer "
+                                                          "access",
                                                       "blocks": "one per row-block into the final rows"}[args.lib_exchange])))},
            "steady_state": steady, "roofline": roofline, "roofline_hbm": roofline_hbm,
            "parity": {"against": "one-launch render of the same frame", "rows": H, "mismatching_pixels": bad}}

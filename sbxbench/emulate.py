@@ -97,10 +97,13 @@ def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
     out = {"metric": "Mpixels/s, APP_%s %dx%d" % (app.upper(), W, H), "value": head["modelled_value_mpixels_s"], "unit": "Mpixels/s",
            "n_gpus": 1, "emulated_ranks": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["modelled_ms_per_frame"],
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "value_is": "MODELLED for %d GPUs from parts timed on ONE: max(root's frame incl. landing and scatter, slowest peer's frame, link "
+           "value_is": "MODELLED for %d GPUs from parts timed on ONE: max(root's frame incl. landing and scatter, slowest peer's frame, "
+               "link "
                        "time at %g GB/s), compute and transfer overlapped; not a measurement of %d GPUs" % (n, args.link_gbps, n),
-           "landing_model": ("RCCL's grouped receive on the root = %d workgroups per peer resident for the link time at %g GB/s, writing the "
-                             "payload at that pace (sbx_model_landing)" % (tuning.CONFIG.landing["wgs_per_peer"], tuning.CONFIG.landing["link_gbps"])) if tuning.CONFIG.landing
+           "landing_model": ("RCCL's grouped receive on the root = %d workgroups per peer resident for the link time at %g GB/s, writing "
+               "the "
+                             "payload at that pace "
+                                 "(sbx_model_landing)" % (tuning.CONFIG.landing["wgs_per_peer"], tuning.CONFIG.landing["link_gbps"])) if tuning.CONFIG.landing
                             else "a device copy of the payload at HBM speed (round 4's stand-in)",
            "config": {"workload": head["workload"], "frames_in_flight": len(streams),
                       "parallelism": "cyclic %d-row blocks over %d EMULATED ranks on one device, exchange %s" % (br, n, args.exchange)},

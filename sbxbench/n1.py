@@ -110,7 +110,8 @@ def sustained(torch, dev, step, ns, pixels, seconds, value, serial):
     out = {"value": round(v, 3), "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "frames": n, "seconds": round(dt, 3),
            "frames_in_flight": ns, "first_half": part(0, dt / 2), "second_half": part(dt / 2, dt),
            "value_over_sustained": round(value / v, 4), "value_serial_over_sustained": round(serial / v, 4),
-           "what": "the timed loop (same launches, same streams) held for %.1f s after the timed region, one synchronisation per %d frames; "
+           "what": "the timed loop (same launches, same streams) held for %.1f s after the timed region, one synchronisation per %d "
+               "frames; "
                    "sclk / power of THIS device (by PCI address) sampled every 20 ms from sysfs; first_half / second_half show whether "
                    "the rate drifts over seconds.  `value` (K frames after the pre-roll) within a per cent of this = the short window "
                    "measured the steady state" % (seconds, 8 * ns)}

@@ -117,7 +117,8 @@ def pmc_committed(app, W, H):
         if not m:
             continue
         got = {k: v for k, v in json.load(open(path)).items() if isinstance(v, (int, float))}
-        got["source"] = "committed: profiles/" + os.path.basename(path) + ("" if path == exact else " (another frame size: per-pixel counts)")
+        got["source"] = "committed: profiles/" + os.path.basename(path) + ("" if path == exact else " (another frame size: per-pixel "
+            "counts)")
         got["committed"] = True
         got["other_size"] = path != exact
         got["frame_pixels"] = int(m.group(1)) * int(m.group(2))

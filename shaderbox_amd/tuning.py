@@ -160,7 +160,8 @@ def timed_loop(torch, dev, fn, k=24, min_ms=60.0):
 def emulated_frame_ms(R, torch, dev, st, frames, app, W, H, t, br, world, r, m0, m, exchange, ch, per_frame):
     """ms per frame of rank `r`'s part of a `world`-rank frame, ALL of it on this one device with the launches in flight on the
     streams `st`: a peer = its launch; the root = its launch BESIDE the landing of the peers' payloads in its HBM (`Landing`: a model
-    of RCCL's receive kernels on their own stream) + the assembly kernel behind both; under the store exchange the root is an ordinary rank (its launch and the two
+    of RCCL's receive kernels on their own stream) + the assembly kernel behind both; under the store exchange the root is an ordinary '
+        'rank (its launch and the two
     flag kernels), and so is a peer (which renders in place into a frame on this device).  Used by the relief calibration on
     rank 0, by --emulate-ranks and by tools/strip_scaling.py; it knows nothing about the links."""
     nb = len(frames)
