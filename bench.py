@@ -296,7 +296,7 @@ def main():
                                       min(args.warmup, 2))
                 if rank == 0:
                     o2 = dist_line(r2, args, oa, ow, oh, t, world)
-                    others.append({k: o2[k] for k in ("value", "unit", "ms_per_step", "steps", "value_serial", "serial", "steady_state",
+                    others.append({k: o2[k] for k in ("value", "unit", "ms_per_step", "steps", "value_pipelined", "ms_per_step_pipelined", "value_serial", "serial", "steady_state",
                                                       "roofline", "phases", "parity", "exchange", "value_rccl_spans", "value_rccl_direct")} |
                                   {"workload": o2["config"]["workload"], "parallelism": o2["config"]["parallelism"],
                                    "kernel": KERNEL_OF.get(oa)})

@@ -92,6 +92,21 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     for i in range(int(npre.item())):
         step(i)
     sync()
+    # TWO timed regions of `steps` frames, as at N = 1 (barrier + synchronize on both sides, MAX over ranks):
+    #   1. one frame at a time — every rank's launch(es), the exchange and the assembly of frame k on ONE stream before frame k + 1
+    #      starts there -> `value`, `ms_per_step`: a frame's LATENCY through the whole pipeline, like with like with N = 1's `value`
+    #   2. ns frames in flight (one plan per stream) -> `value_pipelined`
+    def step1(i=0):
+        with torch.cuda.stream(streams[0]):
+            plans[0].render(app, t)
+    for i in range(warmup):
+        step1(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step1(i)
+    sync()
+    elapsed = time.perf_counter() - t0
     for i in range(warmup):
         step(i)
     sync()
@@ -101,7 +116,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         step(i)
         step_done[i].record(streams[i % ns])
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_pipe = time.perf_counter() - t0
     # every rank's own launch, un-overlapped
     km = []
     frame0 = plans[0].frame
@@ -121,7 +136,8 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
         km.append(R.last_kernel_ms())
     del scratch
     sync()
-    mine = torch.tensor([elapsed, sum(km) / len(km), min(km), float(rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, exchange))],
+    mine = torch.tensor([elapsed, sum(km) / len(km), min(km), float(rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, exchange)),
+                         elapsed_pipe],
                         dtype=torch.float64, device=tuning.CONFIG.coll_dev or dev)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
@@ -131,7 +147,7 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     if rank == 0:
         per = [[float(x) for x in v] for v in allr]
         slow = max(range(world), key=lambda r: per[r][1])
-        res.update({"elapsed": max(p[0] for p in per), "kmean": per[slow][1], "kmin": per[slow][2], "launch_pixels": int(per[slow][3]),
+        res.update({"elapsed": max(p[0] for p in per), "elapsed_pipe": max(p[4] for p in per), "kmean": per[slow][1], "kmin": per[slow][2], "launch_pixels": int(per[slow][3]),
                     "slowest_rank": slow, "per_rank_launch_ms": [round(p[1], 4) for p in per],
                     "steady": steady_state(step_done, ns, W * H), "phases": phases})
         # the assembled frame of the multi-GPU path against a one-launch render of the same frame: same bits
@@ -149,6 +165,7 @@ def dist_line(res, args, app, W, H, t, world):
     pixels = W * H
     relief, ns = res["relief"], res["ns"]
     ms_per_step = res["elapsed"] * 1e3 / res["steps"]
+    ms_pipe = res["elapsed_pipe"] * 1e3 / res["steps"]
     pmc = pmc_committed(app, W, H) if args.pmc != "off" else None
     roofline, roofline_hbm = rooflines(app, res["launch_pixels"], pixels, res["kmean"], res["kmin"], pmc)
     if roofline is not None:
@@ -175,8 +192,8 @@ def dist_line(res, args, app, W, H, t, world):
                      "outside the spans in place)"}[res["exchange"]]
     if args.backend != "nccl":
         exch = exch.replace("RCCL", "gloo (host-staged, TEST form)")
-    # north_star asks for "a single RCCL gather over xGMI": whatever form `value` ran with, the RCCL forms' figures of the SAME ranks are
-    # first-class keys — from the trial phase when the form was chosen by trial (ms per pipelined frame of 12), from the timed
+    # north_star asks for "a single RCCL gather over xGMI": whatever form `value` ran with, the RCCL forms' PIPELINED figures of the SAME
+    # ranks (compare with `value_pipelined`) are first-class keys — from the trial phase when the form was chosen by trial (ms per pipelined frame of 12), from the timed
     # region itself when the run's form is that RCCL form; null under gloo (a test transport) or when the form was not tried
     trials = res.get("exchange_trials_ms") or {}
 
@@ -184,7 +201,7 @@ def dist_line(res, args, app, W, H, t, world):
         if args.backend != "nccl":
             return None
         if res["exchange"] == form:
-            return round(pixels / (ms_per_step * 1e-3) / 1e6, 3)
+            return round(pixels / (ms_pipe * 1e-3) / 1e6, 3)          # (like the trials: frames in flight)
         ms = trials.get(form)
         return round(pixels / (ms * 1e-3) / 1e6, 3) if isinstance(ms, (int, float)) and ms > 0 else None
     out_rccl = dict(res.get("rccl") or {})
@@ -193,8 +210,13 @@ def dist_line(res, args, app, W, H, t, world):
             "unit": "Mpixels/s", "n_gpus": world, "steps": res["steps"], "warmup": res["warmup"],
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_is": "the K timed frames ONE AT A TIME (each rank's launches, the exchange, the assembly of a frame on one stream "
+                        "before the next frame starts there): barrier + synchronize on both sides, slowest rank — a frame's latency, the "
+                        "same form as `value` at N = 1",
+            "value_pipelined": round(pixels / (ms_pipe * 1e-3) / 1e6, 3), "ms_per_step_pipelined": round(ms_pipe, 4),
+            "frames_in_flight_pipelined": ns,
             "config": {"workload": "APP_%s %dx%d u_time=%g u_mouse=0 default aux, fragCoord=(x+.5,y+.5)" % (app.upper(), W, H, t),
-                       "frames_in_flight": ns,
+                       "frames_in_flight": 1,
                        "parallelism": "cyclic %d-row blocks over %d GPUs (root sits out rounds >= %d of %d) + %s (in %d pipelined "
                                       "pieces)%s" % (args.block_rows, world, relief[0], relief[1], exch, res["groups"],
                                                      "" if res["exchange"] in ("stores", "span_stores") else " + assemble")},

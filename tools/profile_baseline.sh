@@ -7,7 +7,7 @@
 #      (what makes ms_per_step < kernel_ms with frames in flight)
 # Output: gpurun_out/<tag>/apps_pmc.txt, gpurun_out/<tag>/streams3_trace.txt; copy into profiles/.
 set -u
-TAG=${1:-r05_baseline}
+TAG=${1:-r06_baseline}
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
