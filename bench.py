@@ -119,9 +119,10 @@ def main():
                     help="N>1: issue the one exchange in this many pipelined pieces ('auto': one per ~12 MB of a peer's payload, "
                          "so a 4K slab goes out whole and an 8K one in 3 pieces; 1 = one plain exchange)")
     ap.add_argument("--exchange", choices=["auto", "spans", "direct", "gather", "stores", "span_stores", "packed_stores"], default="auto",
-                    help="N>1 (engine dist): 'auto' (default) = try 'stores' and 'span_stores' (12- and 16-byte pixels), 'packed_stores', "
-                        "'spans' and 'direct' on the ranks at hand (a few "
-                         "pipelined frames each) and run the fastest; 'span_stores' = 'stores' with only the SPANS of the peers' "
+                    help="N>1 (engine dist): 'auto' (default) = shaderbox_amd.tuning.choose_exchange: the RCCL forms 'spans' and 'direct' — and, "
+                         "where peer stores are allowed (SBX_ENABLE_PEER_STORES=1, or the ranks share one device) and a HIP-IPC pre-flight "
+                         "passes, the store forms with 12- and 16-byte pixels — are soaked and timed on the ranks at hand within "
+                         "--trial-budget-s, and the fastest runs; 'span_stores' = 'stores' with only the SPANS of the peers' "
                              "row-blocks "
                          "stored in place, the root renders the rest (fewer bytes on the links: 30 instead of 50 MB per peer at "
                              "7680x4320); 'stores' = the peers map the root's frame (HIP IPC) and render their row-blocks IN PLACE "
