@@ -159,6 +159,7 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
     # ... and timed regions of at least ~20 ms: ten 0.15 ms frames are 1.5 ms, of which the ramp-in of the first launches and the
     # final synchronisation are a fifth (EGG 1080p read 0.150 ms per frame that way against 0.121 over 60 frames)
     steps = max(steps, min(400, int(20.0 / max(est, .01))))
+    R.set_timing(False)                       # (the per-launch timing events are for the kernel_ms loop below)
     t0 = time.perf_counter()
     for i in range(steps):                    # the config's `value`: SURVEY.md 8d's form, launches one after the other
         step1(i)
@@ -169,6 +170,7 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
         step(i)
     torch.cuda.synchronize(dev)
     ms_pipe = (time.perf_counter() - t0) * 1e3 / steps
+    R.set_timing(True)
     k = []
     for i in range(13):                       # median of >= 10 launches after 2 warm-ups (the first two are dropped)
         R.render(app, W, H, t, out=frames[0])
@@ -247,7 +249,9 @@ def bench_n1(args, R, torch, dev, streams, app, W, H, t):
             step(i)
         torch.cuda.synchronize(dev)
         preroll_frames += ns
-    # ---- timed region 1: the contract's K steps, one launch at a time
+    # ---- timed region 1: the contract's K steps, one launch at a time.  (The per-launch timing events of sbx_set_timing are for the
+    # kernel_ms loop below; inside the timed regions they would be two more packets per launch on the stream: off.)
+    R.set_timing(False)
     for i in range(args.warmup):
         step1(i)
     torch.cuda.synchronize(dev)
@@ -273,11 +277,13 @@ def bench_n1(args, R, torch, dev, streams, app, W, H, t):
     elapsed_pipe = time.perf_counter() - t0
     # per-launch kernel duration, HIP events on the launch stream (outside the timed regions, one launch at a time, so that the
     # event queries do not perturb them)
+    R.set_timing(True)
     kernel_ms = []
     for _ in range(12):
         R.render(app, W, H, t, out=frames[0])
         kernel_ms.append(R.last_kernel_ms())
     kernel_ms = kernel_ms[2:]                            # median of >= 10 launches after 2 warm-ups
+    R.set_timing(False)
     torch.cuda.synchronize(dev)
     kmean = sorted(kernel_ms)[len(kernel_ms) // 2]
     pixels = W * H

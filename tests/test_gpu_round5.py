@@ -129,6 +129,16 @@ def test_store_exchange_wait_times_out_into_the_fault_word(renderer):
     assert ei.value.code == shaderbox_amd.SBX_ERR_FAULT and "store exchange" in str(ei.value)
     renderer.clear_fault()
     assert renderer.fault_status() == 0
+    # round 6: the side whose wait gave up does NOT report that frame as in place — its signal kernel sees the abort
+    # word and stays silent, so the owner's wait for it gives up too instead of reading a frame overwritten under it
+    peer.end(1)
+    owner.set_timeout_ms(30)
+    owner.begin(0)                                 # (frame 1 of the owner's count: released now, too late for the peer's frame 1)
+    owner.end(0)                                   # waits for done[1] >= 1: never signalled
+    torch.cuda.synchronize()
+    assert renderer.fault_status() == shaderbox_amd.SBX_ERR_FAULT
+    renderer.clear_fault()
+    assert peer.nbytes == owner.nbytes == 64 * 36 * 16            # sbx_shared_bytes on the opened side (no blob layout in the binding)
     peer.close()
     owner.close()
     # and the protocol in order works afterwards (a fresh pair: the timed-out one has lost a frame of its count):

@@ -1,4 +1,4 @@
-"""The A/B switches of the kernels (kern_clouds.hip CL_*, kern_planet.hip PL_*, sbx_hashcache.h, kern_raytracer.hip RT_*) cannot rot (VERDICT r4 Weak #11):
+"""The A/B switches of the kernels (kern_clouds.hip CL_*, kern_planet.hip PL_*, sbx_hashcache.h, kern_raytracer.hip RT_*, kern_egg.hip EGG_*) cannot rot (VERDICT r4 Weak #11):
 every non-default setting still COMPILES (CPU, hipcc cross-compiles) and still renders the SAME BITS as the plain kernel on
 random frames (GPU).  Both take minutes, so both are opt-in:   SBX_SLOW_TESTS=1 python -m pytest tests/test_variant_matrix.py
 The builder runs them once per round and commits the output (profiles/r0N_variants.txt)."""
@@ -33,5 +33,5 @@ def test_every_switch_renders_the_same_bits():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_clouds_variants.py"), "--all", "--frames", "60"],
                        capture_output=True, text=True, timeout=3600)
     lines = [l for l in r.stdout.splitlines() if "frames" in l or "FAILED" in l]
-    assert len(lines) >= len(libs) + 3, r.stdout[-3000:] + r.stderr[-2000:]
+    assert len(lines) >= len(libs) + 4, r.stdout[-3000:] + r.stderr[-2000:]
     assert all(l.rstrip().endswith("with a differing pixel: 0") for l in lines), "\n".join(lines)

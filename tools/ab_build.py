@@ -3,7 +3,7 @@
 other objects of the normal build.
 
     python tools/ab_build.py name1:kern_clouds.hip:-DFOO=1,-DBAR name2:kern_planet.hip:-DX ...
-    python tools/ab_build.py --all-variants        # every non-default setting of kern_clouds.hip's CL_*, kern_planet.hip's PL_* and kern_raytracer.hip's RT_* switches, one at a time
+    python tools/ab_build.py --all-variants        # every non-default setting of kern_clouds.hip's CL_*, kern_planet.hip's PL_*, kern_raytracer.hip's RT_* and kern_egg.hip's EGG_* switches, one at a time
 -> build/ab/libsbx_<name>.so   (build/ is git-ignored but travels with gpurun); time them with tools/ab_time.py, check them
 with tools/sweep_clouds_variants.py (same bits as the per-lane kernel on random frames).
 
@@ -34,6 +34,10 @@ PLANET_VARIANTS = [("PL_ATM_FIN", 0), ("PL_PAIRS", 0), ("PL_SPEC", 0), ("PL_TB2"
 
 # kern_raytracer.hip
 RT_VARIANTS = [("RT_AXIS_PLANES", 0), ("RT_WITNESS", 0), ("RT_LDS_FRAME", 0)]
+
+
+# kern_egg.hip.  EGG_COOP 1 = round 6's survivor queue + finisher kernel (bit-exact, measured, not faster: shipped off, kept buildable)
+EGG_VARIANTS = [("EGG_COOP", 1), ("EGG_HOT_FIRST", 0), ("EGG_WITNESS", 0), ("EGG_VCONST", 0)]
 
 
 def build_one(spec):
@@ -78,6 +82,12 @@ def main():
                 print("(switch %s no longer exists)" % k)
                 continue
             specs.append("v_rt_%s_%s:kern_raytracer.hip:-D%s=%s" % (k.lower(), v, k, v))
+        esrc = open(os.path.join(b.CSRC, "kern_egg.hip")).read()
+        for k, v in EGG_VARIANTS:
+            if ("#ifndef %s\n" % k) not in esrc and ("#ifndef %s " % k) not in esrc:
+                print("(switch %s no longer exists)" % k)
+                continue
+            specs.append("v_egg_%s_%s:kern_egg.hip:-D%s=%s" % (k.lower(), v, k, v))
     failed = 0
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         for msg in ex.map(build_one, specs):

@@ -65,10 +65,38 @@ def one_raytracer(path, N):
     print("%-44s frames %d, with a differing pixel: %d%s" % (os.path.basename(path) + " (raytracer)", N, bad, "" if bad == 0 else "   <-- DIFFERENT"))
 
 
+def one_egg(path, N):
+    """APP_EGG (libraries named libsbx_v_egg_*): the default kernel == the witness's test edge (2) == the un-culled IEEE kernel (1) on
+    random (time, mouse, size) frames — for EGG_COOP=1 that is the survivor queue and the finisher kernel against the plain union"""
+    import numpy as np
+    import torch
+    import shaderbox_amd
+    if path != "base":
+        shaderbox_amd.LIB_PATH = path
+    R = shaderbox_amd.Renderer(0)
+    rng = np.random.default_rng(77)
+    bad = 0
+    for i in range(N):
+        t = float(rng.uniform(0, 100))
+        mouse = (float(rng.uniform(1, 900)), float(rng.uniform(1, 500))) if i % 2 else (0.0, 0.0)
+        W, H = [(1920, 1080), (640, 360), (333, 187), (1280, 720)][i % 4]
+        fr = []
+        for v in (0, 2, 1):
+            R.set_variant(v)
+            fr.append(R.render("egg", W, H, t, mouse=mouse).clone())
+        same = (fr[0].view(torch.int32) == fr[1].view(torch.int32)) & (fr[0].view(torch.int32) == fr[2].view(torch.int32))
+        if not bool(same.all()) or R.fault_status() != 0:
+            bad += 1
+    R.set_variant(0)
+    print("%-44s frames %d, with a differing pixel: %d%s" % (os.path.basename(path) + " (egg)", N, bad, "" if bad == 0 else "   <-- DIFFERENT"))
+
+
 def one(path, N):
     import numpy as np
     import torch
     import shaderbox_amd
+    if "libsbx_v_egg_" in os.path.basename(path):
+        return one_egg(path, max(20, N // 3))
     if "libsbx_v_pl_" in os.path.basename(path):
         return one_planet(path, max(20, N // 3))
     if "libsbx_v_rt_" in os.path.basename(path):
@@ -116,6 +144,9 @@ if __name__ == "__main__":
     if "--one-raytracer" in args:
         one_raytracer(args[args.index("--one-raytracer") + 1], N)
         sys.exit(0)
+    if "--one-egg" in args:
+        one_egg(args[args.index("--one-egg") + 1], N)
+        sys.exit(0)
     names = [a for a in args if not a.startswith("--") and not a.isdigit()]
     paths = ["base"] + [os.path.join(ROOT, "build", "ab", "libsbx_%s.so" % n) for n in names]
     if "--all" in args:
@@ -125,6 +156,8 @@ if __name__ == "__main__":
         print(([l for l in r.stdout.splitlines() if "frames" in l] or ["base (planet) FAILED: " + r.stderr[-300:]])[-1])
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-raytracer", "base", "--frames", str(max(20, N // 3))], capture_output=True, text=True)
         print(([l for l in r.stdout.splitlines() if "frames" in l] or ["base (raytracer) FAILED: " + r.stderr[-300:]])[-1])
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-egg", "base", "--frames", str(max(20, N // 3))], capture_output=True, text=True)
+        print(([l for l in r.stdout.splitlines() if "frames" in l] or ["base (egg) FAILED: " + r.stderr[-300:]])[-1])
     for p in paths:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", p, "--frames", str(N)], capture_output=True, text=True)
         out = [l for l in r.stdout.splitlines() if "frames" in l]
