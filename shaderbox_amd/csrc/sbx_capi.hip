@@ -20,7 +20,7 @@
 using namespace sbx;
 
 struct YtabSlot {
-    // launches that read this table and may still be running: one event per stream, re-recorded after every consumer
+    // streams that launched readers of this table (they may still be running), each with the event a rebuild of the slot records on it
     std::vector<std::pair<hipStream_t, hipEvent_t>> users;
 };
 struct TimingPair { hipEvent_t ev0{}, ev1{}; bool complete = false; };
@@ -563,8 +563,17 @@ static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, fl
     if (rebuild) {
         slot = (int)(ctx->ytab_next++ % CLOUDS_YTAB_RING);
         YtabSlot& sl = ctx->slots[slot];
-        for (auto& u : sl.users) {                                 // earlier readers of the slot we are about to overwrite
-            if (u.first != s) (void)hipStreamWaitEvent(s, u.second, 0);
+        // Earlier readers of the slot we are about to overwrite: every stream that launched a reader of it.  The event is recorded
+        // NOW, on the reader's stream — behind everything that stream holds, its readers included — and this stream waits for it.
+        // (Until round 6 every launch re-recorded its stream's event right after the kernel: a barrier packet per frame, 26 us
+        // between two back-to-back 2.4 ms launches of one stream — profiles/r06_streams3_trace.txt — to protect a rebuild that an
+        // animation with the default wind never does.)
+        for (auto& u : sl.users) {
+            if (u.first != s) {
+                const bool ok = !stream_is_capturing(u.first) && hipEventRecord(u.second, u.first) == hipSuccess &&
+                                hipStreamWaitEvent(s, u.second, 0) == hipSuccess;
+                if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); (void)hipGetLastError(); }   // (a stream that is gone)
+            }
             ctx->event_pool.push_back(u.second);
         }
         sl.users.clear();
@@ -581,16 +590,15 @@ static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, fl
         ctx->ytab_stream = s;
         ctx->ytab_valid = true;
     }
-    YtabSlot& sl = ctx->slots[slot];
-    hipEvent_t ev{};
+    YtabSlot& sl = ctx->slots[slot];                               // this stream reads the slot: remembered, nothing recorded
     bool found = false;
-    for (auto& u : sl.users) if (u.first == s) { ev = u.second; found = true; break; }
+    for (auto& u : sl.users) if (u.first == s) { found = true; break; }
     if (!found) {
+        hipEvent_t ev{};
         if (!ctx->event_pool.empty()) { ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
         else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipEventCreate");
         sl.users.emplace_back(s, ev);
     }
-    (void)hipEventRecord(ev, s);
     return SBX_OK;
 }
 
