@@ -1,12 +1,7 @@
 """sbxbench.cpu — the cpu_baseline leg: the CPU oracle (test infrastructure, oracle/) timed on this host's cores AFTER the timed
 region, on a bounded sample of the same frame.  Nothing here runs between the start and the end of a timed region."""
-import json
 import os
-import subprocess
-import sys
 import time
-
-from .common import ROOT
 
 def cpu_rows(H, stride, cores, rows_per_s=None, target_s=12.0):
     """every stride-th row of the frame.  stride 0 = choose: from a measured rate (rows per second of this host, this app) so

@@ -2,13 +2,11 @@
 shaderbox_amd.distributed.FramePlan; and --engine lib (one process drives the GPUs through the library's own multi-GPU path)."""
 import json
 import os
-import sys
 import time
 
 from shaderbox_amd import tuning
-from shaderbox_amd.tuning import auto_groups, choose_relief, relief_candidates
 
-from .common import DIST_OTHER_CONFIGS, KERNEL_OF, claim_stdout, steady_state
+from .common import claim_stdout, steady_state
 from .pmc import pmc_committed, rooflines
 
 def rank_launch_pixels(R, app, W, H, t, br, world, rank, relief, exchange):
@@ -28,8 +26,6 @@ def dist_frame_bench(R, dist, torch, dev, streams, args, app, W, H, t, world, ra
     """relief calibration, plans, first touch, warm-up, the timed K frames (barrier + synchronize on both sides, MAX over ranks),
     every rank's un-overlapped launch, the phases of serial frames, the assembled frame against one launch.  Collective: every
     rank calls it; the returned dict is complete on rank 0."""
-    from shaderbox_amd import shard
-    from shaderbox_amd.distributed import FramePlan
     ns = len(streams)
     br = args.block_rows
     fdist = dist

@@ -1,14 +1,12 @@
 """sbxbench.emulate — --emulate-ranks: every rank's schedule of an N-rank frame through a loopback world on ONE device, checked
 against one launch, timed with frames in flight, and MODELLED N-GPU figures with the exchange budget (n_gpus stays 1)."""
 import json
-import os
-import sys
-import time
 
 from shaderbox_amd import tuning
-from shaderbox_amd.tuning import Landing, auto_groups, choose_relief, emulated_frame_ms, relief_candidates, timed_loop
+from shaderbox_amd.tuning import auto_groups, choose_relief, emulated_frame_ms, timed_loop
 
-from .common import DIST_OTHER_CONFIGS, KERNEL_OF, claim_stdout
+from .common import DIST_OTHER_CONFIGS, claim_stdout
+
 
 def bench_emulated(args, R, torch, dev, streams, app, W, H, t):
     """--emulate-ranks N on one GPU: see the option's help.  Everything printed as 'modelled' is max(root, slowest peer, link)

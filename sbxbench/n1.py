@@ -1,8 +1,6 @@
 """sbxbench.n1 — N = 1: the frame is one kernel launch.  The headline's timed region, the other BASELINE configs, the sustained leg."""
-import json
 import os
 import shutil
-import sys
 import tempfile
 import time
 
