@@ -120,6 +120,22 @@ def test_bench_roofline_is_executed_work():
     # no counters at all: only the useful-work ratio
     r0, _ = bench.rooflines("egg", 1920 * 1080, 1920 * 1080, 0.26, 0.26, None)
     assert r0["frac"] is None and r0["useful_work_ratio"]["value"] > 0
+    # round 6: the issue-cycle-weighted occupancy from the class counters (profiles/r05_apps_pmc.txt, k_clouds): classes x issue
+    # cycles / (1024 SIMDs x active cycles); int32 and the un-named instructions priced at both ends
+    cls = {"SQ_INSTS_VALU": 2161.02e6, "GRBM_GUI_ACTIVE": 45400700.0, "kernel_ms_profiled": 2.4068, "source": "test",
+           "SQ_INSTS_VALU_ADD_F32": 528.788e6, "SQ_INSTS_VALU_MUL_F32": 811.079e6, "SQ_INSTS_VALU_FMA_F32": 133.884e6,
+           "SQ_INSTS_VALU_TRANS_F32": 1.25469e6, "SQ_INSTS_VALU_CVT": 60.8648e6, "SQ_INSTS_VALU_INT32": 165.869e6,
+           "SQ_INSTS_VALU_ADD_F64": 4.47525e6, "SQ_INSTS_VALU_MUL_F64": 10.0215e6, "SQ_INSTS_VALU_FMA_F64": 159.364e6,
+           "SQ_INSTS_VALU_TRANS_F64": 259200.0}
+    rw, _ = bench.rooflines("clouds", px, px, 2.39, 2.37, cls)
+    iw = rw["issue_weighted"]
+    assert abs(iw["frac_lo"] - 0.826) < 0.002 and abs(iw["frac_hi"] - 0.981) < 0.002 and iw["frac_lo"] < iw["frac_lo_at_measured_costs"] < iw["frac_hi_at_measured_costs"]
+    assert sum(iw["classes"].values()) == round(cls["SQ_INSTS_VALU"]) and abs(rw["frac"] - 0.7307) < 0.002 and "frac_basis" not in rw
+    # a sub-millisecond kernel profiled at idle clocks (EGG 1080p: 1.01 ms at 0.5 GHz): frac takes the un-profiled duration and says so
+    egg = {"SQ_INSTS_VALU": 1.2049e8, "GRBM_GUI_ACTIVE": 4.0255e6, "kernel_ms_profiled": 1.0142, "source": "test"}
+    re_, _ = bench.rooflines("egg", 1920 * 1080, 1920 * 1080, 0.199, 0.191, egg)
+    assert abs(re_["frac"] - 0.4927) < 0.002 and re_["frac"] == re_["frac_unprofiled_duration"] and "0.50 GHz" in re_["frac_basis"]
+    assert abs(re_["frac_profiled_pass"] - 0.0967) < 0.001 and re_["issue_weighted"] is None
 
 
 @pytest.mark.gpu
