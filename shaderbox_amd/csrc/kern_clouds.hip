@@ -781,6 +781,7 @@ struct ClArgs { FrameClouds F; RowMap M; float* out; const YRow* ytab; };
 template <bool YTAB, bool REG, int LM, bool SM = false>   // SM: exp_small_ (launch_clouds: the frame's exp arguments lie in its domain)
 __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN)) ? CL_MIN_WAVES : (LM == 2 ? CL_MIN_WAVES_YZ : CL_MIN_WAVES_GEN)) k_clouds(FrameClouds F, RowMap M, float* __restrict__ out_arg,
                                                           const YRow* __restrict__ ytab) {
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();        // (for the dispatch order's cost table, RowMap.cost)
     __shared__ WaveCache cache[CL_TX];
 #if CL_PARK
     // the march state a lit step does not need while its light march runs, parked in LDS for that time (a manual spill to
@@ -988,6 +989,17 @@ __global__ void __launch_bounds__(64 * CL_TX, (LM == 1 && (YTAB || !CL_NOTAB_GEN
         const float a = alpha * smoothstep_(.0f, .2f, dot(dir, V3(0, 1, 0)));
         col = abs3(mix3(sky, V3s(radiance), a));               // :215-217
     }
+    tile_cost_store(ME, tl_t0);
+#ifdef SBX_CL_TIMES
+    {   // timeline census (tools/clouds_timeline.py): lane 0 of every wave writes its start, its duration (100 MHz ticks) and where it ran
+        const unsigned long long tl_t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        reinterpret_cast<float4*>(out)[px.idx] = make_float4(__uint_as_float((unsigned)(tl_t0 & 0xffffffffu)), __uint_as_float((unsigned)(tl_t1 - tl_t0)),
+                                                             __uint_as_float(marches ? 1u : 0u), __uint_as_float(xcc & 0xfu));
+        return;
+    }
+#endif
 #ifdef SBX_CL_STATS
     __builtin_amdgcn_wave_barrier();
     if (lane == 1) { st_steps = S.stat[0]; st_lit = S.stat[1]; st_alive = S.stat[2]; st_litl = S.stat[3]; }
@@ -1039,6 +1051,8 @@ static bool clouds_index_domain(const FrameClouds& F) {
     const double n = 271.0 * (P * std::fabs((double)F.nf) * 2.03 * 18.4 + 2.0);
     return std::isfinite(n) && n <= 549755813888.0;                  // 2^39; NaN compares false
 }
+
+dim3 clouds_grid(const RowMap& M) { return grid_for<CL_TW, CL_TX>(M); }
 
 void launch_clouds(const FrameClouds& F_in, const RowMap& M, float* out, hipStream_t s, int variant, void* ytab, int ytab_rows,
                    bool build_table) {

@@ -182,4 +182,37 @@ int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t 
     return 0;
 }
 
+// DISPATCH ORDER (RowMap.order): the launch's gx x gy tiles sorted by the cost the previous frame measured for them, longest first
+// — a counting sort over 1024 cost classes (cost >> 6: 0.64 us each, the last one open) by ONE workgroup, so the table is a
+// permutation of the tiles whatever the cost words hold (uninitialised memory included): the order is a hint, a missing or a
+// doubled tile would be a wrong frame.
+// (`cls`: the class of every tile as pass 1 read it — launches of other streams may be rewriting `cost` meanwhile, and a tile counted
+// in one class and placed in another would run a class's cursor into its neighbour's range.)
+__global__ void __launch_bounds__(1024) k_order_build(const unsigned* __restrict__ cost, unsigned* __restrict__ cls,
+                                                      unsigned* __restrict__ order, int gx, int gy) {
+    __shared__ unsigned hist[1024], start[1024];
+    const int n = gx * gy, tid = (int)threadIdx.x;
+    hist[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned k = __hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 6;
+        const unsigned c = 1023u - (k < 1023u ? k : 1023u);                  // class 0 = the longest
+        cls[i] = c;
+        atomicAdd(&hist[c], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0u;
+        for (int k = 0; k < 1024; ++k) { start[k] = acc; acc += hist[k]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {                                    // (each thread re-reads the classes it wrote itself)
+        const unsigned pos = atomicAdd(&start[cls[i]], 1u);
+        order[pos] = (unsigned)(i % gx) | ((unsigned)(i / gx) << 16);
+    }
+}
+void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s) {
+    hipLaunchKernelGGL(k_order_build, dim3(1), dim3(1024), 0, s, cost, cls, order, gx, gy);
+}
+
 }  // namespace sbx

@@ -24,6 +24,22 @@ struct YtabSlot {
     std::vector<std::pair<hipStream_t, hipEvent_t>> users;
 };
 struct TimingPair { hipEvent_t ev0{}, ev1{}; bool complete = false; };
+// DISPATCH ORDER of a full-frame launch (RowMap.order / .cost): tiles sorted by the duration the previous frames measured for them,
+// longest first, so that a launch ends on its SHORTEST waves instead of on whichever rows come last — one k_clouds launch of the
+// 3840x2160 frame kept the chip full for 2.04 ms and then drained for 0.29 ms (tools/clouds_timeline.py).  A ring of tables
+// (a launch in flight may still read the one before), rebuilt from the cost table after the first frame of a key and every
+// TILE_ORDER_REFRESH frames after that; one key = one (app, launch shape) at a time.
+constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 16;
+struct TileOrder {
+    unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
+    size_t cap = 0;
+    int key[6] = {-1, 0, 0, 0, 0, 0};      // app, width, nrows, y0, grid x, grid y
+    int cur = -1, age = 0;
+    hipStream_t stream = nullptr;          // where the current table was built
+    hipEvent_t ready{};
+    bool have_ready = false;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> users[TILE_ORDER_RING];     // streams that launched readers of a table
+};
 
 struct sbx_ctx {
     int device = 0;
@@ -108,6 +124,7 @@ struct sbx_ctx {
     struct SpanSlot { std::vector<int> key; std::vector<int> table; int4* dev = nullptr; int max_w = 0; size_t cap = 0; };
     SpanSlot span_slots[4];
     unsigned span_next = 0;
+    TileOrder tile_order;
     void* egg_side = nullptr;        // kern_egg.hip EggSide: queues, streams and events of APP_EGG's finisher launches
     std::string err;
 };
@@ -481,6 +498,9 @@ void sbx_destroy(sbx_ctx* ctx) {
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
     egg_side_destroy(ctx->egg_side);
+    if (ctx->tile_order.mem) (void)hipFree(ctx->tile_order.mem);
+    if (ctx->tile_order.have_ready) (void)hipEventDestroy(ctx->tile_order.ready);
+    for (auto& us : ctx->tile_order.users) for (auto& u : us) (void)hipEventDestroy(u.second);
     if (ctx->hs_dev) (void)hipFree(ctx->hs_dev);
     if (ctx->hs_copy) (void)hipStreamDestroy(ctx->hs_copy);
     for (auto& st : ctx->hs_render) if (st) (void)hipStreamDestroy(st);
@@ -501,6 +521,62 @@ static bool stream_is_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
     return st != hipStreamCaptureStatusNone;
+}
+
+// The dispatch order of a launch (TileOrder above).  tile_order_begin: the table and the cost words of this launch go into M (or
+// nothing: a map that is not one contiguous range of whole rows, a stream being captured, SBX_TILE_ORDER=0); tile_order_end: after
+// the launch is enqueued — remembers the stream as a reader, rebuilds the table when one is due.
+static bool tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing) {
+    static const bool off = [] { const char* v = getenv("SBX_TILE_ORDER"); return v && v[0] == '0'; }();
+    if (off || capturing || M.nranks != 1 || M.frag || M.span_mode || M.r0 != 0 || grid.x > 0xffffu || grid.y > 0xffffu) return false;
+    TileOrder& T = ctx->tile_order;
+    const size_t n = (size_t)grid.x * grid.y;
+    if (n < 4096) return false;                                   // (small launches: nothing to order)
+    const int key[6] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y};
+    if (std::memcmp(key, T.key, sizeof(key)) != 0) {
+        if (n > T.cap) {
+            if (T.mem) { (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0; }
+            if (hipMalloc((void**)&T.mem, n * 4 * (2 + TILE_ORDER_RING)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            T.cap = n;
+        }
+        std::memcpy(T.key, key, sizeof(key));
+        T.cur = -1; T.age = 0;                                    // (tables of the old key stay readable for launches in flight)
+    }
+    if (!T.have_ready) {
+        if (hipEventCreateWithFlags(&T.ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        T.have_ready = true;
+    }
+    M.cost = T.mem;
+    if (T.cur >= 0) {
+        M.order = T.mem + T.cap * (size_t)(2 + T.cur);
+        if (s != T.stream) (void)hipStreamWaitEvent(s, T.ready, 0);          // the table was built on another stream
+        bool found = false;
+        for (auto& u : T.users[T.cur]) if (u.first == s) { found = true; break; }
+        if (!found) {
+            hipEvent_t ev{};
+            if (!ctx->event_pool.empty()) { ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); M.order = nullptr; return true; }
+            T.users[T.cur].emplace_back(s, ev);
+        }
+    }
+    return true;
+}
+static void tile_order_end(sbx_ctx* ctx, hipStream_t s) {
+    TileOrder& T = ctx->tile_order;
+    ++T.age;
+    if (T.cur >= 0 && T.age < TILE_ORDER_REFRESH) return;
+    const int next = (T.cur + 1) % TILE_ORDER_RING;
+    for (auto& u : T.users[next]) {                               // launches that may still read the table about to be rewritten
+        if (u.first != s) {
+            const bool ok = hipEventRecord(u.second, u.first) == hipSuccess && hipStreamWaitEvent(s, u.second, 0) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
+        }
+        ctx->event_pool.push_back(u.second);
+    }
+    T.users[next].clear();
+    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s);
+    (void)hipEventRecord(T.ready, s);
+    T.cur = next; T.stream = s; T.age = 0;
 }
 
 // APP_CLOUDS launch with the y-table bookkeeping.  Three cases:
@@ -581,7 +657,10 @@ static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, fl
         (void)hipStreamWaitEvent(s, ctx->ytab_ready, 0);           // table was built on another stream
     }
     char* tab = ctx->ytab + (size_t)slot * CLOUDS_YTAB_BYTES;
-    launch_clouds(F, M, rgba, s, 0, tab, CLOUDS_YTAB_ROWS, rebuild);
+    RowMap Mo = M;
+    const bool ordered = tile_order_begin(ctx, SBX_APP_CLOUDS, Mo, clouds_grid(M), s, capturing);
+    launch_clouds(F, Mo, rgba, s, 0, tab, CLOUDS_YTAB_ROWS, rebuild);
+    if (ordered) tile_order_end(ctx, s);
     if (rebuild) {
         (void)hipEventRecord(ctx->ytab_ready, s);                  // the build is enqueued: now the cache state is true
         std::memcpy(ctx->ytab_key, key, sizeof(key));

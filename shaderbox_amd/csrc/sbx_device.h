@@ -30,10 +30,28 @@ struct Pixel { int x, y; size_t idx; bool valid; float fx, fy; };   // (fx, fy) 
 // TOP_FIRST: workgroups are dispatched in increasing blockIdx (x fastest, then y); with TOP_FIRST the first ones take
 // the TOP rows of the launch.  For APP_CLOUDS the bottom rows never march (src/app_clouds.h:212), so the launch then ends
 // on its cheapest waves and the end-of-launch drain is not a few 100-step marches on a mostly empty chip.
+// the tile a workgroup renders: its own index, or — with a dispatch-order table (RowMap.order) — the tile the table names (wave-uniform)
+__device__ __forceinline__ void ordered_tile(const RowMap& M, int& bx, int& by) {
+    if (M.order) {
+        const unsigned t = M.order[by * (int)gridDim.x + bx];
+        bx = (int)(t & 0xffffu);
+        by = (int)(t >> 16);
+    }
+}
+// a wave's duration into the cost table of the next frame's dispatch order (lane 0 of the workgroup's first wave; t0: s_memrealtime
+// at the kernel's start)
+__device__ __forceinline__ void tile_cost_store(const RowMap& M, unsigned long long t0) {
+    if (M.cost && threadIdx.x == 0) {
+        int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+        ordered_tile(M, bx, by);
+        M.cost[by * (int)gridDim.x + bx] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0);
+    }
+}
 template <int TW = 8, int TX = WG_TILES_X, bool TOP_FIRST = false>
 __device__ __forceinline__ Pixel pixel_of(const RowMap& M, int tid, int bx, int by_in, int grid_y) {
     constexpr int TH = 64 / TW;
     const int lane = tid & 63, wave = tid >> 6;
+    ordered_tile(M, bx, by_in);
     Pixel p;
     p.x = bx * (TW * TX) + wave * TW + (lane % TW);
     // (dispatching the block rows from the middle of the launch outwards — heaviest tiles first for centred scenes — LOSES:
@@ -145,6 +163,8 @@ void launch_raise_fault(unsigned code, hipStream_t s);
 void launch_assemble_spans(int width, int height, int block_rows, const int4* span, const float* peers, size_t stride_pixels,
                            float* frame, hipStream_t s, bool rgba8);
 void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
+void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s);   // tiles by cost, longest first (kern_util.hip)
+dim3 clouds_grid(const RowMap& M);                // the grid launch_clouds uses for this map (tile shape of kern_clouds.hip)
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);
 void launch_worley_volume(int size, float* out, hipStream_t s);
 void launch_exp4k_eval(const float* a, float* out, size_t n, hipStream_t s);
