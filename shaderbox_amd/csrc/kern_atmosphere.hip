@@ -19,6 +19,7 @@ namespace sbx {
 #endif
 template <bool FIN, int PREC = 0>
 __global__ void __launch_bounds__(64 * ATM_TX, ATM_MIN_WAVES) k_atmosphere(FrameAtmosphere F, RowMap M, float* __restrict__ out) {
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();      // (the dispatch order's cost table, RowMap.cost)
     constexpr bool T64 = FIN && ATM_EXP_REG && ATM_EXP64 && !ATM_EXP4K;
     __shared__ double etab[32];
     __shared__ double etab64[T64 ? 64 : 1];               // exp_reg64_'s table (builds without exp_reg4k_)
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(64 * ATM_TX, ATM_MIN_WAVES) k_atmosphere(Frame
     // get_incident_light returns (0, 0, 0) (:85-88) — 28 % of a 16:9 frame.  A wave whose pixels are ALL out there (the test is
     // wave-uniform) skips the atan2 / acos / two sin / two cos of the mapping, ~600 instructions, and encodes that black.
     if (ATM_FREE_EXIT && __builtin_amdgcn_ballot_w64(!(z2 > 2.0f)) == 0ull) {
+        tile_cost_store(M, tl_t0);
         store_rgba(M, out, px.idx, to_srgb(V3(0.f, 0.f, 0.f)));
         return;
     }
@@ -48,6 +50,7 @@ __global__ void __launch_bounds__(64 * ATM_TX, ATM_MIN_WAVES) k_atmosphere(Frame
     const v3 ro = V3(0, ATM_EARTH_R + 1.f, 0);
 
     const v3 col = atm_incident_light<FIN, PREC>(ro, rd, F.sun_dir, etab, etab64);
+    tile_cost_store(M, tl_t0);
     store_rgba(M, out, px.idx, to_srgb(col));
 }
 
@@ -60,6 +63,8 @@ __global__ void __launch_bounds__(256) k_exp4k_eval(const float* __restrict__ a,
 void launch_exp4k_eval(const float* a, float* out, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_exp4k_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, out, n);
 }
+
+dim3 atmosphere_grid(const RowMap& M) { return grid_for<8, ATM_TX>(M); }
 
 void launch_atmosphere(const FrameAtmosphere& F, const RowMap& M, float* out, hipStream_t s, int precision) {
     // FIN: camera and sun direction are finite numbers (they are for every finite u_res / u_time)

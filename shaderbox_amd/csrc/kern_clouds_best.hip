@@ -91,6 +91,7 @@ __device__ __forceinline__ float snoise(float vx, float vy, float vz) {
 
 template <bool XI>
 __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, RowMap M, float* __restrict__ out) {
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();      // (the dispatch order's cost table, RowMap.cost)
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
@@ -142,8 +143,11 @@ __global__ void __launch_bounds__(WG_THREADS) k_clouds_best(FrameCloudsBest F, R
         const float a = alpha * smoothstep_(.0f, .2f, cutoff);
         col = mix3(sky, V3s(C), a);                                        // :658
     }
+    tile_cost_store(M, tl_t0);
     store_rgba(M, out, px.idx, to_srgb(col));
 }
+
+dim3 clouds_best_grid(const RowMap& M) { return grid_for(M); }
 
 void launch_clouds_best(const FrameCloudsBest& F, const RowMap& M, float* out, hipStream_t s) {
     // XI: lattice coordinates below 2^22.  x, z: |pos| * .001 <= (|eye| + 20 * 100 + 20 * 50 * |march_step|) * .001, plus the

@@ -38,6 +38,7 @@ namespace sbx {
 // march_step with |absorbtion * march_step| <= 80.
 template <bool FAST>
 __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameCloudsUe4 F, RowMap M, float* __restrict__ out) {
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();      // (the dispatch order's cost table, RowMap.cost)
     __shared__ WaveCache cache[WG_THREADS / 64];
     const int lane = threadIdx.x & 63;
     WaveCache& S = cache[threadIdx.x >> 6];
@@ -79,8 +80,11 @@ __global__ void __launch_bounds__(WG_THREADS, UE4_MIN_WAVES) k_clouds_ue4(FrameC
     v3 sky = mix3(V3(.0f, .1f, .4f), V3(.3f, .6f, .8f), 1.0f - dir.y);
     sky = sky + V3(1.f, .7f, .55f) * fmin_(pow_(sun_amount, 1500.0f) * 5.0f, 1.0f);
     sky = sky + V3(1.f, .7f, .55f) * fmin_(pow_(sun_amount, 10.0f) * .6f, 1.0f);
+    tile_cost_store(M, tl_t0);
     store_rgba(M, out, px.idx, to_srgb(mix3(sky, V3s(C), alpha)));
 }
+
+dim3 clouds_ue4_grid(const RowMap& M) { return grid_for(M); }
 
 void launch_clouds_ue4(const FrameCloudsUe4& F, const RowMap& M, float* out, hipStream_t s) {
     const double c = std::fabs((double)F.cov), d = std::fabs((double)F.cov_d);

@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
 #ifdef SBX_EGG_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();      // census build (tools/egg_census.py): 100 MHz counter
 #endif
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();      // (the dispatch order's cost table, RowMap.cost)
     int st_trace = 0, st_shadow = 0;
 #ifndef EGG_VCONST
 #define EGG_VCONST 1       // the constants every sdf() call starts with — the turntable rotation and the cull sphere — in VGPRs: a VALU
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
     // The waves that may hand rays over are those of the hot rectangle — the first hot.w * hot.h workgroups — and the finishers
     // count exactly those home (A.expected): every one of them reports below, whatever its pixels did.
     const bool offer = EGG_COOP && A.q != nullptr && by * (int)gridDim.x + bx < hot.w * hot.h;
-    if (EGG_HOT_FIRST && hot.w > 0) hot_first_tile(hot, (int)gridDim.x, bx, by);          // wave-uniform
+    if (EGG_HOT_FIRST && hot.w > 0 && !M.order) hot_first_tile(hot, (int)gridDim.x, bx, by);          // wave-uniform (a dispatch-order table, once there is one, knows better)
     const Pixel px = pixel_of<EGG_TW, EGG_TX>(M, (int)threadIdx.x, bx, by, (int)gridDim.y);
     if (!(EGG_COOP && offer) && !px.valid) return;           // (an offering wave keeps its invalid lanes: lane 0 reports for the wave)
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
@@ -402,6 +403,7 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
 #endif
         if (!px.valid) return;
     }
+    tile_cost_store(M, tl_t0);
     color = egg_bars(color, pc.x, depth);
 #ifdef SBX_EGG_STATS
     {   // lane 0 of the wave: start / end time, the wave's longest trace, lanes that ran a shadow march, the wave's place
@@ -808,6 +810,8 @@ static void launch_egg_t(const FrameEgg& F, const RowMap& M, float* out, hipStre
     S->was_used[k] = true;
     }
 }
+
+dim3 egg_grid(const RowMap& M) { return grid_for<EGG_TW, EGG_TX>(M); }
 
 // side: the context's EggSide, or nullptr (a stream being captured, a launch that must stay one kernel): the plain kernel
 void launch_egg(const FrameEgg& F, const RowMap& M, float* out, hipStream_t s, int variant, void* side) {

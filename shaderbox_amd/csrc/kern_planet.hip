@@ -418,6 +418,7 @@ __device__ __forceinline__ v3 planet_background(v3 dir) {                       
 #endif
 template <bool SKIP, bool ATM = false>
 __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet F, RowMap M, float* __restrict__ out) {
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();      // (the dispatch order's cost table, RowMap.cost)
     __shared__ double etab[ATM ? 32 : 1];
     if (ATM) {
         if (threadIdx.x < 32) etab[threadIdx.x & (ATM ? 31 : 0)] = kExp2Tab[threadIdx.x];
@@ -625,8 +626,11 @@ __global__ void __launch_bounds__(WG_THREADS, PL_MIN_WAVES) k_planet(FramePlanet
         if (cloud_sky) col = abs3(mix3(planet_background(rde), V3s(sky_r), sky_a));   // :364-366
         if (!hit_atm) col = planet_background(rde);                  // :316-318
     }
+    tile_cost_store(M, tl_t0);
     store_rgba(M, out, pxe.idx, to_srgb(col));
 }
+
+dim3 planet_grid(const RowMap& M) { return grid_for<PL_TW>(M); }
 
 void launch_planet(const FramePlanet& F, const RowMap& M, float* out, hipStream_t s, int variant) {
     if (F.atm_sky) {

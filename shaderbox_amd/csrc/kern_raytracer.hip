@@ -218,6 +218,7 @@ __device__ __forceinline__ v3 rt_pixel(const FrameRaytracer& F, const FrameRaytr
 
 template <int WIT, bool WALLS = false>   // WIT: 0 IEEE forms, 1 witnessed fast forms, 2 the witness's test edge (sbx_set_variant 2); WALLS: hit_walls
 __global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowMap M, float* __restrict__ out) {
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();      // (the dispatch order's cost table, RowMap.cost)
 #if RT_LDS_FRAME
     __shared__ FrameRaytracer Fs;
     lds_frame_fill<FrameRaytracer, WG_THREADS>(Fs);
@@ -241,8 +242,11 @@ __global__ void __launch_bounds__(WG_THREADS) k_raytracer(FrameRaytracer F, RowM
         Wit<false> w0;
         color = rt_pixel<false>(F, RT_F, pc, w0);
     }
+    tile_cost_store(M, tl_t0);
     store_rgba(M, out, px.idx, to_srgb(color));
 }
+
+dim3 raytracer_grid(const RowMap& M) { return grid_for(M); }
 
 void launch_raytracer(const FrameRaytracer& F, const RowMap& M, float* out, hipStream_t s, int variant) {
     // hit_walls' conditions on the frame: the six planes are cornell_box.h's and every number of the frame is finite

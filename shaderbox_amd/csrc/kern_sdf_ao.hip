@@ -159,6 +159,7 @@ __device__ __forceinline__ void ao_pixel(const FrameSdfAo& F, v3 ro, v2 pc, W& w
 
 template <bool CULL, int WIT>      // WIT: 0 IEEE roots, 1 witnessed roots, 2 the witness's test edge (sbx_set_variant 2), as k_egg
 __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo F, RowMap M, float* __restrict__ out) {
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();      // (the dispatch order's cost table, RowMap.cost)
     const Pixel px = pixel_of_thread(M);
     if (!px.valid) return;
     const v2 pc = point_cam(F.cam, px.fx, px.fy);
@@ -182,8 +183,11 @@ __global__ void __launch_bounds__(WG_THREADS, AO_MIN_WAVES) k_sdf_ao(FrameSdfAo 
                            * (1.f - exp_(-t * rd.y * F.fog_falloff))
                            / (rd.y * F.fog_falloff);
     const v3 col = abs3(mix3(rgb, V3(1, 1, 1), fog_factor));
+    tile_cost_store(M, tl_t0);
     store_rgba(M, out, px.idx, to_srgb(col));
 }
+
+dim3 sdf_ao_grid(const RowMap& M) { return grid_for(M); }
 
 void launch_sdf_ao(const FrameSdfAo& F, const RowMap& M, float* out, hipStream_t s, int variant) {
     if (variant == 1) hipLaunchKernelGGL((k_sdf_ao<false, 0>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);

@@ -260,6 +260,7 @@ __device__ __forceinline__ void vinyl_pixel(const FrameVinyl& F, const FrameViny
 
 template <bool CULL, int WIT>      // WIT: 0 IEEE roots, 1 witnessed roots, 2 the witness's test edge (sbx_set_variant 2), as k_egg
 __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F, RowMap M, float* __restrict__ out) {
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();      // (the dispatch order's cost table, RowMap.cost)
 #if VI_LDS_FRAME
     // the frame block (~220 floats of rotations and primitive frames) in LDS: sbx_ldsframe.h
     __shared__ FrameVinyl Fs;
@@ -284,8 +285,11 @@ __global__ void __launch_bounds__(WG_THREADS, VI_MIN_WAVES) k_vinyl(FrameVinyl F
         Wit<false> w0;
         vinyl_pixel<CULL>(F, VI_FS, pc, w0, color);
     }
+    tile_cost_store(M, tl_t0);
     store_rgba(M, out, px.idx, to_srgb(color));
 }
+
+dim3 vinyl_grid(const RowMap& M) { return grid_for(M); }
 
 void launch_vinyl(const FrameVinyl& F, const RowMap& M, float* out, hipStream_t s, int variant) {
     if (variant == 1) hipLaunchKernelGGL((k_vinyl<false, 0>), grid_for(M), dim3(WG_THREADS), 0, s, F, M, out);

@@ -28,7 +28,7 @@ struct TimingPair { hipEvent_t ev0{}, ev1{}; bool complete = false; };
 // longest first, so that a launch ends on its SHORTEST waves instead of on whichever rows come last — one k_clouds launch of the
 // 3840x2160 frame kept the chip full for 2.04 ms and then drained for 0.29 ms (tools/clouds_timeline.py).  A ring of tables
 // (a launch in flight may still read the one before), rebuilt from the cost table after the first frame of a key and every
-// TILE_ORDER_REFRESH frames after that; one key = one (app, launch shape) at a time.
+// TILE_ORDER_REFRESH frames after that; one key = one launch shape per app at a time.
 constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 16;
 struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
@@ -124,7 +124,7 @@ struct sbx_ctx {
     struct SpanSlot { std::vector<int> key; std::vector<int> table; int4* dev = nullptr; int max_w = 0; size_t cap = 0; };
     SpanSlot span_slots[4];
     unsigned span_next = 0;
-    TileOrder tile_order;
+    TileOrder tile_order[16];        // by app id (enum sbx_app)
     void* egg_side = nullptr;        // kern_egg.hip EggSide: queues, streams and events of APP_EGG's finisher launches
     std::string err;
 };
@@ -498,9 +498,11 @@ void sbx_destroy(sbx_ctx* ctx) {
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
     egg_side_destroy(ctx->egg_side);
-    if (ctx->tile_order.mem) (void)hipFree(ctx->tile_order.mem);
-    if (ctx->tile_order.have_ready) (void)hipEventDestroy(ctx->tile_order.ready);
-    for (auto& us : ctx->tile_order.users) for (auto& u : us) (void)hipEventDestroy(u.second);
+    for (auto& T : ctx->tile_order) {
+        if (T.mem) (void)hipFree(T.mem);
+        if (T.have_ready) (void)hipEventDestroy(T.ready);
+        for (auto& us : T.users) for (auto& u : us) (void)hipEventDestroy(u.second);
+    }
     if (ctx->hs_dev) (void)hipFree(ctx->hs_dev);
     if (ctx->hs_copy) (void)hipStreamDestroy(ctx->hs_copy);
     for (auto& st : ctx->hs_render) if (st) (void)hipStreamDestroy(st);
@@ -528,8 +530,9 @@ static bool stream_is_capturing(hipStream_t s) {
 // the launch is enqueued — remembers the stream as a reader, rebuilds the table when one is due.
 static bool tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing) {
     static const bool off = [] { const char* v = getenv("SBX_TILE_ORDER"); return v && v[0] == '0'; }();
-    if (off || capturing || M.nranks != 1 || M.frag || M.span_mode || M.r0 != 0 || grid.x > 0xffffu || grid.y > 0xffffu) return false;
-    TileOrder& T = ctx->tile_order;
+    if (off || capturing || app < 0 || app >= 16 || M.nranks != 1 || M.frag || M.span_mode || M.r0 != 0 || grid.x == 0 ||
+        grid.x > 0xffffu || grid.y > 0xffffu) return false;
+    TileOrder& T = ctx->tile_order[app];
     const size_t n = (size_t)grid.x * grid.y;
     if (n < 4096) return false;                                   // (small launches: nothing to order)
     const int key[6] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y};
@@ -561,8 +564,8 @@ static bool tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStr
     }
     return true;
 }
-static void tile_order_end(sbx_ctx* ctx, hipStream_t s) {
-    TileOrder& T = ctx->tile_order;
+static void tile_order_end(sbx_ctx* ctx, int app, hipStream_t s) {
+    TileOrder& T = ctx->tile_order[app];
     ++T.age;
     if (T.cur >= 0 && T.age < TILE_ORDER_REFRESH) return;
     const int next = (T.cur + 1) % TILE_ORDER_RING;
@@ -657,10 +660,7 @@ static int render_clouds(sbx_ctx* ctx, const FrameClouds& F, const RowMap& M, fl
         (void)hipStreamWaitEvent(s, ctx->ytab_ready, 0);           // table was built on another stream
     }
     char* tab = ctx->ytab + (size_t)slot * CLOUDS_YTAB_BYTES;
-    RowMap Mo = M;
-    const bool ordered = tile_order_begin(ctx, SBX_APP_CLOUDS, Mo, clouds_grid(M), s, capturing);
-    launch_clouds(F, Mo, rgba, s, 0, tab, CLOUDS_YTAB_ROWS, rebuild);
-    if (ordered) tile_order_end(ctx, s);
+    launch_clouds(F, M, rgba, s, 0, tab, CLOUDS_YTAB_ROWS, rebuild);
     if (rebuild) {
         (void)hipEventRecord(ctx->ytab_ready, s);                  // the build is enqueued: now the cache state is true
         std::memcpy(ctx->ytab_key, key, sizeof(key));
@@ -707,12 +707,12 @@ static const char* fault_text(const sbx_ctx* ctx) {
 // clouds_lip_domain in kern_clouds.hip.)
 static bool tame_time(float t) { return std::fabs(t) <= 1e8f; }      // NaN compares false
 
-static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, const RowMap& M,
+static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const void* aux, const RowMap& M_in,
                          float* rgba, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "hipSetDevice", e);
-    if (M.nrows == 0) return SBX_OK;
+    if (M_in.nrows == 0) return SBX_OK;
     if (device_fault(ctx)) return fail(ctx, SBX_ERR_FAULT, fault_text(ctx));
     // argument checks come before anything is enqueued or recorded
     if (app < SBX_APP_PLANET || app > SBX_APP_PLANET_ATMOSPHERE) return fail(ctx, SBX_ERR_UNSUPPORTED, "app is not on the accelerated path");
@@ -743,6 +743,22 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     ctx->st_launches.fetch_add(1, std::memory_order_relaxed);
     const int cull_variant = tame_time(uni->u_time) ? ctx->variant : 1;
     const int sdf_variant = cull_variant == 1 ? 1 : ctx->sdf_roots;      // EGG / SDF_AO / VINYL: 2 / 3 = the witness's test build / IEEE roots
+    // the dispatch order of this launch (TileOrder): the tiles by the cost earlier frames of this app and shape measured, longest first
+    dim3 og(0, 0, 1);
+    switch (app) {
+    case SBX_APP_CLOUDS: case SBX_APP_CLOUDS_SKY: og = ctx->variant == 1 ? og : clouds_grid(M_in); break;
+    case SBX_APP_EGG: og = egg_grid(M_in); break;
+    case SBX_APP_RAYTRACER: og = raytracer_grid(M_in); break;
+    case SBX_APP_ATMOSPHERE: og = atmosphere_grid(M_in); break;
+    case SBX_APP_PLANET: case SBX_APP_PLANET_ATMOSPHERE: og = planet_grid(M_in); break;
+    case SBX_APP_SDF_AO: og = sdf_ao_grid(M_in); break;
+    case SBX_APP_VINYL: case SBX_APP_VINYL_GPU: og = vinyl_grid(M_in); break;
+    case SBX_APP_CLOUDS_BEST: og = clouds_best_grid(M_in); break;
+    case SBX_APP_CLOUDS_UE4: og = clouds_ue4_grid(M_in); break;
+    default: break;
+    }
+    RowMap M = M_in;
+    const bool ordered = tile_order_begin(ctx, app, M, og, s, capturing);
     switch (app) {
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
     case SBX_APP_CLOUDS_SKY: launch_clouds(build_clouds(*uni, AC, true), M, rgba, s, ctx->variant, nullptr, 0, false); break;
@@ -778,6 +794,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     default: break;
     }
     if (tp) { (void)hipEventRecord(tp->ev1, s); tp->complete = true; }
+    if (ordered) tile_order_end(ctx, app, s);               // (a table due for its refresh is rebuilt behind the launch)
     if (rc != SBX_OK) return rc;
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "kernel launch", e);

@@ -164,7 +164,16 @@ void launch_assemble_spans(int width, int height, int block_rows, const int4* sp
                            float* frame, hipStream_t s, bool rgba8);
 void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
 void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s);   // tiles by cost, longest first (kern_util.hip)
-dim3 clouds_grid(const RowMap& M);                // the grid launch_clouds uses for this map (tile shape of kern_clouds.hip)
+// the grid each launcher uses for a map (the tile shapes are private to the kernel files): what a dispatch-order table is built for
+dim3 clouds_grid(const RowMap& M);
+dim3 egg_grid(const RowMap& M);
+dim3 raytracer_grid(const RowMap& M);
+dim3 atmosphere_grid(const RowMap& M);
+dim3 planet_grid(const RowMap& M);
+dim3 sdf_ao_grid(const RowMap& M);
+dim3 vinyl_grid(const RowMap& M);
+dim3 clouds_best_grid(const RowMap& M);
+dim3 clouds_ue4_grid(const RowMap& M);
 int launch_noise_eval(int fn, const float* xyz, const float* par, float* out, size_t n, hipStream_t s);
 void launch_worley_volume(int size, float* out, hipStream_t s);
 void launch_exp4k_eval(const float* a, float* out, size_t n, hipStream_t s);
