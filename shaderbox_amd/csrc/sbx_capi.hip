@@ -33,7 +33,7 @@ constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 16;
 struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
     size_t cap = 0;
-    int key[6] = {-1, 0, 0, 0, 0, 0};      // app, width, nrows, y0, grid x, grid y
+    int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
     int cur = -1, age = 0;
     hipStream_t stream = nullptr;          // where the current table was built
     hipEvent_t ready{};
@@ -526,16 +526,16 @@ static bool stream_is_capturing(hipStream_t s) {
 }
 
 // The dispatch order of a launch (TileOrder above).  tile_order_begin: the table and the cost words of this launch go into M (or
-// nothing: a map that is not one contiguous range of whole rows, a stream being captured, SBX_TILE_ORDER=0); tile_order_end: after
+// nothing: a point list, a sub-range of a slab, a stream being captured, SBX_TILE_ORDER=0); tile_order_end: after
 // the launch is enqueued — remembers the stream as a reader, rebuilds the table when one is due.
 static bool tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing) {
     static const bool off = [] { const char* v = getenv("SBX_TILE_ORDER"); return v && v[0] == '0'; }();
-    if (off || capturing || app < 0 || app >= 16 || M.nranks != 1 || M.frag || M.span_mode || M.r0 != 0 || grid.x == 0 ||
-        grid.x > 0xffffu || grid.y > 0xffffu) return false;
+    if (off || capturing || app < 0 || app >= 16 || M.frag || M.r0 != 0 || grid.x == 0 || grid.x > 0xffffu || grid.y > 0xffffu) return false;
     TileOrder& T = ctx->tile_order[app];
     const size_t n = (size_t)grid.x * grid.y;
     if (n < 4096) return false;                                   // (small launches: nothing to order)
-    const int key[6] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y};
+    const int key[12] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y, M.nranks, M.rank, M.block_rows, M.root_rounds, M.rounds,
+                         M.span_mode * 4 + M.in_place};
     if (std::memcmp(key, T.key, sizeof(key)) != 0) {
         if (n > T.cap) {
             if (T.mem) { (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0; }
@@ -567,7 +567,9 @@ static bool tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStr
 static void tile_order_end(sbx_ctx* ctx, int app, hipStream_t s) {
     TileOrder& T = ctx->tile_order[app];
     ++T.age;
-    if (T.cur >= 0 && T.age < TILE_ORDER_REFRESH) return;
+    // the first table of a key after TWO launches of it in a row (a host that alternates shapes — every rank of an emulated multi-GPU
+    // frame through one context — never pays for tables it would not use), later ones every TILE_ORDER_REFRESH launches
+    if (T.age < (T.cur >= 0 ? TILE_ORDER_REFRESH : 2)) return;
     const int next = (T.cur + 1) % TILE_ORDER_RING;
     for (auto& u : T.users[next]) {                               // launches that may still read the table about to be rewritten
         if (u.first != s) {
@@ -743,18 +745,15 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     ctx->st_launches.fetch_add(1, std::memory_order_relaxed);
     const int cull_variant = tame_time(uni->u_time) ? ctx->variant : 1;
     const int sdf_variant = cull_variant == 1 ? 1 : ctx->sdf_roots;      // EGG / SDF_AO / VINYL: 2 / 3 = the witness's test build / IEEE roots
-    // the dispatch order of this launch (TileOrder): the tiles by the cost earlier frames of this app and shape measured, longest first
+    // The dispatch order of this launch (TileOrder): the tiles by the cost earlier frames of this app and shape measured, longest
+    // first.  For the kernels it was measured to help (profiles/r06_tile_order.txt: CLOUDS 4K 2.41 -> 2.23 ms, CLOUDS_SKY 5.14 ->
+    // 4.91, VINYL 1.25 -> 1.19, VINYL_GPU 1.24 -> 1.14); within +-0.6 % for ATMOSPHERE, PLANET, RAYTRACER, SDF_AO, and a LOSS for
+    // APP_EGG (0.205 -> 0.237 ms: its longest waves are latency-bound, and sorted together they share their SIMDs with the next
+    // longest instead of with short ones — its hot-first order stays) and CLOUDS_BEST (+1.6 %): those keep their own order.
     dim3 og(0, 0, 1);
     switch (app) {
     case SBX_APP_CLOUDS: case SBX_APP_CLOUDS_SKY: og = ctx->variant == 1 ? og : clouds_grid(M_in); break;
-    case SBX_APP_EGG: og = egg_grid(M_in); break;
-    case SBX_APP_RAYTRACER: og = raytracer_grid(M_in); break;
-    case SBX_APP_ATMOSPHERE: og = atmosphere_grid(M_in); break;
-    case SBX_APP_PLANET: case SBX_APP_PLANET_ATMOSPHERE: og = planet_grid(M_in); break;
-    case SBX_APP_SDF_AO: og = sdf_ao_grid(M_in); break;
     case SBX_APP_VINYL: case SBX_APP_VINYL_GPU: og = vinyl_grid(M_in); break;
-    case SBX_APP_CLOUDS_BEST: og = clouds_best_grid(M_in); break;
-    case SBX_APP_CLOUDS_UE4: og = clouds_ue4_grid(M_in); break;
     default: break;
     }
     RowMap M = M_in;
