@@ -65,6 +65,12 @@ int sbx_shared_set_timeout_ms(sbx_shared* s, int ms);
  * a grouped ncclRecv from N-1 peers holds for the time the links need, and the HBM writes of the landing. */
 int sbx_model_landing(sbx_ctx* ctx, const void* src, void* dst, size_t bytes, int workgroups, float duration_us, void* stream);
 
+/* The dispatch-order table of an app (csrc/sbx_capi.hip TileOrder: a full launch's tiles sorted by the cost earlier frames measured,
+ * longest first — a hint about cost, never about pixels): tables built so far for the current launch shape (0 = the launches still
+ * run in plain order), launches since the last one, and — if `table` is not NULL and one exists — the current table copied to the
+ * host (`capacity` words; returns the number of tiles, or a negative sbx_status).  For the test that every table is a permutation. */
+int sbx_debug_tile_order(sbx_ctx* ctx, int app, int* tables_built, int* launches_since, unsigned* table, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,6 +183,8 @@ def load_library(path=None):
     lib.sbx_shared_close.restype = None
     lib.sbx_shared_frame.argtypes = [vp]
     lib.sbx_shared_frame.restype = vp
+    lib.sbx_debug_tile_order.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint),
+                                         ctypes.c_size_t]
     lib.sbx_shared_bytes.argtypes = [vp]
     lib.sbx_shared_bytes.restype = ctypes.c_size_t
     lib.sbx_shared_frame_begin.argtypes = [vp, ci, vp]
@@ -622,6 +624,16 @@ class Renderer:
     def set_variant(self, variant):
         """0 = default kernels, 1 = per-lane cross-check kernels (bit-identical by specification)."""
         self._check(self.lib.sbx_set_variant(self.ctx, int(variant)))
+
+    def tile_order(self, app, capacity=1 << 20):
+        """include/sbx_test.h sbx_debug_tile_order: (tables built for the app's current launch shape, launches since the last one,
+        the current table as a numpy array of bx | by << 16 words or None)"""
+        import numpy as np
+        built, since = ctypes.c_int(), ctypes.c_int()
+        buf = (ctypes.c_uint * int(capacity))()
+        n = self.lib.sbx_debug_tile_order(self.ctx, app_id(app), ctypes.byref(built), ctypes.byref(since), buf, int(capacity))
+        self._check(min(n, 0))
+        return built.value, since.value, (np.frombuffer(buf, dtype=np.uint32, count=n).copy() if n > 0 else None)
 
     def set_timing(self, enabled=True):
         self._check(self.lib.sbx_set_timing(self.ctx, 1 if enabled else 0))

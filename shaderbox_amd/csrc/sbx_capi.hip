@@ -34,7 +34,7 @@ struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
     size_t cap = 0;
     int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
-    int cur = -1, age = 0;
+    int cur = -1, age = 0, built = 0;
     hipStream_t stream = nullptr;          // where the current table was built
     hipEvent_t ready{};
     bool have_ready = false;
@@ -543,7 +543,7 @@ static bool tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStr
             T.cap = n;
         }
         std::memcpy(T.key, key, sizeof(key));
-        T.cur = -1; T.age = 0;                                    // (tables of the old key stay readable for launches in flight)
+        T.cur = -1; T.age = 0; T.built = 0;                       // (tables of the old key stay readable for launches in flight)
     }
     if (!T.have_ready) {
         if (hipEventCreateWithFlags(&T.ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -581,7 +581,7 @@ static void tile_order_end(sbx_ctx* ctx, int app, hipStream_t s) {
     T.users[next].clear();
     launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s);
     (void)hipEventRecord(T.ready, s);
-    T.cur = next; T.stream = s; T.age = 0;
+    T.cur = next; T.stream = s; T.age = 0; ++T.built;
 }
 
 // APP_CLOUDS launch with the y-table bookkeeping.  Three cases:
@@ -1724,6 +1724,21 @@ int sbx_debug_raise_fault(sbx_ctx* ctx, void* stream) {
     launch_raise_fault(1u, (hipStream_t)stream);
     if ((e = hipGetLastError()) != hipSuccess) return fail(ctx, SBX_ERR_HIP, "fault kernel launch", e);
     return SBX_OK;
+}
+
+int sbx_debug_tile_order(sbx_ctx* ctx, int app, int* tables_built, int* launches_since, unsigned* table, size_t capacity) {
+    if (!ctx || app < 0 || app >= 16) return SBX_ERR_ARG;
+    TileOrder& T = ctx->tile_order[app];
+    if (tables_built) *tables_built = T.built;
+    if (launches_since) *launches_since = T.age;
+    if (!table || T.cur < 0) return 0;
+    const size_t n = (size_t)T.key[4] * (size_t)T.key[5];
+    if (n > capacity) return fail(ctx, SBX_ERR_ARG, "sbx_debug_tile_order: table larger than the buffer");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(table, T.mem + T.cap * (size_t)(2 + T.cur), n * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "sbx_debug_tile_order", e);
+    return (int)n;
 }
 
 const char* sbx_last_error(sbx_ctx* ctx) {

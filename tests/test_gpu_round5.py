@@ -467,3 +467,57 @@ def test_render_rows_into_host_memory_rgba8_and_errors(renderer):
                                                ctypes.c_void_p(s.cuda_stream))
         g.capture_end()
     assert rc == shaderbox_amd.SBX_ERR_ARG and b"captured" in renderer.lib.sbx_last_error(renderer.ctx)
+
+
+# ---- round 6: the dispatch order (csrc/sbx_capi.hip TileOrder) -------------------------------------------------------------------
+def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
+    """From the third launch of a shape on, APP_CLOUDS (and CLOUDS_SKY, VINYL) dispatch their tiles by the cost earlier frames
+    measured, longest first.  The table is a permutation of the launch's tiles — whatever the cost words hold —, frames rendered
+    through it equal the per-lane kernel's (which never uses one) bit for bit, on one stream and on three, after a change of shape
+    and after a refresh of the table."""
+    import numpy as np
+    import torch
+    for app, W, H, tw, th, W2, H2 in (("clouds", 1920, 1080, 32, 2, 1280, 720), ("vinyl", 2048, 1152, 32, 8, 2560, 1440)):
+        plain = None
+        for k in range(5):
+            got = renderer.render(app, W, H, 0.37)
+            torch.cuda.synchronize()
+            built, since, table = renderer.tile_order(app)
+            assert built == (0 if k < 1 else 1), (app, k, built)          # the first table comes after two launches of the shape
+            if plain is None:
+                plain = got.clone()                                    # (launches 1 and 2 run in plain order)
+            assert bits_differ(got, plain) == 0, (app, k)
+        gx, gy = (W + tw - 1) // tw, (H + th - 1) // th
+        assert table is not None and table.size == gx * gy
+        tiles = (table >> 16).astype(np.int64) * gx + (table & 0xffff).astype(np.int64)
+        assert np.array_equal(np.sort(tiles), np.arange(gx * gy)), app
+        # longest first: the table's first tiles are marching tiles (rows above the horizon), its last ones are not
+        if app == "clouds":
+            assert (table[:gx] >> 16).min() * th >= 250 and (table[-gx:] >> 16).max() * th < 300
+        renderer.set_variant(1)
+        ref = renderer.render(app, W, H, 0.37)
+        renderer.set_variant(0)
+        assert bits_differ(plain, ref) == 0
+        # three frames in flight on three streams, past a refresh (16 launches), at changing times
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        outs = [torch.empty_like(plain) for _ in range(3)]
+        times = [0.37 + 0.01 * k for k in range(21)]
+        for k, t in enumerate(times):
+            with torch.cuda.stream(streams[k % 3]):
+                renderer.render(app, W, H, t, out=outs[k % 3])
+        torch.cuda.synchronize()
+        assert renderer.tile_order(app)[0] >= 2
+        renderer.set_variant(1)
+        for k in (18, 19, 20):
+            assert bits_differ(outs[k % 3], renderer.render(app, W, H, times[k])) == 0, (app, k)
+        renderer.set_variant(0)
+        # another shape: the table starts over; the old shape's table is not used for it
+        small = renderer.render(app, W2, H2, 0.37)
+        assert renderer.tile_order(app)[0] == 0
+        renderer.set_variant(1)
+        assert bits_differ(small, renderer.render(app, W2, H2, 0.37)) == 0
+        renderer.set_variant(0)
+    # an app without the order (APP_EGG keeps its hot-first dispatch) never builds one
+    for _ in range(4):
+        renderer.render("egg", 1920, 1080, 0.37)
+    assert renderer.tile_order("egg") == (0, 0, None)
