@@ -28,13 +28,15 @@ struct TimingPair { hipEvent_t ev0{}, ev1{}; bool complete = false; };
 // longest first, so that a launch ends on its SHORTEST waves instead of on whichever rows come last — one k_clouds launch of the
 // 3840x2160 frame kept the chip full for 2.04 ms and then drained for 0.29 ms (tools/clouds_timeline.py).  A ring of tables
 // (a launch in flight may still read the one before), rebuilt from the cost table after the first frame of a key and every
-// TILE_ORDER_REFRESH frames after that; one key = one launch shape per app at a time.
-constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 16;
+// TILE_ORDER_REFRESH frames after that.  A context keeps up to TILE_ORDER_KEYS shapes per app (least recently used replaced): the ranks of an
+// emulated multi-GPU frame driven through one context each keep their table, as separate processes would.
+constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 16, TILE_ORDER_KEYS = 8;
 struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
     size_t cap = 0;
     int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
     int cur = -1, age = 0, built = 0;
+    unsigned long long stamp = 0;          // last use (least recently used entry of an app is the one a new shape takes)
     hipStream_t stream = nullptr;          // where the current table was built
     hipEvent_t ready{};
     bool have_ready = false;
@@ -124,7 +126,8 @@ struct sbx_ctx {
     struct SpanSlot { std::vector<int> key; std::vector<int> table; int4* dev = nullptr; int max_w = 0; size_t cap = 0; };
     SpanSlot span_slots[4];
     unsigned span_next = 0;
-    TileOrder tile_order[16];        // by app id (enum sbx_app)
+    TileOrder tile_order[16][TILE_ORDER_KEYS];        // by app id (enum sbx_app), a few launch shapes each
+    unsigned long long tile_order_clock = 0;
     void* egg_side = nullptr;        // kern_egg.hip EggSide: queues, streams and events of APP_EGG's finisher launches
     std::string err;
 };
@@ -498,7 +501,7 @@ void sbx_destroy(sbx_ctx* ctx) {
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
     egg_side_destroy(ctx->egg_side);
-    for (auto& T : ctx->tile_order) {
+    for (auto& per_app : ctx->tile_order) for (auto& T : per_app) {
         if (T.mem) (void)hipFree(T.mem);
         if (T.have_ready) (void)hipEventDestroy(T.ready);
         for (auto& us : T.users) for (auto& u : us) (void)hipEventDestroy(u.second);
@@ -528,25 +531,32 @@ static bool stream_is_capturing(hipStream_t s) {
 // The dispatch order of a launch (TileOrder above).  tile_order_begin: the table and the cost words of this launch go into M (or
 // nothing: a point list, a sub-range of a slab, a stream being captured, SBX_TILE_ORDER=0); tile_order_end: after
 // the launch is enqueued — remembers the stream as a reader, rebuilds the table when one is due.
-static bool tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing) {
+static TileOrder* tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing) {
     static const bool off = [] { const char* v = getenv("SBX_TILE_ORDER"); return v && v[0] == '0'; }();
-    if (off || capturing || app < 0 || app >= 16 || M.frag || M.r0 != 0 || grid.x == 0 || grid.x > 0xffffu || grid.y > 0xffffu) return false;
-    TileOrder& T = ctx->tile_order[app];
+    if (off || capturing || app < 0 || app >= 16 || M.frag || M.r0 != 0 || grid.x == 0 || grid.x > 0xffffu || grid.y > 0xffffu) return nullptr;
     const size_t n = (size_t)grid.x * grid.y;
-    if (n < 4096) return false;                                   // (small launches: nothing to order)
+    if (n < 4096) return nullptr;                                 // (small launches: nothing to order)
     const int key[12] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y, M.nranks, M.rank, M.block_rows, M.root_rounds, M.rounds,
                          M.span_mode * 4 + M.in_place};
-    if (std::memcmp(key, T.key, sizeof(key)) != 0) {
+    TileOrder* hit = nullptr;
+    TileOrder* lru = &ctx->tile_order[app][0];
+    for (auto& E : ctx->tile_order[app]) {
+        if (std::memcmp(key, E.key, sizeof(key)) == 0) { hit = &E; break; }
+        if (E.stamp < lru->stamp) lru = &E;
+    }
+    TileOrder& T = hit ? *hit : *lru;
+    T.stamp = ++ctx->tile_order_clock;
+    if (!hit) {
         if (n > T.cap) {
             if (T.mem) { (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0; }
-            if (hipMalloc((void**)&T.mem, n * 4 * (2 + TILE_ORDER_RING)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipMalloc((void**)&T.mem, n * 4 * (2 + TILE_ORDER_RING)) != hipSuccess) { (void)hipGetLastError(); T.key[0] = -1; return nullptr; }
             T.cap = n;
         }
         std::memcpy(T.key, key, sizeof(key));
         T.cur = -1; T.age = 0; T.built = 0;                       // (tables of the old key stay readable for launches in flight)
     }
     if (!T.have_ready) {
-        if (hipEventCreateWithFlags(&T.ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipEventCreateWithFlags(&T.ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         T.have_ready = true;
     }
     M.cost = T.mem;
@@ -558,17 +568,17 @@ static bool tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStr
         if (!found) {
             hipEvent_t ev{};
             if (!ctx->event_pool.empty()) { ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
-            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); M.order = nullptr; return true; }
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); M.order = nullptr; return &T; }
             T.users[T.cur].emplace_back(s, ev);
         }
     }
-    return true;
+    return &T;
 }
-static void tile_order_end(sbx_ctx* ctx, int app, hipStream_t s) {
-    TileOrder& T = ctx->tile_order[app];
+static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
+    TileOrder& T = *Tp;
     ++T.age;
-    // the first table of a key after TWO launches of it in a row (a host that alternates shapes — every rank of an emulated multi-GPU
-    // frame through one context — never pays for tables it would not use), later ones every TILE_ORDER_REFRESH launches
+    // the first table of a shape after TWO launches of it (a host that renders a shape once never pays for a table it would not use),
+    // later ones every TILE_ORDER_REFRESH launches
     if (T.age < (T.cur >= 0 ? TILE_ORDER_REFRESH : 2)) return;
     const int next = (T.cur + 1) % TILE_ORDER_RING;
     for (auto& u : T.users[next]) {                               // launches that may still read the table about to be rewritten
@@ -757,7 +767,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     default: break;
     }
     RowMap M = M_in;
-    const bool ordered = tile_order_begin(ctx, app, M, og, s, capturing);
+    TileOrder* const ordered = tile_order_begin(ctx, app, M, og, s, capturing);
     switch (app) {
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
     case SBX_APP_CLOUDS_SKY: launch_clouds(build_clouds(*uni, AC, true), M, rgba, s, ctx->variant, nullptr, 0, false); break;
@@ -793,7 +803,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     default: break;
     }
     if (tp) { (void)hipEventRecord(tp->ev1, s); tp->complete = true; }
-    if (ordered) tile_order_end(ctx, app, s);               // (a table due for its refresh is rebuilt behind the launch)
+    if (ordered) tile_order_end(ctx, ordered, s);           // (a table due for its refresh is rebuilt behind the launch)
     if (rc != SBX_OK) return rc;
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "kernel launch", e);
@@ -1728,7 +1738,9 @@ int sbx_debug_raise_fault(sbx_ctx* ctx, void* stream) {
 
 int sbx_debug_tile_order(sbx_ctx* ctx, int app, int* tables_built, int* launches_since, unsigned* table, size_t capacity) {
     if (!ctx || app < 0 || app >= 16) return SBX_ERR_ARG;
-    TileOrder& T = ctx->tile_order[app];
+    TileOrder* mru = &ctx->tile_order[app][0];
+    for (auto& E : ctx->tile_order[app]) if (E.stamp > mru->stamp) mru = &E;
+    TileOrder& T = *mru;                                       // the shape used last
     if (tables_built) *tables_built = T.built;
     if (launches_since) *launches_since = T.age;
     if (!table || T.cur < 0) return 0;
