@@ -211,8 +211,67 @@ __global__ void __launch_bounds__(1024) k_order_build(const unsigned* __restrict
         order[pos] = (unsigned)(i % gx) | ((unsigned)(i / gx) << 16);
     }
 }
-void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s) {
-    hipLaunchKernelGGL(k_order_build, dim3(1), dim3(1024), 0, s, cost, cls, order, gx, gy);
+// The MILD order (mode 1): row order, except that (a) tiles that cost next to nothing (< 1/64 of the longest) go last, and (b) the LONG
+// tiles (> 1/8 of the longest) of the launch's final stretch — the trailing tiles, in row order, whose costs add up to what the chip does
+// in the time of its longest tile (`slots` resident waves x that time) — go first.  What ends a launch late is a long wave that starts
+// late; everything else keeps the neighbours row order gives it (a launch sorted strictly longest-first runs its heavy waves together:
+// 4 % slower with three frames in flight, measured on an eighth-frame strip).  One workgroup; thread t owns the contiguous tiles
+// [t * per, (t + 1) * per); every decision is taken from ONE snapshot of the cost words (`snap`), so the table is a permutation whatever
+// other streams write meanwhile.
+__global__ void __launch_bounds__(1024) k_order_build_mild(const unsigned* __restrict__ cost, unsigned* __restrict__ snap,
+                                                           unsigned* __restrict__ order, int gx, int gy, unsigned slots) {
+    __shared__ unsigned long long sums[1024];
+    __shared__ unsigned cnt[3][1024];
+    __shared__ unsigned lmax_s;
+    const int n = gx * gy, tid = (int)threadIdx.x, per = (n + 1023) / 1024;
+    const int a = min(tid * per, n), b = min(a + per, n);
+    if (tid == 0) lmax_s = 0u;
+    __syncthreads();
+    unsigned mx = 0u;
+    for (int i = a; i < b; ++i) {
+        const unsigned c = min(__hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0x3fffffffu);
+        snap[i] = c;
+        mx = max(mx, c);
+    }
+    atomicMax(&lmax_s, mx);
+    __syncthreads();
+    const unsigned lmax = lmax_s, triv = lmax / 64u, lthr = lmax / 8u;
+    unsigned long long sum = 0ull;
+    for (int i = a; i < b; ++i) { const unsigned c = snap[i]; if (c >= triv) sum += c; }
+    sums[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {                                                          // suffix sums: the cost of the tiles behind a thread's chunk
+        unsigned long long acc = 0ull;
+        for (int t = 1023; t >= 0; --t) { const unsigned long long v = sums[t]; sums[t] = acc; acc += v; }
+    }
+    __syncthreads();
+    const unsigned long long reach = (unsigned long long)slots * (unsigned long long)lmax;
+    unsigned long long run = sums[tid];
+    unsigned c0 = 0u, c1 = 0u, c2 = 0u;
+    for (int i = b - 1; i >= a; --i) {
+        const unsigned c = snap[i];
+        unsigned key = 2u;
+        if (c >= triv) { run += c; key = (run <= reach && c > lthr) ? 0u : 1u; }
+        snap[i] = c | (key << 30);
+        c0 += key == 0u; c1 += key == 1u; c2 += key == 2u;
+    }
+    cnt[0][tid] = c0; cnt[1][tid] = c1; cnt[2][tid] = c2;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0u;
+        for (int k = 0; k < 3; ++k) for (int t = 0; t < 1024; ++t) { const unsigned v = cnt[k][t]; cnt[k][t] = acc; acc += v; }
+    }
+    __syncthreads();
+    unsigned p[3] = {cnt[0][tid], cnt[1][tid], cnt[2][tid]};
+    for (int i = a; i < b; ++i) {
+        const unsigned key = snap[i] >> 30;
+        order[p[key]++] = (unsigned)(i % gx) | ((unsigned)(i / gx) << 16);
+    }
+}
+// mode 0: strictly longest first; 1: the mild order
+void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s, int mode, unsigned slots) {
+    if (mode == 1) hipLaunchKernelGGL(k_order_build_mild, dim3(1), dim3(1024), 0, s, cost, cls, order, gx, gy, slots);
+    else hipLaunchKernelGGL(k_order_build, dim3(1), dim3(1024), 0, s, cost, cls, order, gx, gy);
 }
 
 }  // namespace sbx

@@ -589,7 +589,8 @@ static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
         ctx->event_pool.push_back(u.second);
     }
     T.users[next].clear();
-    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s);
+    static const int mode = [] { const char* v = getenv("SBX_TILE_ORDER_MODE"); return v ? atoi(v) : 1; }();
+    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s, mode, 6144u);
     (void)hipEventRecord(T.ready, s);
     T.cur = next; T.stream = s; T.age = 0; ++T.built;
 }

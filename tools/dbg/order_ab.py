@@ -18,8 +18,21 @@ for _ in range(40):
     R.render("clouds", W, H, 0.37, out=out)
 torch.cuda.synchronize()
 b2b = (time.perf_counter() - t0) * 1e3 / 40
+streams = [torch.cuda.Stream() for _ in range(3)]
+outs = [out, torch.empty_like(out), torch.empty_like(out)]
+for i in range(12):
+    with torch.cuda.stream(streams[i % 3]):
+        R.render("clouds", W, H, 0.37, out=outs[i % 3])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(60):
+    with torch.cuda.stream(streams[i % 3]):
+        R.render("clouds", W, H, 0.37, out=outs[i % 3])
+torch.cuda.synchronize()
+pipe = (time.perf_counter() - t0) * 1e3 / 60
 R.set_variant(1); whole = R.render("clouds", W, H, 0.37); R.set_variant(0)
 torch.cuda.synchronize()
 diff = int((out.view(torch.int32) != whole.view(torch.int32)).any(dim=-1).sum().item())
+print("mode %s " % os.environ.get("SBX_TILE_ORDER_MODE", "1") + "3 in flight %.4f ms/frame | " % pipe, end="")
 print("SBX_TILE_ORDER=%s: kernel ms min %.4f median %.4f | back-to-back %.4f ms/frame | pixels differing from the per-lane kernel: %d"
       % (os.environ.get("SBX_TILE_ORDER", "1"), ms[0], ms[len(ms) // 2], b2b, diff))
