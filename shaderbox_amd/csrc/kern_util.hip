@@ -182,96 +182,55 @@ int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t 
     return 0;
 }
 
-// DISPATCH ORDER (RowMap.order): the launch's gx x gy tiles sorted by the cost the previous frame measured for them, longest first
+// DISPATCH ORDER (RowMap.order): the launch's gx x gy tiles sorted by the cost the previous frames measured for them, longest first
 // — a counting sort over 1024 cost classes (cost >> 6: 0.64 us each, the last one open) by ONE workgroup, so the table is a
 // permutation of the tiles whatever the cost words hold (uninitialised memory included): the order is a hint, a missing or a
 // doubled tile would be a wrong frame.
 // (`cls`: the class of every tile as pass 1 read it — launches of other streams may be rewriting `cost` meanwhile, and a tile counted
 // in one class and placed in another would run a class's cursor into its neighbour's range.)
+// Eight sub-histograms by lane (a third of a CLOUDS frame's tiles fall into ONE class, the sky: one LDS word took 33 000 serialised
+// atomics per pass) and a two-level prefix: 170 -> ~40 us for the 129 600 tiles of a 4K frame.
+// (A MILD order was tried too — row order, the trivial tiles last, only the long tiles of the launch's final stretch moved to the
+// front, to keep the neighbours row order gives a wave: no better with frames in flight and it loses the strips' gain; removed.
+// profiles/r06_tile_order.txt.)
+constexpr int ORDER_SUB = 8;
 __global__ void __launch_bounds__(1024) k_order_build(const unsigned* __restrict__ cost, unsigned* __restrict__ cls,
                                                       unsigned* __restrict__ order, int gx, int gy) {
-    __shared__ unsigned hist[1024], start[1024];
-    const int n = gx * gy, tid = (int)threadIdx.x;
-    hist[tid] = 0u;
+    __shared__ unsigned hist[ORDER_SUB][1024];               // counts, then cursors
+    __shared__ unsigned part[32];
+    const int n = gx * gy, tid = (int)threadIdx.x, sub = tid & (ORDER_SUB - 1);
+    for (int k = 0; k < ORDER_SUB; ++k) hist[k][tid] = 0u;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const unsigned k = __hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 6;
         const unsigned c = 1023u - (k < 1023u ? k : 1023u);                  // class 0 = the longest
         cls[i] = c;
-        atomicAdd(&hist[c], 1u);
+        atomicAdd(&hist[sub][c], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-        unsigned acc = 0u;
-        for (int k = 0; k < 1024; ++k) { start[k] = acc; acc += hist[k]; }
+    // exclusive prefix over (class, sub) in that order: thread c owns class c
+    unsigned mine[ORDER_SUB], tot = 0u;
+    for (int k = 0; k < ORDER_SUB; ++k) { mine[k] = tot; tot += hist[k][tid]; }
+    unsigned incl = tot;                                                     // inclusive scan of the class totals: wave, then workgroup
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o); if ((tid & 63) >= o) incl += v; }
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 16) {
+        unsigned v = part[tid];
+        for (int o = 1; o < 16; o <<= 1) { const unsigned u = __shfl_up(v, o, 16); if (tid >= o) v += u; }
+        part[16 + tid] = v;
     }
+    __syncthreads();
+    const unsigned base = incl - tot + ((tid >> 6) ? part[16 + (tid >> 6) - 1] : 0u);
+    for (int k = 0; k < ORDER_SUB; ++k) hist[k][tid] = base + mine[k];
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {                                    // (each thread re-reads the classes it wrote itself)
-        const unsigned pos = atomicAdd(&start[cls[i]], 1u);
+        const unsigned pos = atomicAdd(&hist[sub][cls[i]], 1u);
         order[pos] = (unsigned)(i % gx) | ((unsigned)(i / gx) << 16);
     }
 }
-// The MILD order (mode 1): row order, except that (a) tiles that cost next to nothing (< 1/64 of the longest) go last, and (b) the LONG
-// tiles (> 1/8 of the longest) of the launch's final stretch — the trailing tiles, in row order, whose costs add up to what the chip does
-// in the time of its longest tile (`slots` resident waves x that time) — go first.  What ends a launch late is a long wave that starts
-// late; everything else keeps the neighbours row order gives it (a launch sorted strictly longest-first runs its heavy waves together:
-// 4 % slower with three frames in flight, measured on an eighth-frame strip).  One workgroup; thread t owns the contiguous tiles
-// [t * per, (t + 1) * per); every decision is taken from ONE snapshot of the cost words (`snap`), so the table is a permutation whatever
-// other streams write meanwhile.
-__global__ void __launch_bounds__(1024) k_order_build_mild(const unsigned* __restrict__ cost, unsigned* __restrict__ snap,
-                                                           unsigned* __restrict__ order, int gx, int gy, unsigned slots) {
-    __shared__ unsigned long long sums[1024];
-    __shared__ unsigned cnt[3][1024];
-    __shared__ unsigned lmax_s;
-    const int n = gx * gy, tid = (int)threadIdx.x, per = (n + 1023) / 1024;
-    const int a = min(tid * per, n), b = min(a + per, n);
-    if (tid == 0) lmax_s = 0u;
-    __syncthreads();
-    unsigned mx = 0u;
-    for (int i = a; i < b; ++i) {
-        const unsigned c = min(__hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0x3fffffffu);
-        snap[i] = c;
-        mx = max(mx, c);
-    }
-    atomicMax(&lmax_s, mx);
-    __syncthreads();
-    const unsigned lmax = lmax_s, triv = lmax / 64u, lthr = lmax / 8u;
-    unsigned long long sum = 0ull;
-    for (int i = a; i < b; ++i) { const unsigned c = snap[i]; if (c >= triv) sum += c; }
-    sums[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {                                                          // suffix sums: the cost of the tiles behind a thread's chunk
-        unsigned long long acc = 0ull;
-        for (int t = 1023; t >= 0; --t) { const unsigned long long v = sums[t]; sums[t] = acc; acc += v; }
-    }
-    __syncthreads();
-    const unsigned long long reach = (unsigned long long)slots * (unsigned long long)lmax;
-    unsigned long long run = sums[tid];
-    unsigned c0 = 0u, c1 = 0u, c2 = 0u;
-    for (int i = b - 1; i >= a; --i) {
-        const unsigned c = snap[i];
-        unsigned key = 2u;
-        if (c >= triv) { run += c; key = (run <= reach && c > lthr) ? 0u : 1u; }
-        snap[i] = c | (key << 30);
-        c0 += key == 0u; c1 += key == 1u; c2 += key == 2u;
-    }
-    cnt[0][tid] = c0; cnt[1][tid] = c1; cnt[2][tid] = c2;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned acc = 0u;
-        for (int k = 0; k < 3; ++k) for (int t = 0; t < 1024; ++t) { const unsigned v = cnt[k][t]; cnt[k][t] = acc; acc += v; }
-    }
-    __syncthreads();
-    unsigned p[3] = {cnt[0][tid], cnt[1][tid], cnt[2][tid]};
-    for (int i = a; i < b; ++i) {
-        const unsigned key = snap[i] >> 30;
-        order[p[key]++] = (unsigned)(i % gx) | ((unsigned)(i / gx) << 16);
-    }
-}
-// mode 0: strictly longest first; 1: the mild order
-void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s, int mode, unsigned slots) {
-    if (mode == 1) hipLaunchKernelGGL(k_order_build_mild, dim3(1), dim3(1024), 0, s, cost, cls, order, gx, gy, slots);
-    else hipLaunchKernelGGL(k_order_build, dim3(1), dim3(1024), 0, s, cost, cls, order, gx, gy);
+void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s) {
+    hipLaunchKernelGGL(k_order_build, dim3(1), dim3(1024), 0, s, cost, cls, order, gx, gy);
 }
 
 }  // namespace sbx

@@ -35,10 +35,9 @@ struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
     size_t cap = 0;
     int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
-    int cur = -1, age = 0, built = 0;
+    int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table being built on the side stream, current once `ready` has passed
     unsigned long long stamp = 0;          // last use (least recently used entry of an app is the one a new shape takes)
-    hipStream_t stream = nullptr;          // where the current table was built
-    hipEvent_t ready{};
+    hipEvent_t ready{}, fork{};            // the pending table is built / where the launch that asked for it stands
     bool have_ready = false;
     std::vector<std::pair<hipStream_t, hipEvent_t>> users[TILE_ORDER_RING];     // streams that launched readers of a table
 };
@@ -128,6 +127,7 @@ struct sbx_ctx {
     unsigned span_next = 0;
     TileOrder tile_order[16][TILE_ORDER_KEYS];        // by app id (enum sbx_app), a few launch shapes each
     unsigned long long tile_order_clock = 0;
+    hipStream_t tile_order_side = nullptr;   // the tables are built here, beside the render streams (no launch ever waits for one)
     void* egg_side = nullptr;        // kern_egg.hip EggSide: queues, streams and events of APP_EGG's finisher launches
     std::string err;
 };
@@ -501,9 +501,10 @@ void sbx_destroy(sbx_ctx* ctx) {
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
     egg_side_destroy(ctx->egg_side);
+    if (ctx->tile_order_side) (void)hipStreamDestroy(ctx->tile_order_side);
     for (auto& per_app : ctx->tile_order) for (auto& T : per_app) {
         if (T.mem) (void)hipFree(T.mem);
-        if (T.have_ready) (void)hipEventDestroy(T.ready);
+        if (T.have_ready) { (void)hipEventDestroy(T.ready); (void)hipEventDestroy(T.fork); }
         for (auto& us : T.users) for (auto& u : us) (void)hipEventDestroy(u.second);
     }
     if (ctx->hs_dev) (void)hipFree(ctx->hs_dev);
@@ -553,16 +554,19 @@ static TileOrder* tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, 
             T.cap = n;
         }
         std::memcpy(T.key, key, sizeof(key));
+        if (T.pending >= 0) { (void)hipEventSynchronize(T.ready); T.pending = -1; }   // (a build of the old shape still running on the side stream)
         T.cur = -1; T.age = 0; T.built = 0;                       // (tables of the old key stay readable for launches in flight)
     }
     if (!T.have_ready) {
         if (hipEventCreateWithFlags(&T.ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipEventCreateWithFlags(&T.fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(T.ready); return nullptr; }
         T.have_ready = true;
     }
     M.cost = T.mem;
+    if (T.pending >= 0 && hipEventQuery(T.ready) == hipSuccess) { T.cur = T.pending; T.pending = -1; ++T.built; }   // the new table is complete: from now on
+    (void)hipGetLastError();                                                  // (hipErrorNotReady is not an error)
     if (T.cur >= 0) {
-        M.order = T.mem + T.cap * (size_t)(2 + T.cur);
-        if (s != T.stream) (void)hipStreamWaitEvent(s, T.ready, 0);          // the table was built on another stream
+        M.order = T.mem + T.cap * (size_t)(2 + T.cur);                         // (complete before this call: no stream has to wait for it)
         bool found = false;
         for (auto& u : T.users[T.cur]) if (u.first == s) { found = true; break; }
         if (!found) {
@@ -579,20 +583,23 @@ static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
     ++T.age;
     // the first table of a shape after TWO launches of it (a host that renders a shape once never pays for a table it would not use),
     // later ones every TILE_ORDER_REFRESH launches
-    if (T.age < (T.cur >= 0 ? TILE_ORDER_REFRESH : 2)) return;
+    if (T.pending >= 0 || T.age < (T.cur >= 0 ? TILE_ORDER_REFRESH : 2)) return;
+    // The build runs on the context's SIDE stream, behind this launch (its costs are the freshest) and behind the launches that may
+    // still read the table about to be rewritten; the render streams never wait for it — they take the new table once its event has
+    // passed (tile_order_begin).  (Built in line it cost every stream ~170 us per refresh: the others waited for the new table.)
+    if (!ctx->tile_order_side && hipStreamCreateWithFlags(&ctx->tile_order_side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipStream_t side = ctx->tile_order_side;
     const int next = (T.cur + 1) % TILE_ORDER_RING;
-    for (auto& u : T.users[next]) {                               // launches that may still read the table about to be rewritten
-        if (u.first != s) {
-            const bool ok = hipEventRecord(u.second, u.first) == hipSuccess && hipStreamWaitEvent(s, u.second, 0) == hipSuccess;
-            if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
-        }
+    bool ok = hipEventRecord(T.fork, s) == hipSuccess && hipStreamWaitEvent(side, T.fork, 0) == hipSuccess;
+    for (auto& u : T.users[next]) {
+        ok = ok && hipEventRecord(u.second, u.first) == hipSuccess && hipStreamWaitEvent(side, u.second, 0) == hipSuccess;
         ctx->event_pool.push_back(u.second);
     }
     T.users[next].clear();
-    static const int mode = [] { const char* v = getenv("SBX_TILE_ORDER_MODE"); return v ? atoi(v) : 1; }();
-    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s, mode, 6144u);
-    (void)hipEventRecord(T.ready, s);
-    T.cur = next; T.stream = s; T.age = 0; ++T.built;
+    if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); (void)hipGetLastError(); }   // (a stream that is gone)
+    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], side);
+    (void)hipEventRecord(T.ready, side);
+    T.pending = next; T.age = 0;
 }
 
 // APP_CLOUDS launch with the y-table bookkeeping.  Three cases:
@@ -1742,6 +1749,7 @@ int sbx_debug_tile_order(sbx_ctx* ctx, int app, int* tables_built, int* launches
     TileOrder* mru = &ctx->tile_order[app][0];
     for (auto& E : ctx->tile_order[app]) if (E.stamp > mru->stamp) mru = &E;
     TileOrder& T = *mru;                                       // the shape used last
+    if (T.pending >= 0 && hipEventSynchronize(T.ready) == hipSuccess) { T.cur = T.pending; T.pending = -1; ++T.built; }
     if (tables_built) *tables_built = T.built;
     if (launches_since) *launches_since = T.age;
     if (!table || T.cur < 0) return 0;
