@@ -189,48 +189,46 @@ int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t 
 // (`cls`: the class of every tile as pass 1 read it — launches of other streams may be rewriting `cost` meanwhile, and a tile counted
 // in one class and placed in another would run a class's cursor into its neighbour's range.)
 // Eight sub-histograms by lane (a third of a CLOUDS frame's tiles fall into ONE class, the sky: one LDS word took 33 000 serialised
-// atomics per pass) and a two-level prefix: 170 -> ~40 us for the 129 600 tiles of a 4K frame.
+// atomics per pass) and a two-level prefix.
 // (A MILD order was tried too — row order, the trivial tiles last, only the long tiles of the launch's final stretch moved to the
 // front, to keep the neighbours row order gives a wave: no better with frames in flight and it loses the strips' gain; removed.
 // profiles/r06_tile_order.txt.)
-constexpr int ORDER_SUB = 8;
-__global__ void __launch_bounds__(1024) k_order_build(const unsigned* __restrict__ cost, unsigned* __restrict__ cls,
-                                                      unsigned* __restrict__ order, int gx, int gy) {
+constexpr int ORDER_SUB = 8, ORDER_T = 256;   // 256 threads: four waves find room beside a saturating render kernel (1024 waited for a CU to drain)
+__global__ void __launch_bounds__(ORDER_T) k_order_build(const unsigned* __restrict__ cost, unsigned* __restrict__ cls,
+                                                         unsigned* __restrict__ order, int gx, int gy) {
     __shared__ unsigned hist[ORDER_SUB][1024];               // counts, then cursors
-    __shared__ unsigned part[32];
+    __shared__ unsigned part[2 * (ORDER_T / 64)];
     const int n = gx * gy, tid = (int)threadIdx.x, sub = tid & (ORDER_SUB - 1);
-    for (int k = 0; k < ORDER_SUB; ++k) hist[k][tid] = 0u;
+    for (int k = 0; k < ORDER_SUB; ++k) for (int c = tid; c < 1024; c += ORDER_T) hist[k][c] = 0u;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = tid; i < n; i += ORDER_T) {
         const unsigned k = __hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 6;
         const unsigned c = 1023u - (k < 1023u ? k : 1023u);                  // class 0 = the longest
         cls[i] = c;
         atomicAdd(&hist[sub][c], 1u);
     }
     __syncthreads();
-    // exclusive prefix over (class, sub) in that order: thread c owns class c
-    unsigned mine[ORDER_SUB], tot = 0u;
-    for (int k = 0; k < ORDER_SUB; ++k) { mine[k] = tot; tot += hist[k][tid]; }
-    unsigned incl = tot;                                                     // inclusive scan of the class totals: wave, then workgroup
+    // exclusive prefix over (class, sub) in that order: thread t owns the classes [4 t, 4 t + 4)
+    constexpr int CPT = 1024 / ORDER_T;
+    unsigned tot = 0u;
+    for (int q = 0; q < CPT; ++q) for (int k = 0; k < ORDER_SUB; ++k) tot += hist[k][tid * CPT + q];
+    unsigned incl = tot;                                                     // inclusive scan of the threads' totals: wave, then workgroup
     for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o); if ((tid & 63) >= o) incl += v; }
     if ((tid & 63) == 63) part[tid >> 6] = incl;
     __syncthreads();
-    if (tid < 16) {
-        unsigned v = part[tid];
-        for (int o = 1; o < 16; o <<= 1) { const unsigned u = __shfl_up(v, o, 16); if (tid >= o) v += u; }
-        part[16 + tid] = v;
-    }
+    if (tid == 0) { unsigned acc = 0u; for (int w = 0; w < ORDER_T / 64; ++w) { part[ORDER_T / 64 + w] = acc; acc += part[w]; } }
     __syncthreads();
-    const unsigned base = incl - tot + ((tid >> 6) ? part[16 + (tid >> 6) - 1] : 0u);
-    for (int k = 0; k < ORDER_SUB; ++k) hist[k][tid] = base + mine[k];
+    unsigned run = incl - tot + part[ORDER_T / 64 + (tid >> 6)];
+    for (int q = 0; q < CPT; ++q)
+        for (int k = 0; k < ORDER_SUB; ++k) { const unsigned v = hist[k][tid * CPT + q]; hist[k][tid * CPT + q] = run; run += v; }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {                                    // (each thread re-reads the classes it wrote itself)
+    for (int i = tid; i < n; i += ORDER_T) {                                 // (each thread re-reads the classes it wrote itself)
         const unsigned pos = atomicAdd(&hist[sub][cls[i]], 1u);
         order[pos] = (unsigned)(i % gx) | ((unsigned)(i / gx) << 16);
     }
 }
 void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s) {
-    hipLaunchKernelGGL(k_order_build, dim3(1), dim3(1024), 0, s, cost, cls, order, gx, gy);
+    hipLaunchKernelGGL(k_order_build, dim3(1), dim3(ORDER_T), 0, s, cost, cls, order, gx, gy);
 }
 
 }  // namespace sbx

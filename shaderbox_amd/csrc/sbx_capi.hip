@@ -127,6 +127,8 @@ struct sbx_ctx {
     unsigned span_next = 0;
     TileOrder tile_order[16][TILE_ORDER_KEYS];        // by app id (enum sbx_app), a few launch shapes each
     unsigned long long tile_order_clock = 0;
+    hipStream_t tile_last_stream = nullptr;  // the stream of the last launch that could take an order, and how many in a row came on it
+    int tile_same_stream = 0;
     hipStream_t tile_order_side = nullptr;   // the tables are built here, beside the render streams (no launch ever waits for one)
     void* egg_side = nullptr;        // kern_egg.hip EggSide: queues, streams and events of APP_EGG's finisher launches
     std::string err;
@@ -565,7 +567,12 @@ static TileOrder* tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, 
     M.cost = T.mem;
     if (T.pending >= 0 && hipEventQuery(T.ready) == hipSuccess) { T.cur = T.pending; T.pending = -1; ++T.built; }   // the new table is complete: from now on
     (void)hipGetLastError();                                                  // (hipErrorNotReady is not an error)
-    if (T.cur >= 0) {
+    // ONE AT A TIME only.  A host that keeps frames in flight (launches alternating over streams) already fills the end of one launch
+    // with the start of the next; there the sorted order buys nothing (4K CLOUDS 2.203 -> 2.217 ms per frame with three in flight) and
+    // costs 4-12 % on an eighth-frame strip, while one launch at a time gains 7 % (full frame) to 18 % (strip).  The sign of frames in
+    // flight: this launch comes on another stream than the last one.  The costs are collected either way.
+    if (s == ctx->tile_last_stream) ++ctx->tile_same_stream; else { ctx->tile_last_stream = s; ctx->tile_same_stream = 0; }
+    if (T.cur >= 0 && ctx->tile_same_stream >= 3) {
         M.order = T.mem + T.cap * (size_t)(2 + T.cur);                         // (complete before this call: no stream has to wait for it)
         bool found = false;
         for (auto& u : T.users[T.cur]) if (u.first == s) { found = true; break; }
@@ -587,7 +594,11 @@ static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
     // The build runs on the context's SIDE stream, behind this launch (its costs are the freshest) and behind the launches that may
     // still read the table about to be rewritten; the render streams never wait for it — they take the new table once its event has
     // passed (tile_order_begin).  (Built in line it cost every stream ~170 us per refresh: the others waited for the new table.)
-    if (!ctx->tile_order_side && hipStreamCreateWithFlags(&ctx->tile_order_side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (!ctx->tile_order_side) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        if (hipStreamCreateWithPriority(&ctx->tile_order_side, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); return; }
+    }
     hipStream_t side = ctx->tile_order_side;
     const int next = (T.cur + 1) % TILE_ORDER_RING;
     bool ok = hipEventRecord(T.fork, s) == hipSuccess && hipStreamWaitEvent(side, T.fork, 0) == hipSuccess;
