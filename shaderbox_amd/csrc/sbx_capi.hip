@@ -27,19 +27,20 @@ struct TimingPair { hipEvent_t ev0{}, ev1{}; bool complete = false; };
 // DISPATCH ORDER of a full-frame launch (RowMap.order / .cost): tiles sorted by the duration the previous frames measured for them,
 // longest first, so that a launch ends on its SHORTEST waves instead of on whichever rows come last — one k_clouds launch of the
 // 3840x2160 frame kept the chip full for 2.04 ms and then drained for 0.29 ms (tools/clouds_timeline.py).  A ring of tables
-// (a launch in flight may still read the one before), rebuilt from the cost table after the first frame of a key and every
-// TILE_ORDER_REFRESH frames after that.  A context keeps up to TILE_ORDER_KEYS shapes per app (least recently used replaced): the ranks of an
+// (a launch in flight may still read the one before), rebuilt from the cost table after the first frames of a key, 16 and 32 launches later and every
+// TILE_ORDER_REFRESH launches after that.  A context keeps up to TILE_ORDER_KEYS shapes per app (least recently used replaced): the ranks of an
 // emulated multi-GPU frame driven through one context each keep their table, as separate processes would.
-constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 16, TILE_ORDER_KEYS = 8;
+constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 64, TILE_ORDER_KEYS = 8;
 struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
     size_t cap = 0;
     int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
     int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table being built on the side stream, current once `ready` has passed
     unsigned long long stamp = 0;          // last use (least recently used entry of an app is the one a new shape takes)
-    hipEvent_t ready{}, fork{};            // the pending table is built / where the launch that asked for it stands
-    bool have_ready = false;
-    std::vector<std::pair<hipStream_t, hipEvent_t>> users[TILE_ORDER_RING];     // streams that launched readers of a table
+    hipEvent_t ready{}, seen{};            // the pending table is built / behind the first launch of the shape (the first table waits for its costs: on the host)
+    bool have_ready = false, seen_recorded = false;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> users[TILE_ORDER_RING];     // streams that launched readers of the CURRENT table
+    std::vector<hipEvent_t> retired[TILE_ORDER_RING];   // recorded behind the last readers of a table that is current no more: the slot is free once all have passed
 };
 
 struct sbx_ctx {
@@ -506,8 +507,9 @@ void sbx_destroy(sbx_ctx* ctx) {
     if (ctx->tile_order_side) (void)hipStreamDestroy(ctx->tile_order_side);
     for (auto& per_app : ctx->tile_order) for (auto& T : per_app) {
         if (T.mem) (void)hipFree(T.mem);
-        if (T.have_ready) { (void)hipEventDestroy(T.ready); (void)hipEventDestroy(T.fork); }
+        if (T.have_ready) { (void)hipEventDestroy(T.ready); (void)hipEventDestroy(T.seen); }
         for (auto& us : T.users) for (auto& u : us) (void)hipEventDestroy(u.second);
+        for (auto& rs : T.retired) for (auto& e : rs) (void)hipEventDestroy(e);
     }
     if (ctx->hs_dev) (void)hipFree(ctx->hs_dev);
     if (ctx->hs_copy) (void)hipStreamDestroy(ctx->hs_copy);
@@ -534,9 +536,28 @@ static bool stream_is_capturing(hipStream_t s) {
 // The dispatch order of a launch (TileOrder above).  tile_order_begin: the table and the cost words of this launch go into M (or
 // nothing: a point list, a sub-range of a slab, a stream being captured, SBX_TILE_ORDER=0); tile_order_end: after
 // the launch is enqueued — remembers the stream as a reader, rebuilds the table when one is due.
+// A table that stops being current: an event behind the last launch of every stream that read it.  Nothing waits for these on the
+// device — tile_order_end rewrites a slot only once they have all passed.
+static void tile_order_retire(sbx_ctx* ctx, TileOrder& T, int slot) {
+    if (slot < 0) return;
+    for (auto& u : T.users[slot]) {
+        if (hipEventRecord(u.second, u.first) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); (void)hipGetLastError(); ctx->event_pool.push_back(u.second); continue; }   // (a stream that is gone)
+        T.retired[slot].push_back(u.second);
+    }
+    T.users[slot].clear();
+}
+static bool tile_order_slot_free(sbx_ctx* ctx, TileOrder& T, int slot) {
+    auto& rs = T.retired[slot];
+    while (!rs.empty()) {
+        if (hipEventQuery(rs.back()) != hipSuccess) { (void)hipGetLastError(); return false; }
+        ctx->event_pool.push_back(rs.back());
+        rs.pop_back();
+    }
+    return true;
+}
 static TileOrder* tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing) {
-    static const bool off = [] { const char* v = getenv("SBX_TILE_ORDER"); return v && v[0] == '0'; }();
-    if (off || capturing || app < 0 || app >= 16 || M.frag || M.r0 != 0 || grid.x == 0 || grid.x > 0xffffu || grid.y > 0xffffu) return nullptr;
+    static const int mode = [] { const char* v = getenv("SBX_TILE_ORDER"); return v ? atoi(v) : 1; }();   // 0 off; 2: costs and tables but no order (debugging)
+    if (mode == 0 || capturing || app < 0 || app >= 16 || M.frag || M.r0 != 0 || grid.x == 0 || grid.x > 0xffffu || grid.y > 0xffffu) return nullptr;
     const size_t n = (size_t)grid.x * grid.y;
     if (n < 4096) return nullptr;                                 // (small launches: nothing to order)
     const int key[12] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y, M.nranks, M.rank, M.block_rows, M.root_rounds, M.rounds,
@@ -550,66 +571,87 @@ static TileOrder* tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, 
     TileOrder& T = hit ? *hit : *lru;
     T.stamp = ++ctx->tile_order_clock;
     if (!hit) {
+        if (T.pending >= 0) { (void)hipEventSynchronize(T.ready); T.pending = -1; }   // (a build of the old shape still running on the side stream)
         if (n > T.cap) {
-            if (T.mem) { (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0; }
+            if (T.mem) {
+                (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0;
+                for (auto& us : T.users) { for (auto& u : us) ctx->event_pool.push_back(u.second); us.clear(); }
+                for (auto& rs : T.retired) { for (auto& e : rs) ctx->event_pool.push_back(e); rs.clear(); }
+            }
             if (hipMalloc((void**)&T.mem, n * 4 * (2 + TILE_ORDER_RING)) != hipSuccess) { (void)hipGetLastError(); T.key[0] = -1; return nullptr; }
             T.cap = n;
         }
         std::memcpy(T.key, key, sizeof(key));
-        if (T.pending >= 0) { (void)hipEventSynchronize(T.ready); T.pending = -1; }   // (a build of the old shape still running on the side stream)
-        T.cur = -1; T.age = 0; T.built = 0;                       // (tables of the old key stay readable for launches in flight)
+        tile_order_retire(ctx, T, T.cur);                         // (the old shape's table stays readable for its launches in flight)
+        T.cur = -1; T.age = 0; T.built = 0; T.seen_recorded = false;
     }
     if (!T.have_ready) {
         if (hipEventCreateWithFlags(&T.ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipEventCreateWithFlags(&T.fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(T.ready); return nullptr; }
+        if (hipEventCreateWithFlags(&T.seen, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(T.ready); return nullptr; }
         T.have_ready = true;
     }
     M.cost = T.mem;
-    if (T.pending >= 0 && hipEventQuery(T.ready) == hipSuccess) { T.cur = T.pending; T.pending = -1; ++T.built; }   // the new table is complete: from now on
+    if (T.pending >= 0 && hipEventQuery(T.ready) == hipSuccess) {              // the new table is complete: current from this launch on
+        tile_order_retire(ctx, T, T.cur);
+        T.cur = T.pending; T.pending = -1; ++T.built;
+    }
     (void)hipGetLastError();                                                  // (hipErrorNotReady is not an error)
     // ONE AT A TIME only.  A host that keeps frames in flight (launches alternating over streams) already fills the end of one launch
     // with the start of the next; there the sorted order buys nothing (4K CLOUDS 2.203 -> 2.217 ms per frame with three in flight) and
     // costs 4-12 % on an eighth-frame strip, while one launch at a time gains 7 % (full frame) to 18 % (strip).  The sign of frames in
     // flight: this launch comes on another stream than the last one.  The costs are collected either way.
     if (s == ctx->tile_last_stream) ++ctx->tile_same_stream; else { ctx->tile_last_stream = s; ctx->tile_same_stream = 0; }
-    if (T.cur >= 0 && ctx->tile_same_stream >= 3) {
-        M.order = T.mem + T.cap * (size_t)(2 + T.cur);                         // (complete before this call: no stream has to wait for it)
+    if (T.cur >= 0 && ctx->tile_same_stream >= 3 && mode == 1) {
         bool found = false;
         for (auto& u : T.users[T.cur]) if (u.first == s) { found = true; break; }
         if (!found) {
             hipEvent_t ev{};
             if (!ctx->event_pool.empty()) { ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
-            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); M.order = nullptr; return &T; }
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return &T; }
             T.users[T.cur].emplace_back(s, ev);
         }
+        M.order = T.mem + T.cap * (size_t)(2 + T.cur);                         // (complete before this call: no stream has to wait for it)
     }
     return &T;
 }
 static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
     TileOrder& T = *Tp;
     ++T.age;
-    // the first table of a shape after TWO launches of it (a host that renders a shape once never pays for a table it would not use),
-    // later ones every TILE_ORDER_REFRESH launches
-    if (T.pending >= 0 || T.age < (T.cur >= 0 ? TILE_ORDER_REFRESH : 2)) return;
-    // The build runs on the context's SIDE stream, behind this launch (its costs are the freshest) and behind the launches that may
-    // still read the table about to be rewritten; the render streams never wait for it — they take the new table once its event has
-    // passed (tile_order_begin).  (Built in line it cost every stream ~170 us per refresh: the others waited for the new table.)
+    // the first table of a shape after TWO launches of it (a host that renders a shape once never pays for a table it would not use)
+    // and once the first of them has FINISHED (its costs are what the table is made of; an event recorded behind it and queried here),
+    // later ones 16 and 32 launches on, then every TILE_ORDER_REFRESH launches
+    if (T.cur < 0 && !T.seen_recorded) {
+        if (hipEventRecord(T.seen, s) != hipSuccess) { (void)hipGetLastError(); return; }
+        T.seen_recorded = true;
+    }
+    // (16, 32, then every 64 launches: the costs drift with the scene, slowly; beside launches in flight every build costs them
+    // about its own duration, ~0.1 ms — 1.5 % of an eighth-frame strip at one build per 16, 0.5 % at one per 64)
+    const int refresh = T.cur < 0 ? 2 : T.built <= 1 ? 16 : T.built == 2 ? 32 : TILE_ORDER_REFRESH;
+    if (T.pending >= 0 || T.age < refresh) return;
+    if (T.cur < 0 && hipEventQuery(T.seen) != hipSuccess) { (void)hipGetLastError(); return; }
+    // The build runs on the context's SIDE stream and NOTHING on the device waits for anything: not the render streams for the table
+    // (they take it once its event has passed, tile_order_begin), not the build for the launches — the cost words may hold any
+    // mixture of frames (a table is a permutation whatever they hold), and the slot it writes is one whose last readers have
+    // finished (their events are queried here, on the host; if no slot is free yet the build is simply tried again at the next
+    // launch).  Round 6 first made the side stream wait for events of the render streams: HIP streams share a few hardware queues,
+    // and a wait parked in a queue holds back the render launches queued behind it — eighth-frame strips with three in flight
+    // lost 8-10 % to a build every 16 launches (profiles/r06_tile_order.txt section 6).
+    int next = -1;
+    for (int k = 1; k < TILE_ORDER_RING && next < 0; ++k) {
+        const int c = ((T.cur < 0 ? 0 : T.cur) + k) % TILE_ORDER_RING;
+        if (c != T.cur && tile_order_slot_free(ctx, T, c)) next = c;
+    }
+    if (next < 0) return;
     if (!ctx->tile_order_side) {
+        // a HIGH-priority stream: not for the priority — HIP multiplexes the streams of one priority over a few hardware queues (four
+        // by default), and a fifth normal stream made two of a host's three render streams share one: three eighth-frame strips in
+        // flight 0.278 -> 0.338 ms per launch.  The high-priority streams have queues of their own.
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
         if (hipStreamCreateWithPriority(&ctx->tile_order_side, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); return; }
     }
-    hipStream_t side = ctx->tile_order_side;
-    const int next = (T.cur + 1) % TILE_ORDER_RING;
-    bool ok = hipEventRecord(T.fork, s) == hipSuccess && hipStreamWaitEvent(side, T.fork, 0) == hipSuccess;
-    for (auto& u : T.users[next]) {
-        ok = ok && hipEventRecord(u.second, u.first) == hipSuccess && hipStreamWaitEvent(side, u.second, 0) == hipSuccess;
-        ctx->event_pool.push_back(u.second);
-    }
-    T.users[next].clear();
-    if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); (void)hipGetLastError(); }   // (a stream that is gone)
-    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], side);
-    (void)hipEventRecord(T.ready, side);
+    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], ctx->tile_order_side);
+    if (hipEventRecord(T.ready, ctx->tile_order_side) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(ctx->tile_order_side); (void)hipGetLastError(); return; }
     T.pending = next; T.age = 0;
 }
 
@@ -1760,7 +1802,7 @@ int sbx_debug_tile_order(sbx_ctx* ctx, int app, int* tables_built, int* launches
     TileOrder* mru = &ctx->tile_order[app][0];
     for (auto& E : ctx->tile_order[app]) if (E.stamp > mru->stamp) mru = &E;
     TileOrder& T = *mru;                                       // the shape used last
-    if (T.pending >= 0 && hipEventSynchronize(T.ready) == hipSuccess) { T.cur = T.pending; T.pending = -1; ++T.built; }
+    if (T.pending >= 0 && hipEventSynchronize(T.ready) == hipSuccess) { tile_order_retire(ctx, T, T.cur); T.cur = T.pending; T.pending = -1; ++T.built; }
     if (tables_built) *tables_built = T.built;
     if (launches_since) *launches_since = T.age;
     if (!table || T.cur < 0) return 0;

@@ -502,8 +502,8 @@ def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
         # three streams (plain order: frames in flight fill each other's drain; the costs are still collected and tables still built)
         streams = [torch.cuda.Stream() for _ in range(3)]
         outs = [torch.empty_like(plain) for _ in range(3)]
-        times = [0.37 + 0.01 * k for k in range(21)]
-        for nstreams in (1, 3):
+        for nstreams, nl in ((1, 21), (3, 42)):                        # (the tables are refreshed 16, 32, then every 64 launches after the first)
+            times = [0.37 + 0.01 * k for k in range(nl)]
             before = renderer.tile_order(app)[0]
             for k, t in enumerate(times):
                 with torch.cuda.stream(streams[k % nstreams]):
@@ -511,7 +511,7 @@ def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
             torch.cuda.synchronize()
             assert renderer.tile_order(app)[0] > before, (app, nstreams)
             renderer.set_variant(1)
-            for k in (18, 19, 20):
+            for k in (nl - 3, nl - 2, nl - 1):
                 assert bits_differ(outs[k % 3], renderer.render(app, W, H, times[k])) == 0, (app, nstreams, k)
             renderer.set_variant(0)
         # another shape: the table starts over; the old shape's table is not used for it
