@@ -193,7 +193,7 @@ int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t 
 // (A MILD order was tried too — row order, the trivial tiles last, only the long tiles of the launch's final stretch moved to the
 // front, to keep the neighbours row order gives a wave: no better with frames in flight and it loses the strips' gain; removed.
 // profiles/r06_tile_order.txt.)
-constexpr int ORDER_SUB = 8, ORDER_T = 256;   // 256 threads: four waves find room beside a saturating render kernel (1024 waited for a CU to drain)
+constexpr int ORDER_SUB = 8, ORDER_T = 1024;  // (runs alone behind a launch of its own stream: one CU's sixteen wave slots are free)
 __global__ void __launch_bounds__(ORDER_T) k_order_build(const unsigned* __restrict__ cost, unsigned* __restrict__ cls,
                                                          unsigned* __restrict__ order, int gx, int gy) {
     __shared__ unsigned hist[ORDER_SUB][1024];               // counts, then cursors
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(ORDER_T) k_order_build(const unsigned* __restr
         atomicAdd(&hist[sub][c], 1u);
     }
     __syncthreads();
-    // exclusive prefix over (class, sub) in that order: thread t owns the classes [4 t, 4 t + 4)
+    // exclusive prefix over (class, sub) in that order: thread t owns the classes [CPT t, CPT t + CPT)
     constexpr int CPT = 1024 / ORDER_T;
     unsigned tot = 0u;
     for (int q = 0; q < CPT; ++q) for (int k = 0; k < ORDER_SUB; ++k) tot += hist[k][tid * CPT + q];

@@ -35,7 +35,7 @@ struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
     size_t cap = 0;
     int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
-    int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table being built on the side stream, current once `ready` has passed
+    int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table whose build is queued, current once `ready` has passed
     unsigned long long stamp = 0;          // last use (least recently used entry of an app is the one a new shape takes)
     hipEvent_t ready{}, seen{};            // the pending table is built / behind the first launch of the shape (the first table waits for its costs: on the host)
     bool have_ready = false, seen_recorded = false;
@@ -130,7 +130,6 @@ struct sbx_ctx {
     unsigned long long tile_order_clock = 0;
     hipStream_t tile_last_stream = nullptr;  // the stream of the last launch that could take an order, and how many in a row came on it
     int tile_same_stream = 0;
-    hipStream_t tile_order_side = nullptr;   // the tables are built here, beside the render streams (no launch ever waits for one)
     void* egg_side = nullptr;        // kern_egg.hip EggSide: queues, streams and events of APP_EGG's finisher launches
     std::string err;
 };
@@ -504,7 +503,6 @@ void sbx_destroy(sbx_ctx* ctx) {
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
     egg_side_destroy(ctx->egg_side);
-    if (ctx->tile_order_side) (void)hipStreamDestroy(ctx->tile_order_side);
     for (auto& per_app : ctx->tile_order) for (auto& T : per_app) {
         if (T.mem) (void)hipFree(T.mem);
         if (T.have_ready) { (void)hipEventDestroy(T.ready); (void)hipEventDestroy(T.seen); }
@@ -571,7 +569,7 @@ static TileOrder* tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, 
     TileOrder& T = hit ? *hit : *lru;
     T.stamp = ++ctx->tile_order_clock;
     if (!hit) {
-        if (T.pending >= 0) { (void)hipEventSynchronize(T.ready); T.pending = -1; }   // (a build of the old shape still running on the side stream)
+        if (T.pending >= 0) { (void)hipEventSynchronize(T.ready); T.pending = -1; }   // (a build of the old shape still queued)
         if (n > T.cap) {
             if (T.mem) {
                 (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0;
@@ -629,29 +627,24 @@ static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
     const int refresh = T.cur < 0 ? 2 : T.built <= 1 ? 16 : T.built == 2 ? 32 : TILE_ORDER_REFRESH;
     if (T.pending >= 0 || T.age < refresh) return;
     if (T.cur < 0 && hipEventQuery(T.seen) != hipSuccess) { (void)hipGetLastError(); return; }
-    // The build runs on the context's SIDE stream and NOTHING on the device waits for anything: not the render streams for the table
-    // (they take it once its event has passed, tile_order_begin), not the build for the launches — the cost words may hold any
-    // mixture of frames (a table is a permutation whatever they hold), and the slot it writes is one whose last readers have
-    // finished (their events are queried here, on the host; if no slot is free yet the build is simply tried again at the next
-    // launch).  Round 6 first made the side stream wait for events of the render streams: HIP streams share a few hardware queues,
-    // and a wait parked in a queue holds back the render launches queued behind it — eighth-frame strips with three in flight
-    // lost 8-10 % to a build every 16 launches (profiles/r06_tile_order.txt section 6).
+    // The build goes IN LINE, on the stream of the launch that is due, and nothing on the device waits for it except that stream's
+    // own next launch (~0.1 ms once per 64 launches): the other render streams take the table once its event has passed (queried on
+    // the host, tile_order_begin), the cost words may hold any mixture of frames (a table is a permutation whatever they hold), and
+    // the slot it writes is one whose last readers have finished (their events are queried here; if no slot is free yet the build
+    // is tried again at the next launch).  What round 6 tried first, and what it cost (profiles/r06_tile_order.txt sections 5-7):
+    // other streams WAITING for the new table (~170 us per refresh, each); a side stream that waits for events of the render
+    // streams (HIP multiplexes streams over a few hardware queues: the wait parks in a queue it shares with a render stream and
+    // holds back the launches behind it, 8-10 % of eighth-frame strips in flight); a fifth normal-priority stream at all (two of a
+    // host's three render streams then share a queue, 0.278 -> 0.338 ms per strip); a high-priority side stream (free in one
+    // process, but eight processes sharing one GPU ran 45 % slower: the priority queues preempt each other's processes).
     int next = -1;
     for (int k = 1; k < TILE_ORDER_RING && next < 0; ++k) {
         const int c = ((T.cur < 0 ? 0 : T.cur) + k) % TILE_ORDER_RING;
         if (c != T.cur && tile_order_slot_free(ctx, T, c)) next = c;
     }
     if (next < 0) return;
-    if (!ctx->tile_order_side) {
-        // a HIGH-priority stream: not for the priority — HIP multiplexes the streams of one priority over a few hardware queues (four
-        // by default), and a fifth normal stream made two of a host's three render streams share one: three eighth-frame strips in
-        // flight 0.278 -> 0.338 ms per launch.  The high-priority streams have queues of their own.
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-        if (hipStreamCreateWithPriority(&ctx->tile_order_side, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); return; }
-    }
-    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], ctx->tile_order_side);
-    if (hipEventRecord(T.ready, ctx->tile_order_side) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(ctx->tile_order_side); (void)hipGetLastError(); return; }
+    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s);
+    if (hipEventRecord(T.ready, s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); (void)hipGetLastError(); return; }
     T.pending = next; T.age = 0;
 }
 
