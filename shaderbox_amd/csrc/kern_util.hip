@@ -183,52 +183,74 @@ int launch_math_eval(int fn, const float* a, const float* b, float* out, size_t 
 }
 
 // DISPATCH ORDER (RowMap.order): the launch's gx x gy tiles sorted by the cost the previous frames measured for them, longest first
-// — a counting sort over 1024 cost classes (cost >> 6: 0.64 us each, the last one open) by ONE workgroup, so the table is a
-// permutation of the tiles whatever the cost words hold (uninitialised memory included): the order is a hint, a missing or a
-// doubled tile would be a wrong frame.
-// (`cls`: the class of every tile as pass 1 read it — launches of other streams may be rewriting `cost` meanwhile, and a tile counted
-// in one class and placed in another would run a class's cursor into its neighbour's range.)
-// Eight sub-histograms by lane (a third of a CLOUDS frame's tiles fall into ONE class, the sky: one LDS word took 33 000 serialised
-// atomics per pass) and a two-level prefix.
-// (A MILD order was tried too — row order, the trivial tiles last, only the long tiles of the launch's final stretch moved to the
-// front, to keep the neighbours row order gives a wave: no better with frames in flight and it loses the strips' gain; removed.
-// profiles/r06_tile_order.txt.)
-constexpr int ORDER_SUB = 8, ORDER_T = 1024;  // (runs alone behind a launch of its own stream: one CU's sixteen wave slots are free)
-__global__ void __launch_bounds__(ORDER_T) k_order_build(const unsigned* __restrict__ cost, unsigned* __restrict__ cls,
-                                                         unsigned* __restrict__ order, int gx, int gy) {
-    __shared__ unsigned hist[ORDER_SUB][1024];               // counts, then cursors
-    __shared__ unsigned part[2 * (ORDER_T / 64)];
-    const int n = gx * gy, tid = (int)threadIdx.x, sub = tid & (ORDER_SUB - 1);
-    for (int k = 0; k < ORDER_SUB; ++k) for (int c = tid; c < 1024; c += ORDER_T) hist[k][c] = 0u;
+// — a counting sort over 1024 cost classes (cost >> 6: 0.64 us each, the last one open), so the table is a permutation of the tiles
+// whatever the cost words hold (uninitialised memory included): the order is a hint, a missing or a doubled tile would be a wrong frame.
+// Three small kernels behind each other on the launch's stream, ORDER_G workgroups over contiguous chunks of the tiles:
+//   k_order_count: the class of every tile, written to `cls` (launches of other streams may be rewriting `cost` meanwhile, and a tile
+//                  counted in one class and placed in another would run a class's cursor into its neighbour's range), and the
+//                  chunk's histogram (LDS) to ghist[chunk][class]
+//   k_order_scan : ghist[chunk][class] := the first place of that chunk's tiles of that class (classes in order, chunks within a class)
+//   k_order_place: every tile takes the next place of its (chunk, class) cursor
+// (Round 6's first form was ONE workgroup doing all of it: 150 us for the 129 600 tiles of a 4K frame, bound by the one CU's VALU —
+// ~100 instructions per tile and pass — not by memory; ~25 us this way.  A MILD order was tried too — row order, the trivial tiles
+// last, only the long tiles of the launch's final stretch moved to the front, to keep the neighbours row order gives a wave: no better
+// with frames in flight and it loses the strips' gain; removed.  profiles/r06_tile_order.txt.)
+constexpr int ORDER_G = 64, ORDER_T = 256, ORDER_CLASSES = 1024;
+__device__ __forceinline__ void order_chunk(int n, int& lo, int& hi) {
+    const int chunk = (n + ORDER_G - 1) / ORDER_G;
+    lo = (int)blockIdx.x * chunk;
+    hi = lo + chunk < n ? lo + chunk : n;
+}
+__global__ void __launch_bounds__(ORDER_T) k_order_count(const unsigned* __restrict__ cost, unsigned* __restrict__ cls,
+                                                         unsigned* __restrict__ ghist, int n) {
+    __shared__ unsigned h[ORDER_CLASSES];
+    const int tid = (int)threadIdx.x;
+    for (int c = tid; c < ORDER_CLASSES; c += ORDER_T) h[c] = 0u;
     __syncthreads();
-    for (int i = tid; i < n; i += ORDER_T) {
+    int lo, hi;
+    order_chunk(n, lo, hi);
+    for (int i = lo + tid; i < hi; i += ORDER_T) {
         const unsigned k = __hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 6;
-        const unsigned c = 1023u - (k < 1023u ? k : 1023u);                  // class 0 = the longest
+        const unsigned c = (unsigned)(ORDER_CLASSES - 1) - (k < (unsigned)(ORDER_CLASSES - 1) ? k : (unsigned)(ORDER_CLASSES - 1));   // class 0 = the longest
         cls[i] = c;
-        atomicAdd(&hist[sub][c], 1u);
+        atomicAdd(&h[c], 1u);
     }
     __syncthreads();
-    // exclusive prefix over (class, sub) in that order: thread t owns the classes [CPT t, CPT t + CPT)
-    constexpr int CPT = 1024 / ORDER_T;
+    for (int c = tid; c < ORDER_CLASSES; c += ORDER_T) ghist[(int)blockIdx.x * ORDER_CLASSES + c] = h[c];
+}
+__global__ void __launch_bounds__(ORDER_CLASSES) k_order_scan(unsigned* __restrict__ ghist) {
+    __shared__ unsigned part[2 * (ORDER_CLASSES / 64)];
+    const int c = (int)threadIdx.x;                                          // one thread per class
     unsigned tot = 0u;
-    for (int q = 0; q < CPT; ++q) for (int k = 0; k < ORDER_SUB; ++k) tot += hist[k][tid * CPT + q];
-    unsigned incl = tot;                                                     // inclusive scan of the threads' totals: wave, then workgroup
-    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o); if ((tid & 63) >= o) incl += v; }
-    if ((tid & 63) == 63) part[tid >> 6] = incl;
+    for (int g = 0; g < ORDER_G; ++g) { const unsigned v = ghist[g * ORDER_CLASSES + c]; ghist[g * ORDER_CLASSES + c] = tot; tot += v; }
+    unsigned incl = tot;                                                     // inclusive scan of the classes' totals: wave, then workgroup
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o); if ((c & 63) >= o) incl += v; }
+    if ((c & 63) == 63) part[c >> 6] = incl;
     __syncthreads();
-    if (tid == 0) { unsigned acc = 0u; for (int w = 0; w < ORDER_T / 64; ++w) { part[ORDER_T / 64 + w] = acc; acc += part[w]; } }
+    if (c == 0) { unsigned acc = 0u; for (int w = 0; w < ORDER_CLASSES / 64; ++w) { part[ORDER_CLASSES / 64 + w] = acc; acc += part[w]; } }
     __syncthreads();
-    unsigned run = incl - tot + part[ORDER_T / 64 + (tid >> 6)];
-    for (int q = 0; q < CPT; ++q)
-        for (int k = 0; k < ORDER_SUB; ++k) { const unsigned v = hist[k][tid * CPT + q]; hist[k][tid * CPT + q] = run; run += v; }
+    const unsigned base = incl - tot + part[ORDER_CLASSES / 64 + (c >> 6)];
+    for (int g = 0; g < ORDER_G; ++g) ghist[g * ORDER_CLASSES + c] += base;
+}
+__global__ void __launch_bounds__(ORDER_T) k_order_place(const unsigned* __restrict__ cls, const unsigned* __restrict__ ghist,
+                                                         unsigned* __restrict__ order, int n, int gx) {
+    __shared__ unsigned cur[ORDER_CLASSES];
+    const int tid = (int)threadIdx.x;
+    for (int c = tid; c < ORDER_CLASSES; c += ORDER_T) cur[c] = ghist[(int)blockIdx.x * ORDER_CLASSES + c];
     __syncthreads();
-    for (int i = tid; i < n; i += ORDER_T) {                                 // (each thread re-reads the classes it wrote itself)
-        const unsigned pos = atomicAdd(&hist[sub][cls[i]], 1u);
+    int lo, hi;
+    order_chunk(n, lo, hi);
+    for (int i = lo + tid; i < hi; i += ORDER_T) {
+        const unsigned pos = atomicAdd(&cur[cls[i]], 1u);
         order[pos] = (unsigned)(i % gx) | ((unsigned)(i / gx) << 16);
     }
 }
-void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s) {
-    hipLaunchKernelGGL(k_order_build, dim3(1), dim3(ORDER_T), 0, s, cost, cls, order, gx, gy);
+void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* ghist, unsigned* order, int gx, int gy, hipStream_t s) {
+    const int n = gx * gy;
+    hipLaunchKernelGGL(k_order_count, dim3(ORDER_G), dim3(ORDER_T), 0, s, cost, cls, ghist, n);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_CLASSES), 0, s, ghist);
+    hipLaunchKernelGGL(k_order_place, dim3(ORDER_G), dim3(ORDER_T), 0, s, cls, ghist, order, n, gx);
 }
+size_t order_build_scratch_words() { return (size_t)ORDER_G * ORDER_CLASSES; }
 
 }  // namespace sbx

@@ -32,7 +32,7 @@ struct TimingPair { hipEvent_t ev0{}, ev1{}; bool complete = false; };
 // emulated multi-GPU frame driven through one context each keep their table, as separate processes would.
 constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 64, TILE_ORDER_KEYS = 8;
 struct TileOrder {
-    unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each
+    unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each | the sort's histograms
     size_t cap = 0;
     int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
     int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table whose build is queued, current once `ready` has passed
@@ -576,7 +576,7 @@ static TileOrder* tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, 
                 for (auto& us : T.users) { for (auto& u : us) ctx->event_pool.push_back(u.second); us.clear(); }
                 for (auto& rs : T.retired) { for (auto& e : rs) ctx->event_pool.push_back(e); rs.clear(); }
             }
-            if (hipMalloc((void**)&T.mem, n * 4 * (2 + TILE_ORDER_RING)) != hipSuccess) { (void)hipGetLastError(); T.key[0] = -1; return nullptr; }
+            if (hipMalloc((void**)&T.mem, (n * (2 + TILE_ORDER_RING) + order_build_scratch_words()) * 4) != hipSuccess) { (void)hipGetLastError(); T.key[0] = -1; return nullptr; }
             T.cap = n;
         }
         std::memcpy(T.key, key, sizeof(key));
@@ -626,9 +626,14 @@ static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
     // about its own duration, ~0.1 ms — 1.5 % of an eighth-frame strip at one build per 16, 0.5 % at one per 64)
     const int refresh = T.cur < 0 ? 2 : T.built <= 1 ? 16 : T.built == 2 ? 32 : TILE_ORDER_REFRESH;
     if (T.pending >= 0 || T.age < refresh) return;
+    // not while the host keeps frames in flight (this launch came on another stream than the last): the table would not be used, and a
+    // 1 024-thread workgroup queued behind a launch of ONE stream waits for a whole CU to drain while the other streams' launches keep
+    // the chip full — up to 8 ms of that stream (rocprofv3, three 4K frames in flight).  The costs keep being collected; the build is
+    // due again at the first launch that follows another one on its stream.
+    if (ctx->tile_same_stream < 1) return;
     if (T.cur < 0 && hipEventQuery(T.seen) != hipSuccess) { (void)hipGetLastError(); return; }
     // The build goes IN LINE, on the stream of the launch that is due, and nothing on the device waits for it except that stream's
-    // own next launch (~0.1 ms once per 64 launches): the other render streams take the table once its event has passed (queried on
+    // own next launch (~25 us once per 64 launches): the other render streams take the table once its event has passed (queried on
     // the host, tile_order_begin), the cost words may hold any mixture of frames (a table is a permutation whatever they hold), and
     // the slot it writes is one whose last readers have finished (their events are queried here; if no slot is free yet the build
     // is tried again at the next launch).  What round 6 tried first, and what it cost (profiles/r06_tile_order.txt sections 5-7):
@@ -643,7 +648,7 @@ static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
         if (c != T.cur && tile_order_slot_free(ctx, T, c)) next = c;
     }
     if (next < 0) return;
-    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s);
+    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + TILE_ORDER_RING), T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s);
     if (hipEventRecord(T.ready, s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); (void)hipGetLastError(); return; }
     T.pending = next; T.age = 0;
 }

@@ -163,7 +163,8 @@ void launch_raise_fault(unsigned code, hipStream_t s);
 void launch_assemble_spans(int width, int height, int block_rows, const int4* span, const float* peers, size_t stride_pixels,
                            float* frame, hipStream_t s, bool rgba8);
 void launch_pack_unorm8(int width, int rows, int flip, const float* in, unsigned char* out, hipStream_t s);
-void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* order, int gx, int gy, hipStream_t s);   // tiles by cost, longest first (kern_util.hip)
+void launch_order_build(const unsigned* cost, unsigned* cls, unsigned* ghist, unsigned* order, int gx, int gy, hipStream_t s);
+size_t order_build_scratch_words();   // tiles by cost, longest first (kern_util.hip)
 // the grid each launcher uses for a map (the tile shapes are private to the kernel files): what a dispatch-order table is built for
 dim3 clouds_grid(const RowMap& M);
 dim3 egg_grid(const RowMap& M);

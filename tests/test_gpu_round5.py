@@ -499,7 +499,7 @@ def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
         renderer.set_variant(0)
         assert bits_differ(plain, ref) == 0
         # past a refresh of the table (16 launches), at changing times: one stream (ordered launches), then three frames in flight on
-        # three streams (plain order: frames in flight fill each other's drain; the costs are still collected and tables still built)
+        # three streams (plain order: frames in flight fill each other's drain; the costs are still collected, no table is built)
         streams = [torch.cuda.Stream() for _ in range(3)]
         outs = [torch.empty_like(plain) for _ in range(3)]
         for nstreams, nl in ((1, 21), (3, 42)):                        # (the tables are refreshed 16, 32, then every 64 launches after the first)
@@ -509,7 +509,8 @@ def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
                 with torch.cuda.stream(streams[k % nstreams]):
                     renderer.render(app, W, H, t, out=outs[k % 3])
             torch.cuda.synchronize()
-            assert renderer.tile_order(app)[0] > before, (app, nstreams)
+            built = renderer.tile_order(app)[0]                         # (no table is built while launches alternate over streams)
+            assert (built > before) if nstreams == 1 else (built == before), (app, nstreams, before, built)
             renderer.set_variant(1)
             for k in (nl - 3, nl - 2, nl - 1):
                 assert bits_differ(outs[k % 3], renderer.render(app, W, H, times[k])) == 0, (app, nstreams, k)
