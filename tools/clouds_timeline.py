@@ -11,14 +11,31 @@ import numpy as np
 import torch
 import shaderbox_amd as sa
 
-name = sys.argv[1] if len(sys.argv) > 1 else "cltimes"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+name = args[0] if args else "cltimes"
+strip = [a for a in sys.argv[1:] if a.startswith("--rank=")]      # --rank=R/N: the launch of rank R of N (cyclic 8-row blocks, in place)
 sa.LIB_PATH = os.path.join(ROOT, "build", "ab", "libsbx_%s.so" % name)
 W, H, TW, TH = 3840, 2160, 32, 2
 r = sa.Renderer()
-for _ in range(30):
-    a = r.render("clouds", W, H, 0.37)
-torch.cuda.synchronize()
-a = r.render("clouds", W, H, 0.37).cpu().numpy().view(np.uint32).reshape(H, W, 4)
+if strip:
+    from shaderbox_amd import shard
+    rank, world = (int(v) for v in strip[0].split("=")[1].split("/"))
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    for k in range(31):
+        r.render_rank_in_place("clouds", W, H, 0.37, 8, rank, world, frame)
+        if k % 4 == 3:
+            torch.cuda.synchronize()                  # (a dispatch table is adopted when the host sees it complete)
+    torch.cuda.synchronize()
+    rows = np.asarray(shard.rank_row_indices(H, 8, rank, world))
+    a = frame.cpu().numpy().view(np.uint32).reshape(H, W, 4)[rows]
+    name += " rank %d of %d (%d rows)" % (rank, world, len(rows))
+else:
+    for k in range(30):
+        a = r.render("clouds", W, H, 0.37)
+        if k % 4 == 3:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    a = r.render("clouds", W, H, 0.37).cpu().numpy().view(np.uint32).reshape(H, W, 4)
 w0 = a[::TH, ::TW]
 t0 = w0[..., 0].astype(np.int64)
 dur = w0[..., 1].astype(np.int64)

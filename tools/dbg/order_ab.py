@@ -1,6 +1,8 @@
 import os, sys, time
 sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/shaderbox_amd") else ".")
 import torch, shaderbox_amd as sa
+if os.environ.get("SBX_AB_LIB"):
+    sa.LIB_PATH = os.path.join("build", "ab", "libsbx_%s.so" % os.environ["SBX_AB_LIB"])
 R = sa.Renderer(0); R.set_timing(True)
 W, H = 3840, 2160
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")

@@ -1,6 +1,8 @@
 import os, sys, time
 sys.path.insert(0, ".")
 import torch, shaderbox_amd as sa
+if os.environ.get("SBX_AB_LIB"):
+    sa.LIB_PATH = os.path.join("build", "ab", "libsbx_%s.so" % os.environ["SBX_AB_LIB"])
 R = sa.Renderer(0)
 W, H, br, world = 3840, 2160, 8, 8
 streams = [torch.cuda.Stream() for _ in range(3)]
