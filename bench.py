@@ -24,6 +24,8 @@ N > 1 : one process per GPU (torch.distributed / RCCL; `--exchange auto` = shade
         it uses the ranks it is given.  The SAME frame is sharded as cyclic 8-row blocks (shaderbox_amd/shard.py), every
         rank renders its blocks, ONE exchange over xGMI brings the slabs to rank 0, and one small kernel scatters them to
         their rows.  Total work is fixed -> "scaling": "strong".  Time = barrier + synchronize bracket, max over ranks.
+        `value` at N > 1 = the THROUGHPUT of the K timed frames with --streams of them in flight (a frame at N > 1 contains the
+        exchange, which a frame sequence overlaps with the next frame's rendering); the K frames one at a time = `value_one_at_a_time`.
         The line also carries `phases` (per rank: render_ms / exchange_wait_ms / assemble_ms of serial frames timed with
         events after the timed region) and `steady_state` (the frames completed between the end of the first burst of
         `frames_in_flight` frames and the start of the last one, rank 0: the pipeline's rate without ramp-in and drain),

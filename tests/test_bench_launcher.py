@@ -165,6 +165,10 @@ def test_bench_whole_multi_rank_program_on_one_gpu(n, exchange):
     assert line["parity"]["mismatching_pixels"] == 0 and line["parity"]["rows"] == 540
     assert len(line["phases"]["per_rank"]) == n and all(p["render_ms"] > 0 for p in line["phases"]["per_rank"])
     assert line["value"] > 0 and line["value_serial"] > 0 and line["roofline"]["bound"] == "valu"
+    # N > 1: `value` is the throughput of the frame sequence (frames in flight), a frame's latency stands beside it
+    assert line["value"] == line["value_pipelined"] and line["ms_per_step"] == line["ms_per_step_pipelined"]
+    assert line["value_one_at_a_time"] > 0 and line["ms_per_step_one_at_a_time"] > 0 and "THROUGHPUT" in line["value_is"]
+    assert line["config"]["frames_in_flight"] == line["frames_in_flight_pipelined"] >= 1
     if n == 2 and exchange == "spans":
         oc = line["other_configs"]
         assert [c["kernel"] for c in oc] == ["k_atmosphere", "k_planet"]
