@@ -8,6 +8,7 @@
 #include "../../include/sbx.h"
 #include "../../include/sbx_test.h"
 #include "sbx_device.h"
+#include "sbx_tile_order.h"
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -24,25 +25,6 @@ struct YtabSlot {
     std::vector<std::pair<hipStream_t, hipEvent_t>> users;
 };
 struct TimingPair { hipEvent_t ev0{}, ev1{}; bool complete = false; };
-// DISPATCH ORDER of a full-frame launch (RowMap.order / .cost): tiles sorted by the duration the previous frames measured for them,
-// longest first, so that a launch ends on its SHORTEST waves instead of on whichever rows come last — one k_clouds launch of the
-// 3840x2160 frame kept the chip full for 2.04 ms and then drained for 0.29 ms (tools/clouds_timeline.py).  A ring of tables
-// (a launch in flight may still read the one before), rebuilt from the cost table after the first frames of a key, 16 and 32 launches later and every
-// TILE_ORDER_REFRESH launches after that.  A context keeps up to TILE_ORDER_KEYS shapes per app (least recently used replaced): the ranks of an
-// emulated multi-GPU frame driven through one context each keep their table, as separate processes would.
-constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 64, TILE_ORDER_KEYS = 8;
-struct TileOrder {
-    unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each | the sort's histograms
-    size_t cap = 0;
-    int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
-    int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table whose build is queued, current once `ready` has passed
-    unsigned long long stamp = 0;          // last use (least recently used entry of an app is the one a new shape takes)
-    hipEvent_t ready{}, seen{};            // the pending table is built / behind the first launch of the shape (the first table waits for its costs: on the host)
-    bool have_ready = false, seen_recorded = false;
-    std::vector<std::pair<hipStream_t, hipEvent_t>> users[TILE_ORDER_RING];     // streams that launched readers of the CURRENT table
-    std::vector<hipEvent_t> retired[TILE_ORDER_RING];   // recorded behind the last readers of a table that is current no more: the slot is free once all have passed
-};
-
 struct sbx_ctx {
     int device = 0;
     bool timing = false;
@@ -126,10 +108,7 @@ struct sbx_ctx {
     struct SpanSlot { std::vector<int> key; std::vector<int> table; int4* dev = nullptr; int max_w = 0; size_t cap = 0; };
     SpanSlot span_slots[4];
     unsigned span_next = 0;
-    TileOrder tile_order[16][TILE_ORDER_KEYS];        // by app id (enum sbx_app), a few launch shapes each
-    unsigned long long tile_order_clock = 0;
-    hipStream_t tile_last_stream = nullptr;  // the stream of the last launch that could take an order, and how many in a row came on it
-    int tile_same_stream = 0;
+    TileOrderSet tile_orders;              // the dispatch order's tables (sbx_tile_order.h)
     void* egg_side = nullptr;        // kern_egg.hip EggSide: queues, streams and events of APP_EGG's finisher launches
     std::string err;
 };
@@ -481,6 +460,7 @@ int sbx_create(int device, sbx_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SBX_ERR_NO_DEVICE;   // kernels exist for gfx950 only
     sbx_ctx* ctx = new sbx_ctx();
     ctx->device = device;
+    ctx->tile_orders.pool = &ctx->event_pool;
     for (auto& en : ctx->mi) for (auto& w : en.key) w.store(0xffffffffu, std::memory_order_relaxed);
     if (hipSetDevice(device) != hipSuccess ||
         hipMalloc((void**)&ctx->ytab, (size_t)(CLOUDS_YTAB_RING + CLOUDS_YTAB_CAPTURE) * CLOUDS_YTAB_BYTES) != hipSuccess ||
@@ -503,12 +483,7 @@ void sbx_destroy(sbx_ctx* ctx) {
     for (float* h : ctx->mi_retired) (void)hipHostFree(h);
     if (ctx->pt_host) (void)hipHostFree(ctx->pt_host);
     egg_side_destroy(ctx->egg_side);
-    for (auto& per_app : ctx->tile_order) for (auto& T : per_app) {
-        if (T.mem) (void)hipFree(T.mem);
-        if (T.have_ready) { (void)hipEventDestroy(T.ready); (void)hipEventDestroy(T.seen); }
-        for (auto& us : T.users) for (auto& u : us) (void)hipEventDestroy(u.second);
-        for (auto& rs : T.retired) for (auto& e : rs) (void)hipEventDestroy(e);
-    }
+    tile_order_destroy(ctx->tile_orders);
     if (ctx->hs_dev) (void)hipFree(ctx->hs_dev);
     if (ctx->hs_copy) (void)hipStreamDestroy(ctx->hs_copy);
     for (auto& st : ctx->hs_render) if (st) (void)hipStreamDestroy(st);
@@ -529,128 +504,6 @@ static bool stream_is_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
     return st != hipStreamCaptureStatusNone;
-}
-
-// The dispatch order of a launch (TileOrder above).  tile_order_begin: the table and the cost words of this launch go into M (or
-// nothing: a point list, a sub-range of a slab, a stream being captured, SBX_TILE_ORDER=0); tile_order_end: after
-// the launch is enqueued — remembers the stream as a reader, rebuilds the table when one is due.
-// A table that stops being current: an event behind the last launch of every stream that read it.  Nothing waits for these on the
-// device — tile_order_end rewrites a slot only once they have all passed.
-static void tile_order_retire(sbx_ctx* ctx, TileOrder& T, int slot) {
-    if (slot < 0) return;
-    for (auto& u : T.users[slot]) {
-        if (hipEventRecord(u.second, u.first) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); (void)hipGetLastError(); ctx->event_pool.push_back(u.second); continue; }   // (a stream that is gone)
-        T.retired[slot].push_back(u.second);
-    }
-    T.users[slot].clear();
-}
-static bool tile_order_slot_free(sbx_ctx* ctx, TileOrder& T, int slot) {
-    auto& rs = T.retired[slot];
-    while (!rs.empty()) {
-        if (hipEventQuery(rs.back()) != hipSuccess) { (void)hipGetLastError(); return false; }
-        ctx->event_pool.push_back(rs.back());
-        rs.pop_back();
-    }
-    return true;
-}
-static TileOrder* tile_order_begin(sbx_ctx* ctx, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing) {
-    static const int mode = [] { const char* v = getenv("SBX_TILE_ORDER"); return v ? atoi(v) : 1; }();   // 0 off; 2: costs and tables but no order (debugging)
-    if (mode == 0 || capturing || app < 0 || app >= 16 || M.frag || M.r0 != 0 || grid.x == 0 || grid.x > 0xffffu || grid.y > 0xffffu) return nullptr;
-    const size_t n = (size_t)grid.x * grid.y;
-    if (n < 4096) return nullptr;                                 // (small launches: nothing to order)
-    const int key[12] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y, M.nranks, M.rank, M.block_rows, M.root_rounds, M.rounds,
-                         M.span_mode * 4 + M.in_place};
-    TileOrder* hit = nullptr;
-    TileOrder* lru = &ctx->tile_order[app][0];
-    for (auto& E : ctx->tile_order[app]) {
-        if (std::memcmp(key, E.key, sizeof(key)) == 0) { hit = &E; break; }
-        if (E.stamp < lru->stamp) lru = &E;
-    }
-    TileOrder& T = hit ? *hit : *lru;
-    T.stamp = ++ctx->tile_order_clock;
-    if (!hit) {
-        if (T.pending >= 0) { (void)hipEventSynchronize(T.ready); T.pending = -1; }   // (a build of the old shape still queued)
-        if (n > T.cap) {
-            if (T.mem) {
-                (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0;
-                for (auto& us : T.users) { for (auto& u : us) ctx->event_pool.push_back(u.second); us.clear(); }
-                for (auto& rs : T.retired) { for (auto& e : rs) ctx->event_pool.push_back(e); rs.clear(); }
-            }
-            if (hipMalloc((void**)&T.mem, (n * (2 + TILE_ORDER_RING) + order_build_scratch_words()) * 4) != hipSuccess) { (void)hipGetLastError(); T.key[0] = -1; return nullptr; }
-            T.cap = n;
-        }
-        std::memcpy(T.key, key, sizeof(key));
-        tile_order_retire(ctx, T, T.cur);                         // (the old shape's table stays readable for its launches in flight)
-        T.cur = -1; T.age = 0; T.built = 0; T.seen_recorded = false;
-    }
-    if (!T.have_ready) {
-        if (hipEventCreateWithFlags(&T.ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipEventCreateWithFlags(&T.seen, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(T.ready); return nullptr; }
-        T.have_ready = true;
-    }
-    M.cost = T.mem;
-    if (T.pending >= 0 && hipEventQuery(T.ready) == hipSuccess) {              // the new table is complete: current from this launch on
-        tile_order_retire(ctx, T, T.cur);
-        T.cur = T.pending; T.pending = -1; ++T.built;
-    }
-    (void)hipGetLastError();                                                  // (hipErrorNotReady is not an error)
-    // ONE AT A TIME only.  A host that keeps frames in flight (launches alternating over streams) already fills the end of one launch
-    // with the start of the next; there the sorted order buys nothing (4K CLOUDS 2.203 -> 2.217 ms per frame with three in flight) and
-    // costs 4-12 % on an eighth-frame strip, while one launch at a time gains 7 % (full frame) to 18 % (strip).  The sign of frames in
-    // flight: this launch comes on another stream than the last one.  The costs are collected either way.
-    if (s == ctx->tile_last_stream) ++ctx->tile_same_stream; else { ctx->tile_last_stream = s; ctx->tile_same_stream = 0; }
-    if (T.cur >= 0 && ctx->tile_same_stream >= 3 && mode == 1) {
-        bool found = false;
-        for (auto& u : T.users[T.cur]) if (u.first == s) { found = true; break; }
-        if (!found) {
-            hipEvent_t ev{};
-            if (!ctx->event_pool.empty()) { ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
-            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return &T; }
-            T.users[T.cur].emplace_back(s, ev);
-        }
-        M.order = T.mem + T.cap * (size_t)(2 + T.cur);                         // (complete before this call: no stream has to wait for it)
-    }
-    return &T;
-}
-static void tile_order_end(sbx_ctx* ctx, TileOrder* Tp, hipStream_t s) {
-    TileOrder& T = *Tp;
-    ++T.age;
-    // the first table of a shape after TWO launches of it (a host that renders a shape once never pays for a table it would not use)
-    // and once the first of them has FINISHED (its costs are what the table is made of; an event recorded behind it and queried here),
-    // later ones 16 and 32 launches on, then every TILE_ORDER_REFRESH launches
-    if (T.cur < 0 && !T.seen_recorded) {
-        if (hipEventRecord(T.seen, s) != hipSuccess) { (void)hipGetLastError(); return; }
-        T.seen_recorded = true;
-    }
-    // (16, 32, then every 64 launches: the costs drift with the scene, slowly; beside launches in flight every build costs them
-    // about its own duration, ~0.1 ms — 1.5 % of an eighth-frame strip at one build per 16, 0.5 % at one per 64)
-    const int refresh = T.cur < 0 ? 2 : T.built <= 1 ? 16 : T.built == 2 ? 32 : TILE_ORDER_REFRESH;
-    if (T.pending >= 0 || T.age < refresh) return;
-    // not while the host keeps frames in flight (this launch came on another stream than the last): the table would not be used, and a
-    // 1 024-thread workgroup queued behind a launch of ONE stream waits for a whole CU to drain while the other streams' launches keep
-    // the chip full — up to 8 ms of that stream (rocprofv3, three 4K frames in flight).  The costs keep being collected; the build is
-    // due again at the first launch that follows another one on its stream.
-    if (ctx->tile_same_stream < 1) return;
-    if (T.cur < 0 && hipEventQuery(T.seen) != hipSuccess) { (void)hipGetLastError(); return; }
-    // The build goes IN LINE, on the stream of the launch that is due, and nothing on the device waits for it except that stream's
-    // own next launch (~25 us once per 64 launches): the other render streams take the table once its event has passed (queried on
-    // the host, tile_order_begin), the cost words may hold any mixture of frames (a table is a permutation whatever they hold), and
-    // the slot it writes is one whose last readers have finished (their events are queried here; if no slot is free yet the build
-    // is tried again at the next launch).  What round 6 tried first, and what it cost (profiles/r06_tile_order.txt sections 5-7):
-    // other streams WAITING for the new table (~170 us per refresh, each); a side stream that waits for events of the render
-    // streams (HIP multiplexes streams over a few hardware queues: the wait parks in a queue it shares with a render stream and
-    // holds back the launches behind it, 8-10 % of eighth-frame strips in flight); a fifth normal-priority stream at all (two of a
-    // host's three render streams then share a queue, 0.278 -> 0.338 ms per strip); a high-priority side stream (free in one
-    // process, but eight processes sharing one GPU ran 45 % slower: the priority queues preempt each other's processes).
-    int next = -1;
-    for (int k = 1; k < TILE_ORDER_RING && next < 0; ++k) {
-        const int c = ((T.cur < 0 ? 0 : T.cur) + k) % TILE_ORDER_RING;
-        if (c != T.cur && tile_order_slot_free(ctx, T, c)) next = c;
-    }
-    if (next < 0) return;
-    launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + TILE_ORDER_RING), T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s);
-    if (hipEventRecord(T.ready, s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); (void)hipGetLastError(); return; }
-    T.pending = next; T.age = 0;
 }
 
 // APP_CLOUDS launch with the y-table bookkeeping.  Three cases:
@@ -826,7 +679,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     default: break;
     }
     RowMap M = M_in;
-    TileOrder* const ordered = tile_order_begin(ctx, app, M, og, s, capturing);
+    TileOrder* const ordered = tile_order_begin(ctx->tile_orders, app, M, og, s, capturing);
     switch (app) {
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
     case SBX_APP_CLOUDS_SKY: launch_clouds(build_clouds(*uni, AC, true), M, rgba, s, ctx->variant, nullptr, 0, false); break;
@@ -862,7 +715,7 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     default: break;
     }
     if (tp) { (void)hipEventRecord(tp->ev1, s); tp->complete = true; }
-    if (ordered) tile_order_end(ctx, ordered, s);           // (a table due for its refresh is rebuilt behind the launch)
+    if (ordered) tile_order_end(ctx->tile_orders, ordered, s);           // (a table due for its refresh is rebuilt behind the launch)
     if (rc != SBX_OK) return rc;
     e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SBX_ERR_HIP, "kernel launch", e);
@@ -1797,10 +1650,7 @@ int sbx_debug_raise_fault(sbx_ctx* ctx, void* stream) {
 
 int sbx_debug_tile_order(sbx_ctx* ctx, int app, int* tables_built, int* launches_since, unsigned* table, size_t capacity) {
     if (!ctx || app < 0 || app >= 16) return SBX_ERR_ARG;
-    TileOrder* mru = &ctx->tile_order[app][0];
-    for (auto& E : ctx->tile_order[app]) if (E.stamp > mru->stamp) mru = &E;
-    TileOrder& T = *mru;                                       // the shape used last
-    if (T.pending >= 0 && hipEventSynchronize(T.ready) == hipSuccess) { tile_order_retire(ctx, T, T.cur); T.cur = T.pending; T.pending = -1; ++T.built; }
+    TileOrder& T = tile_order_latest(ctx->tile_orders, app);   // the shape used last
     if (tables_built) *tables_built = T.built;
     if (launches_since) *launches_since = T.age;
     if (!table || T.cur < 0) return 0;

@@ -54,7 +54,7 @@ struct RowMap {
     int span_mode;
     // DISPATCH ORDER (round 6; a hint about cost, never about pixels): order != NULL makes workgroup i of the launch render tile
     // order[i] = bx | by << 16 instead of tile i — a permutation of the launch's tiles, built from the previous frame's per-tile
-    // cost, longest first (sbx_capi.hip TileOrder, kern_util.hip k_order_count / _scan / _place); cost != NULL: lane 0 of every wave's first tile
+    // cost, longest first (sbx_tile_order.h, kern_util.hip k_order_count / _scan / _place); cost != NULL: lane 0 of every wave's first tile
     // column writes its wave's duration (100 MHz ticks) to cost[tile].
     const unsigned* order = nullptr;
     unsigned* cost = nullptr;

@@ -469,7 +469,7 @@ def test_render_rows_into_host_memory_rgba8_and_errors(renderer):
     assert rc == shaderbox_amd.SBX_ERR_ARG and b"captured" in renderer.lib.sbx_last_error(renderer.ctx)
 
 
-# ---- round 6: the dispatch order (csrc/sbx_capi.hip TileOrder) -------------------------------------------------------------------
+# ---- round 6: the dispatch order (csrc/sbx_tile_order.h) -------------------------------------------------------------------
 def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
     """From the third launch of a shape on, APP_CLOUDS (and CLOUDS_SKY, VINYL) dispatch their tiles by the cost earlier frames
     measured, longest first.  The table is a permutation of the launch's tiles — whatever the cost words hold —, frames rendered

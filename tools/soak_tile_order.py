@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/soak_tile_order.py [cases] [seed] — the dispatch order (csrc/sbx_capi.hip TileOrder) under a host that does everything at
+"""tools/soak_tile_order.py [cases] [seed] — the dispatch order (csrc/sbx_tile_order.h) under a host that does everything at
 once: APP_CLOUDS / CLOUDS_SKY / VINYL launches of more shapes than a context keeps tables for (least-recently-used replacement,
 buffers that grow), whole frames and ranks' strips, runs of launches on one stream (tables built, adopted, refreshed, applied) mixed
 with launches alternating over three streams (plain order), changing u_time; every frame is compared with the per-lane kernel's
