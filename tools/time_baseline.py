@@ -12,8 +12,10 @@ R.set_timing(True)
 CASES = [("clouds", 3840, 2160), ("egg", 1920, 1080), ("raytracer", 3840, 2160), ("atmosphere", 7680, 4320), ("planet", 7680, 4320),
          ("planet_atmosphere", 7680, 4320)]      # (the last: config 5's labelled composite, k_planet<., ATM> — VERDICT r4 Weak #8: it had no counters)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-for _ in range(20):                      # clocks up before the first case
+for k in range(20):                      # clocks up before the first case
     R.render("clouds", 3840, 2160, 0.37)
+    if k % 2 == 1:
+        torch.cuda.synchronize()         # (a host that looks at its frames: the dispatch order's table is adopted when the host sees it complete)
 torch.cuda.synchronize()
 for app, w, h in CASES:
     buf = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
