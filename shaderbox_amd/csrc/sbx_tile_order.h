@@ -15,9 +15,9 @@ namespace sbx {
 // DISPATCH ORDER of a full-frame launch (RowMap.order / .cost): tiles sorted by the duration the previous frames measured for them,
 // longest first, so that a launch ends on its SHORTEST waves instead of on whichever rows come last — one k_clouds launch of the
 // 3840x2160 frame kept the chip full for 2.04 ms and then drained for 0.29 ms (tools/clouds_timeline.py).  A ring of tables
-// (a launch in flight may still read the one before), rebuilt from the cost table after the first frames of a key, 16 and 32 launches later and every
-// TILE_ORDER_REFRESH launches after that.  A context keeps up to TILE_ORDER_KEYS shapes per app (least recently used replaced): the ranks of an
-// emulated multi-GPU frame driven through one context each keep their table, as separate processes would.
+// (a launch in flight may still read the one before), rebuilt from the cost table after the first frames of a key, 16 and 32 launches
+// later and every TILE_ORDER_REFRESH launches after that.  A context keeps up to TILE_ORDER_KEYS shapes per app (least recently used
+// replaced): the ranks of an emulated multi-GPU frame driven through one context each keep their table, as separate processes would.
 constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 64, TILE_ORDER_KEYS = 8;
 struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each | the sort's histograms
@@ -25,7 +25,7 @@ struct TileOrder {
     int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
     int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table whose build is queued, current once `ready` has passed
     unsigned long long stamp = 0;          // last use (least recently used entry of an app is the one a new shape takes)
-    hipEvent_t ready{}, seen{};            // the pending table is built / behind the first launch of the shape (the first table waits for its costs: on the host)
+    hipEvent_t ready{}, seen{};            // the pending table is built / behind the shape's first launch (the first table waits for its costs, on the host)
     bool have_ready = false, seen_recorded = false;
     std::vector<std::pair<hipStream_t, hipEvent_t>> users[TILE_ORDER_RING];     // streams that launched readers of the CURRENT table
     std::vector<hipEvent_t> retired[TILE_ORDER_RING];   // recorded behind the last readers of a table that is current no more: the slot is free once all have passed
@@ -130,14 +130,13 @@ static void tile_order_end(TileOrderSet& S, TileOrder* Tp, hipStream_t s) {
         if (hipEventRecord(T.seen, s) != hipSuccess) { (void)hipGetLastError(); return; }
         T.seen_recorded = true;
     }
-    // (16, 32, then every 64 launches: the costs drift with the scene, slowly; beside launches in flight every build costs them
-    // about its own duration, ~0.1 ms — 1.5 % of an eighth-frame strip at one build per 16, 0.5 % at one per 64)
+    // (16, 32, then every 64 launches: the costs drift with the scene, slowly, and the first table is made of the first launch's)
     const int refresh = T.cur < 0 ? 2 : T.built <= 1 ? 16 : T.built == 2 ? 32 : TILE_ORDER_REFRESH;
     if (T.pending >= 0 || T.age < refresh) return;
-    // not while the host keeps frames in flight (this launch came on another stream than the last): the table would not be used, and a
-    // 1 024-thread workgroup queued behind a launch of ONE stream waits for a whole CU to drain while the other streams' launches keep
-    // the chip full — up to 8 ms of that stream (rocprofv3, three 4K frames in flight).  The costs keep being collected; the build is
-    // due again at the first launch that follows another one on its stream.
+    // not while the host keeps frames in flight (this launch came on another stream than the last): the table would not be used, and
+    // the sort, queued behind a launch of ONE stream, has to find room beside the other streams' launches (as one 1 024-thread
+    // workgroup it waited up to 8 ms for a whole CU to drain: rocprofv3, three 4K frames in flight).  The costs keep being collected;
+    // the build is due again at the first launch that follows another one on its stream.
     if (S.same_stream < 1) return;
     if (T.cur < 0 && hipEventQuery(T.seen) != hipSuccess) { (void)hipGetLastError(); return; }
     // The build goes IN LINE, on the stream of the launch that is due, and nothing on the device waits for it except that stream's
