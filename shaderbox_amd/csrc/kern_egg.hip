@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(64 * EGG_TX) k_egg(FrameEgg F, RowMap M, float
 #endif
         if (!px.valid) return;
     }
-    tile_cost_store(M, tl_t0);
+    tile_cost_store_at(M, tl_t0, bx, by);                  // (bx, by: after the hot-first mapping)
     color = egg_bars(color, pc.x, depth);
 #ifdef SBX_EGG_STATS
     {   // lane 0 of the wave: start / end time, the wave's longest trace, lanes that ran a shadow march, the wave's place

@@ -669,13 +669,15 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     const int sdf_variant = cull_variant == 1 ? 1 : ctx->sdf_roots;      // EGG / SDF_AO / VINYL: 2 / 3 = the witness's test build / IEEE roots
     // The dispatch order of this launch (TileOrder): the tiles by the cost earlier frames of this app and shape measured, longest
     // first.  For the kernels it was measured to help (profiles/r06_tile_order.txt: CLOUDS 4K 2.41 -> 2.23 ms, CLOUDS_SKY 5.14 ->
-    // 4.91, VINYL 1.25 -> 1.19, VINYL_GPU 1.24 -> 1.14); within +-0.6 % for ATMOSPHERE, PLANET, RAYTRACER, SDF_AO, and a LOSS for
-    // APP_EGG (0.205 -> 0.237 ms: its longest waves are latency-bound, and sorted together they share their SIMDs with the next
-    // longest instead of with short ones — its hot-first order stays) and CLOUDS_BEST (+1.6 %): those keep their own order.
+    // 4.91, VINYL 1.25 -> 1.19, VINYL_GPU 1.24 -> 1.14, and APP_EGG 1920x1080 0.205 -> 0.134 ms back to back — its launch drags a tail
+    // of ~350 silhouette waves of up to 175 us behind it, some of which the hot-first order starts 40 us into the launch; under the
+    // table they are the first to start); within +-0.6 % for ATMOSPHERE, PLANET, RAYTRACER, SDF_AO, +1.6 % for CLOUDS_BEST: those
+    // keep their own order.  (Until the table is there, and with frames in flight, k_egg's hot-first order stands.)
     dim3 og(0, 0, 1);
     switch (app) {
     case SBX_APP_CLOUDS: case SBX_APP_CLOUDS_SKY: og = ctx->variant == 1 ? og : clouds_grid(M_in); break;
     case SBX_APP_VINYL: case SBX_APP_VINYL_GPU: og = vinyl_grid(M_in); break;
+    case SBX_APP_EGG: og = egg_grid(M_in); break;
     default: break;
     }
     RowMap M = M_in;

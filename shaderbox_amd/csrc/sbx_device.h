@@ -40,6 +40,15 @@ __device__ __forceinline__ void ordered_tile(const RowMap& M, int& bx, int& by) 
 }
 // a wave's duration into the cost table of the next frame's dispatch order (lane 0 of the workgroup's first wave; t0: s_memrealtime
 // at the kernel's start)
+// (the same for a kernel with an order of its own — APP_EGG's hot-first —: (bx, by) = the tile it hands to pixel_of.  Until this
+// existed k_egg's costs were filed under the WORKGROUP's index, not the tile's: the table built from them was noise, and "the
+// order loses 15 % on APP_EGG" was a measurement of that)
+__device__ __forceinline__ void tile_cost_store_at(const RowMap& M, unsigned long long t0, int bx, int by) {
+    if (M.cost && threadIdx.x == 0) {
+        ordered_tile(M, bx, by);
+        M.cost[by * (int)gridDim.x + bx] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0);
+    }
+}
 __device__ __forceinline__ void tile_cost_store(const RowMap& M, unsigned long long t0) {
     if (M.cost && threadIdx.x == 0) {
         int bx = (int)blockIdx.x, by = (int)blockIdx.y;

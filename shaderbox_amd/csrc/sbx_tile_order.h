@@ -86,6 +86,7 @@ static TileOrder* tile_order_begin(TileOrderSet& S, int app, RowMap& M, dim3 gri
             }
             if (hipMalloc((void**)&T.mem, (n * (2 + TILE_ORDER_RING) + order_build_scratch_words()) * 4) != hipSuccess) { (void)hipGetLastError(); T.key[0] = -1; return nullptr; }
             T.cap = n;
+            (void)hipMemsetAsync(T.mem, 0, n * 4, s);            // (tiles no wave reports for — all of it outside the frame — sort last, not anywhere)
         }
         std::memcpy(T.key, key, sizeof(key));
         tile_order_retire(S, T, T.cur);                         // (the old shape's table stays readable for its launches in flight)

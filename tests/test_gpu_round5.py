@@ -471,7 +471,7 @@ def test_render_rows_into_host_memory_rgba8_and_errors(renderer):
 
 # ---- round 6: the dispatch order (csrc/sbx_tile_order.h) -------------------------------------------------------------------
 def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
-    """From the third launch of a shape on, APP_CLOUDS (and CLOUDS_SKY, VINYL) dispatch their tiles by the cost earlier frames
+    """From the third launch of a shape on, APP_CLOUDS (and CLOUDS_SKY, VINYL, EGG) dispatch their tiles by the cost earlier frames
     measured, longest first.  The table is a permutation of the launch's tiles — whatever the cost words hold —, frames rendered
     through it equal the per-lane kernel's (which never uses one) bit for bit, on one stream and on three (where the library
     falls back to the plain order), after a change of shape and after a refresh of the table."""
@@ -521,7 +521,31 @@ def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
         renderer.set_variant(1)
         assert bits_differ(small, renderer.render(app, W2, H2, 0.37)) == 0
         renderer.set_variant(0)
-    # an app without the order (APP_EGG keeps its hot-first dispatch) never builds one
+    # APP_EGG: its own hot-first order until a table is there, the table from then on (the waves of the silhouette first) — same pixels,
+    # also while the scene moves; an app without the order never builds one
+    first = renderer.render("egg", 1920, 1080, 0.37).clone()
+    torch.cuda.synchronize()
+    frames = {}
+    for k in range(24):
+        t = 0.37 if k % 4 == 0 else 0.37 + 0.05 * k
+        got = renderer.render("egg", 1920, 1080, t)
+        torch.cuda.synchronize()
+        if k % 4 == 0:
+            assert bits_differ(got, first) == 0, k
+        elif k >= 20:
+            frames[t] = got.clone()
+    built, since, table = renderer.tile_order("egg")
+    assert built >= 2 and table is not None and table.size == 120 * 270           # 16 x 4-pixel tiles
+    tiles = (table >> 16).astype(np.int64) * 120 + (table & 0xffff).astype(np.int64)
+    assert np.array_equal(np.sort(tiles), np.arange(120 * 270))
+    fresh = type(renderer)(0)                                       # a context of its own, driven over alternating streams: hot-first order
+    alt = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for k, (t, got) in enumerate(frames.items()):
+        with torch.cuda.stream(alt[k % 2]):
+            ref = fresh.render("egg", 1920, 1080, t)
+        torch.cuda.synchronize()
+        assert bits_differ(got, ref) == 0, t
+    del fresh
     for _ in range(4):
-        renderer.render("egg", 1920, 1080, 0.37)
-    assert renderer.tile_order("egg") == (0, 0, None)
+        renderer.render("raytracer", 1920, 1080, 0.37)
+    assert renderer.tile_order("raytracer") == (0, 0, None)

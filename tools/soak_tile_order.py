@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/soak_tile_order.py [cases] [seed] — the dispatch order (csrc/sbx_tile_order.h) under a host that does everything at
-once: APP_CLOUDS / CLOUDS_SKY / VINYL launches of more shapes than a context keeps tables for (least-recently-used replacement,
+once: APP_CLOUDS / CLOUDS_SKY / VINYL / EGG launches of more shapes than a context keeps tables for (least-recently-used replacement,
 buffers that grow), whole frames and ranks' strips, runs of launches on one stream (tables built, adopted, refreshed, applied) mixed
 with launches alternating over three streams (plain order), changing u_time; every frame is compared with the per-lane kernel's
 (`set_variant(1)`: never uses a table) bit for bit.  Run on the GPU box."""
@@ -16,20 +16,30 @@ import shaderbox_amd as sa
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 R = sa.Renderer(0)
+R0 = sa.Renderer(0)                        # APP_EGG's reference frames (check)
+ref_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+nref = 0
 streams = [torch.cuda.Stream() for _ in range(3)]
 # (app, W, H): every one has >= 4096 tiles (smaller launches take no order); more shapes than TILE_ORDER_KEYS = 8 per app for clouds
 shapes = ([("clouds", w, h) for w, h in ((1920, 1080), (2560, 1440), (3840, 2160), (1280, 720), (2048, 1152), (1600, 900), (3200, 1800),
                                           (2880, 1620), (1366, 768), (3440, 1440), (2560, 1080))]
-          + [("clouds_sky", 1920, 1080), ("vinyl", 2048, 1152), ("vinyl", 2560, 1440), ("vinyl_gpu", 2048, 1152)])
+          + [("clouds_sky", 1920, 1080), ("vinyl", 2048, 1152), ("vinyl", 2560, 1440), ("vinyl_gpu", 2048, 1152),
+             ("egg", 1920, 1080), ("egg", 1280, 720), ("egg", 3840, 2160)])
 bad = launches = ordered_seen = 0
 kinds = {}
 
 
 def check(app, W, H, t, got, rank=None, world=None):
     global bad
-    R.set_variant(1)
-    ref = R.render(app, W, H, t)
-    R.set_variant(0)
+    global nref
+    if app == "egg":                                  # (every k_egg variant takes the table: the reference is a context whose launches
+        nref += 1                                     # alternate over two streams — plain hot-first order)
+        with torch.cuda.stream(ref_streams[nref % 2]):
+            ref = R0.render(app, W, H, t)
+    else:
+        R.set_variant(1)
+        ref = R.render(app, W, H, t)
+        R.set_variant(0)
     torch.cuda.synchronize()
     if rank is None:
         d = (got.view(torch.int32) != ref.view(torch.int32)).any(dim=-1)
