@@ -30,9 +30,13 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 W, H = (int(args[0]), int(args[1])) if len(args) >= 2 else (1920, 1080)
 TW, TH = 16, 4
 r = sa.Renderer()
-for _ in range(20):
+for k in range(20):
     a = r.render("egg", W, H, 0.37)
+    if k % 2 == 1:
+        torch.cuda.synchronize()                     # (the dispatch order's table is adopted when the host sees it complete)
 torch.cuda.synchronize()
+if r.tile_order("egg")[0] > 0:
+    print("# (this launch runs under the dispatch table: SBX_TILE_ORDER=0 in the environment for the kernel's own order)")
 a = r.render("egg", W, H, 0.37).cpu().numpy().view(np.uint32).reshape(H, W, 4)
 w0 = a[::TH, ::TW]                                   # lane 0 of every wave
 t0 = w0[..., 0].astype(np.int64)
