@@ -26,9 +26,9 @@ for pass in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS
             "SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_IFETCH SQ_LDS_BANK_CONFLICT" \
             "VALUBusy VALUUtilization" "WRITE_SIZE" "FETCH_SIZE"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-28)
-  rocprofv3 --kernel-trace -f csv --pmc $pass -d $OUT/$tag -o pmc -- python tools/time_baseline.py 4 > $OUT/$tag.log 2>&1
+  rocprofv3 --kernel-trace -f csv --pmc $pass -d $OUT/$tag -o pmc -- python tools/time_baseline.py 12 > $OUT/$tag.log 2>&1
   f=$(find $OUT/$tag -name '*counter_collection.csv' | head -1)
-  echo "# rocprofv3 --kernel-trace --pmc $pass -- python tools/time_baseline.py 4   (full-frame dispatches only)" >> $S
+  echo "# rocprofv3 --kernel-trace --pmc $pass -- python tools/time_baseline.py 12   (full-frame dispatches only)" >> $S
   if [ -n "$f" ]; then python tools/pmc_summary.py "$f" --largest-grid >> $S; else echo "(no counters; see $tag.log)" >> $S; tail -3 $OUT/$tag.log >> $S; fi
 done
 fi

@@ -19,7 +19,8 @@ for k in range(20):                      # clocks up before the first case
 torch.cuda.synchronize()
 for app, w, h in CASES:
     buf = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
-    R.render(app, w, h, 0.37, out=buf); torch.cuda.synchronize()
+    for _ in range(3):                   # (a dispatch table, where the app takes one, is there from the third launch on)
+        R.render(app, w, h, 0.37, out=buf); torch.cuda.synchronize()
     ms = []
     for _ in range(reps):
         R.render(app, w, h, 0.37, out=buf); ms.append(R.last_kernel_ms())
