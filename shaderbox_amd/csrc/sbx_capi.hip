@@ -681,7 +681,14 @@ static int render_mapped(sbx_ctx* ctx, int app, const sbx_uniforms* uni, const v
     default: break;
     }
     RowMap M = M_in;
-    TileOrder* const ordered = tile_order_begin(ctx->tile_orders, app, M, og, s, capturing);
+    unsigned long long scene = 1469598103934665603ull;           // FNV-1a of the frame's uniforms (and APP_CLOUDS' aux block): "the same scene"
+    if (og.x) {
+        auto mix = [&scene](const void* p, size_t n) { for (size_t i = 0; i < n; ++i) scene = (scene ^ ((const unsigned char*)p)[i]) * 1099511628211ull; };
+        mix(uni, sizeof(*uni));
+        if (app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_SKY) mix(&AC, sizeof(AC));
+    }
+    const int scene_policy = app == SBX_APP_EGG ? TILE_SCENE_KEYED : (app == SBX_APP_CLOUDS || app == SBX_APP_CLOUDS_SKY) ? TILE_SCENE_REFRESH : TILE_SCENE_FREE;
+    TileOrder* const ordered = tile_order_begin(ctx->tile_orders, app, M, og, s, capturing, scene, scene_policy);
     switch (app) {
     case SBX_APP_CLOUDS: rc = render_clouds(ctx, build_clouds(*uni, AC), M, rgba, s, capturing); break;
     case SBX_APP_CLOUDS_SKY: launch_clouds(build_clouds(*uni, AC, true), M, rgba, s, ctx->variant, nullptr, 0, false); break;

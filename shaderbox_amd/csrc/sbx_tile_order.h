@@ -19,10 +19,20 @@ namespace sbx {
 // later and every TILE_ORDER_REFRESH launches after that.  A context keeps up to TILE_ORDER_KEYS shapes per app (least recently used
 // replaced): the ranks of an emulated multi-GPU frame driven through one context each keep their table, as separate processes would.
 constexpr int TILE_ORDER_RING = 4, TILE_ORDER_REFRESH = 64, TILE_ORDER_KEYS = 8;
+// What a MOVING scene means for an app's table (measured on animated frames, profiles/r06_tile_order.txt section 11):
+//   TILE_SCENE_FREE    the costs do not follow the scene (APP_VINYL: -7 % standing or moving): the plain refresh schedule
+//   TILE_SCENE_REFRESH they drift with it (APP_CLOUDS: a table 8-64 frames old keeps 0.6-3 % of the 6 % a fresh one gives): while the
+//                      scene moves the table is rebuilt behind EVERY launch (23 us of a 2.2-3.4 ms frame: -3.6 ... -4.5 %)
+//   TILE_SCENE_KEYED   they jump with it (APP_EGG: the silhouette's 16 x 4-pixel tiles are others a frame later; with tables even one
+//                      frame old an animated launch is 8-27 % SLOWER than in the kernel's own hot-first order): the scene is part of
+//                      the table's key — a scene that stands still gets its table, a moving one never does
+enum { TILE_SCENE_FREE = 0, TILE_SCENE_REFRESH = 1, TILE_SCENE_KEYED = 2 };
 struct TileOrder {
     unsigned* mem = nullptr;               // cost | classes | TILE_ORDER_RING tables, `cap` words each | the sort's histograms
     size_t cap = 0;
-    int key[12] = {-1};                     // app, width, nrows, y0, grid x, grid y, and the split the rows belong to
+    int key[14] = {-1};                     // app, width, nrows, y0, grid x, grid y, the split the rows belong to, and (TILE_SCENE_KEYED) the scene
+    unsigned long long scene = 0;          // the scene (hash of the frame's uniforms) of the last launch; `moving`: it differed from the one before
+    bool moving = false;
     int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table whose build is queued, current once `ready` has passed
     unsigned long long stamp = 0;          // last use (least recently used entry of an app is the one a new shape takes)
     hipEvent_t ready{}, seen{};            // the pending table is built / behind the shape's first launch (the first table waits for its costs, on the host)
@@ -61,13 +71,14 @@ static bool tile_order_slot_free(TileOrderSet& S, TileOrder& T, int slot) {
     }
     return true;
 }
-static TileOrder* tile_order_begin(TileOrderSet& S, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing) {
+static TileOrder* tile_order_begin(TileOrderSet& S, int app, RowMap& M, dim3 grid, hipStream_t s, bool capturing, unsigned long long scene, int scene_policy) {
     static const int mode = [] { const char* v = getenv("SBX_TILE_ORDER"); return v ? atoi(v) : 1; }();   // 0 off; 2: costs and tables but no order (debugging)
     if (mode == 0 || capturing || app < 0 || app >= 16 || M.frag || M.r0 != 0 || grid.x == 0 || grid.x > 0xffffu || grid.y > 0xffffu) return nullptr;
     const size_t n = (size_t)grid.x * grid.y;
     if (n < 4096) return nullptr;                                 // (small launches: nothing to order)
-    const int key[12] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y, M.nranks, M.rank, M.block_rows, M.root_rounds, M.rounds,
-                         M.span_mode * 4 + M.in_place};
+    const bool keyed = scene_policy == TILE_SCENE_KEYED;
+    const int key[14] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y, M.nranks, M.rank, M.block_rows, M.root_rounds, M.rounds,
+                         M.span_mode * 4 + M.in_place, keyed ? (int)(unsigned)scene : 0, keyed ? (int)(unsigned)(scene >> 32) : 0};
     TileOrder* hit = nullptr;
     TileOrder* lru = &S.tab[app][0];
     for (auto& E : S.tab[app]) {
@@ -98,6 +109,8 @@ static TileOrder* tile_order_begin(TileOrderSet& S, int app, RowMap& M, dim3 gri
         T.have_ready = true;
     }
     M.cost = T.mem;
+    T.moving = scene_policy == TILE_SCENE_REFRESH && hit && scene != T.scene;
+    T.scene = scene;
     if (T.pending >= 0 && hipEventQuery(T.ready) == hipSuccess) {              // the new table is complete: current from this launch on
         tile_order_retire(S, T, T.cur);
         T.cur = T.pending; T.pending = -1; ++T.built;
@@ -125,21 +138,21 @@ static void tile_order_end(TileOrderSet& S, TileOrder* Tp, hipStream_t s) {
     TileOrder& T = *Tp;
     ++T.age;
     // the first table of a shape after TWO launches of it (a host that renders a shape once never pays for a table it would not use)
-    // and once the first of them has FINISHED (its costs are what the table is made of; an event recorded behind it and queried here),
+    // and once they have FINISHED (their costs are what the table is made of; an event recorded behind the second and queried here),
     // later ones 16 and 32 launches on, then every TILE_ORDER_REFRESH launches
-    if (T.cur < 0 && !T.seen_recorded) {
-        if (hipEventRecord(T.seen, s) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (T.cur < 0 && !T.seen_recorded && T.age >= 2) {          // (at the SECOND launch of a shape: a shape — or, TILE_SCENE_KEYED, a scene
+        if (hipEventRecord(T.seen, s) != hipSuccess) { (void)hipGetLastError(); return; }   // — that is rendered once costs no packet)
         T.seen_recorded = true;
     }
     // (16, 32, then every 64 launches: the costs drift with the scene, slowly, and the first table is made of the first launch's)
-    const int refresh = T.cur < 0 ? 2 : T.built <= 1 ? 16 : T.built == 2 ? 32 : TILE_ORDER_REFRESH;
+    const int refresh = T.cur < 0 ? 2 : T.moving ? 1 : T.built <= 1 ? 16 : T.built == 2 ? 32 : TILE_ORDER_REFRESH;
     if (T.pending >= 0 || T.age < refresh) return;
     // not while the host keeps frames in flight (this launch came on another stream than the last): the table would not be used, and
     // the sort, queued behind a launch of ONE stream, has to find room beside the other streams' launches (as one 1 024-thread
     // workgroup it waited up to 8 ms for a whole CU to drain: rocprofv3, three 4K frames in flight).  The costs keep being collected;
     // the build is due again at the first launch that follows another one on its stream.
     if (S.same_stream < 1) return;
-    if (T.cur < 0 && hipEventQuery(T.seen) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (T.cur < 0 && (!T.seen_recorded || hipEventQuery(T.seen) != hipSuccess)) { (void)hipGetLastError(); return; }
     // The build goes IN LINE, on the stream of the launch that is due, and nothing on the device waits for it except that stream's
     // own next launch (~25 us once per 64 launches): the other render streams take the table once its event has passed (queried on
     // the host, tile_order_begin), the cost words may hold any mixture of frames (a table is a permutation whatever they hold), and

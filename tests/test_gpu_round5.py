@@ -471,7 +471,7 @@ def test_render_rows_into_host_memory_rgba8_and_errors(renderer):
 
 # ---- round 6: the dispatch order (csrc/sbx_tile_order.h) -------------------------------------------------------------------
 def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
-    """From the third launch of a shape on, APP_CLOUDS (and CLOUDS_SKY, VINYL, EGG) dispatch their tiles by the cost earlier frames
+    """From the fourth launch of a shape on, APP_CLOUDS (and CLOUDS_SKY, VINYL, EGG) dispatch their tiles by the cost earlier frames
     measured, longest first.  The table is a permutation of the launch's tiles — whatever the cost words hold —, frames rendered
     through it equal the per-lane kernel's (which never uses one) bit for bit, on one stream and on three (where the library
     falls back to the plain order), after a change of shape and after a refresh of the table."""
@@ -483,7 +483,7 @@ def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
             got = renderer.render(app, W, H, 0.37)
             torch.cuda.synchronize()
             built, since, table = renderer.tile_order(app)
-            assert built == (0 if k < 1 else 1), (app, k, built)          # the first table comes after two launches of the shape
+            assert built == (0 if k < 2 else 1), (app, k, built)          # the first table: behind the launch that follows two FINISHED ones of the shape
             if plain is None:
                 plain = got.clone()                                    # (launches 1 and 2 run in plain order)
             assert bits_differ(got, plain) == 0, (app, k)
@@ -510,7 +510,8 @@ def test_dispatch_order_is_a_permutation_and_changes_no_pixel(renderer):
                     renderer.render(app, W, H, t, out=outs[k % 3])
             torch.cuda.synchronize()
             built = renderer.tile_order(app)[0]                         # (no table is built while launches alternate over streams)
-            assert (built > before) if nstreams == 1 else (built == before), (app, nstreams, before, built)
+            # (the first of the three-stream launches still follows one on its own stream: at most that one build)
+            assert (built > before) if nstreams == 1 else (built <= before + 1), (app, nstreams, before, built)
             renderer.set_variant(1)
             for k in (nl - 3, nl - 2, nl - 1):
                 assert bits_differ(outs[k % 3], renderer.render(app, W, H, times[k])) == 0, (app, nstreams, k)
