@@ -73,17 +73,22 @@ for c in range(cases):
         check(app, W, H, t0 + 0.01 * (n - 1), frame, rank, world)
         continue
     outs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+    # APP_EGG's table belongs to a scene that stands still: most of its cases repeat one frame (into a poisoned buffer: a tile the table
+    # lost would stay NaN)
+    dtk = 0.0 if (app == "egg" and rng.random() < 0.75) else 0.01
     for k in range(n):
         s = streams[k % 3] if mode == "flight" else streams[1]
         with torch.cuda.stream(s):
-            R.render(app, W, H, t0 + 0.01 * k, out=outs[k % 3])
+            if dtk == 0.0:
+                outs[k % 3].fill_(float("nan"))
+            R.render(app, W, H, t0 + dtk * k, out=outs[k % 3])
         if rng.random() < 0.25:
             torch.cuda.synchronize()                  # (a table is adopted when the host sees its event)
     torch.cuda.synchronize()
     launches += n
     ordered_seen += int(R.tile_order(app)[0] > 0)
     for k in range(max(0, n - 3), n):
-        check(app, W, H, t0 + 0.01 * k, outs[k % 3])
+        check(app, W, H, t0 + dtk * k, outs[k % 3])
 print("soak of the dispatch order: %d cases (%s), %d launches over %d shapes, %d cases ended with a table for their shape; %d cases "
       "with a frame differing from the per-lane kernel's" % (cases, ", ".join("%s %d" % kv for kv in sorted(kinds.items())), launches,
                                                              len(shapes), ordered_seen, bad))
