@@ -203,6 +203,11 @@ def time_config(R, torch, dev, streams, app, W, H, t, steps=10, warmup=2, check_
     return {"workload": "APP_%s %dx%d u_time=%g" % (app.upper(), W, H, t), "value": round(W * H / (ms * 1e-3) / 1e6, 2),
             "unit": "Mpixels/s", "ms_per_step": round(ms, 4), "steps": steps,
             "value_is": "one launch at a time (back to back on one stream, wall clock / steps): SURVEY.md 8d's metric",
+            "scene": "the canonical frame rendered K times — a scene that stands still, as BASELINE's configs are; from "
+                     "the fourth launch on the library dispatches APP_CLOUDS / APP_EGG / APP_VINYL tiles by the cost "
+                     "earlier launches measured (same pixels).  A scene that MOVES: APP_CLOUDS rebuilds that table behind "
+                     "every launch (about -4 % instead of -7 %), APP_EGG keeps its own hot-first order (no gain) — "
+                     "DESIGN.md 5.1",
             "value_pipelined": round(W * H / (ms_pipe * 1e-3) / 1e6, 2), "ms_per_step_pipelined": round(ms_pipe, 4), "frames_in_flight": ns,
             "kernel": KERNEL_OF.get(app), "kernel_ms": round(kmean, 4),
             "serial_value": round(W * H / (kmean * 1e-3) / 1e6, 2), "value_serial": round(W * H / (kmean * 1e-3) / 1e6, 2),
@@ -305,6 +310,11 @@ def bench_n1(args, R, torch, dev, streams, app, W, H, t):
                       "preroll": "%d untimed frames (>= %g ms) before the warm-up steps" % (preroll_frames, args.preroll_ms)},
            "value_is": "SURVEY.md 8d: the K timed frames launched one at a time (back to back on one stream), wall clock between two "
                        "synchronisations / K",
+           "scene": "the canonical frame rendered K times — a scene that stands still, as BASELINE's configs are; from "
+                    "the fourth launch on the library dispatches APP_CLOUDS / APP_EGG / APP_VINYL tiles by the cost "
+                    "earlier launches measured (same pixels).  A scene that MOVES: APP_CLOUDS rebuilds that table behind "
+                    "every launch (about -4 % instead of -7 %), APP_EGG keeps its own hot-first order (no gain) — "
+                    "DESIGN.md 5.1",
            # the same K frames with `frames_in_flight` launches overlapping (one framebuffer per stream: the drain of a frame's
            # last, longest waves overlaps the start of the next frame) — a throughput figure of independent frames, NOT the metric
            "value_pipelined": round(value_pipe, 3), "ms_per_step_pipelined": round(ms_pipe, 4), "frames_in_flight_pipelined": ns,
