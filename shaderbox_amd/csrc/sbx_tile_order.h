@@ -80,15 +80,17 @@ static TileOrder* tile_order_begin(TileOrderSet& S, int app, RowMap& M, dim3 gri
     const int key[14] = {app, M.width, M.nrows, M.y0, (int)grid.x, (int)grid.y, M.nranks, M.rank, M.block_rows, M.root_rounds, M.rounds,
                          M.span_mode * 4 + M.in_place, keyed ? (int)(unsigned)scene : 0, keyed ? (int)(unsigned)(scene >> 32) : 0};
     TileOrder* hit = nullptr;
-    TileOrder* lru = &S.tab[app][0];
+    TileOrder* lru = nullptr;                                     // the least recently used entry that has no build still queued
     for (auto& E : S.tab[app]) {
         if (std::memcmp(key, E.key, sizeof(key)) == 0) { hit = &E; break; }
-        if (E.stamp < lru->stamp) lru = &E;
+        if (E.pending >= 0 && hipEventQuery(E.ready) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (!lru || E.stamp < lru->stamp) lru = &E;
     }
+    if (!hit && !lru) return nullptr;                             // (every entry waits for a build: this launch goes without — the host never blocks here)
     TileOrder& T = hit ? *hit : *lru;
     T.stamp = ++S.clock;
     if (!hit) {
-        if (T.pending >= 0) { (void)hipEventSynchronize(T.ready); T.pending = -1; }   // (a build of the old shape still queued)
+        T.pending = -1;                                           // (a build of the old shape, if any, has finished: see above)
         if (n > T.cap) {
             if (T.mem) {
                 (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0;
