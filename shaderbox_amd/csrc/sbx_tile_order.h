@@ -35,6 +35,7 @@ struct TileOrder {
     bool moving = false;
     int cur = -1, pending = -1, age = 0, built = 0;   // pending: a table whose build is queued, current once `ready` has passed
     unsigned long long stamp = 0;          // last use (least recently used entry of an app is the one a new shape takes)
+    hipStream_t pending_stream = nullptr;  // the stream the pending table's build is queued on: ITS later launches may read the table at once (stream order)
     hipEvent_t ready{}, seen{};            // the pending table is built / behind the shape's first launch (the first table waits for its costs, on the host)
     bool have_ready = false, seen_recorded = false;
     std::vector<std::pair<hipStream_t, hipEvent_t>> users[TILE_ORDER_RING];     // streams that launched readers of the CURRENT table
@@ -90,7 +91,8 @@ static TileOrder* tile_order_begin(TileOrderSet& S, int app, RowMap& M, dim3 gri
     TileOrder& T = hit ? *hit : *lru;
     T.stamp = ++S.clock;
     if (!hit) {
-        T.pending = -1;                                           // (a build of the old shape, if any, has finished: see above)
+        tile_order_retire(S, T, T.pending);                       // (a build of the old shape, if any, has finished: see above; its early readers)
+        T.pending = -1;
         if (n > T.cap) {
             if (T.mem) {
                 (void)hipDeviceSynchronize(); (void)hipFree(T.mem); T.mem = nullptr; T.cap = 0;
@@ -123,16 +125,20 @@ static TileOrder* tile_order_begin(TileOrderSet& S, int app, RowMap& M, dim3 gri
     // costs 4-12 % on an eighth-frame strip, while one launch at a time gains 7 % (full frame) to 18 % (strip).  The sign of frames in
     // flight: this launch comes on another stream than the last one.  The costs are collected either way.
     if (s == S.last_stream) ++S.same_stream; else { S.last_stream = s; S.same_stream = 0; }
-    if (T.cur >= 0 && S.same_stream >= 3 && mode == 1) {
+    // the table of this launch: the current one (complete before this call: no stream waits for it) — or, on the stream its build is
+    // queued on, the PENDING one: stream order puts the build ahead of this launch, so a host that never looks at its frames still
+    // renders frame k + 1 by frame k's costs
+    const int use = (T.pending >= 0 && T.pending_stream == s) ? T.pending : T.cur;
+    if (use >= 0 && S.same_stream >= 3 && mode == 1) {
         bool found = false;
-        for (auto& u : T.users[T.cur]) if (u.first == s) { found = true; break; }
+        for (auto& u : T.users[use]) if (u.first == s) { found = true; break; }
         if (!found) {
             hipEvent_t ev{};
             if (!(*S.pool).empty()) { ev = (*S.pool).back(); (*S.pool).pop_back(); }
             else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return &T; }
-            T.users[T.cur].emplace_back(s, ev);
+            T.users[use].emplace_back(s, ev);
         }
-        M.order = T.mem + T.cap * (size_t)(2 + T.cur);                         // (complete before this call: no stream has to wait for it)
+        M.order = T.mem + T.cap * (size_t)(2 + use);
     }
     return &T;
 }
@@ -173,7 +179,7 @@ static void tile_order_end(TileOrderSet& S, TileOrder* Tp, hipStream_t s) {
     if (next < 0) return;
     launch_order_build(T.mem, T.mem + T.cap, T.mem + T.cap * (size_t)(2 + TILE_ORDER_RING), T.mem + T.cap * (size_t)(2 + next), T.key[4], T.key[5], s);
     if (hipEventRecord(T.ready, s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); (void)hipGetLastError(); return; }
-    T.pending = next; T.age = 0;
+    T.pending = next; T.pending_stream = s; T.age = 0;
 }
 
 // the shape of `app` used last: its pending table adopted (the host waits for it), for sbx_debug_tile_order
